@@ -1,0 +1,200 @@
+/* lap_hip.h — C ABI of liblap_hip.so, the gfx950 (MI355X / CDNA4) kernel library
+ * behind lap_amd's LAP-3B train step and policy-serving path.
+ *
+ * The reference (lihzha/lap) has no FFI: its hot path is a jax.jit program
+ * (scripts/train.py:532-537 -> TrainingStepRunner.__call__ 329-419 ->
+ * LAP.compute_loss src/lap/models/lap.py:380-602 -> gemma.Module
+ * src/lap/models/backbones/gemma.py:396-531).  Each entry point below replaces
+ * the XLA-fused computation of the cited reference lines.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; the caller
+ *     owns all buffers, kernels never allocate;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return value 0 = launched, LAP_ERR_ARG (1001) = rejected argument,
+ *     anything else = hipError_t of the failed launch;
+ *   - bf16 = IEEE bfloat16 bits, f32 = float, i32 = int32_t;
+ *   - thread-safe for distinct streams; no global state.
+ */
+#ifndef LAP_HIP_H_
+#define LAP_HIP_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAP_ABI_VERSION 1
+int lap_abi_version(void);
+
+/* ---------------------------------------------------------------- GEMM ---- */
+#define LAP_GEMM_OUT_F32  1   /* C is f32 (default bf16) */
+#define LAP_GEMM_ACCUM    2   /* C += result (f32 output only) */
+#define LAP_GEMM_GELU     4   /* tanh-GELU after bias (bf16 output only) */
+#define LAP_GEMM_BIAS_F32 8   /* bias is f32 (default bf16) */
+
+/* C[M,N] = epi(alpha * opA . opB): bf16 operands, f32 MFMA accumulate.
+ * a_kc=1: A is [M][lda] (k contiguous); a_kc=0: A is [K][lda] (m contiguous).
+ * b_kc=1: B is [N][ldb] (k contiguous); b_kc=0: B is [K][ldb] (n contiguous).
+ * epi(v) = [gelu](v + bias[n]) + residual[m][n], optionally accumulated into C.
+ * Replaces every jnp.dot / einsum projection of gemma.py:188-202,279-285,
+ * 303-319 (lora.Einsum / FeedForward), Embedder.decode gemma.py:153-154 and the
+ * Flax Dense / MultiHeadDotProductAttention projections of SigLIP
+ * (siglip_gemma3.py:59-114), plus their transposes in the backward pass. */
+int lap_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual,
+                  int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
+                  int a_kc, int b_kc, int flags, void* stream);
+
+/* Small exact-f32 GEMM (VALU, k-ordered fmaf chain):
+ * C[M,N] = alpha * opA . opB (+ bias[n]) (+ C if accum).  Same layout flags as
+ * above.  Used where the reference computes in float32: the SigLIP stem conv
+ * (siglip_gemma3.py:401-408), nnx.Linear action_in_proj / time_mlp_* /
+ * action_out_proj (lap.py:52-62,298) and their gradients. */
+int lap_gemm_f32(const float* A, const float* B, float* C, const float* bias,
+                 int M, int N, int K, int lda, int ldb, int ldc, float alpha,
+                 int a_kc, int b_kc, int accum, void* stream);
+
+/* ------------------------------------------------------- normalisation ---- */
+/* RMSNorm / adaptive RMSNorm forward (gemma.py:113-131).
+ * x,y: bf16 [rows][D]; scale: f32 [D] (plain) or NULL; mod: bf16
+ * [rows/rows_per_sample][3*D] = (scale|shift|gate) from Dense(cond) (adaptive)
+ * or NULL.  rstd: f32 [rows] out (saved for backward), may be NULL. */
+int lap_rmsnorm_fwd(const void* x, const float* scale, const void* mod, void* y, float* rstd,
+                    int rows, int D, int rows_per_sample, float eps, void* stream);
+/* Backward: dx (bf16, overwritten or accumulated into when accum_dx) and
+ * either dscale f32[D] (atomically accumulated; caller zeroes) or dmod f32
+ * [B][3*D] scale/shift thirds (written; gate third untouched). */
+int lap_rmsnorm_bwd(const void* x, const float* scale, const void* mod, const float* rstd, const void* dy,
+                    void* dx, float* dscale, float* dmod,
+                    int rows, int D, int rows_per_sample, int accum_dx, void* stream);
+
+/* LayerNorm (Flax nn.LayerNorm, eps 1e-6, f32 statistics; siglip_gemma3.py:93,104,167).
+ * x,y bf16 [rows][D]; gamma,beta f32 [D]; mean,rstd f32 [rows] saved. */
+int lap_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int rows, int D, float eps, void* stream);
+int lap_layernorm_bwd(const void* x, const float* gamma, const float* mean, const float* rstd, const void* dy,
+                      void* dx, float* dgamma, float* dbeta, int rows, int D, int accum_dx, void* stream);
+
+/* ----------------------------------------------------------- elementwise -- */
+/* RoPE + q-scale + head split (gemma.py:215-218,548-564).
+ * qkv: bf16 [B*T_seg][(NH+2)*HD] (q heads | k | v) of one expert stream;
+ * pos: i32 [B][T_total] joint positions, this stream's tokens start at
+ * seg_off inside each sample.  Writes q [B*T_seg][NH*HD] (rotated, rounded to
+ * bf16, then * q_scale in bf16), k [B*T_seg][HD] rotated, v [B*T_seg][HD]. */
+int lap_rope_split_fwd(const void* qkv, const int32_t* pos, void* q, void* k, void* v,
+                       int B, int T_seg, int T_total, int seg_off, int NH, int HD, float q_scale, void* stream);
+/* Inverse: dq,dk,dv -> dqkv (same layouts). */
+int lap_rope_split_bwd(const void* dq, const void* dk, const void* dv, const int32_t* pos, void* dqkv,
+                       int B, int T_seg, int T_total, int seg_off, int NH, int HD, float q_scale, void* stream);
+
+/* GeGLU (gemma.py:308-312): gu bf16 [rows][2*H] (gate | up), act = gelu_tanh(gate) * up, bf16 [rows][H]. */
+int lap_geglu_fwd(const void* gu, void* act, int rows, int H, void* stream);
+int lap_geglu_bwd(const void* gu, const void* dact, void* dgu, int rows, int H, void* stream);
+/* tanh-GELU (SigLIP MlpBlock, siglip_gemma3.py:76): y = gelu(x); bwd dx = dy * gelu'(x). bf16. */
+int lap_gelu_fwd(const void* x, void* y, long long n, void* stream);
+int lap_gelu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream);
+
+/* Embedding gather (gemma.py:148-151,448): out[r] = bf16(table[tok[r]] * scale), table f32 [V][D].
+ * Rows are written at dst row (r / T) * dst_rows_per_sample + dst_off + r % T (prefix assembly, lap.py:150-166). */
+int lap_embed_gather(const float* table, const int32_t* tok, void* out, int rows, int T, int D,
+                     int dst_rows_per_sample, int dst_off, float scale, void* stream);
+/* Backward: dtable[tok[r]] += scale * dout[row(r)] (f32 atomics). */
+int lap_embed_scatter_add(float* dtable, const int32_t* tok, const void* dout, int rows, int T, int D,
+                          int src_rows_per_sample, int src_off, float scale, void* stream);
+
+/* y = x + u * gate[sample] (gemma.py:577-583), bf16; gate: bf16 [B][ldg] slice (third of mod) or NULL (plain add). */
+int lap_gated_residual_fwd(const void* x, const void* u, const void* gate, void* y,
+                           int rows, int D, int rows_per_sample, int ldg, void* stream);
+/* du = dy * gate; dgate[b] (f32 [B][ldg_out]) = sum_rows dy*u. */
+int lap_gated_residual_bwd(const void* dy, const void* u, const void* gate, void* du, float* dgate,
+                           int rows, int D, int rows_per_sample, int ldg, int ldg_out, void* stream);
+
+/* Generic casts / copies / fills. */
+int lap_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream);
+int lap_cast_bf16_to_f32(const void* x, float* y, long long n, void* stream);
+int lap_add_bf16(const void* a, const void* b, void* y, long long n, void* stream);
+/* Strided 2-D copy of bf16 rows: dst[r*ldd + c] = src[r*lds + c], c < cols. */
+int lap_copy2d_bf16(const void* src, void* dst, int rows, int cols, int lds, int ldd, void* stream);
+/* Row re-blocking: dst row (r / T) * dst_rps + dst_off + r % T  <-  src row (r / T) * src_rps + src_off + r % T. */
+int lap_copy_rows_bf16(const void* src, void* dst, int rows, int T, int D,
+                       int src_rps, int src_off, int dst_rps, int dst_off, int accumulate, void* stream);
+
+/* SigLIP stem helpers (siglip_gemma3.py:398-418): NHWC f32 image -> patch matrix f32 [B*GH*GW][P*P*C]
+ * (row-major over (ph, pw, c) to match a Flax conv kernel reshaped [P,P,C,W]). */
+int lap_im2col_patch(const float* img, float* out, int B, int H, int W, int C, int P, void* stream);
+/* y[bf16] = x[f32] + posemb[f32][r % T]  (stem output + learned posemb, cast to bf16). */
+int lap_add_posemb_cast(const float* x, const float* pos, void* y, int rows, int T, int D, void* stream);
+/* Backward of the above: dx f32 = dy; dpos[t] += sum_b dy[b,t]. */
+int lap_add_posemb_cast_bwd(const void* dy, float* dx, float* dpos, int rows, int T, int D, void* stream);
+
+/* ------------------------------------------------------------ attention --- */
+/* Joint multi-segment masked attention (gemma.py:234-272; Flax MHA for SigLIP).
+ * Queries / keys of one sample are the concatenation of up to 2 segments
+ * (expert streams, or KV-cache prefix + new suffix).  Segment s of Q/O holds
+ * bf16 [B][len_s][NH*HD]; of K/V holds [B][len_s][NKV*HD] (NKV in {1, NH}).
+ * Mask: allowed(i,j) = (qinfo[b][i] >> 24) & (kinfo[b][j] >> 24) != 0  &&
+ *                      (kinfo[b][j] & 0xffffff) <= (qinfo[b][i] & 0xffffff);
+ * NULL infos = no mask.  This encodes make_attn_mask + the LAP prefix/action
+ * block structure (lap.py:303-364) without materialising [B,T,T].
+ * Q must already carry the 1/sqrt(HD) scale.  lse: f32 [B][NH][Tq] out. */
+typedef struct {
+  const void* q[2]; void* o[2];
+  const void* k[2]; const void* v[2];
+  int q_len[2]; int k_len[2];
+  const int32_t* qinfo; const int32_t* kinfo;
+  float* lse;
+  int B, NH, NKV, HD;
+} lap_attn_fwd_args;
+int lap_attention_fwd(const lap_attn_fwd_args* a, void* stream);
+
+typedef struct {
+  const void* q[2]; const void* o[2]; const void* d_o[2];
+  const void* k[2]; const void* v[2];
+  void* dq[2]; void* dk[2]; void* dv[2];
+  int q_len[2]; int k_len[2];
+  const int32_t* qinfo; const int32_t* kinfo;
+  const float* lse;
+  float* delta;              /* scratch f32 [B][NH][Tq] */
+  int B, NH, NKV, HD;
+  int stop_q1_to_k0;         /* stop_action_to_vlm_grad (gemma.py:242-269): no dK/dV from segment-1 queries into segment-0 keys */
+} lap_attn_bwd_args;
+int lap_attention_bwd(const lap_attn_bwd_args* a, void* stream);
+
+/* ----------------------------------------------------------------- loss --- */
+/* Vocab-chunked cross entropy (lap.py:221-260). logits: f32 [rows][ldl] chunk covering vocab
+ * [v0, v0+vc); state m,l (running max / sum-exp), tl (target logit) f32 [rows]. */
+int lap_ce_chunk_update(const float* logits, int ldl, const int32_t* target, float* m, float* l, float* tl,
+                        int rows, int v0, int vc, void* stream);
+/* dlogits chunk (bf16 [rows][ldd]) = w[r] * (softmax - onehot), softmax from (m,l). */
+int lap_ce_chunk_grad(const float* logits, int ldl, const int32_t* target, const float* m, const float* l,
+                      const float* w, void* dlogits, int ldd, int rows, int v0, int vc, void* stream);
+
+/* ------------------------------------------------------------ optimizer --- */
+/* sumsq[0] += sum x^2 (f32 atomics; caller zeroes). */
+int lap_sumsq_f32(const float* x, long long n, float* sumsq, void* stream);
+/* Fused clip-by-global-norm + AdamW + EMA + bf16 weight refresh (train.py:363-396).
+ * scalars (device f32[8]): [0]=sum of squared grads (global), [1]=lr, [2]=bias_corr1, [3]=bias_corr2,
+ * [4]=ema_decay, [5]=ema_enabled (0/1).  clip = min(1, max_norm / (sqrt(s0)+1e-6)).
+ * p,m,v,ema f32 [n]; g f32 [n]; p16 bf16 [n] out (may be NULL); ema may be NULL. */
+int lap_adamw_ema(float* p, float* m, float* v, float* ema, const float* g, void* p16, long long n,
+                  const float* scalars, float b1, float b2, float eps, float wd, float max_norm, void* stream);
+
+/* ------------------------------------------------------- flow matching ---- */
+/* x_t = t*eps + (1-t)*a ; u_t = eps - a  (lap.py:193-197). all f32 [B][n_per]; t f32 [B]. */
+int lap_fm_mix(const float* noise, const float* actions, const float* t, float* x_t, float* u_t,
+               int B, int n_per, void* stream);
+/* posemb_sincos(t, D, min_period, max_period) -> f32 [B][D] (openpi pi0.posemb_sincos, UPSTREAM-RECALL). */
+int lap_posemb_sincos(const float* t, float* out, int B, int D, float min_period, float max_period, void* stream);
+/* swish: y = x * sigmoid(x), f32; bwd dx = dy * (s + x s (1-s)). */
+int lap_swish_fwd(const float* x, float* y, long long n, void* stream);
+int lap_swish_bwd(const float* x, const float* dy, float* dx, long long n, void* stream);
+/* MSE (lap.py:298-299): per_sample[b] = mean_{n_per}((v-u)^2); dv = coef[b] * 2 (v-u) / n_per. f32. */
+int lap_mse_fwd_bwd(const float* v, const float* u, const float* coef, float* per_sample, float* dv,
+                    int B, int n_per, void* stream);
+/* x += dt * v (Euler step, lap.py:667). f32. */
+int lap_axpy_f32(float* x, const float* v, float dt, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAP_HIP_H_ */

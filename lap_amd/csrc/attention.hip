@@ -1,0 +1,502 @@
+// Flash-style joint attention for the LAP hot path on gfx950: forward, and a
+// two-kernel backward (dK/dV per key tile, dQ per query tile).
+//
+// Reference semantics (src/lap/models/backbones/gemma.py:234-272):
+//   logits = einsum(q, k) in f32, masked with -2.38e38, softmax in f32, probs -> bf16,
+//   encoded = einsum(probs, v);  q already carries head_dim^-0.5 (gemma.py:216).
+// The [B,T,T] boolean mask of lap.py:303-364 / make_attn_mask is never built:
+// each token carries one int32 (class bits << 24 | cumulative ar index) and
+//   allowed(q, k) = (class(q) & class(k)) != 0  &&  idx(k) <= idx(q).
+// Queries and keys of a sample are the concatenation of up to two segments (the
+// two expert streams in training; KV-cache prefix + fresh suffix in serving), so
+// neither the token streams nor the cache are ever concatenated in HBM.
+//
+// Tiling: 256 threads = 4 waves; a block owns 64 rows (queries for fwd / dQ, keys
+// for dK/dV), each wave 16 of them; the other side streams through LDS in tiles
+// of 64 rows, zero padded to DP = roundup(HD, 32) columns.  All products are
+// v_mfma_f32_16x16x32_bf16.  S is computed transposed (S^T = K Q^T) so that a
+// lane owns one query column: softmax statistics are per-lane scalars and the C/D
+// registers of S^T are already the k-permuted B operand of O^T = V^T P^T.
+#include "common.hpp"
+#include "../../include/lap_hip.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LSE_EMPTY = 1.0e30f;   // lse of a fully masked row: exp(s - lse) == 0
+
+struct AttnP {
+  const bf16* q[2]; bf16* o[2]; const bf16* k[2]; const bf16* v[2];
+  const bf16* d_o[2]; bf16* dq[2]; bf16* dk[2]; bf16* dv[2];
+  int qlen[2], klen[2];
+  const int32_t* qinfo; const int32_t* kinfo;
+  float* lse; float* delta;
+  int B, NH, NKV, stop;
+};
+
+template <int HD> struct Cfg {
+  static constexpr int DP = (HD + 31) / 32 * 32;   // padded depth
+  static constexpr int KS = DP / 32;               // 32-deep k-steps along d
+  static constexpr int DF = DP / 16;               // 16-wide fragments along d
+  static constexpr int STRIDE = DP * 2 + 32;       // LDS row stride in bytes: b128 and tr reads both conflict free
+  static constexpr int TILE = 64 * STRIDE;
+};
+
+__device__ __forceinline__ bool mask_ok(int qi, int ki) {
+  return (((qi >> 24) & (ki >> 24)) != 0) && ((ki & 0xffffff) <= (qi & 0xffffff));
+}
+
+// 64 x DP tile: global rows (row stride `rs` elements) -> LDS, zero filled outside [valid_rows) x [HD).
+template <int HD>
+__device__ __forceinline__ void load_tile(char* lds, const bf16* base, long long rs, int valid_rows) {
+  constexpr int CH = Cfg<HD>::DP / 8;
+  for (int idx = threadIdx.x; idx < 64 * CH; idx += 256) {
+    const int row = idx / CH, c = idx % CH;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < valid_rows && c * 8 < HD) v = *reinterpret_cast<const bf16x8*>(base + row * rs + c * 8);
+    *reinterpret_cast<bf16x8*>(lds + row * Cfg<HD>::STRIDE + c * 16) = v;
+  }
+}
+// Operand with row/col index = tile row (lane i), contiguous-k along d: one ds_read_b128.
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_kc(const char* t, int row0, int kk, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  return *reinterpret_cast<const bf16x8*>(t + (row0 + i) * Cfg<HD>::STRIDE + (kk * 4 + g) * 16);
+}
+// Operand with row/col index = tile column (col0 + lane i), k = tile rows krow0 + {4g..4g+3, 16+4g..}: two tr reads.
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_tr(const char* t, int krow0, int col0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const char* p = t + (krow0 + 4 * g + (i >> 2)) * Cfg<HD>::STRIDE + (col0 + (i & 3) * 4) * 2;
+  bf16x4 lo = ds_read_tr(p);
+  bf16x4 hi = ds_read_tr(p + 16 * Cfg<HD>::STRIDE);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// Register operand straight from a global row: lane group g takes d = 32kk + 8g .. +7 (zero outside [0,HD) / invalid row).
+template <int HD>
+__device__ __forceinline__ void load_row_frags(const bf16* row, bool valid, int lane, bf16x8 (&f)[Cfg<HD>::KS]) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < Cfg<HD>::KS; ++kk) {
+    const int d = kk * 32 + g * 8;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid && d < HD) v = *reinterpret_cast<const bf16x8*>(row + d);
+    f[kk] = v;
+  }
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = f2bf(a[e]); r[4 + e] = f2bf(b[e]); }
+  return r;
+}
+// lane writes 4 consecutive d (8 bytes) of one row
+__device__ __forceinline__ void store4(bf16* p, const f32x4& v, float s) {
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e] * s);
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+struct BlockId { int b, h, seg, tile; };
+__device__ __forceinline__ BlockId decode_block(int len0, int len1, int nheads) {
+  const int nt0 = (len0 + 63) >> 6, nt1 = (len1 + 63) >> 6, nt = nt0 + nt1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  BlockId r;
+  const int t = bid % nt;
+  r.h = (bid / nt) % nheads;
+  r.b = bid / (nt * nheads);
+  r.seg = t >= nt0;
+  r.tile = r.seg ? t - nt0 : t;
+  return r;
+}
+
+// =============================================================================== forward
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+  using C = Cfg<HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + C::TILE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const BlockId id = decode_block(p.qlen[0], p.qlen[1], p.NH);
+  const int b = id.b, h = id.h;
+  const int qlen = p.qlen[id.seg];
+  const int Tq = p.qlen[0] + p.qlen[1], Tk = p.klen[0] + p.klen[1];
+  const int qinfo_off = id.seg ? p.qlen[0] : 0;
+  const int myq = id.tile * 64 + w * 16 + i;
+  const bool vq = myq < qlen;
+  const int hk = h / (p.NH / p.NKV);
+
+  bf16x8 qf[C::KS];
+  load_row_frags<HD>(p.q[id.seg] + ((long long)(b * (long long)qlen + myq) * p.NH + h) * HD, vq, lane, qf);
+  const int qi = (p.qinfo && vq) ? p.qinfo[(long long)b * Tq + qinfo_off + myq] : 0x7fffffff;
+
+  float m = NEG_BIG, l = 0.f;
+  f32x4 acc_o[C::DF];
+#pragma unroll
+  for (int d = 0; d < C::DF; ++d) acc_o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ks = 0; ks < 2; ++ks) {
+    const int klen = p.klen[ks];
+    if (klen == 0) continue;
+    const int kinfo_off = ks ? p.klen[0] : 0;
+    const long long krs = (long long)p.NKV * HD;
+    const bf16* kb = p.k[ks] + ((long long)b * klen * p.NKV + hk) * HD;
+    const bf16* vb = p.v[ks] + ((long long)b * klen * p.NKV + hk) * HD;
+    for (int kt = 0; kt * 64 < klen; ++kt) {
+      __syncthreads();
+      const int vr = min(64, klen - kt * 64);
+      load_tile<HD>(sK, kb + (long long)kt * 64 * krs, krs, vr);
+      load_tile<HD>(sV, vb + (long long)kt * 64 * krs, krs, vr);
+      __syncthreads();
+
+      f32x4 s[4];
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) s[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < C::KS; ++kk)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) s[nf] = mfma16(frag_kc<HD>(sK, nf * 16, kk, lane), qf[kk], s[nf]);
+
+      // mask + online softmax; lane owns query column i and keys 16nf + 4g + r
+      float smax = NEG_BIG;
+      bool ok[4][4];
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 64 + nf * 16 + 4 * g + r;
+          bool a = key < klen;
+          if (a && p.kinfo) a = mask_ok(qi, p.kinfo[(long long)b * Tk + kinfo_off + key]);
+          ok[nf][r] = a;
+          if (a) smax = fmaxf(smax, s[nf][r]);
+        }
+      smax = fmaxf(smax, __shfl_xor(smax, 16, 64));
+      smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
+      const float m_new = fmaxf(m, smax);
+      const float alpha = __expf(m - m_new);
+      float lsum = 0.f;
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = ok[nf][r] ? __expf(s[nf][r] - m_new) : 0.f;
+          s[nf][r] = pv;
+          lsum += pv;
+        }
+      l = l * alpha + lsum;
+      m = m_new;
+#pragma unroll
+      for (int d = 0; d < C::DF; ++d) acc_o[d] *= alpha;
+      const bf16x8 p0 = pack8(s[0], s[1]), p1 = pack8(s[2], s[3]);
+#pragma unroll
+      for (int d = 0; d < C::DF; ++d) {
+        acc_o[d] = mfma16(frag_tr<HD>(sV, 0, d * 16, lane), p0, acc_o[d]);
+        acc_o[d] = mfma16(frag_tr<HD>(sV, 32, d * 16, lane), p1, acc_o[d]);
+      }
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (!vq) return;
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  bf16* orow = p.o[id.seg] + ((long long)(b * (long long)qlen + myq) * p.NH + h) * HD;
+#pragma unroll
+  for (int d = 0; d < C::DF; ++d) {
+    const int d0 = d * 16 + 4 * g;
+    if (d0 < HD) store4(orow + d0, acc_o[d], inv);
+  }
+  if (p.lse && g == 0) p.lse[((long long)b * p.NH + h) * Tq + qinfo_off + myq] = l > 0.f ? m + __logf(l) : LSE_EMPTY;
+}
+
+// ====================================================================== delta = rowsum(dO * O)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int Tq = p.qlen[0] + p.qlen[1];
+  const long long item = (long long)blockIdx.x * 4 + w;     // (b, t, h)
+  if (item >= (long long)p.B * Tq * p.NH) return;
+  const int h = (int)(item % p.NH);
+  const int t = (int)((item / p.NH) % Tq);
+  const int b = (int)(item / ((long long)p.NH * Tq));
+  const int seg = t >= p.qlen[0];
+  const int tt = seg ? t - p.qlen[0] : t;
+  const long long off = ((long long)(b * (long long)p.qlen[seg] + tt) * p.NH + h) * HD;
+  float acc = 0.f;
+  for (int c = lane * 8; c < HD; c += 512) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(p.o[seg] + off + c);
+    bf16x8 d = *reinterpret_cast<const bf16x8*>(p.d_o[seg] + off + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)d[e];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) p.delta[((long long)b * p.NH + h) * Tq + t] = acc;
+}
+
+// ======================================================================== backward: dK, dV
+// Block = (b, kv head, key tile); wave owns 16 keys (lane column i); loops over the
+// query heads sharing this kv head and over all query tiles.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
+  using C = Cfg<HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQ = smem;
+  char* sD = smem + C::TILE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const BlockId id = decode_block(p.klen[0], p.klen[1], p.NKV);
+  const int b = id.b, hk = id.h, kseg = id.seg;
+  const int klen = p.klen[kseg];
+  const int Tq = p.qlen[0] + p.qlen[1], Tk = p.klen[0] + p.klen[1];
+  const int mykey = id.tile * 64 + w * 16 + i;
+  const bool vk = mykey < klen;
+  const long long koff = ((long long)(b * (long long)klen + mykey) * p.NKV + hk) * HD;
+
+  bf16x8 kf[C::KS], vf[C::KS];
+  load_row_frags<HD>(p.k[kseg] + koff, vk, lane, kf);
+  load_row_frags<HD>(p.v[kseg] + koff, vk, lane, vf);
+  const int ki = (p.kinfo && vk) ? p.kinfo[(long long)b * Tk + (kseg ? p.klen[0] : 0) + mykey] : 0;
+
+  f32x4 acc_dk[C::DF], acc_dv[C::DF];
+#pragma unroll
+  for (int d = 0; d < C::DF; ++d) { acc_dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int hpk = p.NH / p.NKV;
+  for (int hh = 0; hh < hpk; ++hh) {
+    const int h = hk * hpk + hh;
+    for (int qs = 0; qs < 2; ++qs) {
+      const int qlen = p.qlen[qs];
+      if (qlen == 0) continue;
+      if (p.stop && qs == 1 && kseg == 0) continue;   // stop_action_to_vlm_grad
+      const int qinfo_off = qs ? p.qlen[0] : 0;
+      const long long qrs = (long long)p.NH * HD;
+      const bf16* qb = p.q[qs] + ((long long)b * qlen * p.NH + h) * HD;
+      const bf16* dob = p.d_o[qs] + ((long long)b * qlen * p.NH + h) * HD;
+      const float* lse = p.lse + ((long long)b * p.NH + h) * Tq + qinfo_off;
+      const float* dl = p.delta + ((long long)b * p.NH + h) * Tq + qinfo_off;
+      for (int qt = 0; qt * 64 < qlen; ++qt) {
+        __syncthreads();
+        const int vr = min(64, qlen - qt * 64);
+        load_tile<HD>(sQ, qb + (long long)qt * 64 * qrs, qrs, vr);
+        load_tile<HD>(sD, dob + (long long)qt * 64 * qrs, qrs, vr);
+        __syncthreads();
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int qf = 0; qf < 4; ++qf) { s[qf] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kk = 0; kk < C::KS; ++kk)
+#pragma unroll
+          for (int qf = 0; qf < 4; ++qf) {
+            s[qf] = mfma16(frag_kc<HD>(sQ, qf * 16, kk, lane), kf[kk], s[qf]);     // S[q][key]
+            dp[qf] = mfma16(frag_kc<HD>(sD, qf * 16, kk, lane), vf[kk], dp[qf]);   // dP[q][key]
+          }
+        // lane: key column i, query rows 16qf + 4g + r
+#pragma unroll
+        for (int qf = 0; qf < 4; ++qf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = qt * 64 + qf * 16 + 4 * g + r;
+            bool a = vk && q < qlen;
+            if (a && p.qinfo) a = mask_ok(p.qinfo[(long long)b * Tq + qinfo_off + q], ki);
+            float pv = 0.f, ds = 0.f;
+            if (a) {
+              pv = __expf(s[qf][r] - lse[q]);
+              ds = pv * (dp[qf][r] - dl[q]);
+            }
+            s[qf][r] = pv;
+            dp[qf][r] = ds;
+          }
+        const bf16x8 p0 = pack8(s[0], s[1]), p1 = pack8(s[2], s[3]);
+        const bf16x8 d0 = pack8(dp[0], dp[1]), d1 = pack8(dp[2], dp[3]);
+#pragma unroll
+        for (int d = 0; d < C::DF; ++d) {
+          acc_dv[d] = mfma16(frag_tr<HD>(sD, 0, d * 16, lane), p0, acc_dv[d]);    // dV^T[d][key] += dO^T P
+          acc_dv[d] = mfma16(frag_tr<HD>(sD, 32, d * 16, lane), p1, acc_dv[d]);
+          acc_dk[d] = mfma16(frag_tr<HD>(sQ, 0, d * 16, lane), d0, acc_dk[d]);    // dK^T[d][key] += Q^T dS
+          acc_dk[d] = mfma16(frag_tr<HD>(sQ, 32, d * 16, lane), d1, acc_dk[d]);
+        }
+      }
+    }
+  }
+  if (!vk) return;
+#pragma unroll
+  for (int d = 0; d < C::DF; ++d) {
+    const int d0 = d * 16 + 4 * g;
+    if (d0 < HD) {
+      store4(p.dk[kseg] + koff + d0, acc_dk[d], 1.0f);
+      store4(p.dv[kseg] + koff + d0, acc_dv[d], 1.0f);
+    }
+  }
+}
+
+// ============================================================================ backward: dQ
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
+  using C = Cfg<HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + C::TILE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const BlockId id = decode_block(p.qlen[0], p.qlen[1], p.NH);
+  const int b = id.b, h = id.h;
+  const int qlen = p.qlen[id.seg];
+  const int Tq = p.qlen[0] + p.qlen[1], Tk = p.klen[0] + p.klen[1];
+  const int qinfo_off = id.seg ? p.qlen[0] : 0;
+  const int myq = id.tile * 64 + w * 16 + i;
+  const bool vq = myq < qlen;
+  const int hk = h / (p.NH / p.NKV);
+  const long long qoff = ((long long)(b * (long long)qlen + myq) * p.NH + h) * HD;
+
+  bf16x8 qf[C::KS], dof[C::KS];
+  load_row_frags<HD>(p.q[id.seg] + qoff, vq, lane, qf);
+  load_row_frags<HD>(p.d_o[id.seg] + qoff, vq, lane, dof);
+  const int qi = (p.qinfo && vq) ? p.qinfo[(long long)b * Tq + qinfo_off + myq] : 0x7fffffff;
+  const float lse_q = vq ? p.lse[((long long)b * p.NH + h) * Tq + qinfo_off + myq] : LSE_EMPTY;
+  const float dl_q = vq ? p.delta[((long long)b * p.NH + h) * Tq + qinfo_off + myq] : 0.f;
+
+  f32x4 acc[C::DF];
+#pragma unroll
+  for (int d = 0; d < C::DF; ++d) acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ks = 0; ks < 2; ++ks) {
+    const int klen = p.klen[ks];
+    if (klen == 0) continue;
+    const int kinfo_off = ks ? p.klen[0] : 0;
+    const long long krs = (long long)p.NKV * HD;
+    const bf16* kb = p.k[ks] + ((long long)b * klen * p.NKV + hk) * HD;
+    const bf16* vb = p.v[ks] + ((long long)b * klen * p.NKV + hk) * HD;
+    for (int kt = 0; kt * 64 < klen; ++kt) {
+      __syncthreads();
+      const int vr = min(64, klen - kt * 64);
+      load_tile<HD>(sK, kb + (long long)kt * 64 * krs, krs, vr);
+      load_tile<HD>(sV, vb + (long long)kt * 64 * krs, krs, vr);
+      __syncthreads();
+      f32x4 s[4], dp[4];
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) { s[nf] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int kk = 0; kk < C::KS; ++kk)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          s[nf] = mfma16(frag_kc<HD>(sK, nf * 16, kk, lane), qf[kk], s[nf]);      // S^T[key][q]
+          dp[nf] = mfma16(frag_kc<HD>(sV, nf * 16, kk, lane), dof[kk], dp[nf]);   // dP^T[key][q]
+        }
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 64 + nf * 16 + 4 * g + r;
+          bool a = vq && key < klen;
+          if (a && p.kinfo) a = mask_ok(qi, p.kinfo[(long long)b * Tk + kinfo_off + key]);
+          dp[nf][r] = a ? __expf(s[nf][r] - lse_q) * (dp[nf][r] - dl_q) : 0.f;
+        }
+      const bf16x8 d0 = pack8(dp[0], dp[1]), d1 = pack8(dp[2], dp[3]);
+#pragma unroll
+      for (int d = 0; d < C::DF; ++d) {
+        acc[d] = mfma16(frag_tr<HD>(sK, 0, d * 16, lane), d0, acc[d]);    // dQ^T[d][q] += K^T dS^T
+        acc[d] = mfma16(frag_tr<HD>(sK, 32, d * 16, lane), d1, acc[d]);
+      }
+    }
+  }
+  if (!vq) return;
+#pragma unroll
+  for (int d = 0; d < C::DF; ++d) {
+    const int d0 = d * 16 + 4 * g;
+    if (d0 < HD) store4(p.dq[id.seg] + qoff + d0, acc[d], 1.0f);
+  }
+}
+
+template <typename K>
+int set_lds(K kernel, int bytes) {
+  if (bytes > 65536) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+template <int HD>
+int launch_fwd(const AttnP& p, hipStream_t s) {
+  const int nt = (p.qlen[0] + 63) / 64 + (p.qlen[1] + 63) / 64;
+  const int lds = 2 * Cfg<HD>::TILE;
+  if (int e = set_lds(attn_fwd_kernel<HD>, lds)) return e;
+  hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3(p.B * p.NH * nt), dim3(256), lds, s, p);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+template <int HD>
+int launch_bwd(const AttnP& p, hipStream_t s) {
+  const int Tq = p.qlen[0] + p.qlen[1];
+  const int lds = 2 * Cfg<HD>::TILE;
+  const long long items = (long long)p.B * Tq * p.NH;
+  hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p);
+  LAP_CHECK_LAUNCH();
+  const int ntk = (p.klen[0] + 63) / 64 + (p.klen[1] + 63) / 64;
+  if (int e = set_lds(attn_bwd_dkdv_kernel<HD>, lds)) return e;
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HD>, dim3(p.B * p.NKV * ntk), dim3(256), lds, s, p);
+  LAP_CHECK_LAUNCH();
+  const int ntq = (p.qlen[0] + 63) / 64 + (p.qlen[1] + 63) / 64;
+  if (int e = set_lds(attn_bwd_dq_kernel<HD>, lds)) return e;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, dim3(p.B * p.NH * ntq), dim3(256), lds, s, p);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+bool check_common(int B, int NH, int NKV, int HD, const int* qlen, const int* klen) {
+  if (B <= 0 || NH <= 0 || NKV <= 0 || NH % NKV) return false;
+  if (HD != 16 && HD != 72 && HD != 256) return false;
+  if (qlen[0] < 0 || qlen[1] < 0 || klen[0] < 0 || klen[1] < 0) return false;
+  if (qlen[0] + qlen[1] == 0 || klen[0] + klen[1] == 0) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int lap_attention_fwd(const lap_attn_fwd_args* a, void* stream) {
+  if (!a || !check_common(a->B, a->NH, a->NKV, a->HD, a->q_len, a->k_len)) return LAP_ERR_ARG;
+  AttnP p = {};
+  for (int s = 0; s < 2; ++s) {
+    p.q[s] = (const bf16*)a->q[s]; p.o[s] = (bf16*)a->o[s];
+    p.k[s] = (const bf16*)a->k[s]; p.v[s] = (const bf16*)a->v[s];
+    p.qlen[s] = a->q_len[s]; p.klen[s] = a->k_len[s];
+    if (p.qlen[s] && (!p.q[s] || !p.o[s])) return LAP_ERR_ARG;
+    if (p.klen[s] && (!p.k[s] || !p.v[s])) return LAP_ERR_ARG;
+  }
+  if ((a->qinfo == nullptr) != (a->kinfo == nullptr)) return LAP_ERR_ARG;
+  p.qinfo = a->qinfo; p.kinfo = a->kinfo; p.lse = a->lse;
+  p.B = a->B; p.NH = a->NH; p.NKV = a->NKV;
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->HD) {
+    case 16: return launch_fwd<16>(p, s);
+    case 72: return launch_fwd<72>(p, s);
+    case 256: return launch_fwd<256>(p, s);
+  }
+  return LAP_ERR_ARG;
+}
+
+extern "C" int lap_attention_bwd(const lap_attn_bwd_args* a, void* stream) {
+  if (!a || !check_common(a->B, a->NH, a->NKV, a->HD, a->q_len, a->k_len)) return LAP_ERR_ARG;
+  if (!a->lse || !a->delta) return LAP_ERR_ARG;
+  AttnP p = {};
+  for (int s = 0; s < 2; ++s) {
+    p.q[s] = (const bf16*)a->q[s]; p.o[s] = (bf16*)a->o[s]; p.d_o[s] = (const bf16*)a->d_o[s];
+    p.k[s] = (const bf16*)a->k[s]; p.v[s] = (const bf16*)a->v[s];
+    p.dq[s] = (bf16*)a->dq[s]; p.dk[s] = (bf16*)a->dk[s]; p.dv[s] = (bf16*)a->dv[s];
+    p.qlen[s] = a->q_len[s]; p.klen[s] = a->k_len[s];
+    if (p.qlen[s] && (!p.q[s] || !p.o[s] || !p.d_o[s] || !p.dq[s])) return LAP_ERR_ARG;
+    if (p.klen[s] && (!p.k[s] || !p.v[s] || !p.dk[s] || !p.dv[s])) return LAP_ERR_ARG;
+  }
+  if ((a->qinfo == nullptr) != (a->kinfo == nullptr)) return LAP_ERR_ARG;
+  p.qinfo = a->qinfo; p.kinfo = a->kinfo; p.lse = (float*)a->lse; p.delta = a->delta;
+  p.B = a->B; p.NH = a->NH; p.NKV = a->NKV; p.stop = a->stop_q1_to_k0;
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->HD) {
+    case 16: return launch_bwd<16>(p, s);
+    case 72: return launch_bwd<72>(p, s);
+    case 256: return launch_bwd<256>(p, s);
+  }
+  return LAP_ERR_ARG;
+}

@@ -1,0 +1,133 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of lap_amd.
+//
+// Conventions used by every kernel in this directory:
+//   * wave = 64 lanes; blocks are multiples of 64 threads.
+//   * bf16 storage is raw `__bf16`; all arithmetic is fp32 and rounds to bf16
+//     with round-to-nearest-even exactly once where the reference casts.
+//   * MFMA = v_mfma_f32_16x16x32_bf16.  A dot product is order independent, so
+//     any assignment of the 32 k indices of a k-step to (lane group, element)
+//     slots is valid as long as both operands use the same one.  The GEMM uses
+//     the natural one (group g holds k = 8g..8g+7); the attention kernels use
+//     {4g..4g+3} u {16+4g..16+4g+3}, which makes the C/D layout of S^T = K.Q^T
+//     directly reusable as the P operand of P.V (no LDS round trip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+
+#define LAP_OK 0
+#define LAP_ERR_ARG 1001   // bad argument (shape / alignment / unsupported combination)
+
+#define LAP_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t _e = hipGetLastError();                       \
+    if (_e != hipSuccess) return (int)_e;                    \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }  // RNE
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  // jax.nn.gelu(approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  float t = tanhf(u);
+  float du = k0 * (1.0f + 3.0f * k1 * x * x);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blocks of NW waves; `red` is an LDS array of >= NW floats.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ---- LDS fragment reads (GEMM family: contiguous k assignment) ---------------
+// MFMA 16x16x32 operand: lane (i = lane & 15, g = lane >> 4) holds k = 8g .. 8g+7
+// of the 32-deep k-step for operand row i.
+//
+// K-contiguous tile: 128 bytes per row (64 bf16 of k), row = m or n index.
+// 16-byte chunks of a row are XOR-swizzled with ((row >> 1) & 7): every 16-lane
+// service group of ds_read_b128 then covers all 64 banks exactly once.
+__device__ __forceinline__ unsigned kc_tile_off(int row, int chunk16) {
+  return (unsigned)(row * 128 + ((chunk16 ^ ((row >> 1) & 7)) << 4));
+}
+// Fragment for rows [row0, row0+16) and k-step kk (0/1) of a 64-deep tile.
+__device__ __forceinline__ bf16x8 kc_frag(const char* tile, int row0, int kk, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  return *reinterpret_cast<const bf16x8*>(tile + kc_tile_off(row0 + i, kk * 4 + g));
+}
+
+// M-contiguous tile: row = k index (64 rows), MW bf16 of m per row (MW*2 bytes).
+// 32-byte blocks of a row are XOR-swizzled with mc_swz(k) so that the 8 k-rows
+// {8g'+r, r<4, g' in {0,1}} read together by ds_read_b64_tr_b16 are conflict free.
+__device__ __forceinline__ int mc_swz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+template <int MW>
+__device__ __forceinline__ unsigned mc_tile_off(int krow, int chunk16) {
+  return (unsigned)(krow * (MW * 2) + ((chunk16 ^ (mc_swz(krow) << 1)) << 4));
+}
+__device__ __forceinline__ bf16x4 ds_read_tr(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(p));
+}
+// Fragment for m columns [m0, m0+16) and k-step kk of a 64-deep tile.  A
+// 16-lane group reads a [4 k][16 m] block (lane i supplies row i/4, 8 bytes at
+// column 4*(i%4)) and receives column i, 4 consecutive k.
+template <int MW>
+__device__ __forceinline__ bf16x8 mc_frag(const char* tile, int m0, int kk, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int kr = kk * 32 + 8 * g + (i >> 2);
+  const int mcol = m0 + (i & 3) * 4;
+  const int c16 = mcol >> 3, half = (mcol >> 2) & 1;
+  bf16x4 lo = ds_read_tr(tile + mc_tile_off<MW>(kr, c16) + (half << 3));
+  bf16x4 hi = ds_read_tr(tile + mc_tile_off<MW>(kr + 4, c16) + (half << 3));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// XCD-aware block id remap (bijective for any grid size): consecutive logical
+// ids land on the same XCD (blocks are dispatched round-robin over 8 XCDs), so
+// neighbouring tiles share operand panels in one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

@@ -1,0 +1,588 @@
+// HBM-bound elementwise / gather kernels of the LAP hot path.  Every kernel uses
+// 16-byte (8 x bf16 or 4 x f32) accesses and a flat grid; citations name the
+// reference lines each one restates.
+#include "common.hpp"
+#include "../../include/lap_hip.h"
+
+namespace {
+
+__device__ __forceinline__ void ld8(const bf16* p, float (&v)[8]) {
+  bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+}
+__device__ __forceinline__ void st8(bf16* p, const float (&v)[8]) {
+  bf16x8 t;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t[e] = f2bf(v[e]);
+  *reinterpret_cast<bf16x8*>(p) = t;
+}
+
+inline dim3 flat_grid(long long n, int per_block = 256) { return dim3((unsigned)((n + per_block - 1) / per_block)); }
+
+// ------------------------------------------------------------------------ RoPE
+// gemma.py:548-564: radians = pos / 10000^(2i/HD); [x1 c - x2 s, x2 c + x1 s] in f32 -> bf16;
+// gemma.py:216: q *= HD^-0.5 as a bf16 multiply.
+template <bool BWD>
+__global__ __launch_bounds__(256) void rope_split_kernel(const bf16* __restrict__ a0, const bf16* __restrict__ a1,
+                                                         const bf16* __restrict__ a2, const int32_t* __restrict__ pos,
+                                                         bf16* __restrict__ o0, bf16* __restrict__ o1,
+                                                         bf16* __restrict__ o2, int rows, int T_seg, int T_total,
+                                                         int seg_off, int NH, int HD, float q_scale) {
+  // FWD: a0 = qkv, outputs o0 = q, o1 = k, o2 = v.   BWD: a0 = dq, a1 = dk, a2 = dv, output o0 = dqkv.
+  const int cph = HD / 16;               // 8-wide frequency chunks per head
+  const int tpr = (NH + 2) * cph;        // threads per row
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * tpr) return;
+  const int row = (int)(gid / tpr);
+  const int rem = (int)(gid % tpr);
+  const int h = rem / cph, c = rem % cph;
+  const int b = row / T_seg, t = row % T_seg;
+  const int W = (NH + 2) * HD;
+  const int half = HD / 2;
+
+  float x1[8], x2[8];
+  const bf16* src;
+  if (!BWD) src = a0 + (long long)row * W + h * HD;
+  else if (h < NH) src = a0 + (long long)row * NH * HD + h * HD;
+  else if (h == NH) src = a1 + (long long)row * HD;
+  else src = a2 + (long long)row * HD;
+  ld8(src + c * 8, x1);
+  ld8(src + half + c * 8, x2);
+
+  float y1[8], y2[8];
+  if (h <= NH) {
+    const float p = (float)pos[(long long)b * T_total + seg_off + t];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = c * 8 + e;
+      const float fe = (2.0f / (float)HD) * (float)i;
+      const float ts = powf(10000.0f, fe);
+      const float rad = p / ts;
+      float sn, cs;
+      sincosf(rad, &sn, &cs);
+      if (!BWD) {
+        float r1 = bf2f(f2bf(x1[e] * cs - x2[e] * sn));
+        float r2 = bf2f(f2bf(x2[e] * cs + x1[e] * sn));
+        if (h < NH) { r1 *= q_scale; r2 *= q_scale; }
+        y1[e] = r1; y2[e] = r2;
+      } else {
+        float d1 = x1[e], d2 = x2[e];
+        if (h < NH) { d1 *= q_scale; d2 *= q_scale; }
+        y1[e] = d1 * cs + d2 * sn;
+        y2[e] = d2 * cs - d1 * sn;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { y1[e] = x1[e]; y2[e] = x2[e]; }
+  }
+  bf16* dst;
+  if (BWD) dst = o0 + (long long)row * W + h * HD;
+  else if (h < NH) dst = o0 + (long long)row * NH * HD + h * HD;
+  else if (h == NH) dst = o1 + (long long)row * HD;
+  else dst = o2 + (long long)row * HD;
+  st8(dst + c * 8, y1);
+  st8(dst + half + c * 8, y2);
+}
+
+// ----------------------------------------------------------------------- GeGLU
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16* __restrict__ gu, bf16* __restrict__ act,
+                                                        long long nchunk, int H8) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= nchunk) return;
+  const long long row = gid / H8;
+  const int c = (int)(gid % H8) * 8;
+  const long long H = (long long)H8 * 8;
+  float g[8], u[8], o[8];
+  ld8(gu + row * 2 * H + c, g);
+  ld8(gu + row * 2 * H + H + c, u);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(gelu_tanh_f(g[e]))) * u[e];  // gelu output is a bf16 tensor upstream
+  st8(act + row * H + c, o);
+}
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16* __restrict__ gu, const bf16* __restrict__ dact,
+                                                        bf16* __restrict__ dgu, long long nchunk, int H8) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= nchunk) return;
+  const long long row = gid / H8;
+  const int c = (int)(gid % H8) * 8;
+  const long long H = (long long)H8 * 8;
+  float g[8], u[8], d[8], dg[8], du[8];
+  ld8(gu + row * 2 * H + c, g);
+  ld8(gu + row * 2 * H + H + c, u);
+  ld8(dact + row * H + c, d);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    dg[e] = d[e] * u[e] * gelu_tanh_grad_f(g[e]);
+    du[e] = d[e] * bf2f(f2bf(gelu_tanh_f(g[e])));
+  }
+  st8(dgu + row * 2 * H + c, dg);
+  st8(dgu + row * 2 * H + H + c, du);
+}
+
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long long n8) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= n8) return;
+  float v[8];
+  ld8(x + gid * 8, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+  st8(y + gid * 8, v);
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                       bf16* __restrict__ dx, long long n8) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= n8) return;
+  float v[8], d[8];
+  ld8(x + gid * 8, v);
+  ld8(dy + gid * 8, d);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) d[e] *= gelu_tanh_grad_f(v[e]);
+  st8(dx + gid * 8, d);
+}
+
+// ------------------------------------------------------------------- embedding
+__global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ table, const int32_t* __restrict__ tok,
+                                                           bf16* __restrict__ out, int rows, int T, int D8,
+                                                           int dst_rps, int dst_off, float scale) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * D8) return;
+  const int r = (int)(gid / D8), c = (int)(gid % D8) * 8;
+  const long long D = (long long)D8 * 8;
+  const float* src = table + (long long)tok[r] * D + c;
+  f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+  float o[8] = {a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale,
+                b[0] * scale, b[1] * scale, b[2] * scale, b[3] * scale};
+  const long long drow = (long long)(r / T) * dst_rps + dst_off + r % T;
+  st8(out + drow * D + c, o);
+}
+__global__ __launch_bounds__(256) void embed_scatter_kernel(float* __restrict__ dtable, const int32_t* __restrict__ tok,
+                                                            const bf16* __restrict__ dout, int rows, int T, int D8,
+                                                            int src_rps, int src_off, float scale) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * D8) return;
+  const int r = (int)(gid / D8), c = (int)(gid % D8) * 8;
+  const long long D = (long long)D8 * 8;
+  const long long srow = (long long)(r / T) * src_rps + src_off + r % T;
+  float d[8];
+  ld8(dout + srow * D + c, d);
+  float* dst = dtable + (long long)tok[r] * D + c;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) atomicAdd(dst + e, d[e] * scale);
+}
+
+// -------------------------------------------------------------- gated residual
+__global__ __launch_bounds__(256) void gated_res_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ u,
+                                                            const bf16* __restrict__ gate, bf16* __restrict__ y,
+                                                            int rows, int D8, int rps, int ldg) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * D8) return;
+  const int r = (int)(gid / D8), c = (int)(gid % D8) * 8;
+  const long long D = (long long)D8 * 8;
+  float xv[8], uv[8], o[8];
+  ld8(x + r * D + c, xv);
+  ld8(u + r * D + c, uv);
+  if (gate) {
+    float gv[8];
+    ld8(gate + (long long)(r / rps) * ldg + c, gv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = xv[e] + bf2f(f2bf(uv[e] * gv[e]));  // y*gate is a bf16 product upstream
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = xv[e] + uv[e];
+  }
+  st8(y + r * D + c, o);
+}
+// One block per (sample, 8-column chunk group): du = dy*gate ; dgate[b] = sum_rows dy*u.
+__global__ __launch_bounds__(256) void gated_res_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ u,
+                                                            const bf16* __restrict__ gate, bf16* __restrict__ du,
+                                                            float* __restrict__ dgate, int D8, int rps, int ldg,
+                                                            int ldg_out) {
+  const int b = blockIdx.y;
+  const int c8 = blockIdx.x * 256 + threadIdx.x;
+  if (c8 >= D8) return;
+  const int c = c8 * 8;
+  const long long D = (long long)D8 * 8;
+  float gv[8], acc[8];
+  ld8(gate + (long long)b * ldg + c, gv);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int t = 0; t < rps; ++t) {
+    const long long r = (long long)b * rps + t;
+    float d[8], uv[8], o[8];
+    ld8(dy + r * D + c, d);
+    ld8(u + r * D + c, uv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] = d[e] * gv[e]; acc[e] += d[e] * uv[e]; }
+    st8(du + r * D + c, o);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dgate[(long long)b * ldg_out + c + e] = acc[e];
+}
+
+// ----------------------------------------------------------------- casts/copies
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(x + i), b = *reinterpret_cast<const f32x4*>(x + i + 4);
+    float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    st8(y + i, o);
+  } else {
+    for (long long j = i; j < n; ++j) y[j] = f2bf(x[j]);
+  }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    float v[8];
+    ld8(x + i, v);
+    *reinterpret_cast<f32x4*>(y + i) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(y + i + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  } else {
+    for (long long j = i; j < n; ++j) y[j] = bf2f(x[j]);
+  }
+}
+__global__ __launch_bounds__(256) void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
+                                                       bf16* __restrict__ y, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    float u[8], v[8];
+    ld8(a + i, u); ld8(b + i, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u[e] += v[e];
+    st8(y + i, u);
+  } else {
+    for (long long j = i; j < n; ++j) y[j] = f2bf(bf2f(a[j]) + bf2f(b[j]));
+  }
+}
+__global__ __launch_bounds__(256) void copy2d_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int rows,
+                                                     int cols8, int lds_, int ldd) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * cols8) return;
+  const int r = (int)(gid / cols8), c = (int)(gid % cols8) * 8;
+  *reinterpret_cast<bf16x8*>(dst + (long long)r * ldd + c) = *reinterpret_cast<const bf16x8*>(src + (long long)r * lds_ + c);
+}
+__global__ __launch_bounds__(256) void copy_rows_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int rows,
+                                                        int T, int D8, int src_rps, int src_off, int dst_rps,
+                                                        int dst_off, int accumulate) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * D8) return;
+  const int r = (int)(gid / D8), c = (int)(gid % D8) * 8;
+  const long long D = (long long)D8 * 8;
+  const long long srow = (long long)(r / T) * src_rps + src_off + r % T;
+  const long long drow = (long long)(r / T) * dst_rps + dst_off + r % T;
+  if (accumulate) {
+    float a[8], b[8];
+    ld8(src + srow * D + c, a);
+    ld8(dst + drow * D + c, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += b[e];
+    st8(dst + drow * D + c, a);
+  } else {
+    *reinterpret_cast<bf16x8*>(dst + drow * D + c) = *reinterpret_cast<const bf16x8*>(src + srow * D + c);
+  }
+}
+
+// ------------------------------------------------------------------ SigLIP stem
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int H,
+                                                     int W, int C, int P) {
+  const int GH = H / P, GW = W / P;
+  const int PC = P * C;            // one patch row: contiguous in the NHWC image
+  const long long total = (long long)B * GH * GW * P * PC;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int x = (int)(gid % PC);
+  long long t = gid / PC;
+  const int ph = (int)(t % P); t /= P;
+  const int gw = (int)(t % GW); t /= GW;
+  const int gh = (int)(t % GH);
+  const int b = (int)(t / GH);
+  out[gid] = img[(((long long)b * H + gh * P + ph) * W + gw * P) * C + x];
+}
+__global__ __launch_bounds__(256) void add_posemb_cast_kernel(const float* __restrict__ x, const float* __restrict__ pos,
+                                                              bf16* __restrict__ y, int rows, int T, int D8) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * D8) return;
+  const int r = (int)(gid / D8), c = (int)(gid % D8) * 8;
+  const long long D = (long long)D8 * 8;
+  const float* xs = x + r * D + c;
+  const float* ps = pos + (long long)(r % T) * D + c;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = xs[e] + ps[e];
+  st8(y + r * D + c, o);
+}
+// grid (D8 chunks / 256, T): thread owns one (t, 8 columns), loops over the batch.
+__global__ __launch_bounds__(256) void add_posemb_cast_bwd_kernel(const bf16* __restrict__ dy, float* __restrict__ dx,
+                                                                  float* __restrict__ dpos, int nb, int T, int D8) {
+  const int t = blockIdx.y;
+  const int c8 = blockIdx.x * 256 + threadIdx.x;
+  if (c8 >= D8) return;
+  const int c = c8 * 8;
+  const long long D = (long long)D8 * 8;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int b = 0; b < nb; ++b) {
+    const long long r = (long long)b * T + t;
+    float d[8];
+    ld8(dy + r * D + c, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { acc[e] += d[e]; dx[r * D + c + e] = d[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dpos[(long long)t * D + c + e] += acc[e];
+}
+
+// ---------------------------------------------------------------- flow matching
+__global__ __launch_bounds__(256) void fm_mix_kernel(const float* __restrict__ noise, const float* __restrict__ act,
+                                                     const float* __restrict__ t, float* __restrict__ x_t,
+                                                     float* __restrict__ u_t, int B, int n_per) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)B * n_per) return;
+  const float tt = t[gid / n_per];
+  const float e = noise[gid], a = act[gid];
+  x_t[gid] = tt * e + (1.0f - tt) * a;
+  u_t[gid] = e - a;
+}
+// openpi pi0.posemb_sincos [UPSTREAM-RECALL]: fraction = linspace(0,1,D/2); period = min*(max/min)^fraction;
+// out = concat[sin(t * 2pi / period), cos(...)].
+__global__ __launch_bounds__(256) void posemb_sincos_kernel(const float* __restrict__ t, float* __restrict__ out, int B,
+                                                            int D, float min_p, float max_p) {
+  const int half = D / 2;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)B * half) return;
+  const int b = (int)(gid / half), i = (int)(gid % half);
+  const float frac = (half > 1) ? (float)i / (float)(half - 1) : 0.f;
+  const float period = min_p * powf(max_p / min_p, frac);
+  const float ang = t[b] * (6.283185307179586f / period);
+  float sn, cs;
+  sincosf(ang, &sn, &cs);
+  out[(long long)b * D + i] = sn;
+  out[(long long)b * D + half + i] = cs;
+}
+__global__ __launch_bounds__(256) void swish_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  y[i] = v / (1.0f + expf(-v));
+}
+__global__ __launch_bounds__(256) void swish_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        float* __restrict__ dx, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  const float s = 1.0f / (1.0f + expf(-v));
+  dx[i] = dy[i] * (s + v * s * (1.0f - s));
+}
+// one block per sample
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ v, const float* __restrict__ u,
+                                                  const float* __restrict__ coef, float* __restrict__ per_sample,
+                                                  float* __restrict__ dv, int n_per) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float cf = coef ? coef[b] : 0.f;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n_per; i += 256) {
+    const float d = v[(long long)b * n_per + i] - u[(long long)b * n_per + i];
+    acc += d * d;
+    if (dv) dv[(long long)b * n_per + i] = cf * 2.0f * d / (float)n_per;
+  }
+  acc = block_sum<4>(acc, red);
+  if (threadIdx.x == 0) per_sample[b] = acc / (float)n_per;
+}
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ x, const float* __restrict__ v, float dt, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] += dt * v[i];
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+
+extern "C" int lap_abi_version(void) { return LAP_ABI_VERSION; }
+
+extern "C" int lap_rope_split_fwd(const void* qkv, const int32_t* pos, void* q, void* k, void* v, int B, int T_seg,
+                                  int T_total, int seg_off, int NH, int HD, float q_scale, void* stream) {
+  if (B <= 0 || T_seg <= 0 || (HD & 15) || NH <= 0) return LAP_ERR_ARG;
+  const long long n = (long long)B * T_seg * (NH + 2) * (HD / 16);
+  hipLaunchKernelGGL(rope_split_kernel<false>, flat_grid(n), dim3(256), 0, S_, (const bf16*)qkv, nullptr, nullptr, pos,
+                     (bf16*)q, (bf16*)k, (bf16*)v, B * T_seg, T_seg, T_total, seg_off, NH, HD, q_scale);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_rope_split_bwd(const void* dq, const void* dk, const void* dv, const int32_t* pos, void* dqkv, int B,
+                                  int T_seg, int T_total, int seg_off, int NH, int HD, float q_scale, void* stream) {
+  if (B <= 0 || T_seg <= 0 || (HD & 15) || NH <= 0) return LAP_ERR_ARG;
+  const long long n = (long long)B * T_seg * (NH + 2) * (HD / 16);
+  hipLaunchKernelGGL(rope_split_kernel<true>, flat_grid(n), dim3(256), 0, S_, (const bf16*)dq, (const bf16*)dk,
+                     (const bf16*)dv, pos, (bf16*)dqkv, nullptr, nullptr, B * T_seg, T_seg, T_total, seg_off, NH, HD,
+                     q_scale);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_geglu_fwd(const void* gu, void* act, int rows, int H, void* stream) {
+  if (rows <= 0 || H <= 0 || (H & 7)) return LAP_ERR_ARG;
+  const long long n = (long long)rows * (H / 8);
+  hipLaunchKernelGGL(geglu_fwd_kernel, flat_grid(n), dim3(256), 0, S_, (const bf16*)gu, (bf16*)act, n, H / 8);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_geglu_bwd(const void* gu, const void* dact, void* dgu, int rows, int H, void* stream) {
+  if (rows <= 0 || H <= 0 || (H & 7)) return LAP_ERR_ARG;
+  const long long n = (long long)rows * (H / 8);
+  hipLaunchKernelGGL(geglu_bwd_kernel, flat_grid(n), dim3(256), 0, S_, (const bf16*)gu, (const bf16*)dact, (bf16*)dgu, n,
+                     H / 8);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_gelu_fwd(const void* x, void* y, long long n, void* stream) {
+  if (n <= 0 || (n & 7)) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(gelu_fwd_kernel, flat_grid(n / 8), dim3(256), 0, S_, (const bf16*)x, (bf16*)y, n / 8);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_gelu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream) {
+  if (n <= 0 || (n & 7)) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(gelu_bwd_kernel, flat_grid(n / 8), dim3(256), 0, S_, (const bf16*)x, (const bf16*)dy, (bf16*)dx,
+                     n / 8);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_embed_gather(const float* table, const int32_t* tok, void* out, int rows, int T, int D,
+                                int dst_rows_per_sample, int dst_off, float scale, void* stream) {
+  if (rows <= 0 || T <= 0 || (D & 7)) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(embed_gather_kernel, flat_grid((long long)rows * (D / 8)), dim3(256), 0, S_, table, tok, (bf16*)out,
+                     rows, T, D / 8, dst_rows_per_sample, dst_off, scale);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_embed_scatter_add(float* dtable, const int32_t* tok, const void* dout, int rows, int T, int D,
+                                     int src_rows_per_sample, int src_off, float scale, void* stream) {
+  if (rows <= 0 || T <= 0 || (D & 7)) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(embed_scatter_kernel, flat_grid((long long)rows * (D / 8)), dim3(256), 0, S_, dtable, tok,
+                     (const bf16*)dout, rows, T, D / 8, src_rows_per_sample, src_off, scale);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_gated_residual_fwd(const void* x, const void* u, const void* gate, void* y, int rows, int D,
+                                      int rows_per_sample, int ldg, void* stream) {
+  if (rows <= 0 || (D & 7) || (gate && (rows_per_sample <= 0 || (ldg & 7)))) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(gated_res_fwd_kernel, flat_grid((long long)rows * (D / 8)), dim3(256), 0, S_, (const bf16*)x,
+                     (const bf16*)u, (const bf16*)gate, (bf16*)y, rows, D / 8, rows_per_sample > 0 ? rows_per_sample : 1,
+                     ldg);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_gated_residual_bwd(const void* dy, const void* u, const void* gate, void* du, float* dgate, int rows,
+                                      int D, int rows_per_sample, int ldg, int ldg_out, void* stream) {
+  if (rows <= 0 || (D & 7) || !gate || rows_per_sample <= 0 || rows % rows_per_sample || (ldg & 7)) return LAP_ERR_ARG;
+  dim3 grid((D / 8 + 255) / 256, rows / rows_per_sample);
+  hipLaunchKernelGGL(gated_res_bwd_kernel, grid, dim3(256), 0, S_, (const bf16*)dy, (const bf16*)u, (const bf16*)gate,
+                     (bf16*)du, dgate, D / 8, rows_per_sample, ldg, ldg_out);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream) {
+  if (n <= 0) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, flat_grid((n + 7) / 8), dim3(256), 0, S_, x, (bf16*)y, n);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_cast_bf16_to_f32(const void* x, float* y, long long n, void* stream) {
+  if (n <= 0) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, flat_grid((n + 7) / 8), dim3(256), 0, S_, (const bf16*)x, y, n);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_add_bf16(const void* a, const void* b, void* y, long long n, void* stream) {
+  if (n <= 0) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(add_bf16_kernel, flat_grid((n + 7) / 8), dim3(256), 0, S_, (const bf16*)a, (const bf16*)b, (bf16*)y,
+                     n);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_copy2d_bf16(const void* src, void* dst, int rows, int cols, int lds, int ldd, void* stream) {
+  if (rows <= 0 || cols <= 0 || (cols & 7) || (lds & 7) || (ldd & 7)) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(copy2d_kernel, flat_grid((long long)rows * (cols / 8)), dim3(256), 0, S_, (const bf16*)src,
+                     (bf16*)dst, rows, cols / 8, lds, ldd);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_copy_rows_bf16(const void* src, void* dst, int rows, int T, int D, int src_rps, int src_off,
+                                  int dst_rps, int dst_off, int accumulate, void* stream) {
+  if (rows <= 0 || T <= 0 || (D & 7)) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(copy_rows_kernel, flat_grid((long long)rows * (D / 8)), dim3(256), 0, S_, (const bf16*)src,
+                     (bf16*)dst, rows, T, D / 8, src_rps, src_off, dst_rps, dst_off, accumulate);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_im2col_patch(const float* img, float* out, int B, int H, int W, int C, int P, void* stream) {
+  if (B <= 0 || P <= 0 || H % P || W % P) return LAP_ERR_ARG;
+  const long long n = (long long)B * H * W * C;
+  hipLaunchKernelGGL(im2col_kernel, flat_grid(n), dim3(256), 0, S_, img, out, B, H, W, C, P);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_add_posemb_cast(const float* x, const float* pos, void* y, int rows, int T, int D, void* stream) {
+  if (rows <= 0 || T <= 0 || (D & 7)) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(add_posemb_cast_kernel, flat_grid((long long)rows * (D / 8)), dim3(256), 0, S_, x, pos, (bf16*)y,
+                     rows, T, D / 8);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_add_posemb_cast_bwd(const void* dy, float* dx, float* dpos, int rows, int T, int D, void* stream) {
+  if (rows <= 0 || T <= 0 || rows % T || (D & 7)) return LAP_ERR_ARG;
+  dim3 grid((D / 8 + 255) / 256, T);
+  hipLaunchKernelGGL(add_posemb_cast_bwd_kernel, grid, dim3(256), 0, S_, (const bf16*)dy, dx, dpos, rows / T, T, D / 8);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_fm_mix(const float* noise, const float* actions, const float* t, float* x_t, float* u_t, int B,
+                          int n_per, void* stream) {
+  if (B <= 0 || n_per <= 0) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(fm_mix_kernel, flat_grid((long long)B * n_per), dim3(256), 0, S_, noise, actions, t, x_t, u_t, B,
+                     n_per);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_posemb_sincos(const float* t, float* out, int B, int D, float min_period, float max_period,
+                                 void* stream) {
+  if (B <= 0 || D <= 0 || (D & 1)) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(posemb_sincos_kernel, flat_grid((long long)B * (D / 2)), dim3(256), 0, S_, t, out, B, D, min_period,
+                     max_period);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_swish_fwd(const float* x, float* y, long long n, void* stream) {
+  if (n <= 0) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(swish_fwd_kernel, flat_grid(n), dim3(256), 0, S_, x, y, n);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_swish_bwd(const float* x, const float* dy, float* dx, long long n, void* stream) {
+  if (n <= 0) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(swish_bwd_kernel, flat_grid(n), dim3(256), 0, S_, x, dy, dx, n);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_mse_fwd_bwd(const float* v, const float* u, const float* coef, float* per_sample, float* dv, int B,
+                               int n_per, void* stream) {
+  if (B <= 0 || n_per <= 0) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(mse_kernel, dim3(B), dim3(256), 0, S_, v, u, coef, per_sample, dv, n_per);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_axpy_f32(float* x, const float* v, float dt, long long n, void* stream) {
+  if (n <= 0) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(axpy_kernel, flat_grid(n), dim3(256), 0, S_, x, v, dt, n);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}

@@ -1,0 +1,252 @@
+// Cross-entropy over the 257,152-entry vocabulary without one-hot targets
+// (lap.py:221-260 materialises them), the fused clip + AdamW + EMA + bf16
+// refresh step (scripts/train.py:363-396 with optax.chain(clip_by_global_norm,
+// adamw)), and the global-norm reduction (optax.global_norm).  All HBM-bound.
+#include "common.hpp"
+#include "../../include/lap_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------- CE forward
+// One block per row.  Online (max, sum-exp) over this vocab chunk merged into the
+// running state, plus the target logit if the target falls inside the chunk.
+__global__ __launch_bounds__(256) void ce_update_kernel(const float* __restrict__ logits, int ldl,
+                                                        const int32_t* __restrict__ target, float* __restrict__ m,
+                                                        float* __restrict__ l, float* __restrict__ tl, int v0, int vc) {
+  __shared__ float red_m[4], red_l[4];
+  const int r = blockIdx.x;
+  const float* x = logits + (long long)r * ldl;
+  float mm = -3.0e38f, ll = 0.f;
+  for (int v = threadIdx.x * 4; v < vc; v += 1024) {
+    float vals[4];
+    int n = min(4, vc - v);
+    if (n == 4 && ((((uintptr_t)(x + v)) & 15) == 0)) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(x + v);
+      vals[0] = t[0]; vals[1] = t[1]; vals[2] = t[2]; vals[3] = t[3];
+    } else {
+      for (int e = 0; e < n; ++e) vals[e] = x[v + e];
+    }
+    for (int e = 0; e < n; ++e) {
+      const float xv = vals[e];
+      if (xv > mm) { ll = ll * __expf(mm - xv) + 1.0f; mm = xv; }
+      else ll += __expf(xv - mm);
+    }
+  }
+  // wave combine
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mm, o, 64), ol = __shfl_xor(ll, o, 64);
+    const float nm = fmaxf(mm, om);
+    ll = ll * __expf(mm - nm) + ol * __expf(om - nm);
+    mm = nm;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red_m[w] = mm; red_l[w] = ll; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float gm = m[r], gl = l[r];
+    for (int i = 0; i < 4; ++i) {
+      const float nm = fmaxf(gm, red_m[i]);
+      gl = gl * __expf(gm - nm) + red_l[i] * __expf(red_m[i] - nm);
+      gm = nm;
+    }
+    m[r] = gm; l[r] = gl;
+    const int t = target[r];
+    if (t >= v0 && t < v0 + vc) tl[r] = x[t - v0];
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_grad_kernel(const float* __restrict__ logits, int ldl,
+                                                      const int32_t* __restrict__ target, const float* __restrict__ m,
+                                                      const float* __restrict__ l, const float* __restrict__ wgt,
+                                                      bf16* __restrict__ dlogits, int ldd, int v0, int vc) {
+  const int r = blockIdx.y;
+  const int v = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (v >= vc) return;
+  const float lse = m[r] + __logf(l[r]);
+  const float wr = wgt[r];
+  const int t = target[r] - v0;
+  const float* x = logits + (long long)r * ldl + v;
+  bf16* d = dlogits + (long long)r * ldd + v;
+  const int n = min(4, vc - v);
+  for (int e = 0; e < n; ++e) {
+    float p = (wr != 0.f) ? __expf(x[e] - lse) : 0.f;
+    if (v + e == t) p -= 1.0f;
+    d[e] = f2bf(wr * p);
+  }
+}
+
+// -------------------------------------------------------------------- optimizer
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(x + i);
+      acc += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+    } else {
+      for (long long j = i; j < n; ++j) acc += x[j] * x[j];
+    }
+  }
+  acc = block_sum<4>(acc, red);
+  if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+
+__global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                        float* __restrict__ ema, const float* __restrict__ g,
+                                                        bf16* __restrict__ p16, long long n,
+                                                        const float* __restrict__ sc, float b1, float b2, float eps,
+                                                        float wd, float max_norm) {
+  const float gnorm = sqrtf(sc[0]);
+  // optax.clip_by_global_norm: g if norm < max_norm else g / norm * max_norm
+  const float clip = (max_norm <= 0.f || gnorm < max_norm) ? 1.0f : max_norm / gnorm;
+  const float lr = sc[1], bc1 = sc[2], bc2 = sc[3], ed = sc[4];
+  const bool ema_on = ema != nullptr && sc[5] != 0.f;
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    const int cnt = (int)min((long long)4, n - i);
+    float pv[4], mv[4], vv[4], gv[4], ev[4];
+    if (cnt == 4) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(p + i), b = *reinterpret_cast<const f32x4*>(m + i),
+            c = *reinterpret_cast<const f32x4*>(v + i), d = *reinterpret_cast<const f32x4*>(g + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pv[e] = a[e]; mv[e] = b[e]; vv[e] = c[e]; gv[e] = d[e]; }
+      if (ema_on) { f32x4 q = *reinterpret_cast<const f32x4*>(ema + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ev[e] = q[e]; }
+    } else {
+      for (int e = 0; e < cnt; ++e) { pv[e] = p[i + e]; mv[e] = m[i + e]; vv[e] = v[i + e]; gv[e] = g[i + e]; if (ema_on) ev[e] = ema[i + e]; }
+    }
+    for (int e = 0; e < cnt; ++e) {
+      const float gg = gv[e] * clip;
+      mv[e] = b1 * mv[e] + (1.0f - b1) * gg;
+      vv[e] = b2 * vv[e] + (1.0f - b2) * gg * gg;
+      const float upd = (mv[e] / bc1) / (sqrtf(vv[e] / bc2) + eps) + wd * pv[e];
+      pv[e] = pv[e] - lr * upd;
+      if (ema_on) ev[e] = ed * ev[e] + (1.0f - ed) * pv[e];
+    }
+    if (cnt == 4) {
+      *reinterpret_cast<f32x4*>(p + i) = f32x4{pv[0], pv[1], pv[2], pv[3]};
+      *reinterpret_cast<f32x4*>(m + i) = f32x4{mv[0], mv[1], mv[2], mv[3]};
+      *reinterpret_cast<f32x4*>(v + i) = f32x4{vv[0], vv[1], vv[2], vv[3]};
+      if (ema_on) *reinterpret_cast<f32x4*>(ema + i) = f32x4{ev[0], ev[1], ev[2], ev[3]};
+      if (p16) { bf16x4 o; for (int e = 0; e < 4; ++e) o[e] = f2bf(pv[e]); *reinterpret_cast<bf16x4*>(p16 + i) = o; }
+    } else {
+      for (int e = 0; e < cnt; ++e) {
+        p[i + e] = pv[e]; m[i + e] = mv[e]; v[i + e] = vv[e];
+        if (ema_on) ema[i + e] = ev[e];
+        if (p16) p16[i + e] = f2bf(pv[e]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ f32 GEMM
+// 64x64 tile, BK = 16, 256 threads x (4x4) outputs, k-ordered fmaf chain (exact f32).
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                       float* __restrict__ C, const float* __restrict__ bias, int M,
+                                                       int N, int K, int lda, int ldb, int ldc, float alpha, int accum) {
+  __shared__ float As[16][68], Bs[16][68];
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int tx = tid & 15, ty = tid >> 4;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    // 64x16 elements per operand = 1024 -> 4 per thread
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j;
+      int mm, kk;
+      if (A_KC) { mm = idx >> 4; kk = idx & 15; } else { kk = idx >> 6; mm = idx & 63; }
+      float va = 0.f;
+      if (m0 + mm < M && k0 + kk < K)
+        va = A_KC ? A[(long long)(m0 + mm) * lda + k0 + kk] : A[(long long)(k0 + kk) * lda + m0 + mm];
+      As[kk][mm] = va;
+      int nn, kb;
+      if (B_KC) { nn = idx >> 4; kb = idx & 15; } else { kb = idx >> 6; nn = idx & 63; }
+      float vb = 0.f;
+      if (n0 + nn < N && k0 + kb < K)
+        vb = B_KC ? B[(long long)(n0 + nn) * ldb + k0 + kb] : B[(long long)(k0 + kb) * ldb + n0 + nn];
+      Bs[kb][nn] = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = As[kk][ty * 4 + e]; b[e] = Bs[kk][tx * 4 + e]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mrow = m0 + ty * 4 + i;
+    if (mrow >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ncol = n0 + tx * 4 + j;
+      if (ncol >= N) continue;
+      float vv = acc[i][j] * alpha;
+      if (bias) vv += bias[ncol];
+      float* c = C + (long long)mrow * ldc + ncol;
+      if (accum) vv += *c;
+      *c = vv;
+    }
+  }
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+
+extern "C" int lap_ce_chunk_update(const float* logits, int ldl, const int32_t* target, float* m, float* l, float* tl,
+                                   int rows, int v0, int vc, void* stream) {
+  if (rows <= 0 || vc <= 0) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(ce_update_kernel, dim3(rows), dim3(256), 0, S_, logits, ldl, target, m, l, tl, v0, vc);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_ce_chunk_grad(const float* logits, int ldl, const int32_t* target, const float* m, const float* l,
+                                 const float* w, void* dlogits, int ldd, int rows, int v0, int vc, void* stream) {
+  if (rows <= 0 || vc <= 0) return LAP_ERR_ARG;
+  dim3 grid((vc + 1023) / 1024, rows);
+  hipLaunchKernelGGL(ce_grad_kernel, grid, dim3(256), 0, S_, logits, ldl, target, m, l, w, (bf16*)dlogits, ldd, v0, vc);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_sumsq_f32(const float* x, long long n, float* sumsq, void* stream) {
+  if (n <= 0) return LAP_ERR_ARG;
+  const long long blocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, S_, x, n, sumsq);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_adamw_ema(float* p, float* m, float* v, float* ema, const float* g, void* p16, long long n,
+                             const float* scalars, float b1, float b2, float eps, float wd, float max_norm,
+                             void* stream) {
+  if (n <= 0 || !scalars) return LAP_ERR_ARG;
+  const long long blocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, S_, p, m, v, ema, g,
+                     (bf16*)p16, n, scalars, b1, b2, eps, wd, max_norm);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                            int ldb, int ldc, float alpha, int a_kc, int b_kc, int accum, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return LAP_ERR_ARG;
+  dim3 grid((N + 63) / 64, (M + 63) / 64);
+#define GO(AK, BK) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK>), grid, dim3(256), 0, S_, A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, accum)
+  if (a_kc && b_kc) GO(true, true);
+  else if (a_kc && !b_kc) GO(true, false);
+  else if (!a_kc && !b_kc) GO(false, false);
+  else GO(false, true);
+#undef GO
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}

@@ -1,0 +1,364 @@
+// RMSNorm / adaptive RMSNorm (gemma.py:113-131) and LayerNorm (Flax nn.LayerNorm as
+// used by SigLIP, siglip_gemma3.py:93,104,167), forward and backward.
+// HBM-bound row kernels: one wave per row, 16-byte (8 x bf16) accesses, f32
+// statistics.  Per-column parameter gradients are accumulated in registers over
+// a group of rows, combined across the 4 waves through LDS and added to HBM with
+// one f32 atomic per column per block.
+#include "common.hpp"
+#include "../../include/lap_hip.h"
+
+namespace {
+
+constexpr int NWAVE = 4;
+
+__device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {
+  bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+}
+__device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
+  bf16x8 t;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t[e] = f2bf(v[e]);
+  *reinterpret_cast<bf16x8*>(p) = t;
+}
+
+// ------------------------------------------------------------------ RMSNorm fwd
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ scale,
+                                                          const bf16* __restrict__ mod, bf16* __restrict__ y,
+                                                          float* __restrict__ rstd_out, int rows, int D,
+                                                          int rows_per_sample, float eps) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * NWAVE + w;
+  if (row >= rows) return;
+  const bf16* xr = x + (long long)row * D;
+  float xv[NCH][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int c = (lane + 64 * p) * 8;
+    if (c < D) {
+      load8(xr + c, xv[p]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += xv[p][e] * xv[p][e];
+    }
+  }
+  ss = wave_sum(ss);
+  const float r = 1.0f / sqrtf(ss / (float)D + eps);
+  if (rstd_out && lane == 0) rstd_out[row] = r;
+  const bf16* mrow = mod ? mod + (long long)(row / rows_per_sample) * 3 * D : nullptr;
+  bf16* yr = y + (long long)row * D;
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int c = (lane + 64 * p) * 8;
+    if (c < D) {
+      float o[8];
+      if (mrow) {
+        float sc[8], sh[8];
+        load8(mrow + c, sc);
+        load8(mrow + D + c, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = xv[p][e] * r * bf2f(f2bf(1.0f + sc[e])) + sh[e];  // (1 + scale) is a bf16 op in the reference
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = xv[p][e] * r * (1.0f + scale[c + e]);
+      }
+      store8(yr + c, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ RMSNorm bwd
+// Group g covers rows [g*G, (g+1)*G).  Adaptive: G == rows_per_sample.
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict__ x, const float* __restrict__ scale,
+                                                          const bf16* __restrict__ mod, const float* __restrict__ rstd,
+                                                          const bf16* __restrict__ dy, bf16* __restrict__ dx,
+                                                          float* __restrict__ dscale, float* __restrict__ dmod,
+                                                          int rows, int D, int G, int accum_dx) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [NWAVE][2*D] (adaptive) / [NWAVE][D]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = blockIdx.x;
+  const int r0 = g * G, r1 = min(rows, r0 + G);
+  const bool ada = mod != nullptr;
+  const bf16* mrow = ada ? mod + (long long)g * 3 * D : nullptr;
+
+  float wgt[NCH][8];
+  float ds[NCH][8], dh[NCH][8];
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int c = (lane + 64 * p) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ds[p][e] = 0.f; dh[p][e] = 0.f; wgt[p][e] = 0.f; }
+    if (c < D) {
+      if (ada) {
+        float sc[8];
+        load8(mrow + c, sc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wgt[p][e] = bf2f(f2bf(1.0f + sc[e]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wgt[p][e] = 1.0f + scale[c + e];
+      }
+    }
+  }
+  for (int row = r0 + w; row < r1; row += NWAVE) {
+    const bf16* xr = x + (long long)row * D;
+    const bf16* dyr = dy + (long long)row * D;
+    const float r = rstd[row];
+    float xv[NCH][8], gv[NCH][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int p = 0; p < NCH; ++p) {
+      const int c = (lane + 64 * p) * 8;
+      if (c < D) {
+        float dyv[8];
+        load8(xr + c, xv[p]);
+        load8(dyr + c, dyv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          gv[p][e] = dyv[e] * wgt[p][e];
+          dot += gv[p][e] * xv[p][e];
+          ds[p][e] += dyv[e] * xv[p][e] * r;
+          dh[p][e] += dyv[e];
+        }
+      }
+    }
+    dot = wave_sum(dot);
+    const float cc = dot * r * r * r / (float)D;
+    bf16* dxr = dx + (long long)row * D;
+#pragma unroll
+    for (int p = 0; p < NCH; ++p) {
+      const int c = (lane + 64 * p) * 8;
+      if (c < D) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = r * gv[p][e] - xv[p][e] * cc;
+        if (accum_dx) {
+          float old[8];
+          load8(dxr + c, old);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += old[e];
+        }
+        store8(dxr + c, o);
+      }
+    }
+  }
+  // combine the per-wave column partials
+  const int stride = ada ? 2 * D : D;
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int c = (lane + 64 * p) * 8;
+    if (c < D) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[w * stride + c + e] = ds[p][e];
+        if (ada) red[w * stride + D + c + e] = dh[p][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < stride; c += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWAVE; ++i) t += red[i * stride + c];
+    if (ada) {
+      // thirds: [0,D) scale, [D,2D) shift
+      atomicAdd(dmod + (long long)g * 3 * D + c, t);
+    } else {
+      atomicAdd(dscale + c, t);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm fwd
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * NWAVE + w;
+  if (row >= rows) return;
+  const bf16* xr = x + (long long)row * D;
+  float xv[NCH][8];
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int c = (lane + 64 * p) * 8;
+    if (c < D) {
+      load8(xr + c, xv[p]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s += xv[p][e]; ss += xv[p][e] * xv[p][e]; }
+    }
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  const float mean = s / (float)D;
+  // Flax default use_fast_variance=True: var = E[x^2] - E[x]^2, clamped at 0.
+  const float var = fmaxf(ss / (float)D - mean * mean, 0.f);
+  const float r = 1.0f / sqrtf(var + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = r;
+  }
+  bf16* yr = y + (long long)row * D;
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int c = (lane + 64 * p) * 8;
+    if (c < D) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (xv[p][e] - mean) * (r * gamma[c + e]) + beta[c + e];
+      store8(yr + c, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm bwd
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const bf16* __restrict__ dy, bf16* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int rows, int D, int G, int accum_dx) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [NWAVE][2*D]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * G, r1 = min(rows, r0 + G);
+  float gm[NCH][8], dg[NCH][8], db[NCH][8];
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int c = (lane + 64 * p) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[p][e] = 0.f; db[p][e] = 0.f; gm[p][e] = (c < D) ? gamma[c + e] : 0.f; }
+  }
+  for (int row = r0 + w; row < r1; row += NWAVE) {
+    const bf16* xr = x + (long long)row * D;
+    const bf16* dyr = dy + (long long)row * D;
+    const float mu = mean[row], r = rstd[row];
+    float xh[NCH][8], gv[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < NCH; ++p) {
+      const int c = (lane + 64 * p) * 8;
+      if (c < D) {
+        float xv[8], dyv[8];
+        load8(xr + c, xv);
+        load8(dyr + c, dyv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[p][e] = (xv[e] - mu) * r;
+          gv[p][e] = dyv[e] * gm[p][e];
+          s1 += gv[p][e];
+          s2 += gv[p][e] * xh[p][e];
+          dg[p][e] += dyv[e] * xh[p][e];
+          db[p][e] += dyv[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    bf16* dxr = dx + (long long)row * D;
+#pragma unroll
+    for (int p = 0; p < NCH; ++p) {
+      const int c = (lane + 64 * p) * 8;
+      if (c < D) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = r * (gv[p][e] - s1 - xh[p][e] * s2);
+        if (accum_dx) {
+          float old[8];
+          load8(dxr + c, old);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += old[e];
+        }
+        store8(dxr + c, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int c = (lane + 64 * p) * 8;
+    if (c < D) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[w * 2 * D + c + e] = dg[p][e];
+        red[w * 2 * D + D + c + e] = db[p][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWAVE; ++i) t += red[i * 2 * D + c];
+    if (c < D) atomicAdd(dgamma + c, t);
+    else atomicAdd(dbeta + (c - D), t);
+  }
+}
+
+inline int nch_for(int D) { return (D / 8 + 63) / 64; }
+
+}  // namespace
+
+#define DISPATCH_NCH(D, CALL)                          \
+  switch (nch_for(D)) {                                \
+    case 1: { constexpr int NCH = 1; CALL; } break;    \
+    case 2: { constexpr int NCH = 2; CALL; } break;    \
+    case 3: { constexpr int NCH = 3; CALL; } break;    \
+    case 4: { constexpr int NCH = 4; CALL; } break;    \
+    default: return LAP_ERR_ARG;                       \
+  }
+
+extern "C" int lap_rmsnorm_fwd(const void* x, const float* scale, const void* mod, void* y, float* rstd,
+                               int rows, int D, int rows_per_sample, float eps, void* stream) {
+  if (rows <= 0 || D <= 0 || (D & 7) || (!scale && !mod) || (mod && rows_per_sample <= 0)) return LAP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((rows + NWAVE - 1) / NWAVE);
+  DISPATCH_NCH(D, hipLaunchKernelGGL(rmsnorm_fwd_kernel<NCH>, grid, dim3(256), 0, s, (const bf16*)x, scale,
+                                     (const bf16*)mod, (bf16*)y, rstd, rows, D, rows_per_sample, eps));
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_rmsnorm_bwd(const void* x, const float* scale, const void* mod, const float* rstd, const void* dy,
+                               void* dx, float* dscale, float* dmod, int rows, int D, int rows_per_sample,
+                               int accum_dx, void* stream) {
+  if (rows <= 0 || D <= 0 || (D & 7) || !rstd) return LAP_ERR_ARG;
+  if (mod ? (!dmod || rows_per_sample <= 0 || rows % rows_per_sample) : (!scale || !dscale)) return LAP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int G = mod ? rows_per_sample : 64;
+  dim3 grid((rows + G - 1) / G);
+  const size_t shm = (size_t)NWAVE * (mod ? 2 : 1) * D * sizeof(float);
+  DISPATCH_NCH(D, hipLaunchKernelGGL(rmsnorm_bwd_kernel<NCH>, grid, dim3(256), shm, s, (const bf16*)x, scale,
+                                     (const bf16*)mod, rstd, (const bf16*)dy, (bf16*)dx, dscale, dmod, rows, D, G,
+                                     accum_dx));
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                 float* rstd, int rows, int D, float eps, void* stream) {
+  if (rows <= 0 || D <= 0 || (D & 7) || !gamma || !beta) return LAP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((rows + NWAVE - 1) / NWAVE);
+  DISPATCH_NCH(D, hipLaunchKernelGGL(layernorm_fwd_kernel<NCH>, grid, dim3(256), 0, s, (const bf16*)x, gamma, beta,
+                                     (bf16*)y, mean, rstd, rows, D, eps));
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_layernorm_bwd(const void* x, const float* gamma, const float* mean, const float* rstd,
+                                 const void* dy, void* dx, float* dgamma, float* dbeta, int rows, int D, int accum_dx,
+                                 void* stream) {
+  if (rows <= 0 || D <= 0 || (D & 7) || !gamma || !mean || !rstd || !dgamma || !dbeta) return LAP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int G = 64;
+  dim3 grid((rows + G - 1) / G);
+  const size_t shm = (size_t)NWAVE * 2 * D * sizeof(float);
+  DISPATCH_NCH(D, hipLaunchKernelGGL(layernorm_bwd_kernel<NCH>, grid, dim3(256), shm, s, (const bf16*)x, gamma, mean,
+                                     rstd, (const bf16*)dy, (bf16*)dx, dgamma, dbeta, rows, D, G, accum_dx));
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}

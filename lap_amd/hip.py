@@ -1,0 +1,444 @@
+"""ctypes binding of liblap_hip.so — the C ABI declared in include/lap_hip.h.
+
+This module is the only place where Python touches the kernels.  It takes torch tensors
+(device memory + the current HIP stream are PyTorch's job: plumbing), checks dtype /
+contiguity, and passes raw device pointers.  There is NO fallback: if the shared library
+is missing or a launch is rejected, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+
+import torch
+
+_LIB_PATH = pathlib.Path(__file__).resolve().parent / "liblap_hip.so"
+
+GEMM_OUT_F32 = 1
+GEMM_ACCUM = 2
+GEMM_GELU = 4
+GEMM_BIAS_F32 = 8
+
+
+class LapHipError(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not _LIB_PATH.exists():
+        raise ImportError(
+            f"{_LIB_PATH} not found: build it with `python -m lap_amd.build` (hipcc --offload-arch=gfx950). "
+            "lap_amd has no CPU / eager fallback."
+        )
+    return C.CDLL(str(_LIB_PATH))
+
+
+_lib = _load()
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+
+class AttnFwdArgs(C.Structure):
+    _fields_ = [
+        ("q", _vp * 2), ("o", _vp * 2), ("k", _vp * 2), ("v", _vp * 2),
+        ("q_len", _i * 2), ("k_len", _i * 2),
+        ("qinfo", _vp), ("kinfo", _vp), ("lse", _vp),
+        ("B", _i), ("NH", _i), ("NKV", _i), ("HD", _i),
+    ]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [
+        ("q", _vp * 2), ("o", _vp * 2), ("d_o", _vp * 2), ("k", _vp * 2), ("v", _vp * 2),
+        ("dq", _vp * 2), ("dk", _vp * 2), ("dv", _vp * 2),
+        ("q_len", _i * 2), ("k_len", _i * 2),
+        ("qinfo", _vp), ("kinfo", _vp), ("lse", _vp), ("delta", _vp),
+        ("B", _i), ("NH", _i), ("NKV", _i), ("HD", _i), ("stop_q1_to_k0", _i),
+    ]
+
+
+# name -> argtypes; every entry point of include/lap_hip.h must be listed here (tests check it).
+SIGNATURES: dict[str, list] = {
+    "lap_abi_version": [],
+    "lap_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
+    "lap_gemm_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
+    "lap_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "lap_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lap_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "lap_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "lap_rope_split_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "lap_rope_split_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "lap_geglu_fwd": [_vp, _vp, _i, _i, _vp],
+    "lap_geglu_bwd": [_vp, _vp, _vp, _i, _i, _vp],
+    "lap_gelu_fwd": [_vp, _vp, _ll, _vp],
+    "lap_gelu_bwd": [_vp, _vp, _vp, _ll, _vp],
+    "lap_embed_gather": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "lap_embed_scatter_add": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "lap_gated_residual_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lap_gated_residual_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "lap_cast_f32_to_bf16": [_vp, _vp, _ll, _vp],
+    "lap_cast_bf16_to_f32": [_vp, _vp, _ll, _vp],
+    "lap_add_bf16": [_vp, _vp, _vp, _ll, _vp],
+    "lap_copy2d_bf16": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "lap_copy_rows_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "lap_im2col_patch": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "lap_add_posemb_cast": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "lap_add_posemb_cast_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "lap_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],
+    "lap_attention_bwd": [C.POINTER(AttnBwdArgs), _vp],
+    "lap_ce_chunk_update": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "lap_ce_chunk_grad": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lap_sumsq_f32": [_vp, _ll, _vp, _vp],
+    "lap_adamw_ema": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _vp],
+    "lap_fm_mix": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "lap_posemb_sincos": [_vp, _vp, _i, _i, _f, _f, _vp],
+    "lap_swish_fwd": [_vp, _vp, _ll, _vp],
+    "lap_swish_bwd": [_vp, _vp, _vp, _ll, _vp],
+    "lap_mse_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "lap_axpy_f32": [_vp, _vp, _f, _ll, _vp],
+}
+
+_fn = {}
+for _name, _args in SIGNATURES.items():
+    _f_ = getattr(_lib, _name)  # AttributeError here = header / library mismatch: fail loudly
+    _f_.argtypes = _args
+    _f_.restype = C.c_int
+    _fn[_name] = _f_
+
+ABI_VERSION = _fn["lap_abi_version"]()
+LIB_PATH = str(_LIB_PATH)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(rc: int, name: str) -> None:
+    if rc != 0:
+        raise LapHipError(f"{name} failed with code {rc}" + (" (LAP_ERR_ARG: rejected arguments)" if rc == 1001 else ""))
+
+
+def call(name: str, *args) -> None:
+    """Raw call: args are python ints/floats/pointers; the current torch stream is appended."""
+    _chk(_fn[name](*args, _stream()), name)
+
+
+def _req(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
+    if t.dtype != dtype or not t.is_cuda:
+        raise TypeError(f"{name}: expected cuda {dtype}, got {t.device} {t.dtype}")
+
+
+# ------------------------------------------------------------------------------ GEMM
+def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, residual=None, ldr=0,
+         alpha=1.0, gelu=False, accum=False):
+    """out[M,N] = epi(alpha * opA . opB); see include/lap_hip.h lap_gemm_bf16."""
+    _req(a, torch.bfloat16, "A"); _req(b, torch.bfloat16, "B")
+    flags = 0
+    if out.dtype == torch.float32:
+        flags |= GEMM_OUT_F32
+    elif out.dtype != torch.bfloat16:
+        raise TypeError("gemm out must be bf16 or f32")
+    if accum:
+        flags |= GEMM_ACCUM
+    if gelu:
+        flags |= GEMM_GELU
+    if bias is not None and bias.dtype == torch.float32:
+        flags |= GEMM_BIAS_F32
+    call("lap_gemm_bf16", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, ldc, ldr, float(alpha),
+         int(a_kc), int(b_kc), flags)
+    return out
+
+
+def linear_fwd(x, wt, out=None, *, bias=None, residual=None, gelu=False, out_dtype=torch.bfloat16):
+    """y[M,out] = x[M,in] @ wt[out,in]^T (+bias)(gelu)(+residual)."""
+    M, K = x.shape
+    N = wt.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    return gemm(x, wt, out, M=M, N=N, K=K, lda=x.stride(0), ldb=wt.stride(0), ldc=out.stride(0), bias=bias,
+                residual=residual, ldr=(residual.stride(0) if residual is not None else 0), gelu=gelu)
+
+
+def linear_dgrad(dy, wt, out=None, *, out_dtype=torch.bfloat16, accum=False):
+    """dx[M,in] = dy[M,out] @ wt[out,in]."""
+    M, K = dy.shape
+    N = wt.shape[1]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=dy.device)
+    return gemm(dy, wt, out, M=M, N=N, K=K, lda=dy.stride(0), ldb=wt.stride(0), ldc=out.stride(0), a_kc=True,
+                b_kc=False, accum=accum)
+
+
+def linear_wgrad(dy, x, out, *, accum=False):
+    """dWt[out,in] (f32) = dy[M,out]^T @ x[M,in]."""
+    Mrows, Nout = dy.shape
+    Kin = x.shape[1]
+    return gemm(dy, x, out, M=Nout, N=Kin, K=Mrows, lda=dy.stride(0), ldb=x.stride(0), ldc=out.stride(0), a_kc=False,
+                b_kc=False, accum=accum)
+
+
+def gemm_f32(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, alpha=1.0, accum=False):
+    for t, n in ((a, "A"), (b, "B"), (out, "C")):
+        _req(t, torch.float32, n)
+    call("lap_gemm_f32", _p(a), _p(b), _p(out), _p(bias), M, N, K, lda, ldb, ldc, float(alpha), int(a_kc), int(b_kc),
+         int(accum))
+    return out
+
+
+# ------------------------------------------------------------------- normalisation
+def rmsnorm_fwd(x, scale=None, mod=None, rows_per_sample=0, eps=1e-6, save_rstd=True):
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_rstd else None
+    call("lap_rmsnorm_fwd", _p(x), _p(scale), _p(mod), _p(y), _p(rstd), rows, D, rows_per_sample, float(eps))
+    return y, rstd
+
+
+def rmsnorm_bwd(x, dy, rstd, scale=None, mod=None, rows_per_sample=0, dx=None, dscale=None, dmod=None, accum_dx=False):
+    rows, D = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+    call("lap_rmsnorm_bwd", _p(x), _p(scale), _p(mod), _p(rstd), _p(dy), _p(dx), _p(dscale), _p(dmod), rows, D,
+         rows_per_sample, int(accum_dx))
+    return dx
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-6):
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call("lap_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, float(eps))
+    return y, mean, rstd
+
+
+def layernorm_bwd(x, dy, gamma, mean, rstd, dgamma, dbeta, dx=None, accum_dx=False):
+    rows, D = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+    call("lap_layernorm_bwd", _p(x), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dx), _p(dgamma), _p(dbeta), rows, D,
+         int(accum_dx))
+    return dx
+
+
+# --------------------------------------------------------------------- elementwise
+def rope_split_fwd(qkv, pos, B, T_seg, T_total, seg_off, NH, HD, q_scale):
+    rows = B * T_seg
+    q = torch.empty((rows, NH * HD), dtype=torch.bfloat16, device=qkv.device)
+    k = torch.empty((rows, HD), dtype=torch.bfloat16, device=qkv.device)
+    v = torch.empty((rows, HD), dtype=torch.bfloat16, device=qkv.device)
+    call("lap_rope_split_fwd", _p(qkv), _p(pos), _p(q), _p(k), _p(v), B, T_seg, T_total, seg_off, NH, HD, float(q_scale))
+    return q, k, v
+
+
+def rope_split_bwd(dq, dk, dv, pos, B, T_seg, T_total, seg_off, NH, HD, q_scale):
+    dqkv = torch.empty((B * T_seg, (NH + 2) * HD), dtype=torch.bfloat16, device=dq.device)
+    call("lap_rope_split_bwd", _p(dq), _p(dk), _p(dv), _p(pos), _p(dqkv), B, T_seg, T_total, seg_off, NH, HD,
+         float(q_scale))
+    return dqkv
+
+
+def geglu_fwd(gu):
+    rows, H2 = gu.shape
+    act = torch.empty((rows, H2 // 2), dtype=torch.bfloat16, device=gu.device)
+    call("lap_geglu_fwd", _p(gu), _p(act), rows, H2 // 2)
+    return act
+
+
+def geglu_bwd(gu, dact):
+    dgu = torch.empty_like(gu)
+    call("lap_geglu_bwd", _p(gu), _p(dact), _p(dgu), gu.shape[0], gu.shape[1] // 2)
+    return dgu
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    call("lap_gelu_fwd", _p(x), _p(y), x.numel())
+    return y
+
+
+def gelu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    call("lap_gelu_bwd", _p(x), _p(dy), _p(dx), x.numel())
+    return dx
+
+
+def embed_gather(table, tok, out, rows, T, D, dst_rps, dst_off, scale):
+    call("lap_embed_gather", _p(table), _p(tok), _p(out), rows, T, D, dst_rps, dst_off, float(scale))
+
+
+def embed_scatter_add(dtable, tok, dout, rows, T, D, src_rps, src_off, scale):
+    call("lap_embed_scatter_add", _p(dtable), _p(tok), _p(dout), rows, T, D, src_rps, src_off, float(scale))
+
+
+def gated_residual_fwd(x, u, gate=None, rows_per_sample=0, ldg=0):
+    y = torch.empty_like(x)
+    call("lap_gated_residual_fwd", _p(x), _p(u), _p(gate), _p(y), x.shape[0], x.shape[1], rows_per_sample, ldg)
+    return y
+
+
+def gated_residual_bwd(dy, u, gate, rows_per_sample, ldg, dgate, ldg_out):
+    du = torch.empty_like(dy)
+    call("lap_gated_residual_bwd", _p(dy), _p(u), _p(gate), _p(du), _p(dgate), dy.shape[0], dy.shape[1],
+         rows_per_sample, ldg, ldg_out)
+    return du
+
+
+def cast_f32_to_bf16(x, y=None):
+    if y is None:
+        y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    call("lap_cast_f32_to_bf16", _p(x), _p(y), x.numel())
+    return y
+
+
+def cast_bf16_to_f32(x, y=None):
+    if y is None:
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    call("lap_cast_bf16_to_f32", _p(x), _p(y), x.numel())
+    return y
+
+
+def add_bf16(a, b, y=None):
+    if y is None:
+        y = torch.empty_like(a)
+    call("lap_add_bf16", _p(a), _p(b), _p(y), a.numel())
+    return y
+
+
+def copy2d_bf16(src, dst, rows, cols, lds, ldd):
+    call("lap_copy2d_bf16", _p(src), _p(dst), rows, cols, lds, ldd)
+
+
+def copy_rows_bf16(src, dst, rows, T, D, src_rps, src_off, dst_rps, dst_off, accumulate=False):
+    call("lap_copy_rows_bf16", _p(src), _p(dst), rows, T, D, src_rps, src_off, dst_rps, dst_off, int(accumulate))
+
+
+def im2col_patch(img, P):
+    B, H, W, Cc = img.shape
+    out = torch.empty((B * (H // P) * (W // P), P * P * Cc), dtype=torch.float32, device=img.device)
+    call("lap_im2col_patch", _p(img), _p(out), B, H, W, Cc, P)
+    return out
+
+
+def add_posemb_cast(x, pos, T):
+    rows, D = x.shape
+    y = torch.empty((rows, D), dtype=torch.bfloat16, device=x.device)
+    call("lap_add_posemb_cast", _p(x), _p(pos), _p(y), rows, T, D)
+    return y
+
+
+def add_posemb_cast_bwd(dy, dpos, T):
+    rows, D = dy.shape
+    dx = torch.empty((rows, D), dtype=torch.float32, device=dy.device)
+    call("lap_add_posemb_cast_bwd", _p(dy), _p(dx), _p(dpos), rows, T, D)
+    return dx
+
+
+# ----------------------------------------------------------------------- attention
+def attention_fwd(q, k, v, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None, need_lse=True):
+    """q/k/v: lists of up to two segment tensors (None for an empty segment)."""
+    a = AttnFwdArgs()
+    outs = []
+    for s in range(2):
+        qs = q[s] if s < len(q) else None
+        a.q[s] = _p(qs)
+        o = torch.empty_like(qs) if qs is not None else None
+        outs.append(o)
+        a.o[s] = _p(o)
+        a.k[s] = _p(k[s]) if s < len(k) and k[s] is not None else None
+        a.v[s] = _p(v[s]) if s < len(v) and v[s] is not None else None
+        a.q_len[s] = q_len[s] if s < len(q_len) else 0
+        a.k_len[s] = k_len[s] if s < len(k_len) else 0
+    Tq = a.q_len[0] + a.q_len[1]
+    dev = next(t for t in q if t is not None).device
+    lse = torch.empty((B, NH, Tq), dtype=torch.float32, device=dev) if need_lse else None
+    a.qinfo, a.kinfo, a.lse = _p(qinfo), _p(kinfo), _p(lse)
+    a.B, a.NH, a.NKV, a.HD = B, NH, NKV, HD
+    _chk(_fn["lap_attention_fwd"](C.byref(a), _stream()), "lap_attention_fwd")
+    return outs, lse
+
+
+def attention_bwd(q, k, v, o, d_o, lse, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None, stop_q1_to_k0=False):
+    a = AttnBwdArgs()
+    dq, dk, dv = [], [], []
+    for s in range(2):
+        def g(lst):
+            return lst[s] if s < len(lst) else None
+        a.q[s], a.o[s], a.d_o[s] = _p(g(q)), _p(g(o)), _p(g(d_o))
+        a.k[s], a.v[s] = _p(g(k)), _p(g(v))
+        dq.append(torch.empty_like(g(q)) if g(q) is not None else None)
+        dk.append(torch.empty_like(g(k)) if g(k) is not None else None)
+        dv.append(torch.empty_like(g(v)) if g(v) is not None else None)
+        a.dq[s], a.dk[s], a.dv[s] = _p(dq[s]), _p(dk[s]), _p(dv[s])
+        a.q_len[s] = q_len[s] if s < len(q_len) else 0
+        a.k_len[s] = k_len[s] if s < len(k_len) else 0
+    Tq = a.q_len[0] + a.q_len[1]
+    delta = torch.empty((B, NH, Tq), dtype=torch.float32, device=lse.device)
+    a.qinfo, a.kinfo, a.lse, a.delta = _p(qinfo), _p(kinfo), _p(lse), _p(delta)
+    a.B, a.NH, a.NKV, a.HD, a.stop_q1_to_k0 = B, NH, NKV, HD, int(stop_q1_to_k0)
+    _chk(_fn["lap_attention_bwd"](C.byref(a), _stream()), "lap_attention_bwd")
+    return dq, dk, dv
+
+
+# ----------------------------------------------------------------- loss / optimizer
+def ce_chunk_update(logits, target, m, l, tl, v0):
+    rows, vc = logits.shape
+    call("lap_ce_chunk_update", _p(logits), logits.stride(0), _p(target), _p(m), _p(l), _p(tl), rows, v0, vc)
+
+
+def ce_chunk_grad(logits, target, m, l, w, dlogits, v0):
+    rows, vc = logits.shape
+    call("lap_ce_chunk_grad", _p(logits), logits.stride(0), _p(target), _p(m), _p(l), _p(w), _p(dlogits),
+         dlogits.stride(0), rows, v0, vc)
+
+
+def sumsq_f32(x, out):
+    call("lap_sumsq_f32", _p(x), x.numel(), _p(out))
+
+
+def adamw_ema(p, m, v, ema, g, p16, scalars, b1, b2, eps, wd, max_norm):
+    call("lap_adamw_ema", _p(p), _p(m), _p(v), _p(ema), _p(g), _p(p16), p.numel(), _p(scalars), float(b1), float(b2),
+         float(eps), float(wd), float(max_norm))
+
+
+def fm_mix(noise, actions, t):
+    B = noise.shape[0]
+    n_per = noise.numel() // B
+    x_t = torch.empty_like(noise); u_t = torch.empty_like(noise)
+    call("lap_fm_mix", _p(noise), _p(actions), _p(t), _p(x_t), _p(u_t), B, n_per)
+    return x_t, u_t
+
+
+def posemb_sincos(t, D, min_period, max_period):
+    out = torch.empty((t.shape[0], D), dtype=torch.float32, device=t.device)
+    call("lap_posemb_sincos", _p(t), _p(out), t.shape[0], D, float(min_period), float(max_period))
+    return out
+
+
+def swish_fwd(x):
+    y = torch.empty_like(x)
+    call("lap_swish_fwd", _p(x), _p(y), x.numel())
+    return y
+
+
+def swish_bwd(x, dy):
+    dx = torch.empty_like(x)
+    call("lap_swish_bwd", _p(x), _p(dy), _p(dx), x.numel())
+    return dx
+
+
+def mse_fwd_bwd(v, u, coef=None, need_grad=True):
+    B = v.shape[0]
+    n_per = v.numel() // B
+    per = torch.empty(B, dtype=torch.float32, device=v.device)
+    dv = torch.empty_like(v) if need_grad else None
+    call("lap_mse_fwd_bwd", _p(v), _p(u), _p(coef), _p(per), _p(dv), B, n_per)
+    return per, dv
+
+
+def axpy_f32(x, v, dt):
+    call("lap_axpy_f32", _p(x), _p(v), float(dt), x.numel())
