@@ -1,0 +1,208 @@
+"""bench.py — LAP-3B bf16 train-step throughput on MI355X (BASELINE.json metric, config[1] / config[2]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one full train step (forward + hand-written backward + clip + AdamW + EMA, scripts/train.py:329-419) of
+LAP-3B (SigLIP So400m/14 + Gemma-2B + Gemma-300M action expert, random-init weights) on a synthetic batch of 32
+samples per GPU: 2 x 224x224 images, 48-token prompt (last 16 = language-action tokens), 50-step action chunk
+(SURVEY.md §8d).  Weak scaling: per-GPU batch fixed, parameters/optimizer FSDP-sharded over RCCL.
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the bf16 MFMA GEMM, csrc/gemm.hip):
+achieved = sum of 2*M*N*K over the GEMM launches of the timed steps / their summed durations, measured with HIP
+events on the launch stream; `cpu_baseline` times the CPU oracle (oracle/lap_oracle.py, kind "port") on the host
+cores on a bounded slice of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+TRAIN_FLOP_PER_SAMPLE = 8.375e12  # 3 x forward (2.792 TFLOP), recompute not credited
+MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA
+
+
+def synthetic_batch(cfg, B, device, seed):
+    from lap_amd.observation import CoTObservation
+
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    L, H = cfg.max_token_len, cfg.image_size
+    images = {k: (torch.rand(B, H, H, 3, generator=g) * 2 - 1).to(device) for k in cfg.image_keys}
+    la = torch.zeros(B, L, dtype=torch.bool)
+    la[:, L - 16:] = True
+    obs = CoTObservation(
+        images=images, image_masks={k: torch.ones(B, dtype=torch.bool, device=device) for k in cfg.image_keys},
+        state=(torch.rand(B, cfg.action_dim, generator=g) * 2 - 1).to(device),
+        tokenized_prompt=torch.randint(0, cfg.vocab_size, (B, L), generator=g, dtype=torch.int32).to(device),
+        tokenized_prompt_mask=torch.ones(B, L, dtype=torch.bool, device=device),
+        tokenized_langact_mask=la.to(device), token_loss_mask=torch.ones(B, L, dtype=torch.bool, device=device),
+        sample_mask=torch.ones(B, dtype=torch.bool, device=device))
+    actions = torch.randn(B, cfg.action_horizon, cfg.action_dim, generator=g).to(device)
+    return obs, actions
+
+
+class GemmMeter:
+    """Wraps lap_amd.hip.gemm: HIP event pair around every launch of the dominant kernel (on torch's current stream,
+    which is the stream the C ABI launches on)."""
+
+    def __init__(self, hip):
+        self.hip = hip
+        self.orig = hip.gemm
+        self.records = []
+        self.enabled = False
+
+    def install(self):
+        def gemm(a, b, out, *, M, N, K, **kw):
+            if not self.enabled:
+                return self.orig(a, b, out, M=M, N=N, K=K, **kw)
+            s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self.orig(a, b, out, M=M, N=N, K=K, **kw)
+            e.record()
+            self.records.append((s, e, 2.0 * M * N * K))
+            return r
+        self.hip.gemm = gemm
+
+    def summary(self):
+        t = sum(s.elapsed_time(e) for s, e, _ in self.records) * 1e-3
+        fl = sum(f for _, _, f in self.records)
+        return len(self.records), t, fl
+
+
+def cpu_baseline(cores: int):
+    """CPU oracle (f32, torch CPU autograd) on a bounded slice: LAP-3B widths, batch 1, BASELINE shapes, 2 of 18 joint
+    Gemma layers + 2 of 27 SigLIP blocks + a 16k-row vocabulary slice; forward + backward; samples/s extrapolated by
+    the FLOP ratio of the full model to the slice."""
+    import dataclasses
+
+    from oracle import lap_oracle as O
+
+    torch.set_num_threads(cores)
+    O.GEMMA["gemma_2b_d2"] = O.GemmaCfg(2048, 2, 16384, 8, 1, 256)
+    O.GEMMA["gemma_300m_d2"] = O.GemmaCfg(1024, 2, 4096, 8, 1, 256)
+    O.SIGLIP["So400m/14_d2"] = O.SiglipCfg(1152, 2, 4304, 16)
+    V = 16384
+    oc = O.OracleCfg(paligemma_variant="gemma_2b_d2", action_expert_variant="gemma_300m_d2", siglip_variant="So400m/14_d2",
+                     action_horizon=50, max_token_len=48, vocab_size=V, language_loss_weight=0.4)
+    P = O.init_params(oc, 0)
+    g = torch.Generator().manual_seed(0)
+    B, L = 1, 48
+    la = torch.zeros(B, L, dtype=torch.bool); la[:, L - 16:] = True
+    obs = dict(images={k: torch.rand(B, 224, 224, 3, generator=g) * 2 - 1 for k in oc.image_keys},
+               image_masks={k: torch.ones(B, dtype=torch.bool) for k in oc.image_keys},
+               tokenized_prompt=torch.randint(0, V, (B, L), generator=g), tokenized_prompt_mask=torch.ones(B, L, dtype=torch.bool),
+               tokenized_langact_mask=la, token_loss_mask=torch.ones(B, L, dtype=torch.bool), sample_mask=torch.ones(B, dtype=torch.bool))
+    actions = torch.randn(B, 50, 7, generator=g); noise = torch.randn(B, 50, 7, generator=g); t = torch.rand(B, generator=g) * 0.999 + 0.001
+    Pg = {k: v.requires_grad_(True) for k, v in P.items()}
+    t0 = time.perf_counter()
+    loss, _ = O.compute_loss(Pg, oc, obs, actions, noise, t)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    # forward FLOPs of the slice vs the full model (SURVEY.md §8d formula)
+    Tp, S = 560, 50
+    w_sig_l, w_vlm_l, w_exp_l = 412.4e6 / 27, 1.982e9 / 18, 0.311e9 / 18
+    f_slice = 2 * (2 * 256 * 2 * w_sig_l + 2 * 4 * 256 ** 2 * 1152) + 2 * Tp * 2 * w_vlm_l + 2 * 4 * Tp ** 2 * 2048 \
+        + 2 * S * 2 * w_exp_l + 2 * 4 * S * (Tp + S) * 2048 + 2 * 47 * 2048 * V
+    f_full = 2.792e12
+    return {"value": round(1.0 / (dt * f_full / f_slice), 6), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle f32 fwd+bwd, batch 1, LAP-3B widths, 2/18 Gemma layers + 2/27 SigLIP blocks + 16k-row vocab slice "
+                      f"({dt:.1f} s), extrapolated by forward-FLOP ratio {f_full / f_slice:.1f}x; stand-in for the reference's JAX-CPU "
+                      f"path, which cannot be installed offline"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--config", default="lap_bench")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import dataclasses
+
+    from lap_amd import hip
+    from lap_amd.config import get_config
+    from lap_amd.train import TrainingStepRunner, init_train_state
+
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    tc = dataclasses.replace(get_config(args.config), batch_size=args.batch * world, fsdp_devices=world)
+    state = init_train_state(tc, device=dev, world_size=world, rank=rank, use_fsdp=world > 1)
+    runner = TrainingStepRunner(tc)
+    batches = [synthetic_batch(tc.model, args.batch, dev, seed=1000 * rank + i) for i in range(2)]
+    meter = GemmMeter(hip)
+    meter.install()
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        state, info = runner(0, state, batches[i % 2], state.step)
+    sync()
+    meter.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        state, info = runner(0, state, batches[i % 2], state.step)
+    sync()
+    dt = time.perf_counter() - t0
+    meter.enabled = False
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    loss = info["loss"].item()
+    if rank == 0:
+        n_launch, t_gemm, fl_gemm = meter.summary()
+        samples = args.batch * world * args.steps
+        value = samples / dt
+        achieved = fl_gemm / t_gemm / 1e12 if t_gemm > 0 else 0.0
+        out = {
+            "metric": "train-step samples/sec LAP-3B bf16", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "LAP-3B (SigLIP So400m/14 + Gemma-2B + Gemma-300M expert) full train step fwd+bwd+AdamW+EMA, "
+                                   "2x224x224 images + 48-token prompt + 50-step action chunk, random-init weights",
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": 610,
+                       "parallelism": f"fsdp{world}" if world > 1 else "single"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA GEMM, csrc/gemm.hip)", "achieved": round(achieved, 1),
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": n_launch // max(args.steps, 1),
+                         "avg_launch_us": round(t_gemm / max(n_launch, 1) * 1e6, 2),
+                         "gemm_time_frac_of_step": round(t_gemm / dt, 4),
+                         "step_mfu": round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+            "final_loss": round(loss, 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,16 +57,17 @@ int lap_gemm_f32(const float* A, const float* B, float* C, const float* bias,
 /* ------------------------------------------------------- normalisation ---- */
 /* RMSNorm / adaptive RMSNorm forward (gemma.py:113-131).
  * x,y: bf16 [rows][D]; scale: f32 [D] (plain) or NULL; mod: bf16
- * [rows/rows_per_sample][3*D] = (scale|shift|gate) from Dense(cond) (adaptive)
- * or NULL.  rstd: f32 [rows] out (saved for backward), may be NULL. */
+ * [rows/rows_per_sample][mod_ld >= 3*D] = (scale|shift|gate) from Dense(cond)
+ * (adaptive; a column slice of the all-layers modulation matrix) or NULL.
+ * rstd: f32 [rows] out (saved for backward), may be NULL. */
 int lap_rmsnorm_fwd(const void* x, const float* scale, const void* mod, void* y, float* rstd,
-                    int rows, int D, int rows_per_sample, float eps, void* stream);
+                    int rows, int D, int rows_per_sample, int mod_ld, float eps, void* stream);
 /* Backward: dx (bf16, overwritten or accumulated into when accum_dx) and
- * either dscale f32[D] (atomically accumulated; caller zeroes) or dmod f32
- * [B][3*D] scale/shift thirds (written; gate third untouched). */
+ * either dscale f32[D] or dmod f32 [B][dmod_ld] scale/shift thirds — both
+ * accumulated with f32 atomics (caller zeroes); the gate third is untouched. */
 int lap_rmsnorm_bwd(const void* x, const float* scale, const void* mod, const float* rstd, const void* dy,
                     void* dx, float* dscale, float* dmod,
-                    int rows, int D, int rows_per_sample, int accum_dx, void* stream);
+                    int rows, int D, int rows_per_sample, int mod_ld, int dmod_ld, int accum_dx, void* stream);
 
 /* LayerNorm (Flax nn.LayerNorm, eps 1e-6, f32 statistics; siglip_gemma3.py:93,104,167).
  * x,y bf16 [rows][D]; gamma,beta f32 [D]; mean,rstd f32 [rows] saved. */
@@ -94,10 +95,12 @@ int lap_geglu_bwd(const void* gu, const void* dact, void* dgu, int rows, int H, 
 int lap_gelu_fwd(const void* x, void* y, long long n, void* stream);
 int lap_gelu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream);
 
-/* Embedding gather (gemma.py:148-151,448): out[r] = bf16(table[tok[r]] * scale), table f32 [V][D].
- * Rows are written at dst row (r / T) * dst_rows_per_sample + dst_off + r % T (prefix assembly, lap.py:150-166). */
+/* Embedding gather (gemma.py:148-151,448): out[r] = bf16(table[tok[r]] * scale), table f32.
+ * `table` holds vocabulary rows [row_lo, row_hi) (the whole table, or this rank's FSDP shard); tokens
+ * outside the range produce zero rows.  Rows are written at dst row
+ * (r / T) * dst_rows_per_sample + dst_off + r % T (prefix assembly, lap.py:150-166). */
 int lap_embed_gather(const float* table, const int32_t* tok, void* out, int rows, int T, int D,
-                     int dst_rows_per_sample, int dst_off, float scale, void* stream);
+                     int dst_rows_per_sample, int dst_off, float scale, int row_lo, int row_hi, void* stream);
 /* Backward: dtable[tok[r]] += scale * dout[row(r)] (f32 atomics). */
 int lap_embed_scatter_add(float* dtable, const int32_t* tok, const void* dout, int rows, int T, int D,
                           int src_rows_per_sample, int src_off, float scale, void* stream);
@@ -108,6 +111,11 @@ int lap_gated_residual_fwd(const void* x, const void* u, const void* gate, void*
 /* du = dy * gate; dgate[b] (f32 [B][ldg_out]) = sum_rows dy*u. */
 int lap_gated_residual_bwd(const void* dy, const void* u, const void* gate, void* du, float* dgate,
                            int rows, int D, int rows_per_sample, int ldg, int ldg_out, void* stream);
+
+/* Column sums: out[c] += sum_r x[r][c]  (bias gradients). x bf16 [rows][ld], out f32 [cols] (caller zeroes). */
+int lap_colsum_bf16(const void* x, float* out, int rows, int cols, int ld, void* stream);
+/* Same for f32 input. */
+int lap_colsum_f32(const float* x, float* out, int rows, int cols, int ld, void* stream);
 
 /* Generic casts / copies / fills. */
 int lap_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream);
@@ -136,13 +144,16 @@ int lap_add_posemb_cast_bwd(const void* dy, float* dx, float* dpos, int rows, in
  *                      (kinfo[b][j] & 0xffffff) <= (qinfo[b][i] & 0xffffff);
  * NULL infos = no mask.  This encodes make_attn_mask + the LAP prefix/action
  * block structure (lap.py:303-364) without materialising [B,T,T].
- * Q must already carry the 1/sqrt(HD) scale.  lse: f32 [B][NH][Tq] out. */
+ * logits = scale * q.k (Gemma: q already carries 1/sqrt(HD) from the RoPE kernel, scale = 1).
+ * lse: f32 [B][NH][Tq] out. */
 typedef struct {
   const void* q[2]; void* o[2];
   const void* k[2]; const void* v[2];
   int q_len[2]; int k_len[2];
+  int q_rs[2]; int kv_rs[2]; int o_rs[2];   /* row strides in elements; 0 = packed (NH*HD / NKV*HD) */
   const int32_t* qinfo; const int32_t* kinfo;
   float* lse;
+  float scale;                                /* logits = scale * q.k (1.0 when q is pre-scaled) */
   int B, NH, NKV, HD;
 } lap_attn_fwd_args;
 int lap_attention_fwd(const lap_attn_fwd_args* a, void* stream);
@@ -152,9 +163,11 @@ typedef struct {
   const void* k[2]; const void* v[2];
   void* dq[2]; void* dk[2]; void* dv[2];
   int q_len[2]; int k_len[2];
+  int q_rs[2]; int kv_rs[2]; int o_rs[2];   /* q/dq, k/v/dk/dv, o/dO row strides; 0 = packed */
   const int32_t* qinfo; const int32_t* kinfo;
   const float* lse;
   float* delta;              /* scratch f32 [B][NH][Tq] */
+  float scale;
   int B, NH, NKV, HD;
   int stop_q1_to_k0;         /* stop_action_to_vlm_grad (gemma.py:242-269): no dK/dV from segment-1 queries into segment-0 keys */
 } lap_attn_bwd_args;

@@ -1,0 +1,406 @@
+"""Configuration surface of the reference, kept so that its callers stay drop-in.
+
+Mirrors (names, defaults, argument meaning):
+  * gemma variants            src/lap/models/backbones/gemma.py:43-109
+  * LAPConfig                 src/lap/models/lap_config.py:22-130
+  * TrainConfig / EMA / registry / get_config
+                              src/lap/training/config.py:372-603, 607-862
+  * AdamW / CosineDecaySchedule defaults: openpi.training.optimizer [UPSTREAM-RECALL], with the LAP
+    overrides of training/config.py:69-82,516-519.
+Only the fields the hot path reads are functional; data / wandb / weight-loader fields are carried as
+plain values so existing config code keeps constructing.
+"""
+from __future__ import annotations
+
+import dataclasses
+import difflib
+import math
+import pathlib
+from typing import Literal
+
+PALIGEMMA_VOCAB_SIZE = 257_152
+IMAGE_RESOLUTION = (224, 224)
+
+
+# ------------------------------------------------------------------------------ backbones
+@dataclasses.dataclass(frozen=True)
+class GemmaConfig:
+    width: int
+    depth: int
+    mlp_dim: int
+    num_heads: int
+    num_kv_heads: int
+    head_dim: int
+
+
+_GEMMA = {
+    "dummy": GemmaConfig(64, 4, 128, 8, 1, 16),
+    "gemma_300m": GemmaConfig(1024, 18, 4096, 8, 1, 256),
+    "gemma_2b": GemmaConfig(2048, 18, 16384, 8, 1, 256),
+}
+
+
+def get_gemma_config(variant: str) -> GemmaConfig:
+    if variant not in _GEMMA:
+        raise ValueError(f"Unknown variant: {variant}")  # gemma.py:109 (LoRA / gemma3 variants are out of scope)
+    return _GEMMA[variant]
+
+
+@dataclasses.dataclass(frozen=True)
+class SiglipConfig:
+    width: int
+    depth: int
+    mlp_dim: int
+    num_heads: int
+    patch: int = 14
+
+
+_SIGLIP = {"So400m/14": SiglipConfig(1152, 27, 4304, 16), "mu/14": SiglipConfig(32, 1, 128, 2)}
+
+
+def get_siglip_config(variant: str) -> SiglipConfig:
+    if variant not in _SIGLIP:
+        raise ValueError(f"Unknown SigLIP variant: {variant}")
+    return _SIGLIP[variant]
+
+
+# ------------------------------------------------------------------------------ model config
+@dataclasses.dataclass(frozen=True)
+class LAPConfig:
+    """lap_config.py:22-75.  `siglip_variant`, `image_size` and `vocab_size` are additions used only by the
+    small test configurations; their defaults are the reference's constants."""
+
+    dtype: str = "bfloat16"
+    paligemma_variant: str = "gemma_2b"
+    action_expert_variant: str = "gemma_300m"
+    action_dim: int = 7
+    action_horizon: int = 16
+    max_token_len: int = 220
+    verbose_mode: bool = False
+    pi05: bool = True
+    discrete_state_input: bool = True
+    prompt_format: str = "lap"
+    prediction_format: str = "default"
+    use_fast: bool = False
+    aug_wrist_image: bool = True
+    enable_image_augmentation: bool = True
+    use_bimanual: bool = False
+    enable_action_training: bool = False
+    enable_langact_training: bool = True
+    enable_prediction_training: bool = False
+    enable_vqa_training: bool = False
+    language_loss_weight: float = 1.0
+    action_loss_weight: float = 1.0
+    prediction_loss_weight: float = 1.0
+    vqa_loss_weight: float = 0.1
+    vqa_loss_weights: dict | None = None
+    state_dropout: float = 0.0
+    reasoning_mask_prob: float = 0.0
+    stop_action_to_vlm_grad: bool = False
+    # --- additions (test-size models) ---
+    siglip_variant: str = "So400m/14"
+    image_size: int = 224
+    vocab_size: int = PALIGEMMA_VOCAB_SIZE
+
+    def __post_init__(self):
+        if self.max_token_len is None:
+            object.__setattr__(self, "max_token_len", 200 if self.pi05 else 48)
+        if self.dtype != "bfloat16":
+            raise ValueError("lap_amd computes in bfloat16 (the reference's LAPConfig.dtype default)")
+        if not self.pi05:
+            raise NotImplementedError("pi0-style state token (pi05=False) is not on the LAP-3B path")
+        if "gemma3" in self.paligemma_variant:
+            raise NotImplementedError("Gemma3 LAP variants are out of scope (SURVEY.md §2)")
+
+    @property
+    def image_keys(self) -> tuple[str, ...]:
+        if self.use_bimanual:
+            return ("base_0_rgb", "left_wrist_0_rgb", "right_wrist_0_rgb")
+        return ("base_0_rgb", "left_wrist_0_rgb")
+
+    @property
+    def image_resolution(self) -> tuple[int, int]:
+        return (self.image_size, self.image_size)
+
+    @property
+    def model_type(self) -> str:
+        return "lap_fast" if self.use_fast else "lap"
+
+    def create(self, rng=0, **kw):
+        """lap_config.py:102-111: build a randomly initialised model (rng = integer seed here)."""
+        from lap_amd.model import LAP
+
+        return LAP(self, seed=int(rng), **kw)
+
+    def load(self, params: dict, **kw):
+        """openpi BaseModelConfig.load: build a model from a reference-layout parameter tree."""
+        from lap_amd.model import LAP
+
+        return LAP(self, params=params, **kw)
+
+    def inputs_spec(self, *, batch_size: int = 1):
+        """lap_config.py:113-130: (observation spec, action spec) as {name: (shape, dtype)}."""
+        img = ((batch_size, *self.image_resolution, 3), "float32")
+        obs = {
+            "images": dict.fromkeys(self.image_keys, img),
+            "image_masks": dict.fromkeys(self.image_keys, ((batch_size,), "bool")),
+            "state": ((batch_size, self.action_dim), "float32"),
+            "tokenized_prompt": ((batch_size, self.max_token_len), "int32"),
+            "tokenized_prompt_mask": ((batch_size, self.max_token_len), "bool"),
+            "tokenized_langact_mask": ((batch_size, self.max_token_len), "bool"),
+            "critical_token_mask": ((batch_size, self.max_token_len), "bool"),
+        }
+        return obs, ((batch_size, self.action_horizon, self.action_dim), "float32")
+
+
+# ------------------------------------------------------------------------------ optimizer configs
+@dataclasses.dataclass(frozen=True)
+class CosineDecaySchedule:
+    warmup_steps: int = 1_000
+    peak_lr: float = 2.5e-5
+    decay_steps: int = 30_000
+    decay_lr: float = 2.5e-6
+
+    def __call__(self, step: int) -> float:
+        """optax.warmup_cosine_decay_schedule(init=peak/(warmup+1), peak, warmup, decay_steps, end=decay_lr)."""
+        init = self.peak_lr / (self.warmup_steps + 1)
+        if step < self.warmup_steps:
+            return init + (self.peak_lr - init) * step / self.warmup_steps
+        frac = min(max((step - self.warmup_steps) / max(self.decay_steps - self.warmup_steps, 1), 0.0), 1.0)
+        return self.decay_lr + (self.peak_lr - self.decay_lr) * 0.5 * (1 + math.cos(math.pi * frac))
+
+
+@dataclasses.dataclass(frozen=True)
+class AdamW:
+    b1: float = 0.9
+    b2: float = 0.95
+    eps: float = 1e-8
+    weight_decay: float = 1e-10
+    clip_gradient_norm: float = 1.0
+
+
+def build_cosine_lr(*, warmup_steps=5_000, peak_lr=1e-4, decay_steps=40_000, decay_lr=1e-4) -> CosineDecaySchedule:
+    return CosineDecaySchedule(warmup_steps, peak_lr, decay_steps, decay_lr)  # training/config.py:69-82
+
+
+# ------------------------------------------------------------------------------ EMA (config.py:372-504)
+@dataclasses.dataclass(frozen=True)
+class EmaStage:
+    start_step: int
+    end_step: int | None = None
+    decay: float | None = None
+
+    def validate(self):
+        if self.start_step < 0:
+            raise ValueError(f"start_step must be >= 0, got {self.start_step}")
+        if self.end_step is not None and self.end_step <= self.start_step:
+            raise ValueError(f"end_step ({self.end_step}) must be > start_step ({self.start_step})")
+        if self.decay is not None and not 0.0 < self.decay < 1.0:
+            raise ValueError(f"decay must be in (0.0, 1.0), got {self.decay}")
+
+
+@dataclasses.dataclass(frozen=True)
+class EmaSchedule:
+    stages: tuple[EmaStage, ...]
+
+    def __post_init__(self):
+        if not self.stages:
+            raise ValueError("EmaSchedule must have at least one stage")
+        for s in self.stages:
+            s.validate()
+        for i in range(len(self.stages) - 1):
+            cur, nxt = self.stages[i], self.stages[i + 1]
+            if cur.end_step is None:
+                raise ValueError(f"Stage {i} (starting at {cur.start_step}) has end_step=None but is not the last stage")
+            if nxt.start_step < cur.end_step:
+                raise ValueError(f"Stage {i + 1} (starting at {nxt.start_step}) overlaps with stage {i} (ending at {cur.end_step})")
+
+    def get_stage_for_step(self, step: int) -> EmaStage:
+        for s in self.stages:
+            if s.start_step <= step and (s.end_step is None or step < s.end_step):
+                return s
+        raise ValueError(f"No EMA stage covers step {step}. Available stages: {[(s.start_step, s.end_step) for s in self.stages]}")
+
+    def get_decay_for_step(self, step: int) -> tuple[float, bool]:
+        decay, enabled = 0.0, False
+        for s in self.stages:
+            if step >= s.start_step and (s.end_step is None or step < s.end_step):
+                decay, enabled = (0.0 if s.decay is None else s.decay), s.decay is not None
+        return decay, enabled
+
+    def has_ema(self) -> bool:
+        return any(s.decay is not None for s in self.stages)
+
+
+@dataclasses.dataclass(frozen=True)
+class EmaScheduleChoice:
+    kind: Literal["disabled", "constant", "delayed", "cosine_delayed"] = "delayed"
+    start_step: int = 10000
+
+    def build(self, *, decay: float | None) -> EmaSchedule | None:
+        if self.kind in ("disabled", "cosine_delayed") or decay is None:
+            return None
+        if self.kind == "constant" or self.start_step <= 0:
+            return EmaSchedule((EmaStage(0, None, decay),))
+        if self.kind == "delayed":
+            return EmaSchedule((EmaStage(0, self.start_step, None), EmaStage(self.start_step, None, decay)))
+        raise ValueError(f"Unsupported EMA schedule kind: {self.kind}")
+
+
+# ------------------------------------------------------------------------------ data / weights (carried, not executed)
+@dataclasses.dataclass(frozen=True)
+class RLDSDataConfig:
+    repo_id: str | None = None
+    asset_id: str | None = None
+    data_mix: str | None = None
+    rlds_data_dir: str | None = None
+    shuffle_buffer_size: int = 1_000_000
+    val_fraction: float = 0.02
+    random_base_prob: float = 0.0
+    max_samples: int | None = None
+
+
+@dataclasses.dataclass(frozen=True)
+class WeightLoaderChoice:
+    kind: str = "none"
+    params_path: str | None = None
+
+
+# ------------------------------------------------------------------------------ TrainConfig (config.py:507-603)
+@dataclasses.dataclass(frozen=True)
+class TrainConfig:
+    name: str = "lap"
+    project_name: str = "lap"
+    exp_name: str = ""
+    model: LAPConfig = dataclasses.field(default_factory=LAPConfig)
+    weight_loader: WeightLoaderChoice = dataclasses.field(default_factory=WeightLoaderChoice)
+    data: RLDSDataConfig = dataclasses.field(default_factory=RLDSDataConfig)
+    lr_schedule: CosineDecaySchedule = dataclasses.field(default_factory=build_cosine_lr)
+    optimizer: AdamW = dataclasses.field(default_factory=lambda: AdamW(weight_decay=0.0001))
+    batch_size: int = 32
+    num_train_steps: int = 40_000
+    save_interval: int = 1000
+    log_interval: int = 50
+    keep_period: int | None = 5000
+    resume: bool = True
+    overwrite: bool = False
+    seed: int = 0
+    fsdp_devices: int = 1
+    ema_decay: float | None = 0.999
+    ema_schedule_choice: EmaScheduleChoice = dataclasses.field(
+        default_factory=lambda: EmaScheduleChoice(kind="cosine_delayed", start_step=5000))
+    checkpoint_base_dir: str = "./checkpoints"
+    assets_base_dir: str = "./assets"
+    allow_partial_weights: bool = True
+    use_validation: bool = False
+    val_interval: int = 2000
+
+    @property
+    def ema_schedule(self) -> EmaSchedule | None:
+        return self.ema_schedule_choice.build(decay=self.ema_decay)
+
+    def get_ema_init(self) -> tuple[float | None, bool]:
+        if self.ema_schedule_choice.kind == "cosine_delayed":
+            return (None, False) if self.ema_decay is None else (0.0, True)
+        sched = self.ema_schedule
+        if sched is None:
+            return self.ema_decay, self.ema_decay is not None
+        return sched.get_stage_for_step(0).decay, sched.has_ema()
+
+    def get_ema_decay_for_step(self, step: int) -> tuple[float, bool]:
+        if self.ema_schedule_choice.kind == "cosine_delayed":
+            if self.ema_decay is None:
+                return 0.0, False
+            start = self.ema_schedule_choice.start_step
+            dur = max(self.num_train_steps - start, 1)
+            prog = min(max((step - start) / dur, 0.0), 1.0)
+            return self.ema_decay * (1.0 - math.cos(math.pi * prog)) / 2.0, step >= start
+        sched = self.ema_schedule
+        if sched is not None:
+            return sched.get_decay_for_step(step)
+        if self.ema_decay is None:
+            return 0.0, False
+        return float(self.ema_decay), True
+
+    @property
+    def assets_dirs(self) -> pathlib.Path:
+        return pathlib.Path(self.assets_base_dir) / self.name
+
+    @property
+    def checkpoint_dir(self) -> pathlib.Path:
+        if not self.exp_name:
+            raise ValueError("--exp_name must be set")
+        return pathlib.Path(self.checkpoint_base_dir) / self.name / self.exp_name
+
+
+_CONFIGS = [
+    TrainConfig(  # config.py:608-619
+        name="lap",
+        data=RLDSDataConfig(random_base_prob=0.5),
+        model=LAPConfig(action_dim=7, action_horizon=16, max_token_len=180, enable_action_training=True,
+                        stop_action_to_vlm_grad=True),
+        batch_size=2048,
+    ),
+    TrainConfig(  # config.py:752-785
+        name="lap_libero",
+        model=LAPConfig(action_dim=7, action_horizon=10, max_token_len=180, enable_action_training=True,
+                        stop_action_to_vlm_grad=False, language_loss_weight=0.4, enable_image_augmentation=False),
+        data=RLDSDataConfig(shuffle_buffer_size=100000, repo_id="libero", asset_id="libero", data_mix="libero_finetune",
+                            val_fraction=0.0),
+        lr_schedule=CosineDecaySchedule(warmup_steps=1000, peak_lr=5e-5, decay_steps=40_000, decay_lr=5e-5),
+        weight_loader=WeightLoaderChoice(kind="checkpoint", params_path="checkpoints/lap/params"),
+        save_interval=2000, keep_period=2000, num_train_steps=40_001, batch_size=256,
+        ema_schedule_choice=EmaScheduleChoice(kind="constant"),
+    ),
+    TrainConfig(  # BASELINE.json synthetic shapes: 48-token prompt, 50-step chunk
+        name="lap_bench",
+        model=LAPConfig(action_dim=7, action_horizon=50, max_token_len=48, enable_action_training=True,
+                        stop_action_to_vlm_grad=False, language_loss_weight=0.4, enable_image_augmentation=False),
+        lr_schedule=CosineDecaySchedule(warmup_steps=1000, peak_lr=5e-5, decay_steps=40_000, decay_lr=5e-5),
+        batch_size=32, ema_schedule_choice=EmaScheduleChoice(kind="constant"),
+    ),
+    TrainConfig(  # tiny model for tests (gemma "dummy" variant gemma.py:60-68, SigLIP "mu")
+        name="debug",
+        model=LAPConfig(paligemma_variant="dummy", action_expert_variant="dummy", siglip_variant="mu/14", image_size=56,
+                        vocab_size=512, action_dim=7, action_horizon=10, max_token_len=24, enable_action_training=True,
+                        language_loss_weight=0.4, enable_image_augmentation=False),
+        lr_schedule=CosineDecaySchedule(warmup_steps=2, peak_lr=1e-3, decay_steps=100, decay_lr=1e-3),
+        batch_size=2, num_train_steps=10, ema_schedule_choice=EmaScheduleChoice(kind="constant"),
+    ),
+]
+if len({c.name for c in _CONFIGS}) != len(_CONFIGS):
+    raise ValueError("Config names must be unique.")
+_CONFIGS_DICT = {c.name: c for c in _CONFIGS}
+
+
+def get_config(config_name: str) -> TrainConfig:
+    """training/config.py:843-862."""
+    if config_name in _CONFIGS_DICT:
+        return _CONFIGS_DICT[config_name]
+    closest = difflib.get_close_matches(config_name, _CONFIGS_DICT.keys(), n=3, cutoff=0.0)
+    closest_str = f" Did you mean one of: {', '.join(repr(c) for c in closest)}?" if closest else ""
+    raise ValueError(f"Config '{config_name}' not found.{closest_str}")
+
+
+def cli(argv=None) -> TrainConfig:
+    """Minimal stand-in for tyro.extras.overridable_config_cli (config.py:839): `<name> [--field value ...]`
+    for top-level scalar fields (exp-name, batch-size, fsdp-devices, num-train-steps, seed, ...)."""
+    import sys
+
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv:
+        raise SystemExit(f"usage: <config> [--field value]; configs: {sorted(_CONFIGS_DICT)}")
+    cfg = get_config(argv.pop(0))
+    upd = {}
+    while argv:
+        key = argv.pop(0)
+        if not key.startswith("--") or not argv:
+            raise SystemExit(f"bad argument {key}")
+        name = key[2:].replace("-", "_")
+        field = {f.name: f for f in dataclasses.fields(cfg)}.get(name)
+        if field is None:
+            raise SystemExit(f"unknown option {key}")
+        cur = getattr(cfg, name)
+        val = argv.pop(0)
+        upd[name] = type(cur)(val) if cur is not None and not isinstance(cur, bool) else (val.lower() in ("1", "true") if isinstance(cur, bool) else val)
+    return dataclasses.replace(cfg, **upd)

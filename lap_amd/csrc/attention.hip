@@ -29,8 +29,10 @@ struct AttnP {
   const bf16* q[2]; bf16* o[2]; const bf16* k[2]; const bf16* v[2];
   const bf16* d_o[2]; bf16* dq[2]; bf16* dk[2]; bf16* dv[2];
   int qlen[2], klen[2];
+  int q_rs[2], kv_rs[2], o_rs[2];   // row strides (elements) of q/dq, k/v/dk/dv, o/dO
   const int32_t* qinfo; const int32_t* kinfo;
   float* lse; float* delta;
+  float scale;                      // logits = scale * q.k
   int B, NH, NKV, stop;
 };
 
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   const int hk = h / (p.NH / p.NKV);
 
   bf16x8 qf[C::KS];
-  load_row_frags<HD>(p.q[id.seg] + ((long long)(b * (long long)qlen + myq) * p.NH + h) * HD, vq, lane, qf);
+  load_row_frags<HD>(p.q[id.seg] + (b * (long long)qlen + myq) * p.q_rs[id.seg] + h * HD, vq, lane, qf);
   const int qi = (p.qinfo && vq) ? p.qinfo[(long long)b * Tq + qinfo_off + myq] : 0x7fffffff;
 
   float m = NEG_BIG, l = 0.f;
@@ -142,9 +144,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     const int klen = p.klen[ks];
     if (klen == 0) continue;
     const int kinfo_off = ks ? p.klen[0] : 0;
-    const long long krs = (long long)p.NKV * HD;
-    const bf16* kb = p.k[ks] + ((long long)b * klen * p.NKV + hk) * HD;
-    const bf16* vb = p.v[ks] + ((long long)b * klen * p.NKV + hk) * HD;
+    const long long krs = p.kv_rs[ks];
+    const bf16* kb = p.k[ks] + (long long)b * klen * krs + hk * HD;
+    const bf16* vb = p.v[ks] + (long long)b * klen * krs + hk * HD;
     for (int kt = 0; kt * 64 < klen; ++kt) {
       __syncthreads();
       const int vr = min(64, klen - kt * 64);
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
           bool a = key < klen;
           if (a && p.kinfo) a = mask_ok(qi, p.kinfo[(long long)b * Tk + kinfo_off + key]);
           ok[nf][r] = a;
+          s[nf][r] *= p.scale;
           if (a) smax = fmaxf(smax, s[nf][r]);
         }
       smax = fmaxf(smax, __shfl_xor(smax, 16, 64));
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   l += __shfl_xor(l, 32, 64);
   if (!vq) return;
   const float inv = l > 0.f ? 1.0f / l : 0.f;
-  bf16* orow = p.o[id.seg] + ((long long)(b * (long long)qlen + myq) * p.NH + h) * HD;
+  bf16* orow = p.o[id.seg] + (b * (long long)qlen + myq) * p.o_rs[id.seg] + h * HD;
 #pragma unroll
   for (int d = 0; d < C::DF; ++d) {
     const int d0 = d * 16 + 4 * g;
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
   const int b = (int)(item / ((long long)p.NH * Tq));
   const int seg = t >= p.qlen[0];
   const int tt = seg ? t - p.qlen[0] : t;
-  const long long off = ((long long)(b * (long long)p.qlen[seg] + tt) * p.NH + h) * HD;
+  const long long off = (b * (long long)p.qlen[seg] + tt) * p.o_rs[seg] + h * HD;
   float acc = 0.f;
   for (int c = lane * 8; c < HD; c += 512) {
     bf16x8 a = *reinterpret_cast<const bf16x8*>(p.o[seg] + off + c);
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
   const int Tq = p.qlen[0] + p.qlen[1], Tk = p.klen[0] + p.klen[1];
   const int mykey = id.tile * 64 + w * 16 + i;
   const bool vk = mykey < klen;
-  const long long koff = ((long long)(b * (long long)klen + mykey) * p.NKV + hk) * HD;
+  const long long koff = (b * (long long)klen + mykey) * p.kv_rs[kseg] + hk * HD;
 
   bf16x8 kf[C::KS], vf[C::KS];
   load_row_frags<HD>(p.k[kseg] + koff, vk, lane, kf);
@@ -271,16 +274,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
       if (qlen == 0) continue;
       if (p.stop && qs == 1 && kseg == 0) continue;   // stop_action_to_vlm_grad
       const int qinfo_off = qs ? p.qlen[0] : 0;
-      const long long qrs = (long long)p.NH * HD;
-      const bf16* qb = p.q[qs] + ((long long)b * qlen * p.NH + h) * HD;
-      const bf16* dob = p.d_o[qs] + ((long long)b * qlen * p.NH + h) * HD;
+      const long long qrs = p.q_rs[qs], ors = p.o_rs[qs];
+      const bf16* qb = p.q[qs] + (long long)b * qlen * qrs + h * HD;
+      const bf16* dob = p.d_o[qs] + (long long)b * qlen * ors + h * HD;
       const float* lse = p.lse + ((long long)b * p.NH + h) * Tq + qinfo_off;
       const float* dl = p.delta + ((long long)b * p.NH + h) * Tq + qinfo_off;
       for (int qt = 0; qt * 64 < qlen; ++qt) {
         __syncthreads();
         const int vr = min(64, qlen - qt * 64);
         load_tile<HD>(sQ, qb + (long long)qt * 64 * qrs, qrs, vr);
-        load_tile<HD>(sD, dob + (long long)qt * 64 * qrs, qrs, vr);
+        load_tile<HD>(sD, dob + (long long)qt * 64 * ors, ors, vr);
         __syncthreads();
         f32x4 s[4], dp[4];
 #pragma unroll
@@ -302,8 +305,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
             if (a && p.qinfo) a = mask_ok(p.qinfo[(long long)b * Tq + qinfo_off + q], ki);
             float pv = 0.f, ds = 0.f;
             if (a) {
-              pv = __expf(s[qf][r] - lse[q]);
-              ds = pv * (dp[qf][r] - dl[q]);
+              pv = __expf(s[qf][r] * p.scale - lse[q]);
+              ds = pv * (dp[qf][r] - dl[q]) * p.scale;
             }
             s[qf][r] = pv;
             dp[qf][r] = ds;
@@ -348,11 +351,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   const int myq = id.tile * 64 + w * 16 + i;
   const bool vq = myq < qlen;
   const int hk = h / (p.NH / p.NKV);
-  const long long qoff = ((long long)(b * (long long)qlen + myq) * p.NH + h) * HD;
+  const long long qoff = (b * (long long)qlen + myq) * p.q_rs[id.seg] + h * HD;
+  const long long ooff = (b * (long long)qlen + myq) * p.o_rs[id.seg] + h * HD;
 
   bf16x8 qf[C::KS], dof[C::KS];
   load_row_frags<HD>(p.q[id.seg] + qoff, vq, lane, qf);
-  load_row_frags<HD>(p.d_o[id.seg] + qoff, vq, lane, dof);
+  load_row_frags<HD>(p.d_o[id.seg] + ooff, vq, lane, dof);
   const int qi = (p.qinfo && vq) ? p.qinfo[(long long)b * Tq + qinfo_off + myq] : 0x7fffffff;
   const float lse_q = vq ? p.lse[((long long)b * p.NH + h) * Tq + qinfo_off + myq] : LSE_EMPTY;
   const float dl_q = vq ? p.delta[((long long)b * p.NH + h) * Tq + qinfo_off + myq] : 0.f;
@@ -365,9 +369,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     const int klen = p.klen[ks];
     if (klen == 0) continue;
     const int kinfo_off = ks ? p.klen[0] : 0;
-    const long long krs = (long long)p.NKV * HD;
-    const bf16* kb = p.k[ks] + ((long long)b * klen * p.NKV + hk) * HD;
-    const bf16* vb = p.v[ks] + ((long long)b * klen * p.NKV + hk) * HD;
+    const long long krs = p.kv_rs[ks];
+    const bf16* kb = p.k[ks] + (long long)b * klen * krs + hk * HD;
+    const bf16* vb = p.v[ks] + (long long)b * klen * krs + hk * HD;
     for (int kt = 0; kt * 64 < klen; ++kt) {
       __syncthreads();
       const int vr = min(64, klen - kt * 64);
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
           const int key = kt * 64 + nf * 16 + 4 * g + r;
           bool a = vq && key < klen;
           if (a && p.kinfo) a = mask_ok(qi, p.kinfo[(long long)b * Tk + kinfo_off + key]);
-          dp[nf][r] = a ? __expf(s[nf][r] - lse_q) * (dp[nf][r] - dl_q) : 0.f;
+          dp[nf][r] = a ? __expf(s[nf][r] * p.scale - lse_q) * (dp[nf][r] - dl_q) * p.scale : 0.f;
         }
       const bf16x8 d0 = pack8(dp[0], dp[1]), d1 = pack8(dp[2], dp[3]);
 #pragma unroll
@@ -462,11 +466,16 @@ extern "C" int lap_attention_fwd(const lap_attn_fwd_args* a, void* stream) {
     p.q[s] = (const bf16*)a->q[s]; p.o[s] = (bf16*)a->o[s];
     p.k[s] = (const bf16*)a->k[s]; p.v[s] = (const bf16*)a->v[s];
     p.qlen[s] = a->q_len[s]; p.klen[s] = a->k_len[s];
+    p.q_rs[s] = a->q_rs[s] ? a->q_rs[s] : a->NH * a->HD;
+    p.o_rs[s] = a->o_rs[s] ? a->o_rs[s] : a->NH * a->HD;
+    p.kv_rs[s] = a->kv_rs[s] ? a->kv_rs[s] : a->NKV * a->HD;
+    if ((p.q_rs[s] | p.o_rs[s] | p.kv_rs[s]) & 7) return LAP_ERR_ARG;
     if (p.qlen[s] && (!p.q[s] || !p.o[s])) return LAP_ERR_ARG;
     if (p.klen[s] && (!p.k[s] || !p.v[s])) return LAP_ERR_ARG;
   }
   if ((a->qinfo == nullptr) != (a->kinfo == nullptr)) return LAP_ERR_ARG;
   p.qinfo = a->qinfo; p.kinfo = a->kinfo; p.lse = a->lse;
+  p.scale = a->scale;
   p.B = a->B; p.NH = a->NH; p.NKV = a->NKV;
   hipStream_t s = (hipStream_t)stream;
   switch (a->HD) {
@@ -486,11 +495,16 @@ extern "C" int lap_attention_bwd(const lap_attn_bwd_args* a, void* stream) {
     p.k[s] = (const bf16*)a->k[s]; p.v[s] = (const bf16*)a->v[s];
     p.dq[s] = (bf16*)a->dq[s]; p.dk[s] = (bf16*)a->dk[s]; p.dv[s] = (bf16*)a->dv[s];
     p.qlen[s] = a->q_len[s]; p.klen[s] = a->k_len[s];
+    p.q_rs[s] = a->q_rs[s] ? a->q_rs[s] : a->NH * a->HD;
+    p.o_rs[s] = a->o_rs[s] ? a->o_rs[s] : a->NH * a->HD;
+    p.kv_rs[s] = a->kv_rs[s] ? a->kv_rs[s] : a->NKV * a->HD;
+    if ((p.q_rs[s] | p.o_rs[s] | p.kv_rs[s]) & 7) return LAP_ERR_ARG;
     if (p.qlen[s] && (!p.q[s] || !p.o[s] || !p.d_o[s] || !p.dq[s])) return LAP_ERR_ARG;
     if (p.klen[s] && (!p.k[s] || !p.v[s] || !p.dk[s] || !p.dv[s])) return LAP_ERR_ARG;
   }
   if ((a->qinfo == nullptr) != (a->kinfo == nullptr)) return LAP_ERR_ARG;
   p.qinfo = a->qinfo; p.kinfo = a->kinfo; p.lse = (float*)a->lse; p.delta = a->delta;
+  p.scale = a->scale;
   p.B = a->B; p.NH = a->NH; p.NKV = a->NKV; p.stop = a->stop_q1_to_k0;
   hipStream_t s = (hipStream_t)stream;
   switch (a->HD) {

@@ -145,15 +145,19 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ 
 // ------------------------------------------------------------------- embedding
 __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ table, const int32_t* __restrict__ tok,
                                                            bf16* __restrict__ out, int rows, int T, int D8,
-                                                           int dst_rps, int dst_off, float scale) {
+                                                           int dst_rps, int dst_off, float scale, int row_lo, int row_hi) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (long long)rows * D8) return;
   const int r = (int)(gid / D8), c = (int)(gid % D8) * 8;
   const long long D = (long long)D8 * 8;
-  const float* src = table + (long long)tok[r] * D + c;
-  f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
-  float o[8] = {a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale,
-                b[0] * scale, b[1] * scale, b[2] * scale, b[3] * scale};
+  const int t = tok[r];
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (t >= row_lo && t < row_hi) {   // rows owned by another FSDP shard contribute zeros (summed by reduce-scatter)
+    const float* src = table + (long long)(t - row_lo) * D + c;
+    f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a[e] * scale; o[4 + e] = b[e] * scale; }
+  }
   const long long drow = (long long)(r / T) * dst_rps + dst_off + r % T;
   st8(out + drow * D + c, o);
 }
@@ -282,6 +286,19 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16* __restrict__
   } else {
     *reinterpret_cast<bf16x8*>(dst + drow * D + c) = *reinterpret_cast<const bf16x8*>(src + srow * D + c);
   }
+}
+
+// ------------------------------------------------------------------ column sums
+// grid (ceil(cols/256), ceil(rows/128)): thread owns one column over a 128-row slab -> one atomic.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int rows, int cols,
+                                                     int ld) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * 128, r1 = min(rows, r0 + 128);
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) acc += (float)x[(long long)r * ld + c];
+  atomicAdd(out + c, acc);
 }
 
 // ------------------------------------------------------------------ SigLIP stem
@@ -453,10 +470,10 @@ extern "C" int lap_gelu_bwd(const void* x, const void* dy, void* dx, long long n
 }
 
 extern "C" int lap_embed_gather(const float* table, const int32_t* tok, void* out, int rows, int T, int D,
-                                int dst_rows_per_sample, int dst_off, float scale, void* stream) {
-  if (rows <= 0 || T <= 0 || (D & 7)) return LAP_ERR_ARG;
+                                int dst_rows_per_sample, int dst_off, float scale, int row_lo, int row_hi, void* stream) {
+  if (rows <= 0 || T <= 0 || (D & 7) || row_hi < row_lo) return LAP_ERR_ARG;
   hipLaunchKernelGGL(embed_gather_kernel, flat_grid((long long)rows * (D / 8)), dim3(256), 0, S_, table, tok, (bf16*)out,
-                     rows, T, D / 8, dst_rows_per_sample, dst_off, scale);
+                     rows, T, D / 8, dst_rows_per_sample, dst_off, scale, row_lo, row_hi);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
@@ -484,6 +501,21 @@ extern "C" int lap_gated_residual_bwd(const void* dy, const void* u, const void*
   dim3 grid((D / 8 + 255) / 256, rows / rows_per_sample);
   hipLaunchKernelGGL(gated_res_bwd_kernel, grid, dim3(256), 0, S_, (const bf16*)dy, (const bf16*)u, (const bf16*)gate,
                      (bf16*)du, dgate, D / 8, rows_per_sample, ldg, ldg_out);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_colsum_bf16(const void* x, float* out, int rows, int cols, int ld, void* stream) {
+  if (rows <= 0 || cols <= 0) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(colsum_kernel<bf16>, dim3((cols + 255) / 256, (rows + 127) / 128), dim3(256), 0, S_, (const bf16*)x,
+                     out, rows, cols, ld);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_colsum_f32(const float* x, float* out, int rows, int cols, int ld, void* stream) {
+  if (rows <= 0 || cols <= 0) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(colsum_kernel<float>, dim3((cols + 255) / 256, (rows + 127) / 128), dim3(256), 0, S_, x, out, rows,
+                     cols, ld);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

@@ -28,7 +28,7 @@ template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ scale,
                                                           const bf16* __restrict__ mod, bf16* __restrict__ y,
                                                           float* __restrict__ rstd_out, int rows, int D,
-                                                          int rows_per_sample, float eps) {
+                                                          int rows_per_sample, int mod_ld, float eps) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = blockIdx.x * NWAVE + w;
   if (row >= rows) return;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16* __restrict
   ss = wave_sum(ss);
   const float r = 1.0f / sqrtf(ss / (float)D + eps);
   if (rstd_out && lane == 0) rstd_out[row] = r;
-  const bf16* mrow = mod ? mod + (long long)(row / rows_per_sample) * 3 * D : nullptr;
+  const bf16* mrow = mod ? mod + (long long)(row / rows_per_sample) * mod_ld : nullptr;
   bf16* yr = y + (long long)row * D;
 #pragma unroll
   for (int p = 0; p < NCH; ++p) {
@@ -76,13 +76,14 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
                                                           const bf16* __restrict__ mod, const float* __restrict__ rstd,
                                                           const bf16* __restrict__ dy, bf16* __restrict__ dx,
                                                           float* __restrict__ dscale, float* __restrict__ dmod,
-                                                          int rows, int D, int G, int accum_dx) {
+                                                          int rows, int D, int G, int mod_ld, int dmod_ld,
+                                                          int accum_dx) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [NWAVE][2*D] (adaptive) / [NWAVE][D]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = blockIdx.x;
   const int r0 = g * G, r1 = min(rows, r0 + G);
   const bool ada = mod != nullptr;
-  const bf16* mrow = ada ? mod + (long long)g * 3 * D : nullptr;
+  const bf16* mrow = ada ? mod + (long long)g * mod_ld : nullptr;
 
   float wgt[NCH][8];
   float ds[NCH][8], dh[NCH][8];
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
     for (int i = 0; i < NWAVE; ++i) t += red[i * stride + c];
     if (ada) {
       // thirds: [0,D) scale, [D,2D) shift
-      atomicAdd(dmod + (long long)g * 3 * D + c, t);
+      atomicAdd(dmod + (long long)g * dmod_ld + c, t);
     } else {
       atomicAdd(dscale + c, t);
     }
@@ -312,19 +313,20 @@ inline int nch_for(int D) { return (D / 8 + 63) / 64; }
   }
 
 extern "C" int lap_rmsnorm_fwd(const void* x, const float* scale, const void* mod, void* y, float* rstd,
-                               int rows, int D, int rows_per_sample, float eps, void* stream) {
-  if (rows <= 0 || D <= 0 || (D & 7) || (!scale && !mod) || (mod && rows_per_sample <= 0)) return LAP_ERR_ARG;
+                               int rows, int D, int rows_per_sample, int mod_ld, float eps, void* stream) {
+  if (rows <= 0 || D <= 0 || (D & 7) || (!scale && !mod) || (mod && (rows_per_sample <= 0 || (mod_ld & 7) || mod_ld < 3 * D)))
+    return LAP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((rows + NWAVE - 1) / NWAVE);
   DISPATCH_NCH(D, hipLaunchKernelGGL(rmsnorm_fwd_kernel<NCH>, grid, dim3(256), 0, s, (const bf16*)x, scale,
-                                     (const bf16*)mod, (bf16*)y, rstd, rows, D, rows_per_sample, eps));
+                                     (const bf16*)mod, (bf16*)y, rstd, rows, D, rows_per_sample, mod_ld, eps));
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
 
 extern "C" int lap_rmsnorm_bwd(const void* x, const float* scale, const void* mod, const float* rstd, const void* dy,
                                void* dx, float* dscale, float* dmod, int rows, int D, int rows_per_sample,
-                               int accum_dx, void* stream) {
+                               int mod_ld, int dmod_ld, int accum_dx, void* stream) {
   if (rows <= 0 || D <= 0 || (D & 7) || !rstd) return LAP_ERR_ARG;
   if (mod ? (!dmod || rows_per_sample <= 0 || rows % rows_per_sample) : (!scale || !dscale)) return LAP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -333,7 +335,7 @@ extern "C" int lap_rmsnorm_bwd(const void* x, const float* scale, const void* mo
   const size_t shm = (size_t)NWAVE * (mod ? 2 : 1) * D * sizeof(float);
   DISPATCH_NCH(D, hipLaunchKernelGGL(rmsnorm_bwd_kernel<NCH>, grid, dim3(256), shm, s, (const bf16*)x, scale,
                                      (const bf16*)mod, rstd, (const bf16*)dy, (bf16*)dx, dscale, dmod, rows, D, G,
-                                     accum_dx));
+                                     mod_ld, dmod_ld, accum_dx));
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

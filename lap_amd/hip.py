@@ -42,7 +42,9 @@ class AttnFwdArgs(C.Structure):
     _fields_ = [
         ("q", _vp * 2), ("o", _vp * 2), ("k", _vp * 2), ("v", _vp * 2),
         ("q_len", _i * 2), ("k_len", _i * 2),
+        ("q_rs", _i * 2), ("kv_rs", _i * 2), ("o_rs", _i * 2),
         ("qinfo", _vp), ("kinfo", _vp), ("lse", _vp),
+        ("scale", _f),
         ("B", _i), ("NH", _i), ("NKV", _i), ("HD", _i),
     ]
 
@@ -52,7 +54,9 @@ class AttnBwdArgs(C.Structure):
         ("q", _vp * 2), ("o", _vp * 2), ("d_o", _vp * 2), ("k", _vp * 2), ("v", _vp * 2),
         ("dq", _vp * 2), ("dk", _vp * 2), ("dv", _vp * 2),
         ("q_len", _i * 2), ("k_len", _i * 2),
+        ("q_rs", _i * 2), ("kv_rs", _i * 2), ("o_rs", _i * 2),
         ("qinfo", _vp), ("kinfo", _vp), ("lse", _vp), ("delta", _vp),
+        ("scale", _f),
         ("B", _i), ("NH", _i), ("NKV", _i), ("HD", _i), ("stop_q1_to_k0", _i),
     ]
 
@@ -62,8 +66,8 @@ SIGNATURES: dict[str, list] = {
     "lap_abi_version": [],
     "lap_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
     "lap_gemm_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
-    "lap_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
-    "lap_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lap_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "lap_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lap_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "lap_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_rope_split_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
@@ -72,10 +76,12 @@ SIGNATURES: dict[str, list] = {
     "lap_geglu_bwd": [_vp, _vp, _vp, _i, _i, _vp],
     "lap_gelu_fwd": [_vp, _vp, _ll, _vp],
     "lap_gelu_bwd": [_vp, _vp, _vp, _ll, _vp],
-    "lap_embed_gather": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "lap_embed_gather": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
     "lap_embed_scatter_add": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "lap_gated_residual_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lap_gated_residual_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "lap_colsum_bf16": [_vp, _vp, _i, _i, _i, _vp],
+    "lap_colsum_f32": [_vp, _vp, _i, _i, _i, _vp],
     "lap_cast_f32_to_bf16": [_vp, _vp, _ll, _vp],
     "lap_cast_bf16_to_f32": [_vp, _vp, _ll, _vp],
     "lap_add_bf16": [_vp, _vp, _vp, _ll, _vp],
@@ -191,10 +197,12 @@ def gemm_f32(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=No
 
 # ------------------------------------------------------------------- normalisation
 def rmsnorm_fwd(x, scale=None, mod=None, rows_per_sample=0, eps=1e-6, save_rstd=True):
+    """mod: bf16 [B, >=3D] view (row stride = mod.stride(0)) holding scale|shift|gate."""
     rows, D = x.shape
     y = torch.empty_like(x)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_rstd else None
-    call("lap_rmsnorm_fwd", _p(x), _p(scale), _p(mod), _p(y), _p(rstd), rows, D, rows_per_sample, float(eps))
+    call("lap_rmsnorm_fwd", _p(x), _p(scale), _p(mod), _p(y), _p(rstd), rows, D, rows_per_sample,
+         mod.stride(0) if mod is not None else 0, float(eps))
     return y, rstd
 
 
@@ -203,7 +211,8 @@ def rmsnorm_bwd(x, dy, rstd, scale=None, mod=None, rows_per_sample=0, dx=None, d
     if dx is None:
         dx = torch.empty_like(x)
     call("lap_rmsnorm_bwd", _p(x), _p(scale), _p(mod), _p(rstd), _p(dy), _p(dx), _p(dscale), _p(dmod), rows, D,
-         rows_per_sample, int(accum_dx))
+         rows_per_sample, mod.stride(0) if mod is not None else 0, dmod.stride(0) if dmod is not None else 0,
+         int(accum_dx))
     return dx
 
 
@@ -267,8 +276,11 @@ def gelu_bwd(x, dy):
     return dx
 
 
-def embed_gather(table, tok, out, rows, T, D, dst_rps, dst_off, scale):
-    call("lap_embed_gather", _p(table), _p(tok), _p(out), rows, T, D, dst_rps, dst_off, float(scale))
+def embed_gather(table, tok, out, rows, T, D, dst_rps, dst_off, scale, row_lo=0, row_hi=None):
+    """table: f32 rows [row_lo, row_hi) of the vocabulary (default: the whole table)."""
+    if row_hi is None:
+        row_hi = row_lo + table.shape[0]
+    call("lap_embed_gather", _p(table), _p(tok), _p(out), rows, T, D, dst_rps, dst_off, float(scale), row_lo, row_hi)
 
 
 def embed_scatter_add(dtable, tok, dout, rows, T, D, src_rps, src_off, scale):
@@ -286,6 +298,14 @@ def gated_residual_bwd(dy, u, gate, rows_per_sample, ldg, dgate, ldg_out):
     call("lap_gated_residual_bwd", _p(dy), _p(u), _p(gate), _p(du), _p(dgate), dy.shape[0], dy.shape[1],
          rows_per_sample, ldg, ldg_out)
     return du
+
+
+def colsum(x, out, rows=None, cols=None, ld=None):
+    """out[c] += sum_r x[r, c] (f32 atomics; caller zeroes)."""
+    rows = x.shape[0] if rows is None else rows
+    cols = x.shape[1] if cols is None else cols
+    ld = x.stride(0) if ld is None else ld
+    call("lap_colsum_bf16" if x.dtype == torch.bfloat16 else "lap_colsum_f32", _p(x), _p(out), rows, cols, ld)
 
 
 def cast_f32_to_bf16(x, y=None):
@@ -339,46 +359,63 @@ def add_posemb_cast_bwd(dy, dpos, T):
 
 
 # ----------------------------------------------------------------------- attention
-def attention_fwd(q, k, v, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None, need_lse=True):
-    """q/k/v: lists of up to two segment tensors (None for an empty segment)."""
+def attention_fwd(q, k, v, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None, need_lse=True, scale=1.0,
+                  q_rs=(0, 0), kv_rs=(0, 0)):
+    """q/k/v: lists of up to two segment tensors (None for an empty segment).  q_rs / kv_rs: row strides in
+    elements when q / k / v are column slices of a wider (fused qkv) buffer; outputs are packed [B*len, NH*HD]."""
     a = AttnFwdArgs()
     outs = []
     for s in range(2):
         qs = q[s] if s < len(q) else None
         a.q[s] = _p(qs)
-        o = torch.empty_like(qs) if qs is not None else None
+        a.q_rs[s], a.kv_rs[s], a.o_rs[s] = q_rs[s], kv_rs[s], 0
+        o = None
+        if qs is not None:
+            o = torch.empty((B * q_len[s], NH * HD), dtype=torch.bfloat16, device=qs.device)
         outs.append(o)
         a.o[s] = _p(o)
         a.k[s] = _p(k[s]) if s < len(k) and k[s] is not None else None
         a.v[s] = _p(v[s]) if s < len(v) and v[s] is not None else None
         a.q_len[s] = q_len[s] if s < len(q_len) else 0
         a.k_len[s] = k_len[s] if s < len(k_len) else 0
+    for nm, inf in (("qinfo", qinfo), ("kinfo", kinfo)):
+        if inf is not None and (inf.dtype != torch.int32 or not inf.is_contiguous()):
+            raise TypeError(f"{nm} must be a contiguous int32 tensor, got {inf.dtype}")
     Tq = a.q_len[0] + a.q_len[1]
     dev = next(t for t in q if t is not None).device
     lse = torch.empty((B, NH, Tq), dtype=torch.float32, device=dev) if need_lse else None
     a.qinfo, a.kinfo, a.lse = _p(qinfo), _p(kinfo), _p(lse)
+    a.scale = float(scale)
     a.B, a.NH, a.NKV, a.HD = B, NH, NKV, HD
     _chk(_fn["lap_attention_fwd"](C.byref(a), _stream()), "lap_attention_fwd")
     return outs, lse
 
 
-def attention_bwd(q, k, v, o, d_o, lse, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None, stop_q1_to_k0=False):
+def attention_bwd(q, k, v, o, d_o, lse, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None, stop_q1_to_k0=False,
+                  scale=1.0, q_rs=(0, 0), kv_rs=(0, 0), dq_out=None, dk_out=None, dv_out=None):
+    """Gradients are written with the same row strides as q / k / v (pass dq_out/dk_out/dv_out views of a fused
+    dqkv buffer when q_rs / kv_rs are set)."""
     a = AttnBwdArgs()
     dq, dk, dv = [], [], []
     for s in range(2):
         def g(lst):
-            return lst[s] if s < len(lst) else None
+            return lst[s] if lst is not None and s < len(lst) else None
         a.q[s], a.o[s], a.d_o[s] = _p(g(q)), _p(g(o)), _p(g(d_o))
         a.k[s], a.v[s] = _p(g(k)), _p(g(v))
-        dq.append(torch.empty_like(g(q)) if g(q) is not None else None)
-        dk.append(torch.empty_like(g(k)) if g(k) is not None else None)
-        dv.append(torch.empty_like(g(v)) if g(v) is not None else None)
+        a.q_rs[s], a.kv_rs[s], a.o_rs[s] = q_rs[s], kv_rs[s], 0
+        dq.append(g(dq_out) if g(dq_out) is not None else (torch.empty_like(g(q)) if g(q) is not None else None))
+        dk.append(g(dk_out) if g(dk_out) is not None else (torch.empty_like(g(k)) if g(k) is not None else None))
+        dv.append(g(dv_out) if g(dv_out) is not None else (torch.empty_like(g(v)) if g(v) is not None else None))
         a.dq[s], a.dk[s], a.dv[s] = _p(dq[s]), _p(dk[s]), _p(dv[s])
         a.q_len[s] = q_len[s] if s < len(q_len) else 0
         a.k_len[s] = k_len[s] if s < len(k_len) else 0
+    for nm, inf in (("qinfo", qinfo), ("kinfo", kinfo)):
+        if inf is not None and (inf.dtype != torch.int32 or not inf.is_contiguous()):
+            raise TypeError(f"{nm} must be a contiguous int32 tensor, got {inf.dtype}")
     Tq = a.q_len[0] + a.q_len[1]
     delta = torch.empty((B, NH, Tq), dtype=torch.float32, device=lse.device)
     a.qinfo, a.kinfo, a.lse, a.delta = _p(qinfo), _p(kinfo), _p(lse), _p(delta)
+    a.scale = float(scale)
     a.B, a.NH, a.NKV, a.HD, a.stop_q1_to_k0 = B, NH, NKV, HD, int(stop_q1_to_k0)
     _chk(_fn["lap_attention_bwd"](C.byref(a), _stream()), "lap_attention_bwd")
     return dq, dk, dv

@@ -1,0 +1,568 @@
+"""LAP on MI355X: the model object behind `LAPConfig.create()` / `.load()`.
+
+Keeps the reference's model surface (src/lap/models/lap.py):
+    compute_loss(rng, observation, actions, *, train=False, ...) -> (loss, metrics)      lap.py:380-602
+    sample_actions(rng, observation, *, num_steps=10, noise=None) -> [b, ah, ad]         lap.py:605-675
+and adds `loss_and_grad(...)`, the fused forward + hand-written backward that the train step uses (the
+reference gets it from nnx.value_and_grad, scripts/train.py:358-361).
+
+Everything numeric is a call into liblap_hip.so (lap_amd/hip.py); torch only owns device memory, the stream,
+and a few O(batch x tokens) integer tensors (masks -> per-token info words, positions).  There is no autograd
+and no fallback path.  Activations needed by the backward are kept in HBM (288 GB per MI355X) instead of being
+recomputed — the reference rematerialises every block (gemma.py:418-423 nothing_saveable), which costs a
+fourth forward pass.
+
+Joint two-expert transformer (gemma.py:455-531): the prefix stream (SigLIP tokens + prompt, width of the VLM)
+and the suffix stream (action tokens, width of the action expert) keep separate activations and weights and
+meet only inside the attention kernel, which takes both as segments.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+
+import torch
+
+from lap_amd import hip
+from lap_amd.config import LAPConfig, get_gemma_config, get_siglip_config
+from lap_amd.observation import CoTObservation, preprocess_observation
+from lap_amd.params import ParamStore
+
+SUFFIX_IDX_BASE = 0x800000  # suffix ar-indices live above every prefix index (see _train_infos)
+
+
+class _NullComm:
+    """world_size == 1: parameters are always resident, gradients stay where they are written."""
+    world_size = 1
+
+    def wait_unit(self, name): pass
+    def grads_ready(self, name): pass
+    def all_reduce_sum(self, t): return t
+
+
+def _gen(rng, device):
+    if isinstance(rng, torch.Generator):
+        return rng
+    g = torch.Generator(device=device)
+    g.manual_seed(int(rng) if rng is not None else 0)
+    return g
+
+
+class LAP:
+    EOS_TOKEN = 1
+
+    def __init__(self, config: LAPConfig, seed: int = 0, params: dict | None = None, device="cuda", store: ParamStore | None = None,
+                 comm=None, with_optimizer: bool = False, with_ema: bool = False, with_grads: bool = True):
+        self.config = config
+        self.device = torch.device(device)
+        self.v = get_gemma_config(config.paligemma_variant)
+        self.e = get_gemma_config(config.action_expert_variant)
+        self.s = get_siglip_config(config.siglip_variant)
+        self.action_dim, self.action_horizon, self.max_token_len = config.action_dim, config.action_horizon, config.max_token_len
+        self.comm = comm if comm is not None else _NullComm()
+        if store is None:
+            store = ParamStore(config, device, with_optimizer=with_optimizer, with_ema=with_ema, with_grads=with_grads)
+            if params is not None:
+                store.load_reference_tree(params)
+            else:
+                store.init_random(seed)
+        self.ps = store
+        self.n_img_tok = (config.image_size // self.s.patch) ** 2
+        self.deterministic = True
+
+    # ------------------------------------------------------------------ small helpers
+    def W(self, name):
+        return self.ps.w16(name)
+
+    def F(self, name):
+        return self.ps.f32(name)
+
+    def G(self, name):
+        return self.ps.g(name)
+
+    def _lin32(self, x, wname, bname):
+        """nnx.Linear in f32: y = x @ W^T + b (W stored [out][in])."""
+        w = self.F(wname)
+        out = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+        return hip.gemm_f32(x, w, out, M=x.shape[0], N=w.shape[0], K=w.shape[1], lda=x.stride(0), ldb=w.stride(0), ldc=w.shape[0],
+                            bias=self.F(bname))
+
+    def _lin32_bwd(self, x, dy, wname, bname, need_dx=True):
+        """Gradients of _lin32: dW += dy^T x, db += colsum(dy), returns dx = dy @ W."""
+        w = self.F(wname)
+        hip.gemm_f32(dy, x, self.G(wname), M=w.shape[0], N=w.shape[1], K=x.shape[0], lda=dy.stride(0), ldb=x.stride(0), ldc=w.shape[1],
+                     a_kc=False, b_kc=False, accum=True)
+        hip.colsum(dy, self.G(bname))
+        if not need_dx:
+            return None
+        dx = torch.empty_like(x)
+        return hip.gemm_f32(dy, w, dx, M=x.shape[0], N=w.shape[1], K=w.shape[0], lda=dy.stride(0), ldb=w.stride(0), ldc=w.shape[1],
+                            a_kc=True, b_kc=False)
+
+    # ================================================================== SigLIP
+    def _siglip_fwd(self, images: torch.Tensor, save: bool, collect=None):
+        """images f32 [N,H,W,3] -> tokens bf16 [N*T, Dv].  openpi siglip (missing) restated in
+        siglip_gemma3.py:382-545 minus :432, plus head bias."""
+        s, T = self.s, self.n_img_tok
+        N = images.shape[0]
+        W = s.width
+        hd = W // s.num_heads
+        ctx = {"blocks": []} if save else None
+        patches = hip.im2col_patch(images.contiguous(), s.patch)
+        stem = self._lin32(patches, "img/stem_w", "img/stem_b")
+        x = hip.add_posemb_cast(stem, self.F("img/pos"), T)
+        del stem
+        if collect is not None:
+            collect["img/stem"] = x
+        if save:
+            ctx["patches"] = patches
+        for l in range(s.depth):
+            self.comm.wait_unit(f"img{l}")
+            p = f"img/{l}/"
+            y, mean1, rstd1 = hip.layernorm_fwd(x, self.F(p + "ln1_g"), self.F(p + "ln1_b"))
+            qkv = hip.linear_fwd(y, self.W(p + "wqkv"), bias=self.F(p + "bqkv"))
+            (o, _), lse = hip.attention_fwd([qkv[:, :W]], [qkv[:, W:2 * W]], [qkv[:, 2 * W:]], [T], [T], N, s.num_heads, s.num_heads, hd,
+                                            scale=hd ** -0.5, q_rs=(3 * W, 0), kv_rs=(3 * W, 0), need_lse=save)
+            x1 = hip.linear_fwd(o, self.W(p + "wo"), bias=self.F(p + "bo"), residual=x)
+            y2, mean2, rstd2 = hip.layernorm_fwd(x1, self.F(p + "ln2_g"), self.F(p + "ln2_b"))
+            h = hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"))
+            a = hip.gelu_fwd(h)
+            x2 = hip.linear_fwd(a, self.W(p + "w2"), bias=self.F(p + "b2"), residual=x1)
+            if save:
+                ctx["blocks"].append((x, y, mean1, rstd1, qkv, o, lse, x1, y2, mean2, rstd2, h, a))
+            x = x2
+            if collect is not None:
+                collect[f"img/block{l:02d}"] = x
+        self.comm.wait_unit("img_head")
+        enc, mean, rstd = hip.layernorm_fwd(x, self.F("img/norm_g"), self.F("img/norm_b"))
+        tok = hip.linear_fwd(enc, self.W("img/head_w"), bias=self.F("img/head_b"))
+        if save:
+            ctx["final"] = (x, enc, mean, rstd)
+        if collect is not None:
+            collect["img/out"] = tok
+        return tok, ctx
+
+    def _siglip_bwd(self, ctx, dtok: torch.Tensor):
+        s, T = self.s, self.n_img_tok
+        W = s.width
+        hd = W // s.num_heads
+        x, enc, mean, rstd = ctx["final"]
+        N = x.shape[0] // T
+        hip.colsum(dtok, self.G("img/head_b"))
+        hip.linear_wgrad(dtok, enc, self.G("img/head_w"))
+        denc = hip.linear_dgrad(dtok, self.W("img/head_w"))
+        self.comm.grads_ready("img_head")
+        dx = hip.layernorm_bwd(x, denc, self.F("img/norm_g"), mean, rstd, self.G("img/norm_g"), self.G("img/norm_b"))
+        for l in reversed(range(s.depth)):
+            p = f"img/{l}/"
+            x, y, mean1, rstd1, qkv, o, lse, x1, y2, mean2, rstd2, h, a = ctx["blocks"][l]
+            hip.colsum(dx, self.G(p + "b2"))
+            hip.linear_wgrad(dx, a, self.G(p + "w2"))
+            da = hip.linear_dgrad(dx, self.W(p + "w2"))
+            dh = hip.gelu_bwd(h, da)
+            del da
+            hip.colsum(dh, self.G(p + "b1"))
+            hip.linear_wgrad(dh, y2, self.G(p + "w1"))
+            dy2 = hip.linear_dgrad(dh, self.W(p + "w1"))
+            del dh
+            hip.layernorm_bwd(x1, dy2, self.F(p + "ln2_g"), mean2, rstd2, self.G(p + "ln2_g"), self.G(p + "ln2_b"), dx=dx, accum_dx=True)
+            hip.colsum(dx, self.G(p + "bo"))
+            hip.linear_wgrad(dx, o, self.G(p + "wo"))
+            do = hip.linear_dgrad(dx, self.W(p + "wo"))
+            dqkv = torch.empty_like(qkv)
+            hip.attention_bwd([qkv[:, :W]], [qkv[:, W:2 * W]], [qkv[:, 2 * W:]], [o], [do], lse, [T], [T], N, s.num_heads, s.num_heads, hd,
+                              scale=hd ** -0.5, q_rs=(3 * W, 0), kv_rs=(3 * W, 0),
+                              dq_out=[dqkv[:, :W]], dk_out=[dqkv[:, W:2 * W]], dv_out=[dqkv[:, 2 * W:]])
+            hip.colsum(dqkv, self.G(p + "bqkv"))
+            hip.linear_wgrad(dqkv, y, self.G(p + "wqkv"))
+            dy = hip.linear_dgrad(dqkv, self.W(p + "wqkv"))
+            hip.layernorm_bwd(x, dy, self.F(p + "ln1_g"), mean1, rstd1, self.G(p + "ln1_g"), self.G(p + "ln1_b"), dx=dx, accum_dx=True)
+            ctx["blocks"][l] = None
+            self.comm.grads_ready(f"img{l}")
+        dstem = hip.add_posemb_cast_bwd(dx, self.G("img/pos"), T)
+        self._lin32_bwd(ctx["patches"], dstem, "img/stem_w", "img/stem_b", need_dx=False)
+
+    # ================================================================== token info words / positions
+    def _prefix_masks(self, obs: CoTObservation):
+        """lap.py:118-170: input mask and ar mask over [image tokens ..., prompt tokens]."""
+        B = obs.tokenized_prompt.shape[0]
+        T = self.n_img_tok
+        im = [obs.image_masks[k][:, None].expand(B, T) for k in self.config.image_keys]
+        prefix_mask = torch.cat(im + [obs.tokenized_prompt_mask], 1)
+        zeros = torch.zeros(B, T * len(im), dtype=torch.bool, device=prefix_mask.device)
+        la = obs.tokenized_langact_mask if obs.tokenized_langact_mask is not None else torch.zeros_like(obs.tokenized_prompt_mask)
+        return prefix_mask, torch.cat([zeros, la], 1)
+
+    def _train_infos(self, obs: CoTObservation, S: int):
+        """Per-token info words equivalent to _build_combined_attention_mask / make_attn_mask (lap.py:303-364):
+        class bit 1: valid prefix token (seen by prefix queries);  bit 2: in prefix_mask_action (seen by action
+        queries);  bit 4: suffix token.  Low 24 bits: cumulative ar index (suffix indices offset above all prefix
+        ones).  Positions per lap.py:366-377."""
+        prefix_mask, prefix_ar = self._prefix_masks(obs)
+        B, Pn = prefix_mask.shape
+        dev = prefix_mask.device
+        pma = prefix_mask & ~prefix_ar if obs.tokenized_langact_mask is not None else prefix_mask  # lap.py:303-325
+        cs = torch.cumsum(prefix_ar.to(torch.int32), 1)
+        kcls = prefix_mask.to(torch.int32) | (pma.to(torch.int32) << 1)
+        kinfo_p = (kcls << 24) | cs
+        qinfo_p = (prefix_mask.to(torch.int32) << 24) | cs
+        # suffix: mask all ones, ar = [1, 0, ...] (embed_suffix pi05) -> one block
+        s_idx = torch.full((B, S), SUFFIX_IDX_BASE + 1, dtype=torch.int32, device=dev)
+        kinfo = torch.cat([kinfo_p, (4 << 24) | s_idx], 1).to(torch.int32).contiguous()  # cumsum promoted to int64
+        qinfo = torch.cat([qinfo_p, (6 << 24) | s_idx], 1).to(torch.int32).contiguous()
+        ppos = torch.cumsum(prefix_mask.to(torch.int32), 1) - 1
+        spos = pma.sum(-1, keepdim=True).to(torch.int32) + torch.arange(S, dtype=torch.int32, device=dev)[None]
+        pos = torch.cat([ppos, spos], 1).to(torch.int32).contiguous()
+        return qinfo, kinfo, pos
+
+    def _serve_infos(self, obs: CoTObservation, S: int):
+        """sample_actions masks (lap.py:624-654): prefix attends per make_attn_mask(prefix_mask, prefix_ar); suffix
+        queries see every valid prefix token and all suffix tokens; suffix positions follow sum(prefix_mask)."""
+        prefix_mask, prefix_ar = self._prefix_masks(obs)
+        B, Pn = prefix_mask.shape
+        dev = prefix_mask.device
+        cs = torch.cumsum(prefix_ar.to(torch.int32), 1)
+        pm = prefix_mask.to(torch.int32)
+        kinfo_p = ((pm | (pm << 1)) << 24) | cs
+        qinfo_p = (pm << 24) | cs
+        s_idx = torch.full((B, S), SUFFIX_IDX_BASE + 1, dtype=torch.int32, device=dev)
+        kinfo_s, qinfo_s = (4 << 24) | s_idx, (6 << 24) | s_idx
+        ppos = (torch.cumsum(pm, 1) - 1).to(torch.int32).contiguous()
+        spos = (pm.sum(-1, keepdim=True) + torch.arange(S, dtype=torch.int32, device=dev)[None]).to(torch.int32)
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        return (i32(qinfo_p), i32(kinfo_p), ppos, i32(qinfo_s), i32(torch.cat([kinfo_p, kinfo_s], 1)), i32(torch.cat([ppos, spos], 1)))
+
+    # ================================================================== embedding of the two streams
+    def _embed_prefix(self, obs: CoTObservation, save: bool, collect=None):
+        """lap.py:118-170 -> x0 bf16 [B*Pn, Dv] with rows (b, [img0 | img1 | prompt])."""
+        cfg = self.config
+        keys = cfg.image_keys
+        B = obs.tokenized_prompt.shape[0]
+        T, Lt, Dv = self.n_img_tok, obs.tokenized_prompt.shape[1], self.v.width
+        Pn = T * len(keys) + Lt
+        images = torch.cat([obs.images[k] for k in keys], 0)
+        tok, ictx = self._siglip_fwd(images, save, collect)
+        x0 = torch.empty((B * Pn, Dv), dtype=torch.bfloat16, device=self.device)
+        for i in range(len(keys)):
+            hip.copy_rows_bf16(tok[i * B * T:(i + 1) * B * T], x0, B * T, T, Dv, T, 0, Pn, i * T)
+        self.comm.wait_unit("embed")
+        tokens = obs.tokenized_prompt.to(torch.int32).contiguous()
+        rows, lo, hi = self.ps.embed_rows()
+        if self.comm.world_size == 1:
+            hip.embed_gather(rows, tokens, x0, B * Lt, Lt, Dv, Pn, T * len(keys), math.sqrt(Dv), lo, hi)
+        else:
+            self.comm.sharded_embed_gather(rows, lo, hi, tokens, x0, Lt, Dv, Pn, T * len(keys), math.sqrt(Dv))
+        return x0, Pn, (ictx, tokens)
+
+    def _embed_prefix_bwd(self, pctx, dx0, B, Pn):
+        ictx, tokens = pctx
+        keys = self.config.image_keys
+        T, Lt, Dv = self.n_img_tok, tokens.shape[1], self.v.width
+        hip.embed_scatter_add(self.G("llm/embed"), tokens, dx0, B * Lt, Lt, Dv, Pn, T * len(keys), math.sqrt(Dv))
+        self.comm.grads_ready("embed")
+        dtok = torch.empty((len(keys) * B * T, Dv), dtype=torch.bfloat16, device=self.device)
+        for i in range(len(keys)):
+            hip.copy_rows_bf16(dx0, dtok[i * B * T:(i + 1) * B * T], B * T, T, Dv, Pn, i * T, T, 0)
+        self._siglip_bwd(ictx, dtok)
+
+    def _embed_suffix(self, x_t: torch.Tensor, time: torch.Tensor, save: bool):
+        """[UPSTREAM-RECALL] openpi Pi0.embed_suffix (pi05): action tokens, adaRMS condition."""
+        B, S, ad = x_t.shape
+        We = self.e.width
+        xt2 = x_t.reshape(B * S, ad).contiguous()
+        a_tok = self._lin32(xt2, "act/in_w", "act/in_b")
+        x1 = hip.cast_f32_to_bf16(a_tok)
+        temb = hip.posemb_sincos(time.contiguous(), We, 4e-3, 4.0)
+        h1 = self._lin32(temb, "act/time_in_w", "act/time_in_b")
+        s1 = hip.swish_fwd(h1)
+        h2 = self._lin32(s1, "act/time_out_w", "act/time_out_b")
+        cond = hip.swish_fwd(h2)
+        cond16 = hip.cast_f32_to_bf16(cond)
+        self.comm.wait_unit("ada")
+        mod = hip.linear_fwd(cond16, self.W("ada/w"), bias=self.F("ada/b"))   # [B, nslots*3We] bf16 (gemma.py:128)
+        return x1, mod, ((xt2, temb, h1, s1, h2, cond16) if save else None)
+
+    def _embed_suffix_bwd(self, sctx, dx1, dmod):
+        xt2, temb, h1, s1, h2, cond16 = sctx
+        dmod16 = hip.cast_f32_to_bf16(dmod)
+        hip.colsum(dmod, self.G("ada/b"))
+        hip.linear_wgrad(dmod16, cond16, self.G("ada/w"))
+        dcond = hip.cast_bf16_to_f32(hip.linear_dgrad(dmod16, self.W("ada/w")))
+        self.comm.grads_ready("ada")
+        dh2 = hip.swish_bwd(h2, dcond)
+        ds1 = self._lin32_bwd(s1, dh2, "act/time_out_w", "act/time_out_b")
+        dh1 = hip.swish_bwd(h1, ds1)
+        self._lin32_bwd(temb, dh1, "act/time_in_w", "act/time_in_b", need_dx=False)
+        self._lin32_bwd(xt2, hip.cast_bf16_to_f32(dx1), "act/in_w", "act/in_b", need_dx=False)
+
+    # ================================================================== joint Gemma layers
+    def _mod_slot(self, mod, slot):
+        W3 = 3 * self.e.width
+        return mod[:, slot * W3:(slot + 1) * W3]
+
+    def _llm_fwd(self, x0, x1, mod, pos, qinfo, kinfo, B, n0, n1, save: bool, kv_cache=None, cache_out=None, collect=None):
+        """gemma.Module.__call__ layers (gemma.py:336-387,167-290).  x0 [B*n0, Dv] or None, x1 [B*n1, De] or None.
+        kv_cache: per-layer (k, v) of the prefix used as key segment 0 when x0 is None (serving).
+        Returns final pre-norm activations and the saved context."""
+        v, e = self.v, self.e
+        NH, HD, KV = v.num_heads, v.head_dim, v.num_kv_heads
+        Ttot = pos.shape[1]
+        ctx = [] if save else None
+        for l in range(v.depth):
+            self.comm.wait_unit(f"llm{l}")
+            p = f"llm/{l}/"
+            q = [None, None]; k = [None, None]; vv = [None, None]; h = [None, None]; rstd_a = [None, None]
+            if x0 is not None:
+                h[0], rstd_a[0] = hip.rmsnorm_fwd(x0, scale=self.F(p + "n_attn"), save_rstd=save)
+                qkv = hip.linear_fwd(h[0], self.W(p + "wqkv0"))
+                q[0], k[0], vv[0] = hip.rope_split_fwd(qkv, pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5)
+                del qkv
+            elif kv_cache is not None:
+                k[0], vv[0] = kv_cache[l]
+            if x1 is not None:
+                h[1], rstd_a[1] = hip.rmsnorm_fwd(x1, mod=self._mod_slot(mod, 2 * l), rows_per_sample=n1, save_rstd=save)
+                qkv = hip.linear_fwd(h[1], self.W(p + "wqkv1"))
+                q[1], k[1], vv[1] = hip.rope_split_fwd(qkv, pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
+                del qkv
+            if cache_out is not None:
+                cache_out.append((k[0], vv[0]))
+            qlen = [n0 if x0 is not None else 0, n1 if x1 is not None else 0]
+            klen = [k[0].shape[0] // B if k[0] is not None else 0, n1 if x1 is not None else 0]
+            o, lse = hip.attention_fwd(q, k, vv, qlen, klen, B, NH, KV, HD, qinfo, kinfo, need_lse=save)
+            xa = [None, None]; y1 = None; hf = [None, None]; rstd_f = [None, None]; gu = [None, None]; act = [None, None]; y1f = None
+            xn = [None, None]
+            if x0 is not None:
+                xa[0] = hip.linear_fwd(o[0], self.W(p + "wo0"), residual=x0)
+                hf[0], rstd_f[0] = hip.rmsnorm_fwd(xa[0], scale=self.F(p + "n_ffw"), save_rstd=save)
+                gu[0] = hip.linear_fwd(hf[0], self.W(p + "wgu0"))
+                act[0] = hip.geglu_fwd(gu[0])
+                xn[0] = hip.linear_fwd(act[0], self.W(p + "wd0"), residual=xa[0])
+            if x1 is not None:
+                We3 = 3 * e.width
+                y1 = hip.linear_fwd(o[1], self.W(p + "wo1"))
+                xa[1] = hip.gated_residual_fwd(x1, y1, self._mod_slot(mod, 2 * l)[:, 2 * e.width:], n1, mod.stride(0))
+                hf[1], rstd_f[1] = hip.rmsnorm_fwd(xa[1], mod=self._mod_slot(mod, 2 * l + 1), rows_per_sample=n1, save_rstd=save)
+                gu[1] = hip.linear_fwd(hf[1], self.W(p + "wgu1"))
+                act[1] = hip.geglu_fwd(gu[1])
+                y1f = hip.linear_fwd(act[1], self.W(p + "wd1"))
+                xn[1] = hip.gated_residual_fwd(xa[1], y1f, self._mod_slot(mod, 2 * l + 1)[:, 2 * e.width:], n1, mod.stride(0))
+            if save:
+                ctx.append(dict(x=[x0, x1], h=h, rstd_a=rstd_a, q=q, k=k, v=vv, o=o, lse=lse, xa=xa, y1=y1, hf=hf, rstd_f=rstd_f,
+                                gu=gu, act=act, y1f=y1f))
+            x0, x1 = xn
+            if collect is not None:
+                collect[f"llm/layer{l:02d}/x0"], collect[f"llm/layer{l:02d}/x1"] = x0, x1
+        return x0, x1, ctx
+
+    def _llm_bwd(self, ctx, dx0, dx1, mod, dmod, pos, qinfo, kinfo, B, n0, n1):
+        v, e = self.v, self.e
+        NH, HD, KV = v.num_heads, v.head_dim, v.num_kv_heads
+        Ttot = pos.shape[1]
+        ldm = mod.stride(0)
+        for l in reversed(range(v.depth)):
+            p = f"llm/{l}/"
+            c = ctx[l]
+            d_o = [None, None]
+            # ---- FFN, prefix stream: xn = xa + act @ wd^T
+            hip.linear_wgrad(dx0, c["act"][0], self.G(p + "wd0"))
+            dact = hip.linear_dgrad(dx0, self.W(p + "wd0"))
+            dgu = hip.geglu_bwd(c["gu"][0], dact)
+            del dact
+            hip.linear_wgrad(dgu, c["hf"][0], self.G(p + "wgu0"))
+            dhf = hip.linear_dgrad(dgu, self.W(p + "wgu0"))
+            del dgu
+            hip.rmsnorm_bwd(c["xa"][0], dhf, c["rstd_f"][0], scale=self.F(p + "n_ffw"), dx=dx0, dscale=self.G(p + "n_ffw"), accum_dx=True)
+            del dhf
+            hip.linear_wgrad(dx0, c["o"][0], self.G(p + "wo0"))
+            d_o[0] = hip.linear_dgrad(dx0, self.W(p + "wo0"))
+            # ---- FFN, suffix stream: xn = xa + y1f * gate_f
+            slot_f, slot_a = 2 * l + 1, 2 * l
+            gate_f = self._mod_slot(mod, slot_f)[:, 2 * e.width:]
+            dy1f = hip.gated_residual_bwd(dx1, c["y1f"], gate_f, n1, ldm, self._mod_slot(dmod, slot_f)[:, 2 * e.width:], dmod.stride(0))
+            hip.linear_wgrad(dy1f, c["act"][1], self.G(p + "wd1"))
+            dact = hip.linear_dgrad(dy1f, self.W(p + "wd1"))
+            dgu = hip.geglu_bwd(c["gu"][1], dact)
+            hip.linear_wgrad(dgu, c["hf"][1], self.G(p + "wgu1"))
+            dhf = hip.linear_dgrad(dgu, self.W(p + "wgu1"))
+            hip.rmsnorm_bwd(c["xa"][1], dhf, c["rstd_f"][1], mod=self._mod_slot(mod, slot_f), rows_per_sample=n1, dx=dx1,
+                            dmod=self._mod_slot(dmod, slot_f), accum_dx=True)
+            gate_a = self._mod_slot(mod, slot_a)[:, 2 * e.width:]
+            dy1 = hip.gated_residual_bwd(dx1, c["y1"], gate_a, n1, ldm, self._mod_slot(dmod, slot_a)[:, 2 * e.width:], dmod.stride(0))
+            hip.linear_wgrad(dy1, c["o"][1], self.G(p + "wo1"))
+            d_o[1] = hip.linear_dgrad(dy1, self.W(p + "wo1"))
+            # ---- attention
+            dq, dk, dv = hip.attention_bwd(c["q"], c["k"], c["v"], c["o"], d_o, c["lse"], [n0, n1], [n0, n1], B, NH, KV, HD, qinfo, kinfo,
+                                           stop_q1_to_k0=self.config.stop_action_to_vlm_grad)
+            dqkv = hip.rope_split_bwd(dq[0], dk[0], dv[0], pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5)
+            hip.linear_wgrad(dqkv, c["h"][0], self.G(p + "wqkv0"))
+            dh = hip.linear_dgrad(dqkv, self.W(p + "wqkv0"))
+            hip.rmsnorm_bwd(c["x"][0], dh, c["rstd_a"][0], scale=self.F(p + "n_attn"), dx=dx0, dscale=self.G(p + "n_attn"), accum_dx=True)
+            dqkv = hip.rope_split_bwd(dq[1], dk[1], dv[1], pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
+            hip.linear_wgrad(dqkv, c["h"][1], self.G(p + "wqkv1"))
+            dh = hip.linear_dgrad(dqkv, self.W(p + "wqkv1"))
+            hip.rmsnorm_bwd(c["x"][1], dh, c["rstd_a"][1], mod=self._mod_slot(mod, slot_a), rows_per_sample=n1, dx=dx1,
+                            dmod=self._mod_slot(dmod, slot_a), accum_dx=True)
+            ctx[l] = None
+            self.comm.grads_ready(f"llm{l}")
+        return dx0, dx1
+
+    # ================================================================== training forward (+ backward)
+    def _loss_impl(self, rng, observation: CoTObservation, actions: torch.Tensor, *, train: bool, noise=None, time=None,
+                   backward: bool, collect: dict | None = None):
+        cfg = self.config
+        if not (cfg.enable_action_training and cfg.enable_langact_training):
+            raise NotImplementedError("lap_amd implements the LAP-3B training path: action + langact losses enabled")
+        if cfg.enable_vqa_training or cfg.enable_prediction_training:
+            raise NotImplementedError("VQA / prediction loss mixing is not on the benchmarked path")
+        dev = self.device
+        obs = preprocess_observation(observation, train=train, image_keys=cfg.image_keys, image_resolution=cfg.image_resolution,
+                                     enable_image_augmentation=cfg.enable_image_augmentation)
+        actions = actions.to(dev, torch.float32).contiguous()
+        B, S, ad = actions.shape
+        if S != self.action_horizon:
+            raise ValueError(f"actions horizon {S} != action_horizon {self.action_horizon}")
+        # lap.py:185-207 prepare_suffix — noise ~ N(0,1), time ~ Beta(1.5, 1) * 0.999 + 0.001
+        g = _gen(rng, dev)
+        if noise is None:
+            noise = torch.randn(actions.shape, generator=g, device=dev, dtype=torch.float32)
+        if time is None:
+            u1 = torch.rand(B, generator=g, device=dev, dtype=torch.float32)
+            time = u1.pow(1.0 / 1.5) * 0.999 + 0.001  # Beta(a, 1) by inverse CDF
+        noise = noise.to(dev, torch.float32).contiguous(); time = time.to(dev, torch.float32).contiguous()
+        x_t, u_t = hip.fm_mix(noise, actions, time)
+        x1, mod, sctx = self._embed_suffix(x_t, time, backward)
+        x0, Pn, pctx = self._embed_prefix(obs, backward, collect)
+        qinfo, kinfo, pos = self._train_infos(obs, S)
+        if collect is not None:
+            collect["x0_in"], collect["x1_in"], collect["pos"], collect["mod"] = x0, x1, pos, mod
+        xf0, xf1, lctx = self._llm_fwd(x0, x1, mod, pos, qinfo, kinfo, B, Pn, S, backward, collect=collect)
+        if collect is not None:
+            collect["x0_out"], collect["x1_out"] = xf0, xf1
+
+        # ---- language loss (lap.py:209-289): rows Pn-Lt .. Pn-2 predict tokens 1 .. Lt-1
+        Lt = obs.tokenized_prompt.shape[1]
+        Dv, V = self.v.width, cfg.vocab_size
+        R = B * (Lt - 1)
+        rows = torch.empty((R, Dv), dtype=torch.bfloat16, device=dev)
+        hip.copy_rows_bf16(xf0, rows, R, Lt - 1, Dv, Pn, Pn - Lt, Lt - 1, 0)
+        pl, rstd_pl = hip.rmsnorm_fwd(rows, scale=self.F("llm/final_norm"), save_rstd=backward)
+        table16 = self.W("llm/embed")
+        targets = obs.tokenized_prompt[:, 1:].to(torch.int32).contiguous().view(-1)
+        # vocab chunks: one when [R, V] bf16 stays below the 2 GiB buffer-descriptor range of the GEMM (B <= 32 here)
+        vc_max = max(1024, (int(1.5e9) // (2 * R)) // 1024 * 1024)
+        chunks = [(v0, min(vc_max, V - v0)) for v0 in range(0, V, vc_max)]
+        m = torch.full((R,), -3.0e38, dtype=torch.float32, device=dev)
+        lsum = torch.zeros(R, dtype=torch.float32, device=dev); tl = torch.zeros(R, dtype=torch.float32, device=dev)
+        logit_chunks = []
+        for v0, vc in chunks:
+            lg = torch.empty((R, vc), dtype=torch.float32, device=dev)
+            hip.gemm(pl, table16[v0:v0 + vc], lg, M=R, N=vc, K=Dv, lda=Dv, ldb=Dv, ldc=vc)
+            hip.ce_chunk_update(lg, targets, m, lsum, tl, v0)
+            logit_chunks.append(lg if backward else None)
+        nll = (m + torch.log(lsum) - tl).view(B, Lt - 1)
+        loss_mask = obs.tokenized_langact_mask[:, 1:] & obs.tokenized_prompt_mask[:, 1:]
+        if obs.token_loss_mask is not None:
+            loss_mask = loss_mask & obs.token_loss_mask[:, 1:]
+        lm = loss_mask.to(torch.float32)
+        if obs.sample_mask is not None:
+            lm = lm * obs.sample_mask[:, None].to(torch.float32)
+        cnt = torch.clamp(lm.sum(-1), min=1.0)
+        lang_loss = (nll * lm).sum(-1) / cnt
+        # ---- action loss (lap.py:291-301)
+        pre1, rstd_p1 = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=backward)
+        pre1f = hip.cast_bf16_to_f32(pre1)
+        v_t = self._lin32(pre1f, "act/out_w", "act/out_b")  # [B*S, ad]
+        # ---- combination (lap.py:542-596; VQA / prediction masks absent)
+        nB = self.comm.all_reduce_sum(torch.tensor([float(B)], device=dev))
+        if obs.sample_mask is not None:
+            n_active = torch.clamp(self.comm.all_reduce_sum(obs.sample_mask.to(torch.float32).sum().view(1)), min=1.0)
+        else:
+            n_active = nB
+        coef = torch.full((B,), cfg.action_loss_weight, dtype=torch.float32, device=dev) / nB
+        act_loss, dv = hip.mse_fwd_bwd(v_t.view(B, S * ad), u_t.view(B, S * ad), coef, need_grad=backward)
+        lang_term = (cfg.language_loss_weight * lang_loss).sum() / n_active
+        action_term = (cfg.action_loss_weight * act_loss).sum() / nB
+        loss = self.comm.all_reduce_sum((lang_term + action_term).view(1)).view(())
+        metrics = {"lang_loss": lang_loss.mean(), "action_loss": act_loss.mean(), "langact_loss": lang_loss.mean()}
+        if collect is not None:
+            collect.update(pl=pl, pre1=pre1, v_t=v_t.view(B, S, ad), u_t=u_t, per_sample_lang=lang_loss, per_sample_action=act_loss)
+        if not backward:
+            return loss, metrics
+
+        # =============================== backward ===============================
+        We = self.e.width
+        dmod = torch.zeros(mod.shape, dtype=torch.float32, device=dev)
+        # action head
+        dpre1f = self._lin32_bwd(pre1f, dv.view(B * S, ad), "act/out_w", "act/out_b")
+        dx1 = hip.rmsnorm_bwd(xf1, hip.cast_f32_to_bf16(dpre1f), rstd_p1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S,
+                              dmod=self._mod_slot(dmod, 2 * self.v.depth))
+        # language head: dlogits = w * (softmax - onehot); w = d loss / d nll
+        w = (cfg.language_loss_weight * lm / cnt[:, None] / n_active).contiguous().view(-1)
+        dpl32 = torch.empty((R, Dv), dtype=torch.float32, device=dev) if len(chunks) > 1 else None
+        gE = self.G("llm/embed")
+        for ci, (v0, vc) in enumerate(chunks):
+            dlogits = torch.empty((R, vc), dtype=torch.bfloat16, device=dev)
+            hip.ce_chunk_grad(logit_chunks[ci], targets, m, lsum, w, dlogits, v0)
+            logit_chunks[ci] = None
+            hip.linear_wgrad(dlogits, pl, gE[v0:v0 + vc])
+            if dpl32 is None:
+                dpl = hip.linear_dgrad(dlogits, table16[v0:v0 + vc])
+            else:
+                hip.linear_dgrad(dlogits, table16[v0:v0 + vc], out=dpl32, accum=ci > 0)
+            del dlogits
+        if dpl32 is not None:
+            dpl = hip.cast_f32_to_bf16(dpl32)
+        drows = hip.rmsnorm_bwd(rows, dpl, rstd_pl, scale=self.F("llm/final_norm"), dscale=self.G("llm/final_norm"))
+        dx0 = torch.zeros((B * Pn, Dv), dtype=torch.bfloat16, device=dev)
+        hip.copy_rows_bf16(drows, dx0, R, Lt - 1, Dv, Lt - 1, 0, Pn, Pn - Lt)
+        dx0, dx1 = self._llm_bwd(lctx, dx0, dx1, mod, dmod, pos, qinfo, kinfo, B, Pn, S)
+        self._embed_suffix_bwd(sctx, dx1, dmod)
+        self._embed_prefix_bwd(pctx, dx0, B, Pn)
+        self.comm.grads_ready("small")
+        return loss, metrics
+
+    def compute_loss(self, rng, observation, actions, *, train: bool = False, stage_config=None, verbose_mode=None,
+                     return_augmented_images: bool = False, noise=None, time=None, collect=None):
+        """lap.py:380-602.  rng: int seed or torch.Generator.  `noise` / `time` may be given explicitly (parity tests)."""
+        return self._loss_impl(rng, observation, actions, train=train, noise=noise, time=time, backward=False, collect=collect)
+
+    def loss_and_grad(self, rng, observation, actions, *, train: bool = True, noise=None, time=None, collect=None):
+        """Forward + backward; gradients land in self.ps.grad (f32, engine layout).  Caller zeroes them first."""
+        return self._loss_impl(rng, observation, actions, train=train, noise=noise, time=time, backward=True, collect=collect)
+
+    # ================================================================== serving
+    @torch.no_grad()
+    def sample_actions(self, rng, observation, *, num_steps: int = 10, noise=None, collect=None):
+        """lap.py:605-675: prefix prefill once -> per-layer K/V kept in HBM -> `num_steps` Euler steps of the action
+        expert attending to [cached prefix | fresh suffix] as two key segments (the reference concatenates, gemma.py:228-230)."""
+        cfg = self.config
+        dev = self.device
+        obs = preprocess_observation(observation, train=False, image_keys=cfg.image_keys, image_resolution=cfg.image_resolution)
+        B = obs.tokenized_prompt.shape[0]
+        S, ad = self.action_horizon, self.action_dim
+        if noise is None:
+            noise = torch.randn((B, S, ad), generator=_gen(rng, dev), device=dev, dtype=torch.float32)
+        x_t = noise.to(dev, torch.float32).contiguous().clone()
+        x0, Pn, _ = self._embed_prefix(obs, False)
+        qinfo_p, kinfo_p, ppos, qinfo_s, kinfo_all, pos_all = self._serve_infos(obs, S)
+        cache = []
+        self._llm_fwd(x0, None, None, ppos, qinfo_p, kinfo_p, B, Pn, 0, False, cache_out=cache)
+        dt = -1.0 / num_steps
+        t = 1.0
+        step = 0
+        tbuf = torch.empty(B, dtype=torch.float32, device=dev)
+        while t >= -dt / 2:
+            tbuf.fill_(t)
+            x1, mod, _ = self._embed_suffix(x_t, tbuf, False)
+            _, xf1, _ = self._llm_fwd(None, x1, mod, pos_all, qinfo_s, kinfo_all, B, Pn, S, False, kv_cache=cache)
+            pre1, _ = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=False)
+            v_t = self._lin32(hip.cast_bf16_to_f32(pre1), "act/out_w", "act/out_b")
+            if collect is not None:
+                collect[f"v_t/{step}"] = v_t.view(B, S, ad).clone()
+            hip.axpy_f32(x_t, v_t, dt)
+            t += dt
+            step += 1
+        return x_t
+
+    def sample_tokens(self, *a, **k):
+        raise NotImplementedError("AR token sampling (lap.py:678-766) is a 'next' row of SURVEY.md §8(f)")

@@ -1,0 +1,107 @@
+"""CoTObservation — the model-input record of the reference (src/lap/models/model_adapter.py:37-80 on top of
+openpi.models.model.Observation), as a plain dataclass of torch tensors, plus preprocess_observation
+(model_adapter.py:83-181) for the augmentation-off path used by `lap_libero` / the benchmark configs.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+import torch
+
+
+def _t(x, dtype=None, device=None):
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    elif not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(x)
+    if dtype is not None:
+        x = x.to(dtype)
+    if device is not None:
+        x = x.to(device)
+    return x
+
+
+@dataclasses.dataclass
+class CoTObservation:
+    images: dict            # key -> f32 [B,H,W,3] in [-1,1]
+    image_masks: dict       # key -> bool [B]
+    state: torch.Tensor | None = None                 # f32 [B, action_dim]
+    tokenized_prompt: torch.Tensor | None = None      # i32 [B, L]
+    tokenized_prompt_mask: torch.Tensor | None = None  # bool [B, L]
+    token_ar_mask: torch.Tensor | None = None
+    token_loss_mask: torch.Tensor | None = None       # bool [B, L]
+    tokenized_langact_mask: torch.Tensor | None = None  # bool [B, L]
+    critical_token_mask: torch.Tensor | None = None
+    number_token_mask: torch.Tensor | None = None
+    direction_token_mask: torch.Tensor | None = None
+    sample_mask: torch.Tensor | None = None           # bool [B]
+    tokenized_dataset_name: torch.Tensor | None = None
+    is_vqa_sample: torch.Tensor | None = None
+    is_prediction_sample: torch.Tensor | None = None
+    vqa_dataset_id: torch.Tensor | None = None
+
+    @classmethod
+    def from_dict(cls, data: dict, device=None) -> "CoTObservation":
+        """openpi Observation.from_dict + CoT extras (model_adapter.py:51-80): accepts `image` / `image_mask`
+        keys, uint8 images (converted to [-1, 1] floats) and flat or `extras.cot` CoT fields."""
+        if ("tokenized_prompt" in data) != ("tokenized_prompt_mask" in data):
+            raise ValueError("tokenized_prompt and tokenized_prompt_mask must be provided together.")
+        images = {}
+        for k, v in data["image"].items():
+            v = _t(v, device=device)
+            if v.dtype == torch.uint8:
+                v = v.to(torch.float32) / 255.0 * 2.0 - 1.0
+            images[k] = v.to(torch.float32)
+        cot = data.get("extras", {}).get("cot", {}) if isinstance(data.get("extras"), dict) else {}
+        g = lambda k: data.get(k, cot.get(k))
+        b = lambda k: _t(g(k), torch.bool, device)
+        return cls(
+            images=images,
+            image_masks={k: _t(v, torch.bool, device) for k, v in data.get("image_mask", {}).items()},
+            state=_t(data.get("state"), torch.float32, device),
+            tokenized_prompt=_t(data.get("tokenized_prompt"), torch.int32, device),
+            tokenized_prompt_mask=b("tokenized_prompt_mask"),
+            token_ar_mask=_t(data.get("token_ar_mask"), None, device),
+            token_loss_mask=b("token_loss_mask"),
+            tokenized_langact_mask=b("tokenized_langact_mask"),
+            critical_token_mask=b("critical_token_mask"),
+            number_token_mask=b("number_token_mask"),
+            direction_token_mask=b("direction_token_mask"),
+            sample_mask=b("sample_mask"),
+            tokenized_dataset_name=_t(g("tokenized_dataset_name"), None, device),
+            is_vqa_sample=b("is_vqa_sample"),
+            is_prediction_sample=b("is_prediction_sample"),
+            vqa_dataset_id=_t(g("vqa_dataset_id"), None, device),
+        )
+
+    def to(self, device) -> "CoTObservation":
+        mv = lambda x: x.to(device) if isinstance(x, torch.Tensor) else x
+        d = {f.name: getattr(self, f.name) for f in dataclasses.fields(self)}
+        d["images"] = {k: mv(v) for k, v in self.images.items()}
+        d["image_masks"] = {k: mv(v) for k, v in self.image_masks.items()}
+        return CoTObservation(**{k: (v if k in ("images", "image_masks") else mv(v)) for k, v in d.items()})
+
+
+def preprocess_observation(observation: CoTObservation, *, train: bool, image_keys, image_resolution,
+                           enable_image_augmentation: bool = True) -> CoTObservation:
+    """model_adapter.py:83-181 without augmax: selects the image keys, checks the resolution and fills default
+    image masks.  Train-time augmentation (RandomCrop 95% / Resize / Rotate +-5 deg / ColorJitter) is a listed
+    'next' item (SURVEY.md §8 a-bis); asking for it raises instead of silently skipping it."""
+    if train and enable_image_augmentation:
+        raise NotImplementedError("image augmentation is not implemented; use a config with enable_image_augmentation=False")
+    images, masks = {}, {}
+    batch = None
+    for key in image_keys:
+        if key not in observation.images:
+            raise ValueError(f"images dict missing key {key}; got {list(observation.images)}")
+        img = observation.images[key]
+        if tuple(img.shape[1:3]) != tuple(image_resolution):
+            raise NotImplementedError(f"resize_with_pad {tuple(img.shape[1:3])} -> {image_resolution} is not implemented")
+        images[key] = img
+        batch = img.shape[0]
+        m = observation.image_masks.get(key)
+        masks[key] = m if m is not None else torch.ones(batch, dtype=torch.bool, device=img.device)
+    return dataclasses.replace(observation, images=images, image_masks=masks)

@@ -133,7 +133,7 @@ def init_params(cfg: OracleCfg, seed: int = 0, zero_init_like_reference: bool = 
 
     v, e = cfg.vlm, cfg.expert
     L = v.depth
-    P["PaliGemma/llm/embedder/input_embedding"] = normal(cfg.vocab_size, v.width, std=0.02 if cfg.vocab_size > 10000 else 1.0)
+    P["PaliGemma/llm/embedder/input_embedding"] = normal(cfg.vocab_size, v.width, std=0.02 if cfg.vocab_size > 10000 else 0.3)
     for i, c in enumerate((v, e)):
         sfx = "" if i == 0 else f"_{i}"
         P[f"PaliGemma/llm/layers/attn/q_einsum{sfx}/w"] = normal(L, c.num_heads, c.width, c.head_dim, std=c.width ** -0.5)
@@ -274,6 +274,8 @@ def siglip_forward(P, cfg: OracleCfg, image: torch.Tensor, collect: dict | None 
         if collect is not None:
             collect[f"img/block{l:02d}"] = x
     x = ln(x, P["PaliGemma/img/Transformer/encoder_norm/scale"], P["PaliGemma/img/Transformer/encoder_norm/bias"])
+    if collect is not None:
+        collect["img/encoded"] = x
     x = r(r(x @ r(P["PaliGemma/img/head/kernel"])) + r(P["PaliGemma/img/head/bias"]))
     if collect is not None:
         collect["img/out"] = x

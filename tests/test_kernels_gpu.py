@@ -337,7 +337,7 @@ def test_attention_lap_mask_two_segments(hip, HD, Tp, S, n_lang, n_pad, stop):
     else:
         ref = _attn_ref(qf, torch.cat([kf0, kf1], 1), torch.cat([vf0, vf1], 1), mask, NH, NKV)
     valid_q = mask.any(-1)  # padding rows are never consumed
-    o = torch.cat([o0, o1], 1).view(B, Tp + S, NH, HD)
+    o = torch.cat([o0.view(B, Tp, -1), o1.view(B, S, -1)], 1).view(B, Tp + S, NH, HD)
     assert rel_err(o[valid_q], ref[valid_q]) < 1e-2
     assert o[~valid_q].abs().sum() == 0
     do0 = rnd(B, Tp, NH * HD, seed=3); do1 = rnd(B, S, NH * HD, seed=4)
@@ -350,6 +350,34 @@ def test_attention_lap_mask_two_segments(hip, HD, Tp, S, n_lang, n_pad, stop):
     assert rel_err(dqc, qf.grad) < 2e-2
     assert rel_err(dk[0].view_as(kf0), kf0.grad) < 2e-2 and rel_err(dk[1].view_as(kf1), kf1.grad) < 2e-2
     assert rel_err(dv[0].view_as(vf0), vf0.grad) < 2e-2 and rel_err(dv[1].view_as(vf1), vf1.grad) < 2e-2
+
+
+def test_attention_fused_qkv_strided(hip):
+    # SigLIP layout: q|k|v are column slices of one [rows, 3*NH*HD] buffer; gradients land in a fused dqkv buffer
+    B, T, NH, HD = 2, 100, 4, 72
+    W = NH * HD
+    qkv = rnd(B * T, 3 * W, scale=0.5)
+    q, k, v = qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:]
+    sc = HD ** -0.5
+    (o, _), lse = hip.attention_fwd([q], [k], [v], [T], [T], B, NH, NH, HD, scale=sc, q_rs=(3 * W, 0), kv_rs=(3 * W, 0))
+    x = qkv.float().view(B, T, 3, NH, HD).requires_grad_(True)
+    ref = _attn_ref(x[:, :, 0] * sc, x[:, :, 1], x[:, :, 2], None, NH, NH)
+    assert rel_err(o.view(B, T, NH, HD), ref) < 1e-2
+    do = rnd(B * T, W, seed=1)
+    (ref * do.float().view(B, T, NH, HD)).sum().backward()
+    dqkv = torch.zeros_like(qkv)
+    hip.attention_bwd([q], [k], [v], [o], [do], lse, [T], [T], B, NH, NH, HD, scale=sc, q_rs=(3 * W, 0), kv_rs=(3 * W, 0),
+                      dq_out=[dqkv[:, :W]], dk_out=[dqkv[:, W:2 * W]], dv_out=[dqkv[:, 2 * W:]])
+    assert rel_err(dqkv.view(B, T, 3, NH, HD), x.grad) < 2e-2
+
+
+def test_colsum(hip):
+    x = rnd(300, 200); out = torch.zeros(136, device=DEV)
+    hip.colsum(x[:, 8:144], out)
+    assert rel_err(out, x[:, 8:144].float().sum(0)) < 1e-5
+    xf = rnd(70, 33, dtype=torch.float32); o2 = torch.ones(33, device=DEV)
+    hip.colsum(xf, o2)
+    assert rel_err(o2, 1 + xf.sum(0)) < 1e-5
 
 
 def test_attention_suffix_only_queries(hip):
