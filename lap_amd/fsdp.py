@@ -35,6 +35,8 @@ class FsdpComm:
         if store.world_size != self.world_size or store.rank != self.rank:
             raise ValueError("ParamStore world_size/rank do not match the process group")
         self.is_cuda = store.device.type == "cuda"
+        # RCCL ("nccl") has the fused tensor collectives; gloo (CPU tests, single-GPU multi-process tests) does not
+        self.fused = dist.get_backend(group) == "nccl"
         self.side = torch.cuda.Stream(device=store.device) if self.is_cuda else None
         self.param_events: dict[str, object] = {}
         self._pending_grads = False
@@ -57,7 +59,7 @@ class FsdpComm:
                     continue
                 full = self.ps.full16[u.name]
                 a, b = self.ps.shard_range(u)
-                dist.all_gather_into_tensor(full, full[a:b], group=self.group)
+                self._all_gather(full, full[a:b])
                 if self.is_cuda:
                     ev = torch.cuda.Event()
                     ev.record(self.side)
@@ -73,7 +75,7 @@ class FsdpComm:
         u = self.ps.unit_by_name[name]
         with self._on_side():
             if self.ps.sharded(u):
-                dist.reduce_scatter_tensor(self.ps.gshard[name], self.ps.grad[name], op=dist.ReduceOp.SUM, group=self.group)
+                self._reduce_scatter(self.ps.gshard[name], self.ps.grad[name])
             else:
                 dist.all_reduce(self.ps.grad[name], op=dist.ReduceOp.SUM, group=self.group)
         self._pending_grads = True
@@ -82,6 +84,24 @@ class FsdpComm:
         if self.is_cuda and self._pending_grads:
             torch.cuda.current_stream().wait_stream(self.side)
         self._pending_grads = False
+
+    # ---- backend shims
+    def _all_gather(self, full: torch.Tensor, mine: torch.Tensor):
+        if self.fused:
+            dist.all_gather_into_tensor(full, mine, group=self.group)  # in place: `mine` is full[rank*n:(rank+1)*n]
+        else:
+            parts = [torch.empty_like(mine) for _ in range(self.world_size)]
+            dist.all_gather(parts, mine.clone(), group=self.group)
+            full.copy_(torch.cat(parts))
+
+    def _reduce_scatter(self, out: torch.Tensor, full: torch.Tensor):
+        if self.fused:
+            dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            tmp = full.clone()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+            n = out.numel()
+            out.copy_(tmp[self.rank * n:(self.rank + 1) * n])
 
     # ---- small collectives on the compute stream
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
@@ -92,9 +112,9 @@ class FsdpComm:
         B = tokens.shape[0]
         N = self.world_size
         all_tok = torch.empty((N * B, Lt), dtype=torch.int32, device=tokens.device)
-        dist.all_gather_into_tensor(all_tok, tokens, group=self.group)
+        self._all_gather(all_tok.view(-1), tokens.reshape(-1))
         part = torch.empty((N * B * Lt, Dv), dtype=torch.bfloat16, device=tokens.device)
         hip.embed_gather(rows, all_tok, part, N * B * Lt, Lt, Dv, Lt, 0, scale, lo, hi)
         mine = torch.empty((B * Lt, Dv), dtype=torch.bfloat16, device=tokens.device)
-        dist.reduce_scatter_tensor(mine, part, op=dist.ReduceOp.SUM, group=self.group)
+        self._reduce_scatter(mine.view(-1), part.view(-1))
         hip.copy_rows_bf16(mine, x0, B * Lt, Lt, Dv, Lt, 0, Pn, dst_off)

@@ -1,0 +1,106 @@
+"""world_size-2 tests of the FSDP partitioning on CPU (gloo): shard geometry, parameter all-gather, gradient
+reduce-scatter / all-reduce, and that "reduce-scatter -> per-shard AdamW -> all-gather" equals the unsharded
+update (the optimizer arithmetic is the oracle's; the HIP kernel itself is covered by the GPU tests)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lap_amd.config import get_config
+from lap_amd.params import ParamStore
+from oracle import lap_oracle as O
+from tests.common import oracle_cfg
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lap_amd.fsdp import FsdpComm
+
+        cfg = get_config("debug").model
+        P = O.init_params(oracle_cfg(cfg), seed=2)
+        ref = ParamStore(cfg, "cpu", world_size=1, rank=0)
+        ref.load_reference_tree(P)
+        ps = ParamStore(cfg, "cpu", world_size=world, rank=rank)
+        ps.load_reference_tree(P)
+        comm = FsdpComm(ps)
+        for u in ps.units:
+            a, b = ps.shard_range(u)
+            n = ps.padded(u)
+            assert n % world == 0 and (b - a) == (n // world if u.big else n)
+            # master shard == slice of the unsharded master
+            full = torch.zeros(n); full[:ref.master[u.name].numel()] = ref.master[u.name][:n]
+            assert torch.equal(ps.master[u.name], full[a:b]), u.name
+        D = ps.tensor_spec["llm/embed"].shape[1]
+        rows, lo, hi = ps.embed_rows()
+        assert rows.shape[1] == D and (hi - lo) * D == rows.numel() and lo == rank * (hi - lo)
+        # gradients: rank r contributes (r+1) * g  ->  reduce-scatter gives 3 g on every shard
+        g = torch.Generator().manual_seed(0)
+        gfull = {u.name: torch.randn(ps.padded(u), generator=g) for u in ps.units}
+        for u in ps.units:
+            ps.grad[u.name].copy_(gfull[u.name] * (rank + 1))
+            comm.grads_ready(u.name)
+        comm.finish_grads()
+        scale = sum(range(1, world + 1))
+        for u in ps.units:
+            a, b = ps.shard_range(u)
+            assert torch.allclose(ps.gshard[u.name], gfull[u.name][a:b] * scale), u.name
+        # sharded update + in-place all-gather of the bf16 mirror == unsharded update
+        for u in ps.units:
+            a, b = ps.shard_range(u)
+            newp, _, _ = O.adamw_step(ps.master[u.name], ps.gshard[u.name], ps.m[u.name], ps.v[u.name], 1, 1e-3)
+            ps.master[u.name].copy_(newp)
+            if u.big:
+                ps.full16[u.name][a:b].copy_(newp)
+        comm.start_param_gather()
+        for u in ps.units:
+            if not u.big:
+                continue
+            n = ps.padded(u)
+            full = torch.zeros(n); full[:ref.master[u.name].numel()] = ref.master[u.name][:n]
+            exp, _, _ = O.adamw_step(full, gfull[u.name] * scale, torch.zeros(n), torch.zeros(n), 1, 1e-3)
+            assert torch.equal(ps.full16[u.name], exp.to(torch.bfloat16)), u.name
+        t = comm.all_reduce_sum(torch.tensor([float(rank + 1)]))
+        assert t.item() == scale
+        ret[rank] = "ok"
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fsdp_world2_gloo():
+    world = 2
+    port = 29500 + os.getpid() % 500
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    procs = [mp.get_context("spawn").Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
+
+
+def test_config_surface():
+    """training/config.py registry + EMA / LR schedule semantics."""
+    lib = get_config("lap_libero")
+    assert lib.model.action_horizon == 10 and lib.model.max_token_len == 180 and lib.model.language_loss_weight == 0.4
+    assert lib.batch_size == 256 and lib.get_ema_decay_for_step(0) == (0.999, True) and lib.get_ema_init() == (0.999, True)
+    lap = get_config("lap")
+    assert lap.model.stop_action_to_vlm_grad and lap.batch_size == 2048 and lap.ema_schedule_choice.kind == "cosine_delayed"
+    d0, on0 = lap.get_ema_decay_for_step(4999); d1, on1 = lap.get_ema_decay_for_step(40_000)
+    assert (d0, on0) == (0.0, False) and on1 and abs(d1 - 0.999) < 1e-9
+    assert O.ema_decay_for_step("cosine_delayed", 20_000, 0.999, 5000, 40_000)[0] == pytest.approx(lap.get_ema_decay_for_step(20_000)[0])
+    s = lib.lr_schedule
+    assert s(0) == pytest.approx(5e-5 / 1001) and s(1000) == pytest.approx(5e-5) and s(30_000) == pytest.approx(5e-5)
+    assert s(500) == pytest.approx(O.cosine_lr(500, 1000, 5e-5, 40_000, 5e-5))
+    with pytest.raises(ValueError, match="not found"):
+        get_config("nope")
+    with pytest.raises(ValueError):
+        _ = lib.checkpoint_dir  # exp_name must be set
