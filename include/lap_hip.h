@@ -45,6 +45,13 @@ int lap_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const
                   int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
                   int a_kc, int b_kc, int flags, void* stream);
 
+/* Same with explicit scheduling knobs: tile = -1 (heuristic) | 0 (128x128, 2 blocks/CU) | 1 (256x128) |
+ * 2 (256x256); ksplit > 1 splits K over grid.y and accumulates with f32 atomics (requires
+ * LAP_GEMM_OUT_F32 | LAP_GEMM_ACCUM, no bias / residual; C must hold the value to accumulate onto). */
+int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const void* bias, const void* residual,
+                     int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
+                     int a_kc, int b_kc, int flags, int tile, int ksplit, void* stream);
+
 /* Small exact-f32 GEMM (VALU, k-ordered fmaf chain):
  * C[M,N] = alpha * opA . opB (+ bias[n]) (+ C if accum).  Same layout flags as
  * above.  Used where the reference computes in float32: the SigLIP stem conv
@@ -167,7 +174,11 @@ typedef struct {
   const int32_t* qinfo; const int32_t* kinfo;
   const float* lse;
   float* delta;              /* scratch f32 [B][NH][Tq] */
+  float* scratch;            /* optional f32 scratch for hsplit > 1: 2 * hsplit * B * Tk * NKV * HD floats */
+  long long scratch_floats;
   float scale;
+  int hsplit;                /* > 1 (must divide NH/NKV): the query heads sharing a kv head are spread over hsplit
+                                blocks per key tile; partial dK/dV are reduced by a second small kernel */
   int B, NH, NKV, HD;
   int stop_q1_to_k0;         /* stop_action_to_vlm_grad (gemma.py:242-269): no dK/dV from segment-1 queries into segment-0 keys */
 } lap_attn_bwd_args;

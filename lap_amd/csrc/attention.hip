@@ -34,6 +34,8 @@ struct AttnP {
   float* lse; float* delta;
   float scale;                      // logits = scale * q.k
   int B, NH, NKV, stop;
+  int hsplit;                       // dK/dV: query heads of one kv head are split over hsplit blocks ...
+  float* part;                      // ... which write f32 partials [2][hsplit][B*Tk*NKV*HD] reduced by attn_dkdv_reduce_kernel
 };
 
 template <int HD> struct Cfg {
@@ -249,8 +251,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
   char* sD = smem + C::TILE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const BlockId id = decode_block(p.klen[0], p.klen[1], p.NKV);
-  const int b = id.b, hk = id.h, kseg = id.seg;
+  const BlockId id = decode_block(p.klen[0], p.klen[1], p.NKV * p.hsplit);
+  const int b = id.b, hk = id.h / p.hsplit, hg = id.h % p.hsplit, kseg = id.seg;
   const int klen = p.klen[kseg];
   const int Tq = p.qlen[0] + p.qlen[1], Tk = p.klen[0] + p.klen[1];
   const int mykey = id.tile * 64 + w * 16 + i;
@@ -266,8 +268,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
 #pragma unroll
   for (int d = 0; d < C::DF; ++d) { acc_dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  const int hpk = p.NH / p.NKV;
-  for (int hh = 0; hh < hpk; ++hh) {
+  const int hpk = p.NH / p.NKV, hpg = hpk / p.hsplit;
+  for (int hh = hg * hpg; hh < (hg + 1) * hpg; ++hh) {
     const int h = hk * hpk + hh;
     for (int qs = 0; qs < 2; ++qs) {
       const int qlen = p.qlen[qs];
@@ -324,6 +326,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
     }
   }
   if (!vk) return;
+  if (p.hsplit > 1) {
+    // f32 partial of this head group: packed [b][joint key][kv head][HD]
+    const long long n_all = (long long)p.B * Tk * p.NKV * HD;
+    const long long row = ((long long)b * Tk + (kseg ? p.klen[0] : 0) + mykey) * p.NKV + hk;
+    float* pk = p.part + (long long)hg * n_all + row * HD;
+    float* pv = pk + (long long)p.hsplit * n_all;
+#pragma unroll
+    for (int d = 0; d < C::DF; ++d) {
+      const int d0 = d * 16 + 4 * g;
+      if (d0 < HD) {
+        *reinterpret_cast<f32x4*>(pk + d0) = acc_dk[d];
+        *reinterpret_cast<f32x4*>(pv + d0) = acc_dv[d];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int d = 0; d < C::DF; ++d) {
     const int d0 = d * 16 + 4 * g;
@@ -332,6 +350,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
       store4(p.dv[kseg] + koff + d0, acc_dv[d], 1.0f);
     }
   }
+}
+
+// Sum the hsplit f32 partials and write bf16 dK / dV with the caller's row stride.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_dkdv_reduce_kernel(AttnP p) {
+  const int Tk = p.klen[0] + p.klen[1];
+  const long long n_all = (long long)p.B * Tk * p.NKV * HD;
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n_all) return;
+  f32x4 sk = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
+  for (int hgp = 0; hgp < p.hsplit; ++hgp) {
+    sk += *reinterpret_cast<const f32x4*>(p.part + (long long)hgp * n_all + i4);
+    sv += *reinterpret_cast<const f32x4*>(p.part + ((long long)p.hsplit + hgp) * n_all + i4);
+  }
+  const int d0 = (int)(i4 % HD);
+  long long r = i4 / HD;
+  const int hk = (int)(r % p.NKV); r /= p.NKV;
+  const int t = (int)(r % Tk);
+  const int b = (int)(r / Tk);
+  const int seg = t >= p.klen[0];
+  const int tt = seg ? t - p.klen[0] : t;
+  const long long off = (b * (long long)p.klen[seg] + tt) * p.kv_rs[seg] + hk * HD + d0;
+  store4(p.dk[seg] + off, sk, 1.0f);
+  store4(p.dv[seg] + off, sv, 1.0f);
 }
 
 // ============================================================================ backward: dQ
@@ -440,8 +482,13 @@ int launch_bwd(const AttnP& p, hipStream_t s) {
   LAP_CHECK_LAUNCH();
   const int ntk = (p.klen[0] + 63) / 64 + (p.klen[1] + 63) / 64;
   if (int e = set_lds(attn_bwd_dkdv_kernel<HD>, lds)) return e;
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HD>, dim3(p.B * p.NKV * ntk), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HD>, dim3(p.B * p.NKV * p.hsplit * ntk), dim3(256), lds, s, p);
   LAP_CHECK_LAUNCH();
+  if (p.hsplit > 1) {
+    const long long n4 = (long long)p.B * (p.klen[0] + p.klen[1]) * p.NKV * HD / 4;
+    hipLaunchKernelGGL(attn_dkdv_reduce_kernel<HD>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
+    LAP_CHECK_LAUNCH();
+  }
   const int ntq = (p.qlen[0] + 63) / 64 + (p.qlen[1] + 63) / 64;
   if (int e = set_lds(attn_bwd_dq_kernel<HD>, lds)) return e;
   hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, dim3(p.B * p.NH * ntq), dim3(256), lds, s, p);
@@ -506,6 +553,17 @@ extern "C" int lap_attention_bwd(const lap_attn_bwd_args* a, void* stream) {
   p.qinfo = a->qinfo; p.kinfo = a->kinfo; p.lse = (float*)a->lse; p.delta = a->delta;
   p.scale = a->scale;
   p.B = a->B; p.NH = a->NH; p.NKV = a->NKV; p.stop = a->stop_q1_to_k0;
+  // grouped-query models: spread the query heads of a kv head over several blocks when scratch is provided
+  p.hsplit = 1; p.part = nullptr;
+  {
+    const int hpk = a->NH / a->NKV;
+    const long long need = 2LL * a->B * (a->k_len[0] + a->k_len[1]) * a->NKV * a->HD;
+    int hs = a->hsplit > 0 ? a->hsplit : 1;
+    if (hs > 1) {
+      if (hpk % hs || !a->scratch || a->scratch_floats < need * hs) return LAP_ERR_ARG;
+      p.hsplit = hs; p.part = a->scratch;
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
   switch (a->HD) {
     case 16: return launch_bwd<16>(p, s);

@@ -289,16 +289,43 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16* __restrict__
 }
 
 // ------------------------------------------------------------------ column sums
-// grid (ceil(cols/256), ceil(rows/128)): thread owns one column over a 128-row slab -> one atomic.
+// Block = 4 waves over a slab of CS_ROWS rows x 512 columns: lane owns 8 adjacent columns (16-byte loads), waves
+// stride over rows, partials meet in LDS, one f32 atomic per column per block.
+constexpr int CS_ROWS = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int rows, int cols,
                                                      int ld) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  const int r0 = blockIdx.y * 128, r1 = min(rows, r0 + 128);
-  float acc = 0.f;
-  for (int r = r0; r < r1; ++r) acc += (float)x[(long long)r * ld + c];
-  atomicAdd(out + c, acc);
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 512 + lane * 8;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool vec = (c0 + 8 <= cols) && ((ld * (int)sizeof(T)) % 16 == 0) && ((((uintptr_t)x) & 15) == 0) && (c0 * (int)sizeof(T)) % 16 == 0;
+  for (int r = r0 + w; r < r1; r += 4) {
+    const T* row = x + (long long)r * ld;
+    if (vec) {
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(row + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+      } else {
+        f32x4 a = *reinterpret_cast<const f32x4*>(row + c0), b = *reinterpret_cast<const f32x4*>(row + c0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += a[e]; acc[4 + e] += b[e]; }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (c0 + e < cols) acc[e] += (float)row[c0 + e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[w][lane * 8 + e] = acc[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    const int col = blockIdx.x * 512 + c;
+    if (col < cols) atomicAdd(out + col, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  }
 }
 
 // ------------------------------------------------------------------ SigLIP stem
@@ -507,14 +534,14 @@ extern "C" int lap_gated_residual_bwd(const void* dy, const void* u, const void*
 
 extern "C" int lap_colsum_bf16(const void* x, float* out, int rows, int cols, int ld, void* stream) {
   if (rows <= 0 || cols <= 0) return LAP_ERR_ARG;
-  hipLaunchKernelGGL(colsum_kernel<bf16>, dim3((cols + 255) / 256, (rows + 127) / 128), dim3(256), 0, S_, (const bf16*)x,
+  hipLaunchKernelGGL(colsum_kernel<bf16>, dim3((cols + 511) / 512, (rows + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, S_, (const bf16*)x,
                      out, rows, cols, ld);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
 extern "C" int lap_colsum_f32(const float* x, float* out, int rows, int cols, int ld, void* stream) {
   if (rows <= 0 || cols <= 0) return LAP_ERR_ARG;
-  hipLaunchKernelGGL(colsum_kernel<float>, dim3((cols + 255) / 256, (rows + 127) / 128), dim3(256), 0, S_, x, out, rows,
+  hipLaunchKernelGGL(colsum_kernel<float>, dim3((cols + 511) / 512, (rows + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, S_, x, out, rows,
                      cols, ld);
   LAP_CHECK_LAUNCH();
   return LAP_OK;

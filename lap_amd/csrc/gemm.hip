@@ -14,21 +14,27 @@
 //   dgrad    dx = dy . Wt        -> a_kc=1, b_kc=0
 //   wgrad    dWt = dy^T . x      -> a_kc=0, b_kc=0
 //
-// Structure: 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave a
-// 64x64 sub-tile = 4x4 v_mfma_f32_16x16x32_bf16 fragments (64 fp32 acc VGPRs).
-// HBM -> LDS staging is buffer_load_dwordx4 ... lds (LDS-DMA, no VGPR round
-// trip), double buffered: tile t+1 streams in while tile t is multiplied, one
-// barrier per k-tile.  The LDS image is lane-linear per wave instruction, so the
+// Structure: BM x BN x 64 block tile, WGM x WGN waves, each wave a (BM/WGM) x
+// (BN/WGN) sub-tile of v_mfma_f32_16x16x32_bf16 fragments.  Three tile shapes:
+//   256x256 / 8 waves (128x64 per wave): 128 FLOP per L2 byte, one block per CU
+//            (128 KiB LDS) — the large, evenly divisible GEMMs;
+//   256x128 / 8 waves (64x64 per wave):  85 FLOP/B, one block per CU (96 KiB);
+//   128x128 / 4 waves (64x64 per wave):  64 FLOP/B, two blocks per CU — small or
+//            awkward shapes (a 128x128 tile at the 2.5 PF MFMA peak would need
+//            39 TB/s from L2, more than the ~35 TB/s the XCD L2s deliver).
+// HBM -> LDS staging is buffer_load_dwordx4 ... lds (LDS-DMA, no VGPR round trip),
+// double buffered: tile t+1 streams in while tile t is multiplied, one barrier
+// per k-tile.  The LDS image is lane-linear per wave instruction, so the
 // bank-conflict swizzle is applied to the per-lane *source* address and again on
 // the fragment read (common.hpp).  Out-of-range rows / k-tails use an
 // out-of-bounds buffer offset, for which the hardware writes zeros.
+// Split-K (f32 output, atomic accumulate) covers weight gradients whose output
+// has too few tiles to fill 256 CUs.
 #include "common.hpp"
 #include "../../include/lap_hip.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 constexpr unsigned OOB = 0x80000000u;
 
 struct GemmParams {
@@ -40,66 +46,88 @@ struct GemmParams {
   int lda, ldb, ldc, ldr;
   float alpha;
   int tiles_m, tiles_n;
+  int bias_kind;         // 0 none, 1 bf16, 2 f32
+  int gelu, accum;
+  int ksplit, ktiles_per_split;
 };
 
-// Epilogue flags (template): OUT_F32, HAS_BIAS(0 none,1 bf16,2 f32), ACT_GELU, HAS_RES, ACCUM
-template <bool A_KC, bool B_KC, bool OUT_F32, int BIAS, bool GELU, bool RES, bool ACCUM>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
-  // buffer b: A tile at smem + 2b*TILE_BYTES, B tile right behind it.
+// 64-byte-row K-contiguous tile (BK = 32): 16-byte chunk c of row r is stored at chunk c ^ ((-(r >> 2)) & 3), which
+// makes every 16-lane service group of ds_read_b128 cover all 64 banks once.
+__device__ __forceinline__ unsigned kc32_tile_off(int row, int chunk16) {
+  return (unsigned)(row * 64 + ((chunk16 ^ ((-(row >> 2)) & 3)) << 4));
+}
+__device__ __forceinline__ bf16x8 kc32_frag(const char* tile, int row0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  return *reinterpret_cast<const bf16x8*>(tile + kc32_tile_off(row0 + i, g));
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// BK: k-depth of one LDS stage (32 or 64); NS: LDS stages.  Loads of tile t+NS-1 are issued while tile t is
+// multiplied; the wait before the (single, raw) barrier is a COUNTED vmcnt that leaves NS-2 tiles in flight.
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool A_KC, bool B_KC, bool OUT_F32>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
+  constexpr int NW = WGM * WGN;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile
+  constexpr int FM = WTM / 16, FN = WTN / 16;     // fragments per wave
+  constexpr int KSUB = BK / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;  // 1 KiB LDS-DMA pieces per wave
+  static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "tile / wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // NS stages: [A tile | B tile]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 1, wn = w & 1;
+  const int wm = w / WGN, wn = w % WGN;
 
-  // Block -> tile mapping: XCD-aware remap, then groups of 8 m-tiles sweep n.
+  // Block -> tile mapping: XCD-aware remap, then groups of GM m-tiles sweep n.
   const int nblk = p.tiles_m * p.tiles_n;
-  int t = xcd_remap(blockIdx.x, nblk);
-  constexpr int GM = 8;
+  const int t = xcd_remap(blockIdx.x, nblk);
+  constexpr int GM = (BM == 256) ? 4 : 8;
   const int group_sz = GM * p.tiles_n;
-  const int gidx = t / group_sz;
-  const int first_m = gidx * GM;
+  const int first_m = (t / group_sz) * GM;
   const int gm = min(p.tiles_m - first_m, GM);
   const int tm = first_m + (t % group_sz) % gm;
   const int tn = (t % group_sz) / gm;
   const int m0 = tm * BM, n0 = tn * BN;
 
   auto rsA = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.A, 0,
-      (int)min((long long)(A_KC ? p.M : p.K) * p.lda * 2, 0x7fffffffLL), 0x00020000);
+      (void*)p.A, 0, (int)min((long long)(A_KC ? p.M : p.K) * p.lda * 2, 0x7fffffffLL), 0x00020000);
   auto rsB = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.B, 0,
-      (int)min((long long)(B_KC ? p.N : p.K) * p.ldb * 2, 0x7fffffffLL), 0x00020000);
+      (void*)p.B, 0, (int)min((long long)(B_KC ? p.N : p.K) * p.ldb * 2, 0x7fffffffLL), 0x00020000);
 
-  // Per-thread staging descriptors: 4 LDS-DMA pieces per operand per k-tile.
-  // K-contiguous operand: piece q = w*4+j covers tile rows 8q..8q+7 (1 KiB),
-  //   lane -> (row = 8q + lane/8, physical chunk = lane%8).
-  // M-contiguous operand: piece q covers k rows 4q..4q+3 (256 B each),
-  //   lane -> (krow = 4q + lane/16, physical chunk = lane%16).
-  unsigned offA[4], offB[4];     // byte offset at k0 = 0 (OOB if the row is out of range)
-  int kidxA[4], kidxB[4];        // k index (element) this lane's chunk starts at, relative to k0
+  // Staging descriptors.  Piece q covers linear 16-byte chunks [64q, 64q+64) of the tile image;
+  // K-contiguous tile: 8 chunks per row (row = m/n index); M-contiguous tile: BM/8 chunks per k-row.
+  unsigned offA[PA], offB[PB];
+  int kidxA[PA], kidxB[PB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int q = w * 4 + j;
+  for (int j = 0; j < PA; ++j) {
+    const int ci = (w * PA + j) * 64 + lane;
     if (A_KC) {
-      const int row = 8 * q + (lane >> 3), pc = lane & 7;
-      const int c = pc ^ ((row >> 1) & 7);
+      const int row = BK == 64 ? ci >> 3 : ci >> 2, pc = BK == 64 ? ci & 7 : ci & 3;
+      const int c = BK == 64 ? pc ^ ((row >> 1) & 7) : pc ^ ((-(row >> 2)) & 3);
       kidxA[j] = c * 8;
       offA[j] = (m0 + row < p.M) ? (unsigned)(((long long)(m0 + row) * p.lda + c * 8) * 2) : OOB;
     } else {
-      const int kr = 4 * q + (lane >> 4), pc = lane & 15;
+      constexpr int CPR = BM / 8;
+      const int kr = ci / CPR, pc = ci % CPR;
       const int c = pc ^ (mc_swz(kr) << 1);
       kidxA[j] = kr;
       offA[j] = (m0 + c * 8 < p.M) ? (unsigned)(((long long)kr * p.lda + m0 + c * 8) * 2) : OOB;
     }
+  }
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int ci = (w * PB + j) * 64 + lane;
     if (B_KC) {
-      const int row = 8 * q + (lane >> 3), pc = lane & 7;
-      const int c = pc ^ ((row >> 1) & 7);
+      const int row = BK == 64 ? ci >> 3 : ci >> 2, pc = BK == 64 ? ci & 7 : ci & 3;
+      const int c = BK == 64 ? pc ^ ((row >> 1) & 7) : pc ^ ((-(row >> 2)) & 3);
       kidxB[j] = c * 8;
       offB[j] = (n0 + row < p.N) ? (unsigned)(((long long)(n0 + row) * p.ldb + c * 8) * 2) : OOB;
     } else {
-      const int kr = 4 * q + (lane >> 4), pc = lane & 15;
+      constexpr int CPR = BN / 8;
+      const int kr = ci / CPR, pc = ci % CPR;
       const int c = pc ^ (mc_swz(kr) << 1);
       kidxB[j] = kr;
       offB[j] = (n0 + c * 8 < p.N) ? (unsigned)(((long long)kr * p.ldb + n0 + c * 8) * 2) : OOB;
@@ -110,141 +138,164 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
   auto stage = [&](int buf, int kt) {
     const int k0 = kt * BK;
+    char* base = smem + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = w * 4 + j;
+    for (int j = 0; j < PA; ++j) {
       unsigned va = (offA[j] != OOB && k0 + kidxA[j] < p.K) ? offA[j] + (unsigned)kt * stepA : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(base + (w * PA + j) * 1024), 16, va, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
       unsigned vb = (offB[j] != OOB && k0 + kidxB[j] < p.K) ? offB[j] + (unsigned)kt * stepB : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(smem + buf * (2 * TILE_BYTES) + q * 1024), 16, va, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(smem + buf * (2 * TILE_BYTES) + TILE_BYTES + q * 1024), 16, vb, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(base + A_BYTES + (w * PB + j) * 1024), 16, vb, 0, 0, 0);
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nkt = (p.K + BK - 1) / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    __syncthreads();  // tile kt landed (vmcnt(0) + barrier); buffer cur^1 free again
-    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
-    const char* tA = smem + cur * (2 * TILE_BYTES);
-    const char* tB = tA + TILE_BYTES;
+  const int nkt_all = (p.K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * p.ktiles_per_split;
+  const int kt1 = min(nkt_all, kt0 + p.ktiles_per_split);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
+  for (int s = 0; s < NS - 1; ++s)
+    if (kt0 + s < kt1) stage(s, kt0 + s);
+  int cur = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    // my loads of tile kt have landed (NS-2 younger tiles may still be in flight) ...
+    if (NS > 2 && kt + NS - 2 < kt1) wait_vmcnt<(NS - 2) * (PA + PB)>(); else wait_vmcnt<0>();
+    // ... and so have everybody else's; every wave is also done reading the buffer refilled below.
+    __builtin_amdgcn_s_barrier();
+    if (kt + NS - 1 < kt1) stage(cur == 0 ? NS - 1 : cur - 1, kt + NS - 1);
+    const char* tA = smem + cur * STAGE;
+    const char* tB = tA + A_BYTES;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = A_KC ? kc_frag(tA, wm * 64 + i * 16, kk, lane) : mc_frag<BM>(tA, wm * 64 + i * 16, kk, lane);
-        fb[i] = B_KC ? kc_frag(tB, wn * 64 + i * 16, kk, lane) : mc_frag<BN>(tB, wn * 64 + i * 16, kk, lane);
-      }
+    for (int kk = 0; kk < KSUB; ++kk) {
+      bf16x8 fa[FM], fb[FN];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < FM; ++i)
+        fa[i] = A_KC ? (BK == 64 ? kc_frag(tA, wm * WTM + i * 16, kk, lane) : kc32_frag(tA, wm * WTM + i * 16, lane))
+                     : mc_frag<BM>(tA, wm * WTM + i * 16, kk, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < FN; ++j)
+        fb[j] = B_KC ? (BK == 64 ? kc_frag(tB, wn * WTN + j * 16, kk, lane) : kc32_frag(tB, wn * WTN + j * 16, lane))
+                     : mc_frag<BN>(tB, wn * WTN + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
           // Operands swapped on purpose: D[row = n][col = m], so each lane ends up
           // with 4 consecutive n of one output row m -> one 8/16-byte store.
           acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
     }
+    cur = (cur + 1 == NS) ? 0 : cur + 1;
   }
 
   // Epilogue. Lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + 4*(lane>>4).
   const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + li;
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + li;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + 4 * lg;
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + 4 * lg;
       if (n >= p.N) continue;  // N % 4 == 0 is required by the host wrapper
       f32x4 v = acc[i][j] * p.alpha;
-      if (BIAS == 1) {
+      if (p.bias_kind == 1) {
         bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
-      } else if (BIAS == 2) {
-        f32x4 b = *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
-        v += b;
+      } else if (p.bias_kind == 2) {
+        v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
       }
-      if (GELU) {
+      if (p.gelu) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
       }
-      if (RES) {
+      if (p.R) {
         bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
       }
       if (OUT_F32) {
         float* c = (float*)p.C + (long long)m * p.ldc + n;
-        if (ACCUM) v += *reinterpret_cast<const f32x4*>(c);
-        *reinterpret_cast<f32x4*>(c) = v;
-      } else {
-        bf16* c = (bf16*)p.C + (long long)m * p.ldc + n;
-        if (ACCUM) {
-          bf16x4 o = *reinterpret_cast<const bf16x4*>(c);
+        if (p.ksplit > 1) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)o[e];
+          for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+        } else {
+          if (p.accum) v += *reinterpret_cast<const f32x4*>(c);
+          *reinterpret_cast<f32x4*>(c) = v;
         }
+      } else {
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-        *reinterpret_cast<bf16x4*>(c) = o;
+        *reinterpret_cast<bf16x4*>((bf16*)p.C + (long long)m * p.ldc + n) = o;
       }
     }
   }
 }
 
-template <bool A_KC, bool B_KC, bool OUT_F32, int BIAS, bool GELU, bool RES, bool ACCUM>
-int launch(const GemmParams& p, hipStream_t s) {
-  dim3 grid(p.tiles_m * p.tiles_n);
-  hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, OUT_F32, BIAS, GELU, RES, ACCUM>), grid, dim3(256), 0, s, p);
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool A_KC, bool B_KC, bool OUT_F32>
+int launch(GemmParams p, hipStream_t s) {
+  constexpr int LDS = NS * (BM + BN) * BK * 2;
+  auto kern = gemm_kernel<BM, BN, WGM, WGN, BK, NS, A_KC, B_KC, OUT_F32>;
+  if (LDS > 65536) {
+    static bool done = false;  // benign race: the attribute is idempotent
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) return (int)e;
+      done = true;
+    }
+  }
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const int nkt = (p.K + BK - 1) / BK;
+  p.ktiles_per_split = (nkt + p.ksplit - 1) / p.ksplit;
+  dim3 grid(p.tiles_m * p.tiles_n, p.ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), LDS, s, p);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
 
-template <bool A_KC, bool B_KC>
-int dispatch_epi(const GemmParams& p, int flags, hipStream_t s) {
-  const bool f32 = flags & LAP_GEMM_OUT_F32;
-  const bool accum = flags & LAP_GEMM_ACCUM;
-  const bool gelu = flags & LAP_GEMM_GELU;
-  const bool res = p.R != nullptr;
-  const int bias = p.bias ? ((flags & LAP_GEMM_BIAS_F32) ? 2 : 1) : 0;
-  // Instantiate only the combinations the engine uses.
-  if (f32) {
-    if (gelu || res) return LAP_ERR_ARG;
-    if (bias == 0) return accum ? launch<A_KC, B_KC, true, 0, false, false, true>(p, s)
-                                : launch<A_KC, B_KC, true, 0, false, false, false>(p, s);
-    if (bias == 2 && !accum) return launch<A_KC, B_KC, true, 2, false, false, false>(p, s);
-    return LAP_ERR_ARG;
+template <bool A_KC, bool B_KC, bool OUT_F32>
+int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
+  switch (tile) {
+    case 4: return launch<128, 128, 2, 2, 32, 4, A_KC, B_KC, OUT_F32>(p, s);
+    case 3: return launch<256, 256, 2, 4, 32, 4, A_KC, B_KC, OUT_F32>(p, s);
+    case 2: return launch<256, 256, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
+    case 1: return launch<256, 128, 4, 2, 64, 3, A_KC, B_KC, OUT_F32>(p, s);
+    default: return launch<128, 128, 2, 2, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
   }
-  if (accum) return LAP_ERR_ARG;
-  if (bias == 0) {
-    if (gelu) return LAP_ERR_ARG;
-    return res ? launch<A_KC, B_KC, false, 0, false, true, false>(p, s)
-               : launch<A_KC, B_KC, false, 0, false, false, false>(p, s);
+}
+
+// Tile heuristic: estimated time = rounds over the 256 CUs x per-CU work per round / relative efficiency.
+// Efficiencies are measured ratios on MI355X (tools/bench_kernels.py), not guesses about the hardware.
+int pick_tile(int M, int N, int K) {
+  const double eff[3] = {1.0, 0.9, 1.12};
+  const int bm[3] = {128, 256, 256}, bn[3] = {128, 128, 256}, per_cu[3] = {2, 1, 1};
+  double best = 1e300;
+  int arg = 0;
+  for (int t = 0; t < 3; ++t) {
+    const long long tiles = (long long)((M + bm[t] - 1) / bm[t]) * ((N + bn[t] - 1) / bn[t]);
+    const long long slots = 256LL * per_cu[t];
+    const long long rounds = (tiles + slots - 1) / slots;
+    const double cost = (double)rounds * per_cu[t] * bm[t] * bn[t] / eff[t];
+    if (cost < best) { best = cost; arg = t; }
   }
-  if (gelu) {
-    if (res) return LAP_ERR_ARG;
-    return bias == 1 ? launch<A_KC, B_KC, false, 1, true, false, false>(p, s)
-                     : launch<A_KC, B_KC, false, 2, true, false, false>(p, s);
-  }
-  if (bias == 1) return res ? launch<A_KC, B_KC, false, 1, false, true, false>(p, s)
-                            : launch<A_KC, B_KC, false, 1, false, false, false>(p, s);
-  return res ? launch<A_KC, B_KC, false, 2, false, true, false>(p, s)
-             : launch<A_KC, B_KC, false, 2, false, false, false>(p, s);
+  (void)K;
+  return arg;
 }
 
 }  // namespace
 
-extern "C" int lap_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual,
-                             int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
-                             int a_kc, int b_kc, int flags, void* stream) {
+extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const void* bias, const void* residual,
+                                int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
+                                int a_kc, int b_kc, int flags, int tile, int ksplit, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return LAP_ERR_ARG;
   // 16-byte chunk granularity along each contiguous axis; 4-wide epilogue stores.
   if ((N & 3) || (ldc & 3) || (lda & 7) || (ldb & 7)) return LAP_ERR_ARG;
@@ -255,13 +306,34 @@ extern "C" int lap_gemm_bf16(const void* A, const void* B, void* C, const void* 
   // 31-bit byte offsets inside one buffer descriptor.
   if ((long long)(a_kc ? M : K) * lda * 2 >= 0x7fffffffLL) return LAP_ERR_ARG;
   if ((long long)(b_kc ? N : K) * ldb * 2 >= 0x7fffffffLL) return LAP_ERR_ARG;
+  const bool f32 = flags & LAP_GEMM_OUT_F32;
+  if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
+  if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
+  if (tile < -1 || tile > 4 || ksplit < 0) return LAP_ERR_ARG;
+  if (ksplit > 1 && (!f32 || !(flags & LAP_GEMM_ACCUM) || bias || residual)) return LAP_ERR_ARG;
   GemmParams p;
   p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C; p.bias = bias; p.R = (const bf16*)residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.alpha = alpha;
-  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+  p.bias_kind = bias ? ((flags & LAP_GEMM_BIAS_F32) ? 2 : 1) : 0;
+  p.gelu = (flags & LAP_GEMM_GELU) ? 1 : 0;
+  p.accum = (flags & LAP_GEMM_ACCUM) ? 1 : 0;
+  p.ksplit = ksplit > 1 ? ksplit : 1;
+  if (tile < 0) tile = pick_tile(M, N, K);
   hipStream_t s = (hipStream_t)stream;
-  if (a_kc && b_kc) return dispatch_epi<true, true>(p, flags, s);
-  if (a_kc && !b_kc) return dispatch_epi<true, false>(p, flags, s);
-  if (!a_kc && !b_kc) return dispatch_epi<false, false>(p, flags, s);
-  return dispatch_epi<false, true>(p, flags, s);
+  if (f32) {
+    if (a_kc && b_kc) return dispatch_tile<true, true, true>(p, tile, s);
+    if (a_kc && !b_kc) return dispatch_tile<true, false, true>(p, tile, s);
+    if (!a_kc && !b_kc) return dispatch_tile<false, false, true>(p, tile, s);
+    return dispatch_tile<false, true, true>(p, tile, s);
+  }
+  if (a_kc && b_kc) return dispatch_tile<true, true, false>(p, tile, s);
+  if (a_kc && !b_kc) return dispatch_tile<true, false, false>(p, tile, s);
+  if (!a_kc && !b_kc) return dispatch_tile<false, false, false>(p, tile, s);
+  return dispatch_tile<false, true, false>(p, tile, s);
+}
+
+extern "C" int lap_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual,
+                             int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
+                             int a_kc, int b_kc, int flags, void* stream) {
+  return lap_gemm_bf16_ex(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, alpha, a_kc, b_kc, flags, -1, 0, stream);
 }

@@ -56,7 +56,8 @@ class AttnBwdArgs(C.Structure):
         ("q_len", _i * 2), ("k_len", _i * 2),
         ("q_rs", _i * 2), ("kv_rs", _i * 2), ("o_rs", _i * 2),
         ("qinfo", _vp), ("kinfo", _vp), ("lse", _vp), ("delta", _vp),
-        ("scale", _f),
+        ("scratch", _vp), ("scratch_floats", _ll),
+        ("scale", _f), ("hsplit", _i),
         ("B", _i), ("NH", _i), ("NKV", _i), ("HD", _i), ("stop_q1_to_k0", _i),
     ]
 
@@ -65,6 +66,7 @@ class AttnBwdArgs(C.Structure):
 SIGNATURES: dict[str, list] = {
     "lap_abi_version": [],
     "lap_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
+    "lap_gemm_bf16_ex": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
     "lap_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "lap_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -140,8 +142,8 @@ def _req(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
 
 # ------------------------------------------------------------------------------ GEMM
 def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, residual=None, ldr=0,
-         alpha=1.0, gelu=False, accum=False):
-    """out[M,N] = epi(alpha * opA . opB); see include/lap_hip.h lap_gemm_bf16."""
+         alpha=1.0, gelu=False, accum=False, tile=-1, ksplit=0):
+    """out[M,N] = epi(alpha * opA . opB); see include/lap_hip.h lap_gemm_bf16 / lap_gemm_bf16_ex."""
     _req(a, torch.bfloat16, "A"); _req(b, torch.bfloat16, "B")
     flags = 0
     if out.dtype == torch.float32:
@@ -154,37 +156,37 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, 
         flags |= GEMM_GELU
     if bias is not None and bias.dtype == torch.float32:
         flags |= GEMM_BIAS_F32
-    call("lap_gemm_bf16", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, ldc, ldr, float(alpha),
-         int(a_kc), int(b_kc), flags)
+    call("lap_gemm_bf16_ex", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, ldc, ldr, float(alpha),
+         int(a_kc), int(b_kc), flags, tile, ksplit)
     return out
 
 
-def linear_fwd(x, wt, out=None, *, bias=None, residual=None, gelu=False, out_dtype=torch.bfloat16):
+def linear_fwd(x, wt, out=None, *, bias=None, residual=None, gelu=False, out_dtype=torch.bfloat16, tile=-1):
     """y[M,out] = x[M,in] @ wt[out,in]^T (+bias)(gelu)(+residual)."""
     M, K = x.shape
     N = wt.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=x.device)
     return gemm(x, wt, out, M=M, N=N, K=K, lda=x.stride(0), ldb=wt.stride(0), ldc=out.stride(0), bias=bias,
-                residual=residual, ldr=(residual.stride(0) if residual is not None else 0), gelu=gelu)
+                residual=residual, ldr=(residual.stride(0) if residual is not None else 0), gelu=gelu, tile=tile)
 
 
-def linear_dgrad(dy, wt, out=None, *, out_dtype=torch.bfloat16, accum=False):
+def linear_dgrad(dy, wt, out=None, *, out_dtype=torch.bfloat16, accum=False, tile=-1):
     """dx[M,in] = dy[M,out] @ wt[out,in]."""
     M, K = dy.shape
     N = wt.shape[1]
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=dy.device)
     return gemm(dy, wt, out, M=M, N=N, K=K, lda=dy.stride(0), ldb=wt.stride(0), ldc=out.stride(0), a_kc=True,
-                b_kc=False, accum=accum)
+                b_kc=False, accum=accum, tile=tile)
 
 
-def linear_wgrad(dy, x, out, *, accum=False):
-    """dWt[out,in] (f32) = dy[M,out]^T @ x[M,in]."""
+def linear_wgrad(dy, x, out, *, accum=False, ksplit=0, tile=-1):
+    """dWt[out,in] (f32) = dy[M,out]^T @ x[M,in].  ksplit > 1 needs accum=True (adds onto `out`)."""
     Mrows, Nout = dy.shape
     Kin = x.shape[1]
     return gemm(dy, x, out, M=Nout, N=Kin, K=Mrows, lda=dy.stride(0), ldb=x.stride(0), ldc=out.stride(0), a_kc=False,
-                b_kc=False, accum=accum)
+                b_kc=False, accum=accum, ksplit=ksplit, tile=tile)
 
 
 def gemm_f32(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, alpha=1.0, accum=False):
@@ -416,6 +418,15 @@ def attention_bwd(q, k, v, o, d_o, lse, q_len, k_len, B, NH, NKV, HD, qinfo=None
     delta = torch.empty((B, NH, Tq), dtype=torch.float32, device=lse.device)
     a.qinfo, a.kinfo, a.lse, a.delta = _p(qinfo), _p(kinfo), _p(lse), _p(delta)
     a.scale = float(scale)
+    hpk = NH // NKV
+    hsplit = 1
+    if hpk > 1:  # MQA / GQA: more blocks for the dK/dV kernel
+        hsplit = 4 if hpk % 4 == 0 else (2 if hpk % 2 == 0 else 1)
+    a.hsplit = hsplit
+    if hsplit > 1:
+        Tk = a.k_len[0] + a.k_len[1]
+        scratch = torch.empty(2 * hsplit * B * Tk * NKV * HD, dtype=torch.float32, device=lse.device)
+        a.scratch, a.scratch_floats = _p(scratch), scratch.numel()
     a.B, a.NH, a.NKV, a.HD, a.stop_q1_to_k0 = B, NH, NKV, HD, int(stop_q1_to_k0)
     _chk(_fn["lap_attention_bwd"](C.byref(a), _stream()), "lap_attention_bwd")
     return dq, dk, dv

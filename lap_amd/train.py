@@ -72,8 +72,11 @@ class TrainingStepRunner:
         observation, actions = batch
         step = state.step if step is None else int(step)
         dev = model.device
-        for gbuf in ps.grad.values():
-            gbuf.zero_()
+        # weight gradients are written (beta = 0) by the wgrad GEMMs; only the replicated f32 unit is accumulated
+        # into with atomics (norm scales, biases, f32 stem / action head) and must start from zero
+        for u in ps.units:
+            if not u.big:
+                ps.grad[u.name].zero_()
         seed = (int(rng) * 1_000_003 + state.step) if not isinstance(rng, torch.Generator) else rng  # fold_in(rng, step)
         loss, metrics = model.loss_and_grad(seed, observation, actions, train=True, noise=noise, time=time)
         comm = model.comm

@@ -44,8 +44,17 @@ def bench_gemms():
         else:
             dy = rnd(m, n); x = rnd(m, k); out = torch.empty(n, k, dtype=torch.float32, device=dev)
             fn = lambda: hip.linear_wgrad(dy, x, out)
-        t = timeit(fn, iters=10)
-        print(f"gemm {name:14s} {kind:5s} M={m} N={n} K={k}: {t*1e3:8.3f} ms  {2*m*n*k/t/1e12:7.1f} TF/s", flush=True)
+        res = []
+        for tile in (0, 1, 2, 3, 4):
+            if kind == "fwd":
+                fn = lambda: hip.linear_fwd(a, w, out, tile=tile)
+            elif kind == "dgrad":
+                fn = lambda: hip.linear_dgrad(a, w, out, tile=tile)
+            else:
+                fn = lambda: hip.linear_wgrad(dy, x, out, tile=tile)
+            t = timeit(fn, iters=10)
+            res.append(f"t{tile}: {t*1e3:7.3f} ms {2*m*n*k/t/1e12:6.0f} TF")
+        print(f"gemm {name:14s} {kind:5s} M={m} N={n} K={k}: " + " | ".join(res), flush=True)
 
 
 
