@@ -45,12 +45,15 @@ int lap_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const
                   int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
                   int a_kc, int b_kc, int flags, void* stream);
 
-/* Same with explicit scheduling knobs: tile = -1 (heuristic) | 0 (128x128, 2 blocks/CU) | 1 (256x128) |
- * 2 (256x256); ksplit > 1 splits K over grid.y and accumulates with f32 atomics (requires
- * LAP_GEMM_OUT_F32 | LAP_GEMM_ACCUM, no bias / residual; C must hold the value to accumulate onto). */
+/* Same with explicit scheduling knobs: tile = -1 (heuristic) | 0 (128x128x64, 2 blocks/CU) | 1 (256x128x64, 3 stages)
+ * | 2 (256x256x64) | 3 (256x256x32, 4 stages) | 4 (128x128x32, 4 stages).  ksplit > 1 splits K over grid.y:
+ *  - with `scratch` (>= ksplit*M*N*4 bytes): f32 partials + a reduce/epilogue kernel, any output / epilogue
+ *    (deterministic; used for GEMMs with too few output tiles to fill 256 CUs: skinny-M serving, small weights);
+ *  - without scratch: f32 atomics onto C (requires LAP_GEMM_OUT_F32 | LAP_GEMM_ACCUM, no bias / residual). */
 int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const void* bias, const void* residual,
                      int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
-                     int a_kc, int b_kc, int flags, int tile, int ksplit, void* stream);
+                     int a_kc, int b_kc, int flags, int tile, int ksplit, void* scratch, long long scratch_bytes,
+                     void* stream);
 
 /* Small exact-f32 GEMM (VALU, k-ordered fmaf chain):
  * C[M,N] = alpha * opA . opB (+ bias[n]) (+ C if accum).  Same layout flags as
@@ -160,7 +163,11 @@ typedef struct {
   int q_rs[2]; int kv_rs[2]; int o_rs[2];   /* row strides in elements; 0 = packed (NH*HD / NKV*HD) */
   const int32_t* qinfo; const int32_t* kinfo;
   float* lse;
+  float* scratch;                             /* f32 scratch for nsplit > 1: nsplit * B * Tq * NH * (HD + 1) floats */
+  long long scratch_floats;
   float scale;                                /* logits = scale * q.k (1.0 when q is pre-scaled) */
+  int nsplit;                                 /* > 1: key tiles are split over nsplit blocks per query tile (few-query
+                                                 launches such as the batch-1 denoise step) and combined by a 2nd kernel */
   int B, NH, NKV, HD;
 } lap_attn_fwd_args;
 int lap_attention_fwd(const lap_attn_fwd_args* a, void* stream);

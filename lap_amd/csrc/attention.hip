@@ -36,6 +36,8 @@ struct AttnP {
   int B, NH, NKV, stop;
   int hsplit;                       // dK/dV: query heads of one kv head are split over hsplit blocks ...
   float* part;                      // ... which write f32 partials [2][hsplit][B*Tk*NKV*HD] reduced by attn_dkdv_reduce_kernel
+  int nsplit;                       // fwd: key tiles split over nsplit blocks (grid.y); partial O in `part`, partial lse in `lpart`
+  float* lpart;
 };
 
 template <int HD> struct Cfg {
@@ -142,14 +144,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
   for (int d = 0; d < C::DF; ++d) acc_o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int ks = 0; ks < 2; ++ks) {
+  // key tiles of both segments form one list; blockIdx.y takes a contiguous share of it (KV split for launches with
+  // few query tiles, e.g. the batch-1 denoise step: 8 blocks would otherwise walk 10 tiles each, serially)
+  const int nt0 = (p.klen[0] + 63) >> 6, ntk = nt0 + ((p.klen[1] + 63) >> 6);
+  const int per = (ntk + p.nsplit - 1) / p.nsplit;
+  const int gt0 = blockIdx.y * per, gt1 = min(ntk, gt0 + per);
+  for (int gt = gt0; gt < gt1; ++gt) {
+    const int ks = gt >= nt0, kt = ks ? gt - nt0 : gt;
     const int klen = p.klen[ks];
-    if (klen == 0) continue;
     const int kinfo_off = ks ? p.klen[0] : 0;
     const long long krs = p.kv_rs[ks];
     const bf16* kb = p.k[ks] + (long long)b * klen * krs + hk * HD;
     const bf16* vb = p.v[ks] + (long long)b * klen * krs + hk * HD;
-    for (int kt = 0; kt * 64 < klen; ++kt) {
+    {
       __syncthreads();
       const int vr = min(64, klen - kt * 64);
       load_tile<HD>(sK, kb + (long long)kt * 64 * krs, krs, vr);
@@ -207,6 +214,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   l += __shfl_xor(l, 32, 64);
   if (!vq) return;
   const float inv = l > 0.f ? 1.0f / l : 0.f;
+  if (p.nsplit > 1) {
+    // partial result of this key share: normalised O (f32) + its log-sum-exp; combined by attn_fwd_combine_kernel
+    const long long row = ((long long)blockIdx.y * p.B + b) * Tq + qinfo_off + myq;
+    float* op = p.part + (row * p.NH + h) * HD;
+#pragma unroll
+    for (int d = 0; d < C::DF; ++d) {
+      const int d0 = d * 16 + 4 * g;
+      if (d0 < HD) *reinterpret_cast<f32x4*>(op + d0) = acc_o[d] * inv;
+    }
+    if (g == 0) p.lpart[(((long long)blockIdx.y * p.B + b) * p.NH + h) * Tq + qinfo_off + myq] = l > 0.f ? m + __logf(l) : NEG_BIG;
+    return;
+  }
   bf16* orow = p.o[id.seg] + (b * (long long)qlen + myq) * p.o_rs[id.seg] + h * HD;
 #pragma unroll
   for (int d = 0; d < C::DF; ++d) {
@@ -214,6 +233,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     if (d0 < HD) store4(orow + d0, acc_o[d], inv);
   }
   if (p.lse && g == 0) p.lse[((long long)b * p.NH + h) * Tq + qinfo_off + myq] = l > 0.f ? m + __logf(l) : LSE_EMPTY;
+}
+
+// Combine the nsplit partial results: O = sum_i exp(lse_i - lse) O_i.  One thread per (b, q, h, 4 d).
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_combine_kernel(AttnP p) {
+  const int Tq = p.qlen[0] + p.qlen[1];
+  const long long n4 = (long long)p.B * Tq * p.NH * HD / 4;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= n4) return;
+  const int d0 = (int)(gid % (HD / 4)) * 4;
+  long long r = gid / (HD / 4);
+  const int h = (int)(r % p.NH); r /= p.NH;
+  const int t = (int)(r % Tq);
+  const int b = (int)(r / Tq);
+  float mx = NEG_BIG;
+  for (int sp = 0; sp < p.nsplit; ++sp) mx = fmaxf(mx, p.lpart[(((long long)sp * p.B + b) * p.NH + h) * Tq + t]);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float den = 0.f;
+  for (int sp = 0; sp < p.nsplit; ++sp) {
+    const float li = p.lpart[(((long long)sp * p.B + b) * p.NH + h) * Tq + t];
+    if (li <= NEG_BIG * 0.5f) continue;
+    const float wgt = __expf(li - mx);
+    den += wgt;
+    acc += *reinterpret_cast<const f32x4*>(p.part + ((((long long)sp * p.B + b) * Tq + t) * p.NH + h) * HD + d0) * wgt;
+  }
+  const int seg = t >= p.qlen[0];
+  const int tt = seg ? t - p.qlen[0] : t;
+  store4(p.o[seg] + (b * (long long)p.qlen[seg] + tt) * p.o_rs[seg] + h * HD + d0, acc, den > 0.f ? 1.0f / den : 0.f);
+  if (p.lse && d0 == 0) p.lse[((long long)b * p.NH + h) * Tq + t] = den > 0.f ? mx + __logf(den) : LSE_EMPTY;
 }
 
 // ====================================================================== delta = rowsum(dO * O)
@@ -469,8 +517,13 @@ int launch_fwd(const AttnP& p, hipStream_t s) {
   const int nt = (p.qlen[0] + 63) / 64 + (p.qlen[1] + 63) / 64;
   const int lds = 2 * Cfg<HD>::TILE;
   if (int e = set_lds(attn_fwd_kernel<HD>, lds)) return e;
-  hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3(p.B * p.NH * nt), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3(p.B * p.NH * nt, p.nsplit), dim3(256), lds, s, p);
   LAP_CHECK_LAUNCH();
+  if (p.nsplit > 1) {
+    const long long n4 = (long long)p.B * (p.qlen[0] + p.qlen[1]) * p.NH * HD / 4;
+    hipLaunchKernelGGL(attn_fwd_combine_kernel<HD>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
+    LAP_CHECK_LAUNCH();
+  }
   return LAP_OK;
 }
 template <int HD>
@@ -523,6 +576,15 @@ extern "C" int lap_attention_fwd(const lap_attn_fwd_args* a, void* stream) {
   if ((a->qinfo == nullptr) != (a->kinfo == nullptr)) return LAP_ERR_ARG;
   p.qinfo = a->qinfo; p.kinfo = a->kinfo; p.lse = a->lse;
   p.scale = a->scale;
+  p.nsplit = 1; p.hsplit = 1;
+  if (a->nsplit > 1) {
+    const long long Tq = a->q_len[0] + a->q_len[1];
+    const long long need = (long long)a->nsplit * a->B * Tq * a->NH * (a->HD + 1);
+    if (!a->scratch || a->scratch_floats < need || (a->HD & 3)) return LAP_ERR_ARG;
+    p.nsplit = a->nsplit;
+    p.part = a->scratch;
+    p.lpart = a->scratch + (long long)a->nsplit * a->B * Tq * a->NH * a->HD;
+  }
   p.B = a->B; p.NH = a->NH; p.NKV = a->NKV;
   hipStream_t s = (hipStream_t)stream;
   switch (a->HD) {

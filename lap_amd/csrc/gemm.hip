@@ -49,6 +49,7 @@ struct GemmParams {
   int bias_kind;         // 0 none, 1 bf16, 2 f32
   int gelu, accum;
   int ksplit, ktiles_per_split;
+  float* part;           // split-K scratch: f32 [ksplit][M][N] partial products (null: atomic accumulate into C)
 };
 
 // 64-byte-row K-contiguous tile (BK = 32): 16-byte chunk c of row r is stored at chunk c ^ ((-(r >> 2)) & 3), which
@@ -204,6 +205,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
     for (int j = 0; j < FN; ++j) {
       const int n = n0 + wn * WTN + j * 16 + 4 * lg;
       if (n >= p.N) continue;  // N % 4 == 0 is required by the host wrapper
+      if (p.part) {  // split-K partial: raw product, epilogue happens in splitk_reduce_kernel
+        *reinterpret_cast<f32x4*>(p.part + ((long long)blockIdx.y * p.M + m) * p.N + n) = acc[i][j];
+        continue;
+      }
       f32x4 v = acc[i][j] * p.alpha;
       if (p.bias_kind == 1) {
         bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
@@ -237,6 +242,43 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
         *reinterpret_cast<bf16x4*>((bf16*)p.C + (long long)m * p.ldc + n) = o;
       }
     }
+  }
+}
+
+// out = epilogue(alpha * sum_s part[s]) for the two-phase split-K path.
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
+  const long long gid = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (gid >= (long long)p.M * p.N) return;
+  const int m = (int)(gid / p.N), n = (int)(gid % p.N);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < p.ksplit; ++sp) v += *reinterpret_cast<const f32x4*>(p.part + (long long)sp * p.M * p.N + gid);
+  v *= p.alpha;
+  if (p.bias_kind == 1) {
+    bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
+  } else if (p.bias_kind == 2) {
+    v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+  }
+  if (p.gelu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+  }
+  if (p.R) {
+    bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+  }
+  if (OUT_F32) {
+    float* c = (float*)p.C + (long long)m * p.ldc + n;
+    if (p.accum) v += *reinterpret_cast<const f32x4*>(c);
+    *reinterpret_cast<f32x4*>(c) = v;
+  } else {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+    *reinterpret_cast<bf16x4*>((bf16*)p.C + (long long)m * p.ldc + n) = o;
   }
 }
 
@@ -295,7 +337,8 @@ int pick_tile(int M, int N, int K) {
 
 extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const void* bias, const void* residual,
                                 int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
-                                int a_kc, int b_kc, int flags, int tile, int ksplit, void* stream) {
+                                int a_kc, int b_kc, int flags, int tile, int ksplit, void* scratch,
+                                long long scratch_bytes, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return LAP_ERR_ARG;
   // 16-byte chunk granularity along each contiguous axis; 4-wide epilogue stores.
   if ((N & 3) || (ldc & 3) || (lda & 7) || (ldb & 7)) return LAP_ERR_ARG;
@@ -310,7 +353,9 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
   if (tile < -1 || tile > 4 || ksplit < 0) return LAP_ERR_ARG;
-  if (ksplit > 1 && (!f32 || !(flags & LAP_GEMM_ACCUM) || bias || residual)) return LAP_ERR_ARG;
+  const bool two_phase = ksplit > 1 && scratch != nullptr;
+  if (two_phase && scratch_bytes < (long long)ksplit * M * N * 4) return LAP_ERR_ARG;
+  if (ksplit > 1 && !two_phase && (!f32 || !(flags & LAP_GEMM_ACCUM) || bias || residual)) return LAP_ERR_ARG;
   GemmParams p;
   p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C; p.bias = bias; p.R = (const bf16*)residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.alpha = alpha;
@@ -318,8 +363,22 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   p.gelu = (flags & LAP_GEMM_GELU) ? 1 : 0;
   p.accum = (flags & LAP_GEMM_ACCUM) ? 1 : 0;
   p.ksplit = ksplit > 1 ? ksplit : 1;
+  p.part = two_phase ? (float*)scratch : nullptr;
   if (tile < 0) tile = pick_tile(M, N, K);
   hipStream_t s = (hipStream_t)stream;
+  if (two_phase) {
+    int rc;
+    if (a_kc && b_kc) rc = dispatch_tile<true, true, true>(p, tile, s);
+    else if (a_kc && !b_kc) rc = dispatch_tile<true, false, true>(p, tile, s);
+    else if (!a_kc && !b_kc) rc = dispatch_tile<false, false, true>(p, tile, s);
+    else rc = dispatch_tile<false, true, true>(p, tile, s);
+    if (rc) return rc;
+    const long long n4 = (long long)M * N / 4;
+    if (f32) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
+    LAP_CHECK_LAUNCH();
+    return LAP_OK;
+  }
   if (f32) {
     if (a_kc && b_kc) return dispatch_tile<true, true, true>(p, tile, s);
     if (a_kc && !b_kc) return dispatch_tile<true, false, true>(p, tile, s);
@@ -335,5 +394,6 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
 extern "C" int lap_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual,
                              int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
                              int a_kc, int b_kc, int flags, void* stream) {
-  return lap_gemm_bf16_ex(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, alpha, a_kc, b_kc, flags, -1, 0, stream);
+  return lap_gemm_bf16_ex(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, alpha, a_kc, b_kc, flags, -1, 0, nullptr, 0,
+                          stream);
 }

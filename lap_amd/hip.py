@@ -44,7 +44,8 @@ class AttnFwdArgs(C.Structure):
         ("q_len", _i * 2), ("k_len", _i * 2),
         ("q_rs", _i * 2), ("kv_rs", _i * 2), ("o_rs", _i * 2),
         ("qinfo", _vp), ("kinfo", _vp), ("lse", _vp),
-        ("scale", _f),
+        ("scratch", _vp), ("scratch_floats", _ll),
+        ("scale", _f), ("nsplit", _i),
         ("B", _i), ("NH", _i), ("NKV", _i), ("HD", _i),
     ]
 
@@ -66,7 +67,7 @@ class AttnBwdArgs(C.Structure):
 SIGNATURES: dict[str, list] = {
     "lap_abi_version": [],
     "lap_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
-    "lap_gemm_bf16_ex": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp],
+    "lap_gemm_bf16_ex": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _ll, _vp],
     "lap_gemm_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
     "lap_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "lap_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -156,8 +157,16 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, 
         flags |= GEMM_GELU
     if bias is not None and bias.dtype == torch.float32:
         flags |= GEMM_BIAS_F32
+    scratch = None
+    if ksplit == 0 and tile < 0:
+        # too few 128x128 output tiles to fill 256 CUs and a deep K: two-phase split-K (f32 partials + reduce/epilogue)
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        if tiles <= 96 and K >= 1024:
+            ksplit = max(2, min(K // 256, 256 // tiles, 16))
+            tile = 0
+            scratch = torch.empty(ksplit * M * N, dtype=torch.float32, device=a.device)
     call("lap_gemm_bf16_ex", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, ldc, ldr, float(alpha),
-         int(a_kc), int(b_kc), flags, tile, ksplit)
+         int(a_kc), int(b_kc), flags, tile, ksplit, _p(scratch), scratch.numel() * 4 if scratch is not None else 0)
     return out
 
 
@@ -362,7 +371,7 @@ def add_posemb_cast_bwd(dy, dpos, T):
 
 # ----------------------------------------------------------------------- attention
 def attention_fwd(q, k, v, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None, need_lse=True, scale=1.0,
-                  q_rs=(0, 0), kv_rs=(0, 0)):
+                  q_rs=(0, 0), kv_rs=(0, 0), nsplit_hint=None):
     """q/k/v: lists of up to two segment tensors (None for an empty segment).  q_rs / kv_rs: row strides in
     elements when q / k / v are column slices of a wider (fused qkv) buffer; outputs are packed [B*len, NH*HD]."""
     a = AttnFwdArgs()
@@ -388,6 +397,19 @@ def attention_fwd(q, k, v, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None,
     lse = torch.empty((B, NH, Tq), dtype=torch.float32, device=dev) if need_lse else None
     a.qinfo, a.kinfo, a.lse = _p(qinfo), _p(kinfo), _p(lse)
     a.scale = float(scale)
+    # few query tiles (serving): split the key tiles over more blocks
+    ntq = (a.q_len[0] + 63) // 64 + (a.q_len[1] + 63) // 64
+    ntk = (a.k_len[0] + 63) // 64 + (a.k_len[1] + 63) // 64
+    blocks = B * NH * ntq
+    nsplit = 1
+    if nsplit_hint is not None:
+        nsplit = nsplit_hint
+    elif blocks < 128 and ntk > 1:
+        nsplit = min(ntk, max(1, 256 // blocks))
+    a.nsplit = nsplit
+    if nsplit > 1:
+        scratch = torch.empty(nsplit * B * Tq * NH * (HD + 1), dtype=torch.float32, device=dev)
+        a.scratch, a.scratch_floats = _p(scratch), scratch.numel()
     a.B, a.NH, a.NKV, a.HD = B, NH, NKV, HD
     _chk(_fn["lap_attention_fwd"](C.byref(a), _stream()), "lap_attention_fwd")
     return outs, lse

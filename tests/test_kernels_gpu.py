@@ -69,6 +69,17 @@ def test_gemm_tiles_all_layouts(hip, tile):
     assert torch.equal(hip.linear_fwd(a2, w2, tile=tile), w2.t().contiguous())
 
 
+def test_gemm_two_phase_splitk(hip):
+    # skinny-M serving shapes take the automatic two-phase split-K path (f32 partials + reduce/epilogue kernel)
+    for (M, N, K) in [(50, 1024, 4096), (50, 1024, 2048), (50, 2560, 1024), (560, 2048, 16384)]:
+        a = rnd(M, K); wt = rnd(N, K, seed=1); res = rnd(M, N, seed=2); bias = rnd(N, dtype=torch.float32, seed=3)
+        base = a.float() @ wt.float().t()
+        assert rel_err(hip.linear_fwd(a, wt), base) < 4e-3
+        assert rel_err(hip.linear_fwd(a, wt, bias=bias, residual=res), base + bias + res.float()) < 4e-3
+        assert rel_err(hip.linear_fwd(a, wt, bias=bias, gelu=True), torch.nn.functional.gelu(base + bias, approximate="tanh")) < 4e-3
+        assert rel_err(hip.linear_fwd(a, wt, out_dtype=torch.float32), base) < 1e-5
+
+
 def test_gemm_asymmetric_layout(hip):
     # transpose-detecting: A = identity-like selector, asymmetric B (guide rule 16)
     M = N = K = 128
@@ -412,6 +423,12 @@ def test_attention_suffix_only_queries(hip):
     ref = _attn_ref(q1.float().view(B, S, NH, HD), torch.cat([k0, k1], 1).float().view(B, Tp + S, 1, HD),
                     torch.cat([v0, v1], 1).float().view(B, Tp + S, 1, HD), mask, NH, 1)
     assert rel_err(o1.view(B, S, NH, HD), ref) < 1e-2
+    # explicit key-tile splits (combine kernel) give the same result, incl. a split that owns only masked keys
+    for ns in (1, 2, 3):
+        (_, o2), lse2 = hip.attention_fwd([None, q1], [k0, k1], [v0, v1], [0, S], [Tp, S], B, NH, 1, HD, qinfo, kinfo, nsplit_hint=ns)
+        assert rel_err(o2.view(B, S, NH, HD), ref) < 1e-2
+        lg = torch.einsum("bqhd,bkd->bhqk", q1.float().view(B, S, NH, HD), torch.cat([k0, k1], 1).float()).masked_fill(~mask[:, None], float("-inf"))
+        assert rel_err(lse2, torch.logsumexp(lg, -1)) < 1e-3
 
 
 # ------------------------------------------------------------------ loss / optimizer / misc
