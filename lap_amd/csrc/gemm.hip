@@ -14,14 +14,16 @@
 //   dgrad    dx = dy . Wt        -> a_kc=1, b_kc=0
 //   wgrad    dWt = dy^T . x      -> a_kc=0, b_kc=0
 //
-// Structure: BM x BN x 64 block tile, WGM x WGN waves, each wave a (BM/WGM) x
-// (BN/WGN) sub-tile of v_mfma_f32_16x16x32_bf16 fragments.  Three tile shapes:
-//   256x256 / 8 waves (128x64 per wave): 128 FLOP per L2 byte, one block per CU
-//            (128 KiB LDS) — the large, evenly divisible GEMMs;
-//   256x128 / 8 waves (64x64 per wave):  85 FLOP/B, one block per CU (96 KiB);
-//   128x128 / 4 waves (64x64 per wave):  64 FLOP/B, two blocks per CU — small or
+// Structure: BM x BN x BK block tile, WGM x WGN waves, each wave a (BM/WGM) x
+// (BN/WGN) sub-tile of v_mfma_f32_16x16x32_bf16 fragments.  Production shapes:
+//   256x256x64 / 16 waves (64x64 per wave): 128 FLOP per L2 byte, one block per CU
+//            (128 KiB LDS), 4 waves per SIMD hide the ds_read -> MFMA latency and the
+//            per-k-tile barrier — the large GEMMs (1.0-1.3 PF measured);
+//   128x128x64 /  8 waves (64x32 per wave): 64 FLOP/B, two blocks per CU — small or
 //            awkward shapes (a 128x128 tile at the 2.5 PF MFMA peak would need
 //            39 TB/s from L2, more than the ~35 TB/s the XCD L2s deliver).
+// Other instantiations (8-wave 256x256, BK=32 4-stage rings, 256x128) are kept
+// selectable through lap_gemm_bf16_ex for A/B measurements; they measured slower.
 // HBM -> LDS staging is buffer_load_dwordx4 ... lds (LDS-DMA, no VGPR round trip),
 // double buffered: tile t+1 streams in while tile t is multiplied, one barrier
 // per k-tile.  The LDS image is lane-linear per wave instruction, so the
@@ -307,6 +309,9 @@ int launch(GemmParams p, hipStream_t s) {
 template <bool A_KC, bool B_KC, bool OUT_F32>
 int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
   switch (tile) {
+    case 7: return launch<256, 128, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
+    case 6: return launch<128, 128, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
+    case 5: return launch<256, 256, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
     case 4: return launch<128, 128, 2, 2, 32, 4, A_KC, B_KC, OUT_F32>(p, s);
     case 3: return launch<256, 256, 2, 4, 32, 4, A_KC, B_KC, OUT_F32>(p, s);
     case 2: return launch<256, 256, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
@@ -315,22 +320,17 @@ int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
   }
 }
 
-// Tile heuristic: estimated time = rounds over the 256 CUs x per-CU work per round / relative efficiency.
-// Efficiencies are measured ratios on MI355X (tools/bench_kernels.py), not guesses about the hardware.
+// Tile heuristic between the two production shapes (measured on MI355X, tools/bench_kernels.py):
+//   tile 5 = 256x256, 16 waves, 1 block/CU  — 1.0-1.3 PF when its rounds over the 256 CUs are well filled;
+//   tile 6 = 128x128,  8 waves, 2 blocks/CU — 0.9-1.0 PF, finer quantisation, better for short K / few tiles.
+// score = round-fill efficiency x relative kernel efficiency (which grows with K for the big tile).
 int pick_tile(int M, int N, int K) {
-  const double eff[3] = {1.0, 0.9, 1.12};
-  const int bm[3] = {128, 256, 256}, bn[3] = {128, 128, 256}, per_cu[3] = {2, 1, 1};
-  double best = 1e300;
-  int arg = 0;
-  for (int t = 0; t < 3; ++t) {
-    const long long tiles = (long long)((M + bm[t] - 1) / bm[t]) * ((N + bn[t] - 1) / bn[t]);
-    const long long slots = 256LL * per_cu[t];
-    const long long rounds = (tiles + slots - 1) / slots;
-    const double cost = (double)rounds * per_cu[t] * bm[t] * bn[t] / eff[t];
-    if (cost < best) { best = cost; arg = t; }
-  }
-  (void)K;
-  return arg;
+  const long long t5 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  const long long t6 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  const double fill5 = (double)t5 / (256.0 * ((t5 + 255) / 256));
+  const double fill6 = (double)t6 / (512.0 * ((t6 + 511) / 512));
+  const double eff5 = 1.15 + 0.13 * (K >= 8192 ? 1.0 : K / 8192.0);
+  return (fill5 * eff5 > fill6) ? 5 : 6;
 }
 
 }  // namespace
@@ -352,7 +352,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   const bool f32 = flags & LAP_GEMM_OUT_F32;
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
-  if (tile < -1 || tile > 4 || ksplit < 0) return LAP_ERR_ARG;
+  if (tile < -1 || tile > 7 || ksplit < 0) return LAP_ERR_ARG;
   const bool two_phase = ksplit > 1 && scratch != nullptr;
   if (two_phase && scratch_bytes < (long long)ksplit * M * N * 4) return LAP_ERR_ARG;
   if (ksplit > 1 && !two_phase && (!f32 || !(flags & LAP_GEMM_ACCUM) || bias || residual)) return LAP_ERR_ARG;
