@@ -330,7 +330,38 @@ int pick_tile(int M, int N, int K) {
   const double fill5 = (double)t5 / (256.0 * ((t5 + 255) / 256));
   const double fill6 = (double)t6 / (512.0 * ((t6 + 511) / 512));
   const double eff5 = 1.15 + 0.13 * (K >= 8192 ? 1.0 : K / 8192.0);
+  if (t6 <= 256) return 6;  // not even one round of small tiles: finest granularity (+ split-K) wins
   return (fill5 * eff5 > fill6) ? 5 : 6;
+}
+
+// Automatic two-phase split-K (only when the caller lends scratch): fills the last round of a poorly filled
+// 256x256 grid, or spreads a GEMM with a handful of output tiles (skinny-M serving, small weights) over the chip.
+int pick_ksplit(int tile, int M, int N, int K, long long scratch_bytes) {
+  const long long cap = scratch_bytes / ((long long)M * N * 4);
+  if (cap < 2) return 1;
+  if (tile == 5) {
+    const long long t5 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    const double fill1 = (double)t5 / (256.0 * ((t5 + 255) / 256));
+    if (fill1 >= 0.8 || K < 4096) return 1;
+    int best = 1;
+    double score = fill1;
+    for (int sp = 2; sp <= 4 && sp <= cap; ++sp) {
+      const long long w = t5 * sp;
+      const double sc = (double)w / (256.0 * ((w + 255) / 256)) - 0.02 * sp;
+      if (sc > score) { score = sc; best = sp; }
+    }
+    return best;
+  }
+  if (tile == 6 || tile == 0) {
+    const long long t6 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    if (t6 > 96 || K < 1024) return 1;
+    long long sp = 256 / t6;
+    if (sp > K / 256) sp = K / 256;
+    if (sp > 16) sp = 16;
+    if (sp > cap) sp = cap;
+    return sp < 2 ? 1 : (int)sp;
+  }
+  return 1;
 }
 
 }  // namespace
@@ -353,6 +384,8 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
   if (tile < -1 || tile > 7 || ksplit < 0) return LAP_ERR_ARG;
+  if (tile < 0) tile = pick_tile(M, N, K);
+  if (ksplit == 0 && scratch != nullptr) ksplit = pick_ksplit(tile, M, N, K, scratch_bytes);
   const bool two_phase = ksplit > 1 && scratch != nullptr;
   if (two_phase && scratch_bytes < (long long)ksplit * M * N * 4) return LAP_ERR_ARG;
   if (ksplit > 1 && !two_phase && (!f32 || !(flags & LAP_GEMM_ACCUM) || bias || residual)) return LAP_ERR_ARG;
@@ -364,7 +397,6 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   p.accum = (flags & LAP_GEMM_ACCUM) ? 1 : 0;
   p.ksplit = ksplit > 1 ? ksplit : 1;
   p.part = two_phase ? (float*)scratch : nullptr;
-  if (tile < 0) tile = pick_tile(M, N, K);
   hipStream_t s = (hipStream_t)stream;
   if (two_phase) {
     int rc;

@@ -142,6 +142,19 @@ def _req(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
 
 
 # ------------------------------------------------------------------------------ GEMM
+_SCRATCH: dict = {}
+
+
+def _gemm_scratch(device, floats: int = 160 * 1024 * 1024):
+    """Per-device f32 scratch (640 MB) lent to the GEMM for two-phase split-K; all uses are stream-ordered."""
+    key = (device.type, device.index)
+    t = _SCRATCH.get(key)
+    if t is None:
+        t = torch.empty(floats, dtype=torch.float32, device=device)
+        _SCRATCH[key] = t
+    return t
+
+
 def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, residual=None, ldr=0,
          alpha=1.0, gelu=False, accum=False, tile=-1, ksplit=0):
     """out[M,N] = epi(alpha * opA . opB); see include/lap_hip.h lap_gemm_bf16 / lap_gemm_bf16_ex."""
@@ -157,14 +170,8 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, 
         flags |= GEMM_GELU
     if bias is not None and bias.dtype == torch.float32:
         flags |= GEMM_BIAS_F32
-    scratch = None
-    if ksplit == 0 and tile < 0:
-        # too few 128x128 output tiles to fill 256 CUs and a deep K: two-phase split-K (f32 partials + reduce/epilogue)
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        if tiles <= 96 and K >= 1024:
-            ksplit = max(2, min(K // 256, 256 // tiles, 16))
-            tile = 0
-            scratch = torch.empty(ksplit * M * N, dtype=torch.float32, device=a.device)
+    # the library decides on two-phase split-K itself when it is lent scratch (poorly filled grids, skinny-M serving)
+    scratch = _gemm_scratch(a.device) if (ksplit == 0 and not accum) else None
     call("lap_gemm_bf16_ex", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, ldc, ldr, float(alpha),
          int(a_kc), int(b_kc), flags, tile, ksplit, _p(scratch), scratch.numel() * 4 if scratch is not None else 0)
     return out
