@@ -201,6 +201,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   }
 }
 
+// Skinny f32 GEMM (M <= 64 rows, both operands k-contiguous): one wave per output column n and group of 8 rows;
+// the weight row streams once with coalesced 16-byte loads, the k-sum order is fixed (lane-strided, then a
+// butterfly), so results are deterministic.  Serves the batch-1 time-MLP / action head (lap.py:52-62,298).
+__global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                       float* __restrict__ C, const float* __restrict__ bias, int M, int N,
+                                                       int K, int lda, int ldb, int ldc, float alpha, int accum) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + w;
+  const int m0 = blockIdx.y * 8;
+  if (n >= N) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* brow = B + (long long)n * ldb;
+  for (int k = lane; k < K; k += 64) {
+    const float bv = brow[k];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (m0 + r < M) acc[r] = fmaf(A[(long long)(m0 + r) * lda + k], bv, acc[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = wave_sum(acc[r]);
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (m0 + r >= M) break;
+      float v = acc[r] * alpha + (bias ? bias[n] : 0.f);
+      float* c = C + (long long)(m0 + r) * ldc + n;
+      if (accum) v += *c;
+      *c = v;
+    }
+  }
+}
+
 }  // namespace
 
 #define S_ ((hipStream_t)stream)
@@ -240,6 +272,12 @@ extern "C" int lap_adamw_ema(float* p, float* m, float* v, float* ema, const flo
 extern "C" int lap_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                             int ldb, int ldc, float alpha, int a_kc, int b_kc, int accum, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return LAP_ERR_ARG;
+  if (a_kc && b_kc && M <= 64) {
+    hipLaunchKernelGGL(gemv_f32_kernel, dim3((N + 3) / 4, (M + 7) / 8), dim3(256), 0, S_, A, B, C, bias, M, N, K, lda, ldb, ldc,
+                       alpha, accum);
+    LAP_CHECK_LAUNCH();
+    return LAP_OK;
+  }
   dim3 grid((N + 63) / 64, (M + 63) / 64);
 #define GO(AK, BK) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK>), grid, dim3(256), 0, S_, A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, accum)
   if (a_kc && b_kc) GO(true, true);

@@ -314,7 +314,7 @@ inline int nch_for(int D) { return (D / 8 + 63) / 64; }
 
 extern "C" int lap_rmsnorm_fwd(const void* x, const float* scale, const void* mod, void* y, float* rstd,
                                int rows, int D, int rows_per_sample, int mod_ld, float eps, void* stream) {
-  if (rows <= 0 || D <= 0 || (D & 7) || (!scale && !mod) || (mod && (rows_per_sample <= 0 || (mod_ld & 7) || mod_ld < 3 * D)))
+  if (rows <= 0 || D <= 0 || (D & 7) || (!scale && !mod) || (mod && (rows_per_sample <= 0 || (mod_ld & 7) || (mod_ld != 0 && mod_ld < 3 * D))))  // mod_ld == 0: one modulation row shared by all samples
     return LAP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((rows + NWAVE - 1) / NWAVE);
@@ -330,7 +330,7 @@ extern "C" int lap_rmsnorm_bwd(const void* x, const float* scale, const void* mo
   if (rows <= 0 || D <= 0 || (D & 7) || !rstd) return LAP_ERR_ARG;
   if (mod ? (!dmod || rows_per_sample <= 0 || rows % rows_per_sample) : (!scale || !dscale)) return LAP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int G = mod ? rows_per_sample : 64;
+  const int G = mod ? rows_per_sample : 16;   // 4 rows per wave: >= 1000 blocks at LAP-3B row counts (latency hiding); one f32 atomic per column per block
   dim3 grid((rows + G - 1) / G);
   const size_t shm = (size_t)NWAVE * (mod ? 2 : 1) * D * sizeof(float);
   DISPATCH_NCH(D, hipLaunchKernelGGL(rmsnorm_bwd_kernel<NCH>, grid, dim3(256), shm, s, (const bf16*)x, scale,
@@ -356,7 +356,7 @@ extern "C" int lap_layernorm_bwd(const void* x, const float* gamma, const float*
                                  void* stream) {
   if (rows <= 0 || D <= 0 || (D & 7) || !gamma || !mean || !rstd || !dgamma || !dbeta) return LAP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int G = 64;
+  const int G = 16;
   dim3 grid((rows + G - 1) / G);
   const size_t shm = (size_t)NWAVE * 2 * D * sizeof(float);
   DISPATCH_NCH(D, hipLaunchKernelGGL(layernorm_bwd_kernel<NCH>, grid, dim3(256), shm, s, (const bf16*)x, gamma, mean,

@@ -214,13 +214,15 @@ def gemm_f32(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=No
 
 
 # ------------------------------------------------------------------- normalisation
-def rmsnorm_fwd(x, scale=None, mod=None, rows_per_sample=0, eps=1e-6, save_rstd=True):
-    """mod: bf16 [B, >=3D] view (row stride = mod.stride(0)) holding scale|shift|gate."""
+def rmsnorm_fwd(x, scale=None, mod=None, rows_per_sample=0, eps=1e-6, save_rstd=True, mod_ld=None):
+    """mod: bf16 [B, >=3D] view (row stride = mod.stride(0)) holding scale|shift|gate; mod_ld=0 shares row 0
+    between all samples (serving: the condition depends on the denoise time only)."""
     rows, D = x.shape
     y = torch.empty_like(x)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_rstd else None
-    call("lap_rmsnorm_fwd", _p(x), _p(scale), _p(mod), _p(y), _p(rstd), rows, D, rows_per_sample,
-         mod.stride(0) if mod is not None else 0, float(eps))
+    if mod_ld is None:
+        mod_ld = mod.stride(0) if mod is not None else 0
+    call("lap_rmsnorm_fwd", _p(x), _p(scale), _p(mod), _p(y), _p(rstd), rows, D, rows_per_sample, mod_ld, float(eps))
     return y, rstd
 
 

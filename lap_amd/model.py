@@ -265,13 +265,11 @@ class LAP:
             hip.copy_rows_bf16(dx0, dtok[i * B * T:(i + 1) * B * T], B * T, T, Dv, Pn, i * T, T, 0)
         self._siglip_bwd(ictx, dtok)
 
-    def _embed_suffix(self, x_t: torch.Tensor, time: torch.Tensor, save: bool):
-        """[UPSTREAM-RECALL] openpi Pi0.embed_suffix (pi05): action tokens, adaRMS condition."""
-        B, S, ad = x_t.shape
+    def _time_mod(self, time: torch.Tensor, save: bool):
+        """[UPSTREAM-RECALL] openpi Pi0.embed_suffix (pi05), time branch: posemb_sincos -> time_mlp_in -> swish ->
+        time_mlp_out -> swish = adaRMS condition; then all 2L+1 adaRMS Dense layers (gemma.py:128) as ONE GEMM against the
+        adaRMS bank.  time f32 [n] -> mod bf16 [n, nslots*3*We]."""
         We = self.e.width
-        xt2 = x_t.reshape(B * S, ad).contiguous()
-        a_tok = self._lin32(xt2, "act/in_w", "act/in_b")
-        x1 = hip.cast_f32_to_bf16(a_tok)
         temb = hip.posemb_sincos(time.contiguous(), We, 4e-3, 4.0)
         h1 = self._lin32(temb, "act/time_in_w", "act/time_in_b")
         s1 = hip.swish_fwd(h1)
@@ -279,8 +277,19 @@ class LAP:
         cond = hip.swish_fwd(h2)
         cond16 = hip.cast_f32_to_bf16(cond)
         self.comm.wait_unit("ada")
-        mod = hip.linear_fwd(cond16, self.W("ada/w"), bias=self.F("ada/b"))   # [B, nslots*3We] bf16 (gemma.py:128)
-        return x1, mod, ((xt2, temb, h1, s1, h2, cond16) if save else None)
+        mod = hip.linear_fwd(cond16, self.W("ada/w"), bias=self.F("ada/b"))
+        return mod, ((temb, h1, s1, h2, cond16) if save else None)
+
+    def _embed_actions(self, x_t: torch.Tensor):
+        """action_in_proj (f32 nnx.Linear, lap.py:52) on the noisy actions -> bf16 suffix tokens."""
+        B, S, ad = x_t.shape
+        xt2 = x_t.reshape(B * S, ad).contiguous()
+        return hip.cast_f32_to_bf16(self._lin32(xt2, "act/in_w", "act/in_b")), xt2
+
+    def _embed_suffix(self, x_t: torch.Tensor, time: torch.Tensor, save: bool):
+        x1, xt2 = self._embed_actions(x_t)
+        mod, tctx = self._time_mod(time, save)
+        return x1, mod, ((xt2, *tctx) if save else None)
 
     def _embed_suffix_bwd(self, sctx, dx1, dmod):
         xt2, temb, h1, s1, h2, cond16 = sctx
@@ -300,7 +309,8 @@ class LAP:
         W3 = 3 * self.e.width
         return mod[:, slot * W3:(slot + 1) * W3]
 
-    def _llm_fwd(self, x0, x1, mod, pos, qinfo, kinfo, B, n0, n1, save: bool, kv_cache=None, cache_out=None, collect=None):
+    def _llm_fwd(self, x0, x1, mod, pos, qinfo, kinfo, B, n0, n1, save: bool, kv_cache=None, cache_out=None, collect=None,
+                 mod_shared: bool = False):
         """gemma.Module.__call__ layers (gemma.py:336-387,167-290).  x0 [B*n0, Dv] or None, x1 [B*n1, De] or None.
         kv_cache: per-layer (k, v) of the prefix used as key segment 0 when x0 is None (serving).
         Returns final pre-norm activations and the saved context."""
@@ -308,6 +318,7 @@ class LAP:
         NH, HD, KV = v.num_heads, v.head_dim, v.num_kv_heads
         Ttot = pos.shape[1]
         ctx = [] if save else None
+        mld = 0 if mod_shared else (mod.stride(0) if mod is not None else 0)  # 0: one modulation row for every sample
         for l in range(v.depth):
             self.comm.wait_unit(f"llm{l}")
             p = f"llm/{l}/"
@@ -320,7 +331,7 @@ class LAP:
             elif kv_cache is not None:
                 k[0], vv[0] = kv_cache[l]
             if x1 is not None:
-                h[1], rstd_a[1] = hip.rmsnorm_fwd(x1, mod=self._mod_slot(mod, 2 * l), rows_per_sample=n1, save_rstd=save)
+                h[1], rstd_a[1] = hip.rmsnorm_fwd(x1, mod=self._mod_slot(mod, 2 * l), rows_per_sample=n1, save_rstd=save, mod_ld=mld)
                 qkv = hip.linear_fwd(h[1], self.W(p + "wqkv1"))
                 q[1], k[1], vv[1] = hip.rope_split_fwd(qkv, pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
                 del qkv
@@ -340,12 +351,12 @@ class LAP:
             if x1 is not None:
                 We3 = 3 * e.width
                 y1 = hip.linear_fwd(o[1], self.W(p + "wo1"))
-                xa[1] = hip.gated_residual_fwd(x1, y1, self._mod_slot(mod, 2 * l)[:, 2 * e.width:], n1, mod.stride(0))
-                hf[1], rstd_f[1] = hip.rmsnorm_fwd(xa[1], mod=self._mod_slot(mod, 2 * l + 1), rows_per_sample=n1, save_rstd=save)
+                xa[1] = hip.gated_residual_fwd(x1, y1, self._mod_slot(mod, 2 * l)[:, 2 * e.width:], n1, mld)
+                hf[1], rstd_f[1] = hip.rmsnorm_fwd(xa[1], mod=self._mod_slot(mod, 2 * l + 1), rows_per_sample=n1, save_rstd=save, mod_ld=mld)
                 gu[1] = hip.linear_fwd(hf[1], self.W(p + "wgu1"))
                 act[1] = hip.geglu_fwd(gu[1])
                 y1f = hip.linear_fwd(act[1], self.W(p + "wd1"))
-                xn[1] = hip.gated_residual_fwd(xa[1], y1f, self._mod_slot(mod, 2 * l + 1)[:, 2 * e.width:], n1, mod.stride(0))
+                xn[1] = hip.gated_residual_fwd(xa[1], y1f, self._mod_slot(mod, 2 * l + 1)[:, 2 * e.width:], n1, mld)
             if save:
                 ctx.append(dict(x=[x0, x1], h=h, rstd_a=rstd_a, q=q, k=k, v=vv, o=o, lse=lse, xa=xa, y1=y1, hf=hf, rstd_f=rstd_f,
                                 gu=gu, act=act, y1f=y1f))
@@ -548,20 +559,23 @@ class LAP:
         cache = []
         self._llm_fwd(x0, None, None, ppos, qinfo_p, kinfo_p, B, Pn, 0, False, cache_out=cache)
         dt = -1.0 / num_steps
-        t = 1.0
-        step = 0
-        tbuf = torch.empty(B, dtype=torch.float32, device=dev)
-        while t >= -dt / 2:
-            tbuf.fill_(t)
-            x1, mod, _ = self._embed_suffix(x_t, tbuf, False)
-            _, xf1, _ = self._llm_fwd(None, x1, mod, pos_all, qinfo_s, kinfo_all, B, Pn, S, False, kv_cache=cache)
-            pre1, _ = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=False)
+        times, t = [], 1.0
+        while t >= -dt / 2:  # lap.py:669-674 loop condition, unrolled on the host (the time grid is data independent)
+            times.append(t)
+            t += dt
+        # the adaRMS condition depends on the denoise time only: all steps' modulations in one pass over the adaRMS bank
+        # built on the device (no host->device copy: the sampler is captured into a HIP graph and replayed)
+        tvec = 1.0 + dt * torch.arange(len(times), dtype=torch.float32, device=dev)
+        mods, _ = self._time_mod(tvec, False)
+        for step in range(len(times)):
+            mod = mods[step:step + 1]
+            x1, _ = self._embed_actions(x_t)
+            _, xf1, _ = self._llm_fwd(None, x1, mod, pos_all, qinfo_s, kinfo_all, B, Pn, S, False, kv_cache=cache, mod_shared=True)
+            pre1, _ = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=False, mod_ld=0)
             v_t = self._lin32(hip.cast_bf16_to_f32(pre1), "act/out_w", "act/out_b")
             if collect is not None:
                 collect[f"v_t/{step}"] = v_t.view(B, S, ad).clone()
             hip.axpy_f32(x_t, v_t, dt)
-            t += dt
-            step += 1
         return x_t
 
     def sample_tokens(self, *a, **k):
