@@ -198,7 +198,9 @@ def main():
             "final_loss": round(loss, 5),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            # 16 host threads: torch-CPU matmuls of this size stop scaling well beyond that (256 threads on the
+            # GPU box took 166 s for the same slice)
+            out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
