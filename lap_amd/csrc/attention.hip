@@ -104,6 +104,30 @@ __device__ __forceinline__ void store4(bf16* p, const f32x4& v, float s) {
   *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+// Stage the info words of one 64-row tile into LDS (ints [0,64)) with three summaries: [64] AND of the class bits,
+// [65] OR of the class bits, [66] max (keys) / min (queries) of the index field.  Rows past `valid` get class 0.
+// Executed by wave 0 between the two tile-load barriers.  With these a wave decides per tile, without touching the
+// individual words, whether every (query, key) pair is allowed (no masking work at all), none is (tile skipped),
+// or the tile is mixed (per-element path).  `want_min` selects min instead of max for the index summary.
+__device__ __forceinline__ void stage_infos(int* sInfo, const int32_t* info, int valid, bool want_min) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const int v = (lane < valid) ? info[lane] : 0;
+    sInfo[lane] = v;
+    int c_and = (lane < valid) ? (v >> 24) : 0, c_or = v >> 24;
+    int idx = (lane < valid) ? (v & 0xffffff) : (want_min ? 0 : 0xffffff);
+    if (valid < 64 && lane >= valid) { c_and = 0; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      c_and &= __shfl_xor(c_and, o, 64);
+      c_or |= __shfl_xor(c_or, o, 64);
+      const int other = __shfl_xor(idx, o, 64);
+      idx = want_min ? min(idx, other) : max(idx, other);
+    }
+    if (lane == 0) { sInfo[64] = c_and; sInfo[65] = c_or; sInfo[66] = idx; }
+  }
+}
+
 struct BlockId { int b, h, seg, tile; };
 __device__ __forceinline__ BlockId decode_block(int len0, int len1, int nheads) {
   const int nt0 = (len0 + 63) >> 6, nt1 = (len1 + 63) >> 6, nt = nt0 + nt1;
@@ -124,6 +148,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sV = smem + C::TILE;
+  int* sInfo = reinterpret_cast<int*>(smem + 2 * C::TILE);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const BlockId id = decode_block(p.qlen[0], p.qlen[1], p.NH);
@@ -161,7 +186,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       const int vr = min(64, klen - kt * 64);
       load_tile<HD>(sK, kb + (long long)kt * 64 * krs, krs, vr);
       load_tile<HD>(sV, vb + (long long)kt * 64 * krs, krs, vr);
+      if (p.kinfo) stage_infos(sInfo, p.kinfo + (long long)b * Tk + kinfo_off + kt * 64, vr, false);
       __syncthreads();
+
+      // tile-level mask decision (wave uniform): skip / no masking needed / per-element
+      bool all_ok = vr == 64, none = false;
+      if (p.kinfo) {
+        const int kand = sInfo[64], kor = sInfo[65], kmax = sInfo[66];
+        all_ok = all_ok && (((qi >> 24) & kand) != 0) && (kmax <= (qi & 0xffffff));
+        none = vq && (((qi >> 24) & kor) == 0);
+      }
+      if (__all(none || !vq)) continue;       // nothing in this tile is visible to this wave's queries
+      const bool fast = __all(all_ok || !vq);
 
       f32x4 s[4];
 #pragma unroll
@@ -175,16 +211,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       float smax = NEG_BIG;
       bool ok[4][4];
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
+      for (int nf = 0; nf < 4; ++nf) {
+        i32x4 kw = {0, 0, 0, 0};
+        if (!fast && p.kinfo) kw = *reinterpret_cast<const i32x4*>(sInfo + nf * 16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kt * 64 + nf * 16 + 4 * g + r;
-          bool a = key < klen;
-          if (a && p.kinfo) a = mask_ok(qi, p.kinfo[(long long)b * Tk + kinfo_off + key]);
+          bool a = true;
+          if (!fast) {
+            const int key = kt * 64 + nf * 16 + 4 * g + r;
+            a = key < klen;
+            if (a && p.kinfo) a = mask_ok(qi, kw[r]);
+          }
           ok[nf][r] = a;
           s[nf][r] *= p.scale;
           if (a) smax = fmaxf(smax, s[nf][r]);
         }
+      }
       smax = fmaxf(smax, __shfl_xor(smax, 16, 64));
       smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
       const float m_new = fmaxf(m, smax);
@@ -297,6 +339,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sQ = smem;
   char* sD = smem + C::TILE;
+  int* sInfo = reinterpret_cast<int*>(smem + 2 * C::TILE);        // 64 query info words + 3 summaries
+  float* sLse = reinterpret_cast<float*>(smem + 2 * C::TILE + 320);  // lse and delta of the 64 query rows
+  float* sDl = sLse + 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const BlockId id = decode_block(p.klen[0], p.klen[1], p.NKV * p.hsplit);
@@ -334,7 +379,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
         const int vr = min(64, qlen - qt * 64);
         load_tile<HD>(sQ, qb + (long long)qt * 64 * qrs, qrs, vr);
         load_tile<HD>(sD, dob + (long long)qt * 64 * ors, ors, vr);
+        if (p.qinfo) stage_infos(sInfo, p.qinfo + (long long)b * Tq + qinfo_off + qt * 64, vr, true);
+        if (threadIdx.x >= 64 && threadIdx.x < 128) {
+          const int r = threadIdx.x - 64;
+          sLse[r] = r < vr ? lse[qt * 64 + r] : LSE_EMPTY;
+          sDl[r] = r < vr ? dl[qt * 64 + r] : 0.f;
+        }
         __syncthreads();
+        bool all_ok = vk && vr == 64, none = false;
+        if (p.qinfo) {
+          const int qand = sInfo[64], qor = sInfo[65], qmin = sInfo[66];
+          all_ok = all_ok && (((ki >> 24) & qand) != 0) && ((ki & 0xffffff) <= qmin);
+          none = ((ki >> 24) & qor) == 0;
+        }
+        if (__all(none || !vk)) continue;      // no query of this tile sees this wave's keys
+        const bool fast = __all(all_ok);
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int qf = 0; qf < 4; ++qf) { s[qf] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -347,20 +406,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
           }
         // lane: key column i, query rows 16qf + 4g + r
 #pragma unroll
-        for (int qf = 0; qf < 4; ++qf)
+        for (int qf = 0; qf < 4; ++qf) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + qf * 16 + 4 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + qf * 16 + 4 * g);
+          i32x4 qw = {0, 0, 0, 0};
+          if (!fast && p.qinfo) qw = *reinterpret_cast<const i32x4*>(sInfo + qf * 16 + 4 * g);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int q = qt * 64 + qf * 16 + 4 * g + r;
-            bool a = vk && q < qlen;
-            if (a && p.qinfo) a = mask_ok(p.qinfo[(long long)b * Tq + qinfo_off + q], ki);
+            bool a = true;
+            if (!fast) {
+              a = vk && (qt * 64 + qf * 16 + 4 * g + r) < qlen;
+              if (a && p.qinfo) a = mask_ok(qw[r], ki);
+            }
             float pv = 0.f, ds = 0.f;
             if (a) {
-              pv = __expf(s[qf][r] * p.scale - lse[q]);
-              ds = pv * (dp[qf][r] - dl[q]) * p.scale;
+              pv = __expf(s[qf][r] * p.scale - l4[r]);
+              ds = pv * (dp[qf][r] - d4[r]) * p.scale;
             }
             s[qf][r] = pv;
             dp[qf][r] = ds;
           }
+        }
         const bf16x8 p0 = pack8(s[0], s[1]), p1 = pack8(s[2], s[3]);
         const bf16x8 d0 = pack8(dp[0], dp[1]), d1 = pack8(dp[2], dp[3]);
 #pragma unroll
@@ -431,6 +497,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sV = smem + C::TILE;
+  int* sInfo = reinterpret_cast<int*>(smem + 2 * C::TILE);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const BlockId id = decode_block(p.qlen[0], p.qlen[1], p.NH);
@@ -467,7 +534,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
       const int vr = min(64, klen - kt * 64);
       load_tile<HD>(sK, kb + (long long)kt * 64 * krs, krs, vr);
       load_tile<HD>(sV, vb + (long long)kt * 64 * krs, krs, vr);
+      if (p.kinfo) stage_infos(sInfo, p.kinfo + (long long)b * Tk + kinfo_off + kt * 64, vr, false);
       __syncthreads();
+      bool all_ok = vr == 64, none = false;
+      if (p.kinfo) {
+        const int kand = sInfo[64], kor = sInfo[65], kmax = sInfo[66];
+        all_ok = all_ok && (((qi >> 24) & kand) != 0) && (kmax <= (qi & 0xffffff));
+        none = vq && (((qi >> 24) & kor) == 0);
+      }
+      if (__all(none || !vq)) continue;
+      const bool fast = __all(all_ok || !vq);
       f32x4 s[4], dp[4];
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) { s[nf] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -479,14 +555,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
           dp[nf] = mfma16(frag_kc<HD>(sV, nf * 16, kk, lane), dof[kk], dp[nf]);   // dP^T[key][q]
         }
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
+      for (int nf = 0; nf < 4; ++nf) {
+        i32x4 kw = {0, 0, 0, 0};
+        if (!fast && p.kinfo) kw = *reinterpret_cast<const i32x4*>(sInfo + nf * 16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kt * 64 + nf * 16 + 4 * g + r;
-          bool a = vq && key < klen;
-          if (a && p.kinfo) a = mask_ok(qi, p.kinfo[(long long)b * Tk + kinfo_off + key]);
+          bool a = vq;
+          if (!fast) {
+            const int key = kt * 64 + nf * 16 + 4 * g + r;
+            a = vq && key < klen;
+            if (a && p.kinfo) a = mask_ok(qi, kw[r]);
+          }
           dp[nf][r] = a ? __expf(s[nf][r] * p.scale - lse_q) * (dp[nf][r] - dl_q) * p.scale : 0.f;
         }
+      }
       const bf16x8 d0 = pack8(dp[0], dp[1]), d1 = pack8(dp[2], dp[3]);
 #pragma unroll
       for (int d = 0; d < C::DF; ++d) {
@@ -515,7 +597,7 @@ int set_lds(K kernel, int bytes) {
 template <int HD>
 int launch_fwd(const AttnP& p, hipStream_t s) {
   const int nt = (p.qlen[0] + 63) / 64 + (p.qlen[1] + 63) / 64;
-  const int lds = 2 * Cfg<HD>::TILE;
+  const int lds = 2 * Cfg<HD>::TILE + 1024;   // + staged info words / lse / delta
   if (int e = set_lds(attn_fwd_kernel<HD>, lds)) return e;
   hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3(p.B * p.NH * nt, p.nsplit), dim3(256), lds, s, p);
   LAP_CHECK_LAUNCH();
@@ -529,7 +611,7 @@ int launch_fwd(const AttnP& p, hipStream_t s) {
 template <int HD>
 int launch_bwd(const AttnP& p, hipStream_t s) {
   const int Tq = p.qlen[0] + p.qlen[1];
-  const int lds = 2 * Cfg<HD>::TILE;
+  const int lds = 2 * Cfg<HD>::TILE + 1024;   // + staged info words / lse / delta
   const long long items = (long long)p.B * Tq * p.NH;
   hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p);
   LAP_CHECK_LAUNCH();

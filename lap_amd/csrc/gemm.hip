@@ -64,6 +64,47 @@ __device__ __forceinline__ bf16x8 kc32_frag(const char* tile, int row0, int lane
   return *reinterpret_cast<const bf16x8*>(tile + kc32_tile_off(row0 + i, g));
 }
 
+// Epilogue for 4 consecutive outputs C[m][n..n+3] held by one lane (shared by every kernel shape).
+template <bool OUT_F32>
+__device__ __forceinline__ void store_tile4(const GemmParams& p, int m, int n, f32x4 a) {
+  if (p.part) {  // split-K partial: raw product, epilogue happens in splitk_reduce_kernel
+    *reinterpret_cast<f32x4*>(p.part + ((long long)blockIdx.y * p.M + m) * p.N + n) = a;
+    return;
+  }
+  f32x4 v = a * p.alpha;
+  if (p.bias_kind == 1) {
+    bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
+  } else if (p.bias_kind == 2) {
+    v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+  }
+  if (p.gelu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+  }
+  if (p.R) {
+    bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+  }
+  if (OUT_F32) {
+    float* c = (float*)p.C + (long long)m * p.ldc + n;
+    if (p.ksplit > 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+    } else {
+      if (p.accum) v += *reinterpret_cast<const f32x4*>(c);
+      *reinterpret_cast<f32x4*>(c) = v;
+    }
+  } else {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+    *reinterpret_cast<bf16x4*>((bf16*)p.C + (long long)m * p.ldc + n) = o;
+  }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // BK: k-depth of one LDS stage (32 or 64); NS: LDS stages.  Loads of tile t+NS-1 are issued while tile t is
@@ -207,44 +248,192 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
     for (int j = 0; j < FN; ++j) {
       const int n = n0 + wn * WTN + j * 16 + 4 * lg;
       if (n >= p.N) continue;  // N % 4 == 0 is required by the host wrapper
-      if (p.part) {  // split-K partial: raw product, epilogue happens in splitk_reduce_kernel
-        *reinterpret_cast<f32x4*>(p.part + ((long long)blockIdx.y * p.M + m) * p.N + n) = acc[i][j];
-        continue;
-      }
-      f32x4 v = acc[i][j] * p.alpha;
-      if (p.bias_kind == 1) {
-        bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
-      } else if (p.bias_kind == 2) {
-        v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
-      }
-      if (p.gelu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-      }
-      if (p.R) {
-        bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-      }
-      if (OUT_F32) {
-        float* c = (float*)p.C + (long long)m * p.ldc + n;
-        if (p.ksplit > 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
-        } else {
-          if (p.accum) v += *reinterpret_cast<const f32x4*>(c);
-          *reinterpret_cast<f32x4*>(c) = v;
-        }
-      } else {
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-        *reinterpret_cast<bf16x4*>((bf16*)p.C + (long long)m * p.ldc + n) = o;
-      }
+      store_tile4<OUT_F32>(p, m, n, acc[i][j]);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong 256x256x64 kernel: 8 waves (2 x 4), 128x64 per wave, one block per CU.  Each k-tile is cut into four
+// phases (one 64x32 quadrant of the wave's output x K = 64 = 16 MFMAs); a phase is
+//     [ds_read the fragments this quadrant needs | issue the next k-tile's LDS-DMA]  barrier  [16 MFMAs]  barrier
+// and the second wave row runs one barrier behind the first, so on every SIMD one wave is in its MFMA segment while
+// its partner is in its LDS segment: the matrix pipe and the LDS port work concurrently by construction instead of
+// by luck of the wave scheduler.  Quadrant order (0,0) (0,1) (1,1) (1,0) reuses the A half for two phases and keeps
+// both B halves in registers: 12 / 4 / 8 / 0 ds_read_b128 per phase.  The next tile's loads are issued in phase 1
+// and waited for (vmcnt(0)) in phase 4's LDS segment, one barrier before they are read.
+template <bool A_KC, bool B_KC, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, BK = 64, NW = 8;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;   // waves 0-3: row 0 (leading group), waves 4-7: row 1 (one barrier behind)
+
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nblk);
+  constexpr int GM = 4;
+  const int group_sz = GM * p.tiles_n;
+  const int first_m = (t / group_sz) * GM;
+  const int gm = min(p.tiles_m - first_m, GM);
+  const int tm = first_m + (t % group_sz) % gm;
+  const int tn = (t % group_sz) / gm;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  auto rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.A, 0, (int)min((long long)(A_KC ? p.M : p.K) * p.lda * 2, 0x7fffffffLL), 0x00020000);
+  auto rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.B, 0, (int)min((long long)(B_KC ? p.N : p.K) * p.ldb * 2, 0x7fffffffLL), 0x00020000);
+  unsigned offA[PA], offB[PB];
+  int kidxA[PA], kidxB[PB];
+#pragma unroll
+  for (int j = 0; j < PA; ++j) {
+    const int ci = (w * PA + j) * 64 + lane;
+    if (A_KC) {
+      const int row = ci >> 3, pc = ci & 7, c = pc ^ ((row >> 1) & 7);
+      kidxA[j] = c * 8;
+      offA[j] = (m0 + row < p.M) ? (unsigned)(((long long)(m0 + row) * p.lda + c * 8) * 2) : OOB;
+    } else {
+      const int kr = ci / (BM / 8), pc = ci % (BM / 8), c = pc ^ (mc_swz(kr) << 1);
+      kidxA[j] = kr;
+      offA[j] = (m0 + c * 8 < p.M) ? (unsigned)(((long long)kr * p.lda + m0 + c * 8) * 2) : OOB;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int ci = (w * PB + j) * 64 + lane;
+    if (B_KC) {
+      const int row = ci >> 3, pc = ci & 7, c = pc ^ ((row >> 1) & 7);
+      kidxB[j] = c * 8;
+      offB[j] = (n0 + row < p.N) ? (unsigned)(((long long)(n0 + row) * p.ldb + c * 8) * 2) : OOB;
+    } else {
+      const int kr = ci / (BN / 8), pc = ci % (BN / 8), c = pc ^ (mc_swz(kr) << 1);
+      kidxB[j] = kr;
+      offB[j] = (n0 + c * 8 < p.N) ? (unsigned)(((long long)kr * p.ldb + n0 + c * 8) * 2) : OOB;
+    }
+  }
+  const unsigned stepA = A_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.lda * 2);
+  const unsigned stepB = B_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.ldb * 2);
+  auto stage = [&](int buf, int kt) {
+    const int k0 = kt * BK;
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      unsigned va = (offA[j] != OOB && k0 + kidxA[j] < p.K) ? offA[j] + (unsigned)kt * stepA : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(base + (w * PA + j) * 1024), 16, va, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      unsigned vb = (offB[j] != OOB && k0 + kidxB[j] < p.K) ? offB[j] + (unsigned)kt * stepB : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(base + A_BYTES + (w * PB + j) * 1024), 16, vb, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt_all = (p.K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * p.ktiles_per_split;
+  const int kt1 = min(nkt_all, kt0 + p.ktiles_per_split);
+
+  bf16x8 fa[4][2], fb[2][2][2];   // A half: [m-frag][kk]; B: [n-half][n-frag][kk]
+  auto load_a = [&](const char* tA, int mh) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        fa[i][kk] = A_KC ? kc_frag(tA, wm * 128 + mh * 64 + i * 16, kk, lane) : mc_frag<BM>(tA, wm * 128 + mh * 64 + i * 16, kk, lane);
+  };
+  auto load_b = [&](const char* tB, int nh) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        fb[nh][j][kk] = B_KC ? kc_frag(tB, wn * 64 + nh * 32 + j * 16, kk, lane) : mc_frag<BN>(tB, wn * 64 + nh * 32 + j * 16, kk, lane);
+  };
+#define PP_MMA(MH, NH)                                                                         \
+  {                                                                                            \
+    __builtin_amdgcn_s_barrier();                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                           \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
+          acc[MH * 4 + i][NH * 2 + j] = mfma16(fb[NH][j][kk], fa[i][kk], acc[MH * 4 + i][NH * 2 + j]); \
+    __builtin_amdgcn_s_setprio(0);                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_barrier();                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  }
+
+  if (kt0 < kt1) {
+    stage(0, kt0);
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();               // tile kt0 visible to everybody
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // second wave row drops one barrier behind
+  __builtin_amdgcn_sched_barrier(0);
+  int cur = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const char* tA = smem + cur * STAGE;
+    const char* tB = tA + A_BYTES;
+    // phase 1: quadrant (0,0)
+    load_a(tA, 0);
+    load_b(tB, 0);
+    if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
+    PP_MMA(0, 0)
+    // phase 2: quadrant (0,1)
+    load_b(tB, 1);
+    PP_MMA(0, 1)
+    // phase 3: quadrant (1,1)
+    load_a(tA, 1);
+    PP_MMA(1, 1)
+    // phase 4: quadrant (1,0) — nothing to read; retire the prefetch one barrier before its first reader
+    wait_vmcnt<0>();
+    PP_MMA(1, 0)
+    cur ^= 1;
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
+#undef PP_MMA
+
+  const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * lg;
+      if (n >= p.N) continue;
+      store_tile4<OUT_F32>(p, m, n, acc[i][j]);
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC, bool OUT_F32>
+int launch_pp(GemmParams p, hipStream_t s) {
+  constexpr int LDS = 2 * (256 + 256) * 64 * 2;
+  auto kern = gemm_pp_kernel<A_KC, B_KC, OUT_F32>;
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  const int nkt = (p.K + 63) / 64;
+  p.ktiles_per_split = (nkt + p.ksplit - 1) / p.ksplit;
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.ksplit), dim3(512), LDS, s, p);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
 }
 
 // out = epilogue(alpha * sum_s part[s]) for the two-phase split-K path.
@@ -309,6 +498,7 @@ int launch(GemmParams p, hipStream_t s) {
 template <bool A_KC, bool B_KC, bool OUT_F32>
 int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
   switch (tile) {
+    case 8: return launch_pp<A_KC, B_KC, OUT_F32>(p, s);
     case 7: return launch<256, 128, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
     case 6: return launch<128, 128, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
     case 5: return launch<256, 256, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
@@ -339,7 +529,7 @@ int pick_tile(int M, int N, int K) {
 int pick_ksplit(int tile, int M, int N, int K, long long scratch_bytes) {
   const long long cap = scratch_bytes / ((long long)M * N * 4);
   if (cap < 2) return 1;
-  if (tile == 5) {
+  if (tile == 5 || tile == 8) {
     const long long t5 = (long long)((M + 255) / 256) * ((N + 255) / 256);
     const double fill1 = (double)t5 / (256.0 * ((t5 + 255) / 256));
     if (fill1 >= 0.8 || K < 4096) return 1;
@@ -383,7 +573,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   const bool f32 = flags & LAP_GEMM_OUT_F32;
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
-  if (tile < -1 || tile > 7 || ksplit < 0) return LAP_ERR_ARG;
+  if (tile < -1 || tile > 8 || ksplit < 0) return LAP_ERR_ARG;
   if (tile < 0) tile = pick_tile(M, N, K);
   if (ksplit == 0 && scratch != nullptr) ksplit = pick_ksplit(tile, M, N, K, scratch_bytes);
   const bool two_phase = ksplit > 1 && scratch != nullptr;

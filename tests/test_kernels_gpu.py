@@ -50,7 +50,7 @@ def test_gemm_wgrad(hip, rows, out_f, in_f):
     assert rel_err(g2, 2 * ref) < 1e-5
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_tiles_all_layouts(hip, tile):
     M, N, K = 520, 392, 200   # partial tiles in every dimension for every tile shape
     a = rnd(M, K); wt = rnd(N, K, seed=1)
