@@ -1,111 +1,212 @@
-"""FSDP over RCCL/xGMI for the MI355X engine: one process per GPU, torch.distributed (backend "nccl" = RCCL).
+"""Per-unit step pipeline on a side HIP stream: gradient reduction, gradient-norm partial sums, the fused optimizer
+and (with FSDP) the parameter all-gather — overlapped with the compute stream.  One process per GPU;
+torch.distributed backend "nccl" (= RCCL over xGMI) when world_size > 1.
 
 Reference: parameters / optimizer state / EMA sharded by `fsdp_sharding` over the `fsdp` mesh axis and XLA GSPMD
 inserting a per-layer parameter all-gather in the forward, a second one in the rematerialised backward, and a
-gradient reduce-scatter (src/lap/training/mh_sharding.py:14-100, scripts/train.py:532-537).
+gradient reduce-scatter (src/lap/training/mh_sharding.py:14-100, scripts/train.py:532-537); the
+optax update runs after the backward inside the same jit (train.py:363-396).
 
-MI355X-first partitioning (ZeRO-3 state, resident bf16 replicas):
+MI355X-first schedule (ZeRO-3 state, resident bf16 replicas, optimizer off the critical path):
   * each rank owns a contiguous 1/N slice of every big unit's f32 master / Adam m,v / EMA (lap_amd/params.py);
-  * the fused optimizer kernel writes the updated bf16 values of the owned slice straight into the unit's bf16
-    mirror; `start_param_gather` then all-gathers the mirrors IN PLACE, unit by unit in forward order, on a side
-    HIP stream, overlapping with the next step's forward (a unit's first GEMM waits on that unit's event only);
+  * `grads_ready(unit)` — called by the backward the moment a unit's gradients are final — enqueues on the side
+    stream: reduce-scatter (sum) of that unit's f32 gradient buffer (all-reduce for the small replicated unit) and
+    the unit's contribution to the global gradient norm.  Both overlap with the rest of the backward;
+  * `run_optimizer(...)` enqueues, unit by unit IN FORWARD ORDER on the side stream: fused clip+AdamW+EMA on the
+    owned slice (which also writes the bf16 values into the unit's bf16 mirror), then the in-place all-gather of
+    that mirror, then an event.  The next step's forward waits per unit (`wait_unit`), so the HBM-bound optimizer
+    and the xGMI all-gather of later units hide under the MFMA-bound forward of earlier ones;
   * 288 GB of HBM per GPU keeps all gathered bf16 weights (6.7 GB) resident, so the backward needs NO second
     all-gather: 2 x 5.9 GB of xGMI traffic per step instead of the reference's 3 x 5.9 GB;
-  * gradients are produced in full f32 unit buffers; `grads_ready(unit)` enqueues a reduce-scatter (sum) of that
-    unit on the side stream as soon as its backward is done, overlapping with the remaining backward;
-  * the small replicated unit (norm scales, biases, f32 stem / action head) is all-reduced;
   * the embedding gather needs f32 rows (gemma.py:148-151): every rank looks up the rows it owns for ALL ranks'
     tokens, and one bf16 reduce-scatter (sum of one non-zero and N-1 zero rows: exact) hands each rank its rows.
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
-import torch.distributed as dist
 
 from lap_amd import hip
 from lap_amd.params import ParamStore
 
 
-class FsdpComm:
-    def __init__(self, store: ParamStore, group=None):
+class UnitPipeline:
+    """world_size == 1 pipeline; FsdpComm adds the collectives."""
+
+    world_size = 1
+    rank = 0
+
+    def __init__(self, store: ParamStore):
         self.ps = store
+        self.is_cuda = store.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=store.device) if self.is_cuda else None
+        self.unit_events: dict[str, object] = {}
+        self.sumsq = torch.zeros(2, dtype=torch.float32, device=store.device)   # [sharded units, replicated unit]
+        self.scal = torch.zeros(8, dtype=torch.float32, device=store.device)
+        self.gnorm = torch.zeros((), dtype=torch.float32, device=store.device)
+        self._opt_done = None
+        self._pending = False
+
+    # ---- stream helpers (CPU/gloo tests run everything inline)
+    def _on_side(self, wait_compute: bool = True):
+        if not self.is_cuda:
+            return contextlib.nullcontext()
+        if wait_compute:
+            self.side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self.side)
+
+    # ---- step protocol -------------------------------------------------------------------------------------------
+    def begin_step(self):
+        """Start of a train step: the replicated f32 unit is needed (and its gradient buffer re-zeroed) first."""
+        self.wait_unit("small")
+        with self._on_side(wait_compute=False):
+            self.sumsq.zero_()   # ordered behind the previous optimizer pass on the side stream
+
+    def before_backward(self):
+        """The previous optimizer pass must be done READING the gradient buffers before the backward rewrites them."""
+        if self.is_cuda and self._opt_done is not None:
+            torch.cuda.current_stream().wait_event(self._opt_done)
+            self._opt_done = None
+
+    def wait_unit(self, name: str):
+        ev = self.unit_events.pop(name, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def _reduce_grads(self, u):
+        pass  # single rank: gradients are already complete
+
+    def grads_ready(self, name: str):
+        u = self.ps.unit_by_name[name]
+        with self._on_side():
+            self._reduce_grads(u)
+            if self.is_cuda:  # (the CPU/gloo tests exercise the collectives only; kernels need a GPU)
+                slot = 0 if (self.ps.sharded(u) or self.world_size == 1) else 1
+                hip.sumsq_f32(self.ps.gshard[name], self.sumsq[slot:slot + 1])
+        self._pending = True
+
+    def finish_grads(self):
+        """Compute stream waits for every reduction / norm partial (needed for the returned grad_norm)."""
+        if self.is_cuda and self._pending:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self._pending = False
+
+    def _after_unit_update(self, u):
+        pass
+
+    def run_optimizer(self, lr, bc1, bc2, ema_decay, ema_on, opt):
+        """Side stream: global norm -> per-unit fused update (+ all-gather) in forward order, one event per unit."""
+        ps = self.ps
+        h = torch.tensor([0.0, lr, bc1, bc2, ema_decay, 1.0 if ema_on else 0.0, 0.0, 0.0], dtype=torch.float32)
+        if self.is_cuda:
+            h = h.pin_memory()
+        with self._on_side():
+            self._reduce_norm()
+            self.scal.copy_(h, non_blocking=True)
+            self.scal[0:1] = self.sumsq[0:1] + self.sumsq[1:2]
+            self.gnorm.copy_(self.scal[0].sqrt())
+            if self.is_cuda:
+                norm_ready = torch.cuda.Event()
+                norm_ready.record(self.side)
+            for u in ps.units:  # build_specs puts the small replicated unit first, then forward order
+                a, b = ps.shard_range(u)
+                p16 = ps.full16[u.name][a:b] if u.big else None
+                hip.adamw_ema(ps.master[u.name], ps.m[u.name], ps.v[u.name], ps.ema.get(u.name), ps.gshard[u.name], p16,
+                              self.scal, opt.b1, opt.b2, opt.eps, opt.weight_decay, opt.clip_gradient_norm)
+                self._after_unit_update(u)
+                if self.is_cuda:
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                    self.unit_events[u.name] = ev
+            if self.is_cuda:
+                self._opt_done = torch.cuda.Event()
+                self._opt_done.record(self.side)
+        if self.is_cuda:
+            torch.cuda.current_stream().wait_event(norm_ready)   # so that `gnorm` can be read from the compute stream
+        return self.gnorm
+
+    def _reduce_norm(self):
+        pass
+
+    def synchronize(self):
+        if self.is_cuda:
+            self.side.synchronize()
+
+    # ---- small collectives (identity on one rank)
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+    def sharded_embed_gather(self, *a, **k):
+        raise RuntimeError("sharded_embed_gather is only used with world_size > 1")
+
+
+class FsdpComm(UnitPipeline):
+    def __init__(self, store: ParamStore, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
         self.group = group
+        super().__init__(store)
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         if store.world_size != self.world_size or store.rank != self.rank:
             raise ValueError("ParamStore world_size/rank do not match the process group")
-        self.is_cuda = store.device.type == "cuda"
         # RCCL ("nccl") has the fused tensor collectives; gloo (CPU tests, single-GPU multi-process tests) does not
         self.fused = dist.get_backend(group) == "nccl"
-        self.side = torch.cuda.Stream(device=store.device) if self.is_cuda else None
-        self.param_events: dict[str, object] = {}
-        self._pending_grads = False
-
-    # ---- streams (CPU/gloo tests run everything inline)
-    def _on_side(self):
-        import contextlib
-
-        if not self.is_cuda:
-            return contextlib.nullcontext()
-        self.side.wait_stream(torch.cuda.current_stream())
-        return torch.cuda.stream(self.side)
-
-    # ---- parameters
-    def start_param_gather(self):
-        """All-gather every big unit's bf16 mirror (forward order) after the optimizer updated the owned slices."""
-        with self._on_side():
-            for u in self.ps.units:
-                if not self.ps.sharded(u):
-                    continue
-                full = self.ps.full16[u.name]
-                a, b = self.ps.shard_range(u)
-                self._all_gather(full, full[a:b])
-                if self.is_cuda:
-                    ev = torch.cuda.Event()
-                    ev.record(self.side)
-                    self.param_events[u.name] = ev
-
-    def wait_unit(self, name: str):
-        ev = self.param_events.pop(name, None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
 
     # ---- gradients
-    def grads_ready(self, name: str):
-        u = self.ps.unit_by_name[name]
-        with self._on_side():
-            if self.ps.sharded(u):
-                self._reduce_scatter(self.ps.gshard[name], self.ps.grad[name])
-            else:
-                dist.all_reduce(self.ps.grad[name], op=dist.ReduceOp.SUM, group=self.group)
-        self._pending_grads = True
+    def _reduce_grads(self, u):
+        if self.ps.sharded(u):
+            self._reduce_scatter(self.ps.gshard[u.name], self.ps.grad[u.name])
+        else:
+            self.dist.all_reduce(self.ps.grad[u.name], op=self.dist.ReduceOp.SUM, group=self.group)
 
-    def finish_grads(self):
-        if self.is_cuda and self._pending_grads:
-            torch.cuda.current_stream().wait_stream(self.side)
-        self._pending_grads = False
+    def _reduce_norm(self):
+        # slot 0: partial sums over the shards -> sum over ranks.  slot 1: the replicated unit's sum, computed by
+        # every rank from identical gradients but with rank-dependent atomic ordering (differs in the last ulp):
+        # average it over ranks too, so that every rank applies the bit-identical clip factor and replicas never drift.
+        self.sumsq[1:2] /= self.world_size
+        self.dist.all_reduce(self.sumsq, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    # ---- parameters
+    def _after_unit_update(self, u):
+        if self.ps.sharded(u):
+            full = self.ps.full16[u.name]
+            a, b = self.ps.shard_range(u)
+            self._all_gather(full, full[a:b])
+
+    def start_param_gather(self):
+        """Stand-alone gather of every bf16 mirror (tests / after loading weights)."""
+        with self._on_side():
+            for u in self.ps.units:
+                self._after_unit_update(u)
+                if self.is_cuda and self.ps.sharded(u):
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                    self.unit_events[u.name] = ev
 
     # ---- backend shims
     def _all_gather(self, full: torch.Tensor, mine: torch.Tensor):
         if self.fused:
-            dist.all_gather_into_tensor(full, mine, group=self.group)  # in place: `mine` is full[rank*n:(rank+1)*n]
+            self.dist.all_gather_into_tensor(full, mine, group=self.group)  # in place: `mine` is full[rank*n:(rank+1)*n]
         else:
             parts = [torch.empty_like(mine) for _ in range(self.world_size)]
-            dist.all_gather(parts, mine.clone(), group=self.group)
+            self.dist.all_gather(parts, mine.clone(), group=self.group)
             full.copy_(torch.cat(parts))
 
     def _reduce_scatter(self, out: torch.Tensor, full: torch.Tensor):
         if self.fused:
-            dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
+            self.dist.reduce_scatter_tensor(out, full, op=self.dist.ReduceOp.SUM, group=self.group)
         else:
             tmp = full.clone()
-            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+            self.dist.all_reduce(tmp, op=self.dist.ReduceOp.SUM, group=self.group)
             n = out.numel()
             out.copy_(tmp[self.rank * n:(self.rank + 1) * n])
 
     # ---- small collectives on the compute stream
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
     def sharded_embed_gather(self, rows, lo, hi, tokens, x0, Lt, Dv, Pn, dst_off, scale):

@@ -37,6 +37,7 @@ class _NullComm:
 
     def wait_unit(self, name): pass
     def grads_ready(self, name): pass
+    def before_backward(self): pass
     def all_reduce_sum(self, t): return t
 
 
@@ -426,6 +427,7 @@ class LAP:
         if cfg.enable_vqa_training or cfg.enable_prediction_training:
             raise NotImplementedError("VQA / prediction loss mixing is not on the benchmarked path")
         dev = self.device
+        self.comm.wait_unit("small")
         obs = preprocess_observation(observation, train=train, image_keys=cfg.image_keys, image_resolution=cfg.image_resolution,
                                      enable_image_augmentation=cfg.enable_image_augmentation)
         actions = actions.to(dev, torch.float32).contiguous()
@@ -441,8 +443,9 @@ class LAP:
             time = u1.pow(1.0 / 1.5) * 0.999 + 0.001  # Beta(a, 1) by inverse CDF
         noise = noise.to(dev, torch.float32).contiguous(); time = time.to(dev, torch.float32).contiguous()
         x_t, u_t = hip.fm_mix(noise, actions, time)
-        x1, mod, sctx = self._embed_suffix(x_t, time, backward)
+        # prefix first: its units (SigLIP blocks) are the first ones the pipelined optimizer releases
         x0, Pn, pctx = self._embed_prefix(obs, backward, collect)
+        x1, mod, sctx = self._embed_suffix(x_t, time, backward)
         qinfo, kinfo, pos = self._train_infos(obs, S)
         if collect is not None:
             collect["x0_in"], collect["x1_in"], collect["pos"], collect["mod"] = x0, x1, pos, mod
@@ -501,6 +504,7 @@ class LAP:
             return loss, metrics
 
         # =============================== backward ===============================
+        self.comm.before_backward()
         We = self.e.width
         dmod = torch.zeros(mod.shape, dtype=torch.float32, device=dev)
         # action head
@@ -548,6 +552,7 @@ class LAP:
         expert attending to [cached prefix | fresh suffix] as two key segments (the reference concatenates, gemma.py:228-230)."""
         cfg = self.config
         dev = self.device
+        self.comm.wait_unit("small")
         obs = preprocess_observation(observation, train=False, image_keys=cfg.image_keys, image_resolution=cfg.image_resolution)
         B = obs.tokenized_prompt.shape[0]
         S, ad = self.action_horizon, self.action_dim

@@ -53,10 +53,10 @@ def init_train_state(config: TrainConfig, seed: int | None = None, *, device="cu
         store.load_reference_tree(params)
     else:
         store.init_random(config.seed if seed is None else seed)
-    if use_fsdp and comm is None:
-        from lap_amd.fsdp import FsdpComm
+    if comm is None:
+        from lap_amd.fsdp import FsdpComm, UnitPipeline
 
-        comm = FsdpComm(store)
+        comm = FsdpComm(store) if use_fsdp else UnitPipeline(store)
     model = LAP(config.model, device=device, store=store, comm=comm)
     return TrainState(step=0, model=model, ema_decay=ema_decay)
 
@@ -71,7 +71,10 @@ class TrainingStepRunner:
         model, ps = state.model, state.model.ps
         observation, actions = batch
         step = state.step if step is None else int(step)
-        dev = model.device
+        pipe = model.comm
+        if not hasattr(pipe, "run_optimizer"):
+            raise RuntimeError("train step needs a UnitPipeline / FsdpComm (use init_train_state)")
+        pipe.begin_step()
         # weight gradients are written (beta = 0) by the wgrad GEMMs; only the replicated f32 unit is accumulated
         # into with atomics (norm scales, biases, f32 stem / action head) and must start from zero
         for u in ps.units:
@@ -79,36 +82,19 @@ class TrainingStepRunner:
                 ps.grad[u.name].zero_()
         seed = (int(rng) * 1_000_003 + state.step) if not isinstance(rng, torch.Generator) else rng  # fold_in(rng, step)
         loss, metrics = model.loss_and_grad(seed, observation, actions, train=True, noise=noise, time=time)
-        comm = model.comm
-        comm.finish_grads() if hasattr(comm, "finish_grads") else None
-        # global gradient norm over this rank's shards (+ replicated unit once), then across ranks
-        sumsq = torch.zeros(2, dtype=torch.float32, device=dev)
-        for u in ps.units:
-            hip.sumsq_f32(ps.gshard[u.name], sumsq[0:1] if ps.sharded(u) or comm.world_size == 1 else sumsq[1:2])
-        if comm.world_size > 1:
-            comm.all_reduce_sum(sumsq[0:1])
-        total = (sumsq[0] + sumsq[1]).view(1)
-        lr = cfg.lr_schedule(step)
+        # gradient reductions / norm partials were enqueued per unit during the backward; the fused clip+AdamW+EMA
+        # (+ parameter all-gather) now runs unit by unit on the side stream and overlaps with the next forward
         opt = cfg.optimizer
         t = state.step + 1
         ema_decay, ema_on = cfg.get_ema_decay_for_step(step)
-        scal = torch.tensor([0.0, lr, 1.0 - opt.b1 ** t, 1.0 - opt.b2 ** t, ema_decay, 1.0 if ema_on else 0.0, 0.0, 0.0],
-                            dtype=torch.float32, device=dev)
-        scal[0:1] = total
-        for u in ps.units:
-            a, b = ps.shard_range(u)
-            p16 = ps.full16[u.name][a:b] if u.big else None
-            hip.adamw_ema(ps.master[u.name], ps.m[u.name], ps.v[u.name], ps.ema.get(u.name), ps.gshard[u.name], p16, scal,
-                          opt.b1, opt.b2, opt.eps, opt.weight_decay, opt.clip_gradient_norm)
-        if hasattr(comm, "start_param_gather"):
-            comm.start_param_gather()
-        grad_norm = total.sqrt().view(())
+        grad_norm = pipe.run_optimizer(cfg.lr_schedule(step), 1.0 - opt.b1 ** t, 1.0 - opt.b2 ** t, ema_decay, ema_on, opt)
         info = {"loss": loss, "grad_norm": grad_norm, "grad_norm_f32": grad_norm, **metrics}
         return dataclasses.replace(state, step=state.step + 1), info
 
     def param_norm(self, state: TrainState) -> torch.Tensor:
         """optax.global_norm over kernel parameters (train.py:401-415); computed on demand (logging interval)."""
         ps = state.model.ps
+        state.model.comm.synchronize() if hasattr(state.model.comm, "synchronize") else None
         acc = torch.zeros(1, dtype=torch.float32, device=state.model.device)
         for name, spec in ps.tensor_spec.items():
             if _is_kernel_param(name, spec.shape) and not ps.sharded(ps.tensor_unit[name]):
