@@ -1,0 +1,95 @@
+"""Host-side logic on CPU (no kernel launches): reference <-> engine key map, parameter store geometry,
+observation parsing, and the per-token info words / positions against the oracle's boolean mask."""
+import numpy as np
+import pytest
+import torch
+
+from lap_amd import params as PR
+from lap_amd.config import get_config
+from lap_amd.observation import CoTObservation
+from oracle import lap_oracle as O
+from tests.common import debug_model_cfg, make_inputs, oracle_cfg, to_observation
+
+
+def test_reference_engine_key_map_round_trip():
+    cfg = debug_model_cfg()
+    P = O.init_params(oracle_cfg(cfg), 0)
+    E = PR.reference_to_engine(cfg, P)
+    P2 = PR.engine_to_reference(cfg, E)
+    assert set(P) == set(P2)
+    for k in P:
+        assert P[k].shape == P2[k].shape and torch.equal(P[k], P2[k]), k
+    ps = PR.ParamStore(cfg, device="cpu")
+    ps.load_reference_tree(P)
+    assert set(ps.names()) == set(E)
+    for name in ("llm/0/wqkv0", "img/0/w1", "act/out_w", "ada/w"):
+        assert torch.equal(ps._view(ps.master[ps.tensor_unit[name].name], name), E[name]), name
+    P3 = ps.to_reference_tree("master")
+    assert all(torch.equal(P3[k], P[k]) for k in P)
+    with pytest.raises(KeyError):
+        ps.load_reference_tree({k: v for k, v in P.items() if "time_mlp_in" not in k})
+
+
+def test_lap3b_parameter_count_and_units():
+    units = PR.build_specs(get_config("lap_bench").model)
+    n = sum(t.numel for u in units for t in u.tensors)
+    assert abs(n - 3.353e9) < 2e6   # 3.353 B parameters
+    names = [u.name for u in units]
+    assert names[0] == "small" and names.count("embed") == 1 and sum(x.startswith("llm") for x in names) == 18
+    assert sum(x.startswith("img") and x[3:].isdigit() for x in names) == 27
+    for ws in (1, 2, 4, 8):   # shard geometry: equal slices, embedding shards on whole vocabulary rows
+        ps_geom = PR.ParamStore.__new__(PR.ParamStore)
+        ps_geom.world_size, ps_geom.rank = ws, ws - 1
+        for u in units:
+            pad = PR.ParamStore.padded(ps_geom, u)
+            assert pad % ws == 0 and pad >= u.numel
+            if u.name == "embed":
+                assert (pad // ws) % u.tensors[0].shape[1] == 0
+
+
+def test_observation_from_dict_accepts_reference_batch():
+    B, L = 2, 24
+    d = {"image": {"base_0_rgb": np.zeros((B, 56, 56, 3), np.uint8), "left_wrist_0_rgb": np.full((B, 56, 56, 3), 255, np.uint8)},
+         "image_mask": {"base_0_rgb": np.ones(B, bool), "left_wrist_0_rgb": np.ones(B, bool)},
+         "state": np.zeros((B, 7), np.float32), "tokenized_prompt": np.zeros((B, L), np.int64),
+         "tokenized_prompt_mask": np.ones((B, L), bool), "extras": {"cot": {"tokenized_langact_mask": np.zeros((B, L), bool)}},
+         "sample_mask": np.ones(B, bool)}
+    o = CoTObservation.from_dict(d)
+    assert o.images["base_0_rgb"].dtype == torch.float32 and o.images["base_0_rgb"].min() == -1.0
+    assert o.images["left_wrist_0_rgb"].max() == 1.0 and o.tokenized_prompt.dtype == torch.int32
+    assert o.tokenized_langact_mask is not None and o.sample_mask.dtype == torch.bool
+    with pytest.raises(ValueError):
+        CoTObservation.from_dict({"image": {}, "tokenized_prompt": np.zeros((1, 2))})
+
+
+def _mask_from_info(qinfo, kinfo):
+    qc, qx, kc, kx = qinfo >> 24, qinfo & 0xFFFFFF, kinfo >> 24, kinfo & 0xFFFFFF
+    return ((qc[:, :, None] & kc[:, None, :]) != 0) & (kx[:, None, :] <= qx[:, :, None])
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_info_words_reproduce_reference_masks_and_positions(ragged):
+    from lap_amd.model import LAP
+
+    cfg = debug_model_cfg()
+    oc = oracle_cfg(cfg)
+    obs, actions, noise, time = make_inputs(cfg, B=3, ragged=ragged)
+    model = LAP(cfg, seed=0, device="cpu", with_grads=False)
+    S = cfg.action_horizon
+    qinfo, kinfo, pos = model._train_infos(to_observation(obs, "cpu"), S)
+    assert qinfo.dtype == torch.int32 and kinfo.dtype == torch.int32 and pos.dtype == torch.int32
+    # oracle: boolean mask + positions of lap.py:303-377
+    T = model.n_img_tok
+    pm = torch.cat([obs["image_masks"][k][:, None].expand(3, T) for k in cfg.image_keys] + [obs["tokenized_prompt_mask"]], 1)
+    ar = torch.cat([torch.zeros(3, 2 * T, dtype=torch.bool), obs["tokenized_langact_mask"]], 1)
+    sm = torch.ones(3, S, dtype=torch.bool); sar = torch.zeros(3, S, dtype=torch.bool); sar[:, 0] = True
+    _, mask, positions = O.build_masks_positions(oc, obs, pm, ar, sm, sar)
+    assert torch.equal(_mask_from_info(qinfo, kinfo), mask)
+    assert torch.equal(pos.long(), positions)
+    # serving: prefix attends per make_attn_mask(prefix_mask, 0); suffix sees every valid prefix token and all suffix tokens
+    so = {k: v for k, v in obs.items() if k != "tokenized_langact_mask"} | {"tokenized_langact_mask": None}
+    qp, kp, ppos, qs, kall, pall = model._serve_infos(to_observation(so, "cpu"), S)
+    assert torch.equal(_mask_from_info(qp, kp), O.make_attn_mask(pm, torch.zeros_like(pm)))
+    full = torch.cat([pm[:, None, :].expand(3, S, -1), torch.ones(3, S, S, dtype=torch.bool)], -1)
+    assert torch.equal(_mask_from_info(qs, kall), full)
+    assert torch.equal(pall[:, -S:].long(), pm.long().sum(-1)[:, None] + torch.arange(S)[None])
