@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--config", default="lap_bench")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for flow tests)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,6 +135,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    local = local % torch.cuda.device_count()   # (flow tests run several ranks on one GPU with --backend gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -148,7 +150,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     tc = dataclasses.replace(get_config(args.config), batch_size=args.batch * world, fsdp_devices=world)
     state = init_train_state(tc, device=dev, world_size=world, rank=rank, use_fsdp=world > 1)
     runner = TrainingStepRunner(tc)
@@ -185,8 +190,9 @@ def main():
             "metric": "train-step samples/sec LAP-3B bf16", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "LAP-3B (SigLIP So400m/14 + Gemma-2B + Gemma-300M expert) full train step fwd+bwd+AdamW+EMA, "
-                                   "2x224x224 images + 48-token prompt + 50-step action chunk, random-init weights",
+            "config": {"workload": ("LAP-3B (SigLIP So400m/14 + Gemma-2B + Gemma-300M expert) full train step fwd+bwd+AdamW+EMA, "
+                                    "2x224x224 images + 48-token prompt + 50-step action chunk, random-init weights")
+                       if args.config == "lap_bench" else f"NON-HEADLINE flow test: config {args.config}",
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": 610,
                        "parallelism": f"fsdp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA GEMM, csrc/gemm.hip)", "achieved": round(achieved, 1),

@@ -32,6 +32,8 @@ int lap_abi_version(void);
 #define LAP_GEMM_ACCUM    2   /* C += result (f32 output only) */
 #define LAP_GEMM_GELU     4   /* tanh-GELU after bias (bf16 output only) */
 #define LAP_GEMM_BIAS_F32 8   /* bias is f32 (default bf16) */
+#define LAP_GEMM_PARTIALS 16  /* lap_gemm_bf16_ex only: leave the ksplit raw f32 partial products [ksplit][M][N] in `scratch`
+                                 and skip the reduce/epilogue kernel (C unused) — consumed by the lap_fused_reduce_* kernels */
 
 /* C[M,N] = epi(alpha * opA . opB): bf16 operands, f32 MFMA accumulate.
  * a_kc=1: A is [M][lda] (k contiguous); a_kc=0: A is [K][lda] (m contiguous).
@@ -190,6 +192,17 @@ typedef struct {
   int stop_q1_to_k0;         /* stop_action_to_vlm_grad (gemma.py:242-269): no dK/dV from segment-1 queries into segment-0 keys */
 } lap_attn_bwd_args;
 int lap_attention_bwd(const lap_attn_bwd_args* a, void* stream);
+
+/* ---------------------------------------- fused consumers of GEMM partials (serving) -- */
+/* partials: f32 [ksplit][rows][cols] from lap_gemm_bf16_ex(LAP_GEMM_PARTIALS).  Each kernel sums the slabs, rounds to
+ * bf16 like the GEMM would have, and applies the ops that follow the projection in gemma.py:336-387. */
+int lap_fused_reduce_rope_split(const float* partials, int ksplit, const int32_t* pos, void* q, void* k, void* v,
+                                int B, int T_seg, int T_total, int seg_off, int NH, int HD, float q_scale, void* stream);
+int lap_fused_reduce_geglu(const float* partials, int ksplit, void* act, int rows, int H, void* stream);
+/* xn = x + bf16(y * gate[sample]) (gate NULL: plain add); h = adaptive RMSNorm(xn; mod) when mod != NULL. */
+int lap_fused_reduce_residual_norm(const float* partials, int ksplit, const void* x, const void* gate, int ldg,
+                                   const void* mod, int mod_ld, void* xn, void* h, int rows, int D,
+                                   int rows_per_sample, float eps, void* stream);
 
 /* ----------------------------------------------------------------- loss --- */
 /* Vocab-chunked cross entropy (lap.py:221-260). logits: f32 [rows][ldl] chunk covering vocab

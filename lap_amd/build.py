@@ -14,7 +14,7 @@ import sys
 ROOT = pathlib.Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 LIB = ROOT / "liblap_hip.so"
-SOURCES = ["gemm.hip", "norm.hip", "elementwise.hip", "attention.hip", "loss_optim.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "elementwise.hip", "attention.hip", "loss_optim.hip", "serve_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]  # no fast-math: parity with the f32 reference ops
 
 

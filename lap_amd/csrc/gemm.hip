@@ -588,13 +588,18 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   p.ksplit = ksplit > 1 ? ksplit : 1;
   p.part = two_phase ? (float*)scratch : nullptr;
   hipStream_t s = (hipStream_t)stream;
-  if (two_phase) {
+  if (flags & LAP_GEMM_PARTIALS) {
+    if (!scratch || ksplit < 1 || scratch_bytes < (long long)(ksplit > 1 ? ksplit : 1) * M * N * 4) return LAP_ERR_ARG;
+    p.part = (float*)scratch;   // also valid for ksplit == 1: one slab
+  }
+  if (two_phase || (flags & LAP_GEMM_PARTIALS)) {
     int rc;
     if (a_kc && b_kc) rc = dispatch_tile<true, true, true>(p, tile, s);
     else if (a_kc && !b_kc) rc = dispatch_tile<true, false, true>(p, tile, s);
     else if (!a_kc && !b_kc) rc = dispatch_tile<false, false, true>(p, tile, s);
     else rc = dispatch_tile<false, true, true>(p, tile, s);
     if (rc) return rc;
+    if (flags & LAP_GEMM_PARTIALS) return LAP_OK;
     const long long n4 = (long long)M * N / 4;
     if (f32) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);

@@ -1,0 +1,190 @@
+// Fused consumers of split-K GEMM partials for the batch-1 denoise step (lap.py:634-667 through
+// gemma.py:336-387 with only the action-expert stream active).  At M = 50 rows every projection is a
+// weight-streaming GEMM split over K to fill 256 CUs; instead of a generic reduce kernel followed by separate
+// RoPE / GeGLU / gated-residual / adaRMS kernels, the reduction happens inside the consumer:
+//   qkv partials      -> sum -> RoPE + q-scale + head split                       (gemma.py:188-218)
+//   gate|up partials  -> sum -> GeGLU                                             (gemma.py:303-312)
+//   out / down partials -> sum -> gated residual -> (next) adaptive RMSNorm       (gemma.py:577-583,113-131)
+// Rounding points are identical to the unfused kernels (the summed projection is rounded to bf16 first), so the
+// serving path matches the training-path numerics bit for bit.
+#include "common.hpp"
+#include "../../include/lap_hip.h"
+
+namespace {
+
+__device__ __forceinline__ void st8(bf16* p, const float (&v)[8]) {
+  bf16x8 t;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t[e] = f2bf(v[e]);
+  *reinterpret_cast<bf16x8*>(p) = t;
+}
+__device__ __forceinline__ void ld8(const bf16* p, float (&v)[8]) {
+  bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+}
+// sum of ks f32 partial slabs (slab stride = `slab` floats) at 8 consecutive columns, rounded to bf16 like a GEMM output
+__device__ __forceinline__ void sum8(const float* part, long long off, int ks, long long slab, float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  for (int s = 0; s < ks; ++s) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(part + s * slab + off);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(part + s * slab + off + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+}
+
+// ---------------------------------------------------------------- reduce + RoPE + split
+__global__ __launch_bounds__(256) void reduce_rope_kernel(const float* __restrict__ part, int ks, const int32_t* __restrict__ pos,
+                                                          bf16* __restrict__ q, bf16* __restrict__ k, bf16* __restrict__ v,
+                                                          int rows, int T_seg, int T_total, int seg_off, int NH, int HD,
+                                                          float q_scale) {
+  const int cph = HD / 16, tpr = (NH + 2) * cph;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * tpr) return;
+  const int row = (int)(gid / tpr), rem = (int)(gid % tpr);
+  const int h = rem / cph, c = rem % cph;
+  const int b = row / T_seg, t = row % T_seg;
+  const int W = (NH + 2) * HD, half = HD / 2;
+  const long long slab = (long long)rows * W;
+  float x1[8], x2[8], y1[8], y2[8];
+  sum8(part, (long long)row * W + h * HD + c * 8, ks, slab, x1);
+  sum8(part, (long long)row * W + h * HD + half + c * 8, ks, slab, x2);
+  if (h <= NH) {
+    const float p = (float)pos[(long long)b * T_total + seg_off + t];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float fe = (2.0f / (float)HD) * (float)(c * 8 + e);
+      const float rad = p / powf(10000.0f, fe);
+      float sn, cs;
+      sincosf(rad, &sn, &cs);
+      float r1 = bf2f(f2bf(x1[e] * cs - x2[e] * sn));
+      float r2 = bf2f(f2bf(x2[e] * cs + x1[e] * sn));
+      if (h < NH) { r1 *= q_scale; r2 *= q_scale; }
+      y1[e] = r1; y2[e] = r2;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { y1[e] = x1[e]; y2[e] = x2[e]; }
+  }
+  bf16* dst = h < NH ? q + (long long)row * NH * HD + h * HD : (h == NH ? k + (long long)row * HD : v + (long long)row * HD);
+  st8(dst + c * 8, y1);
+  st8(dst + half + c * 8, y2);
+}
+
+// ---------------------------------------------------------------- reduce + GeGLU
+__global__ __launch_bounds__(256) void reduce_geglu_kernel(const float* __restrict__ part, int ks, bf16* __restrict__ act,
+                                                           int rows, int H8) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * H8) return;
+  const long long row = gid / H8;
+  const int c = (int)(gid % H8) * 8;
+  const long long H = (long long)H8 * 8, slab = (long long)rows * 2 * H;
+  float g[8], u[8], o[8];
+  sum8(part, row * 2 * H + c, ks, slab, g);
+  sum8(part, row * 2 * H + H + c, ks, slab, u);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(gelu_tanh_f(g[e]))) * u[e];
+  st8(act + row * H + c, o);
+}
+
+// ---------------------------------------------------------------- reduce + gated residual + adaptive RMSNorm
+// One wave per row (D <= 2048).  xn = x + bf16(y * gate);  h = adaRMS(xn; mod) when mod != null.
+template <int NCH>
+__global__ __launch_bounds__(256) void reduce_residual_norm_kernel(const float* __restrict__ part, int ks,
+                                                                   const bf16* __restrict__ x, const bf16* __restrict__ gate,
+                                                                   int ldg, const bf16* __restrict__ mod, int mod_ld,
+                                                                   bf16* __restrict__ xn, bf16* __restrict__ hout, int rows,
+                                                                   int D, int rps, float eps) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  const int b = row / rps;
+  const long long slab = (long long)rows * D;
+  float v[NCH][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int c = (lane + 64 * p) * 8;
+    if (c < D) {
+      float y[8], xv[8], gv[8];
+      sum8(part, (long long)row * D + c, ks, slab, y);
+      ld8(x + (long long)row * D + c, xv);
+      if (gate) {
+        ld8(gate + (long long)b * ldg + c, gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[p][e] = bf2f(f2bf(xv[e] + bf2f(f2bf(y[e] * gv[e]))));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[p][e] = bf2f(f2bf(xv[e] + y[e]));
+      }
+      st8(xn + (long long)row * D + c, v[p]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += v[p][e] * v[p][e];
+    }
+  }
+  if (!mod) return;
+  ss = wave_sum(ss);
+  const float r = 1.0f / sqrtf(ss / (float)D + eps);
+  const bf16* mrow = mod + (long long)b * mod_ld;
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int c = (lane + 64 * p) * 8;
+    if (c < D) {
+      float sc[8], sh[8], o[8];
+      ld8(mrow + c, sc);
+      ld8(mrow + D + c, sh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = v[p][e] * r * bf2f(f2bf(1.0f + sc[e])) + sh[e];
+      st8(hout + (long long)row * D + c, o);
+    }
+  }
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+
+extern "C" int lap_fused_reduce_rope_split(const float* partials, int ksplit, const int32_t* pos, void* q, void* k, void* v,
+                                           int B, int T_seg, int T_total, int seg_off, int NH, int HD, float q_scale,
+                                           void* stream) {
+  if (!partials || ksplit < 1 || B <= 0 || T_seg <= 0 || (HD & 15) || NH <= 0) return LAP_ERR_ARG;
+  const long long n = (long long)B * T_seg * (NH + 2) * (HD / 16);
+  hipLaunchKernelGGL(reduce_rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_, partials, ksplit, pos, (bf16*)q,
+                     (bf16*)k, (bf16*)v, B * T_seg, T_seg, T_total, seg_off, NH, HD, q_scale);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_fused_reduce_geglu(const float* partials, int ksplit, void* act, int rows, int H, void* stream) {
+  if (!partials || ksplit < 1 || rows <= 0 || H <= 0 || (H & 7)) return LAP_ERR_ARG;
+  const long long n = (long long)rows * (H / 8);
+  hipLaunchKernelGGL(reduce_geglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_, partials, ksplit, (bf16*)act, rows,
+                     H / 8);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_fused_reduce_residual_norm(const float* partials, int ksplit, const void* x, const void* gate, int ldg,
+                                              const void* mod, int mod_ld, void* xn, void* h, int rows, int D,
+                                              int rows_per_sample, float eps, void* stream) {
+  if (!partials || ksplit < 1 || rows <= 0 || D <= 0 || (D & 7) || rows_per_sample <= 0 || (ldg & 7) || (mod_ld & 7)) return LAP_ERR_ARG;
+  if (mod && !h) return LAP_ERR_ARG;
+  const int nch = (D / 8 + 63) / 64;
+  dim3 grid((rows + 3) / 4);
+#define GO(N) hipLaunchKernelGGL(reduce_residual_norm_kernel<N>, grid, dim3(256), 0, S_, partials, ksplit, (const bf16*)x, \
+                                 (const bf16*)gate, ldg, (const bf16*)mod, mod_ld, (bf16*)xn, (bf16*)h, rows, D, rows_per_sample, eps)
+  switch (nch) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 3: GO(3); break;
+    case 4: GO(4); break;
+    default: return LAP_ERR_ARG;
+  }
+#undef GO
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}

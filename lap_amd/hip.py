@@ -18,6 +18,7 @@ GEMM_OUT_F32 = 1
 GEMM_ACCUM = 2
 GEMM_GELU = 4
 GEMM_BIAS_F32 = 8
+GEMM_PARTIALS = 16
 
 
 class LapHipError(RuntimeError):
@@ -95,6 +96,9 @@ SIGNATURES: dict[str, list] = {
     "lap_add_posemb_cast_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],
     "lap_attention_bwd": [C.POINTER(AttnBwdArgs), _vp],
+    "lap_fused_reduce_rope_split": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "lap_fused_reduce_geglu": [_vp, _i, _vp, _i, _i, _vp],
+    "lap_fused_reduce_residual_norm": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp],
     "lap_ce_chunk_update": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_ce_chunk_grad": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lap_sumsq_f32": [_vp, _ll, _vp, _vp],
@@ -521,3 +525,45 @@ def mse_fwd_bwd(v, u, coef=None, need_grad=True):
 
 def axpy_f32(x, v, dt):
     call("lap_axpy_f32", _p(x), _p(v), float(dt), x.numel())
+
+
+# ------------------------------------------------ split-K partials + fused consumers (batch-1 denoise step)
+def linear_partials(x, wt, scratch, ksplit=None):
+    """Raw f32 partial products of y = x @ wt^T, [ksplit, M, N] in `scratch` (a 1-D f32 tensor); returns (view, ksplit)."""
+    M, K = x.shape
+    N = wt.shape[0]
+    if ksplit is None:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        ksplit = max(1, min(K // 256, 256 // max(tiles, 1), 16))
+    need = ksplit * M * N
+    if scratch.numel() < need:
+        raise ValueError("scratch too small for the requested split")
+    call("lap_gemm_bf16_ex", _p(x), _p(wt), None, None, None, M, N, K, x.stride(0), wt.stride(0), N, 0, 1.0, 1, 1,
+         GEMM_OUT_F32 | GEMM_PARTIALS, 6, ksplit, _p(scratch), scratch.numel() * 4)
+    return scratch[:need].view(ksplit, M, N), ksplit
+
+
+def fused_reduce_rope_split(part, ksplit, pos, B, T_seg, T_total, seg_off, NH, HD, q_scale):
+    rows = B * T_seg
+    dev = part.device
+    q = torch.empty((rows, NH * HD), dtype=torch.bfloat16, device=dev)
+    k = torch.empty((rows, HD), dtype=torch.bfloat16, device=dev)
+    v = torch.empty((rows, HD), dtype=torch.bfloat16, device=dev)
+    call("lap_fused_reduce_rope_split", _p(part), ksplit, _p(pos), _p(q), _p(k), _p(v), B, T_seg, T_total, seg_off, NH, HD,
+         float(q_scale))
+    return q, k, v
+
+
+def fused_reduce_geglu(part, ksplit, rows, H):
+    act = torch.empty((rows, H), dtype=torch.bfloat16, device=part.device)
+    call("lap_fused_reduce_geglu", _p(part), ksplit, _p(act), rows, H)
+    return act
+
+
+def fused_reduce_residual_norm(part, ksplit, x, gate, ldg, mod, mod_ld, rows_per_sample, eps=1e-6):
+    rows, D = x.shape
+    xn = torch.empty_like(x)
+    h = torch.empty_like(x) if mod is not None else None
+    call("lap_fused_reduce_residual_norm", _p(part), ksplit, _p(x), _p(gate), ldg, _p(mod), mod_ld, _p(xn), _p(h), rows, D,
+         rows_per_sample, float(eps))
+    return xn, h

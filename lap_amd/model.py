@@ -418,6 +418,34 @@ class LAP:
             self.comm.grads_ready(f"llm{l}")
         return dx0, dx1
 
+    def _expert_denoise_fwd(self, x1, mod, pos, qinfo, kinfo, B, Pn, S, cache):
+        """The 18 action-expert layers of one denoise step (gemma.py:336-387 with xs = [None, suffix], kv_cache given)
+        on the fused serving kernels: every projection is a split-K GEMM that leaves f32 partials, and the reduction
+        happens inside the consumer (RoPE+split / GeGLU / gated residual + next adaptive RMSNorm).  `mod` is the single
+        modulation row of this step (shared by all samples).  Returns the final adaRMS-normed suffix activations."""
+        v, e = self.v, self.e
+        NH, HD, KV = v.num_heads, v.head_dim, v.num_kv_heads
+        Ttot = pos.shape[1]
+        We = e.width
+        scratch = hip._gemm_scratch(self.device)
+        slot = lambda j: self._mod_slot(mod, j)
+        h, _ = hip.rmsnorm_fwd(x1, mod=slot(0), rows_per_sample=S, save_rstd=False, mod_ld=0)
+        x = x1
+        for l in range(v.depth):
+            self.comm.wait_unit(f"llm{l}")
+            p = f"llm/{l}/"
+            part, ks = hip.linear_partials(h, self.W(p + "wqkv1"), scratch)
+            q, k, vv = hip.fused_reduce_rope_split(part, ks, pos, B, S, Ttot, Ttot - S, NH, HD, HD ** -0.5)
+            ck, cv = cache[l]
+            o, _ = hip.attention_fwd([None, q], [ck, k], [cv, vv], [0, S], [Pn, S], B, NH, KV, HD, qinfo, kinfo, need_lse=False)
+            part, ks = hip.linear_partials(o[1], self.W(p + "wo1"), scratch)
+            xa, hf = hip.fused_reduce_residual_norm(part, ks, x, slot(2 * l)[:, 2 * We:], 0, slot(2 * l + 1), 0, S)
+            part, ks = hip.linear_partials(hf, self.W(p + "wgu1"), scratch)
+            act = hip.fused_reduce_geglu(part, ks, B * S, e.mlp_dim)
+            part, ks = hip.linear_partials(act, self.W(p + "wd1"), scratch)
+            x, h = hip.fused_reduce_residual_norm(part, ks, xa, slot(2 * l + 1)[:, 2 * We:], 0, slot(2 * l + 2), 0, S)
+        return h   # slot 2L is final_norm_1: h == final adaRMS norm of the last layer's output
+
     # ================================================================== training forward (+ backward)
     def _loss_impl(self, rng, observation: CoTObservation, actions: torch.Tensor, *, train: bool, noise=None, time=None,
                    backward: bool, collect: dict | None = None):
@@ -547,7 +575,7 @@ class LAP:
 
     # ================================================================== serving
     @torch.no_grad()
-    def sample_actions(self, rng, observation, *, num_steps: int = 10, noise=None, collect=None):
+    def sample_actions(self, rng, observation, *, num_steps: int = 10, noise=None, collect=None, fused: bool = True):
         """lap.py:605-675: prefix prefill once -> per-layer K/V kept in HBM -> `num_steps` Euler steps of the action
         expert attending to [cached prefix | fresh suffix] as two key segments (the reference concatenates, gemma.py:228-230)."""
         cfg = self.config
@@ -575,8 +603,11 @@ class LAP:
         for step in range(len(times)):
             mod = mods[step:step + 1]
             x1, _ = self._embed_actions(x_t)
-            _, xf1, _ = self._llm_fwd(None, x1, mod, pos_all, qinfo_s, kinfo_all, B, Pn, S, False, kv_cache=cache, mod_shared=True)
-            pre1, _ = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=False, mod_ld=0)
+            if fused:
+                pre1 = self._expert_denoise_fwd(x1, mod, pos_all, qinfo_s, kinfo_all, B, Pn, S, cache)
+            else:  # generic path (same numerics; kept for A/B tests)
+                _, xf1, _ = self._llm_fwd(None, x1, mod, pos_all, qinfo_s, kinfo_all, B, Pn, S, False, kv_cache=cache, mod_shared=True)
+                pre1, _ = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=False, mod_ld=0)
             v_t = self._lin32(hip.cast_bf16_to_f32(pre1), "act/out_w", "act/out_b")
             if collect is not None:
                 collect[f"v_t/{step}"] = v_t.view(B, S, ad).clone()

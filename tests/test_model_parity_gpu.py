@@ -88,6 +88,8 @@ def test_sample_actions_matches_oracle(hip):
     model = _engine(cfg, P)
     o = to_observation(so | {"tokenized_langact_mask": None}, DEV)
     out = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV))
+    # the fused serving kernels (split-K partial consumers) are bit-identical to the generic layer path
+    assert torch.equal(out, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused=False))
     err, base = rel(out, ref), rel(ref16, ref)
     assert out.shape == (2, cfg.action_horizon, cfg.action_dim)
     assert err < max(3 * base, 1e-2), (err, base)
