@@ -192,6 +192,10 @@ typedef struct {
   int stop_q1_to_k0;         /* stop_action_to_vlm_grad (gemma.py:242-269): no dK/dV from segment-1 queries into segment-0 keys */
 } lap_attn_bwd_args;
 int lap_attention_bwd(const lap_attn_bwd_args* a, void* stream);
+/* Kernel-selection knob for tests / benchmarks (process-wide, not thread safe): -1 automatic (default);
+   0 = generic padded-LDS kernels also for HD = 256; 1 = the HD = 256 LDS-DMA kernels.  Both agree to bf16
+   rounding of the probabilities. */
+int lap_attention_set_variant(int variant);
 
 /* ---------------------------------------- fused consumers of GEMM partials (serving) -- */
 /* partials: f32 [ksplit][rows][cols] from lap_gemm_bf16_ex(LAP_GEMM_PARTIALS).  Each kernel sums the slabs, rounds to

@@ -585,6 +585,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   }
 }
 
+#include "attention_dma.hpp"
+
 template <typename K>
 int set_lds(K kernel, int bytes) {
   if (bytes > 65536) {
@@ -594,8 +596,43 @@ int set_lds(K kernel, int bytes) {
   return 0;
 }
 
+// Tuning / test knob (lap_attention_set_variant): -1 = automatic; 0 = generic kernels also for HD = 256;
+// 1 = the HD = 256 LDS-DMA kernels (what automatic picks whenever their LDS info table fits).
+int g_attn_variant = -1;
+int attn_variant() { return g_attn_variant; }
+
+// HD = 256 LDS-DMA kernels keep the info words of every key (query) tile in LDS: 144 bytes per 32-row tile
+constexpr int DMA_MAX_INFO_BYTES = 16384;
+bool dma_path_ok(const AttnP& p) {
+  const int ntk = (p.klen[0] + 31) / 32 + (p.klen[1] + 31) / 32, ntq = (p.qlen[0] + 31) / 32 + (p.qlen[1] + 31) / 32;
+  // (and the per-wave tile decisions in 64-bit masks: at most 64 streamed tiles per block)
+  const int per = (ntk + p.nsplit - 1) / p.nsplit;
+  return attn_variant() != 0 && max(ntk, ntq) * 144 <= DMA_MAX_INFO_BYTES && per <= 64 && ntq <= 64 && p.scale > 0.f;
+}
+
+int launch_fwd256(const AttnP& p, hipStream_t s) {
+  const int nt = (p.qlen[0] + p.qlen[1] + 63) / 64;
+  const int ntk = (p.klen[0] + 31) / 32 + (p.klen[1] + 31) / 32;
+  const int lds = 4 * T32_TILE + ntk * 144;
+  if (int e = set_lds(attn256_fwd_kernel, lds)) return e;
+  hipLaunchKernelGGL(attn256_fwd_kernel, dim3(p.B * p.NH * nt, p.nsplit), dim3(256), lds, s, p);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
 template <int HD>
 int launch_fwd(const AttnP& p, hipStream_t s) {
+  if constexpr (HD == 256) {
+    if (dma_path_ok(p)) {
+      if (int e = launch_fwd256(p, s)) return e;
+      if (p.nsplit > 1) {
+        const long long n4 = (long long)p.B * (p.qlen[0] + p.qlen[1]) * p.NH * HD / 4;
+        hipLaunchKernelGGL(attn_fwd_combine_kernel<HD>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
+        LAP_CHECK_LAUNCH();
+      }
+      return LAP_OK;
+    }
+  }
   const int nt = (p.qlen[0] + 63) / 64 + (p.qlen[1] + 63) / 64;
   const int lds = 2 * Cfg<HD>::TILE + 1024;   // + staged info words / lse / delta
   if (int e = set_lds(attn_fwd_kernel<HD>, lds)) return e;
@@ -640,6 +677,12 @@ bool check_common(int B, int NH, int NKV, int HD, const int* qlen, const int* kl
 }
 
 }  // namespace
+
+extern "C" int lap_attention_set_variant(int variant) {
+  if (variant < -1 || variant > 1) return LAP_ERR_ARG;
+  g_attn_variant = variant;
+  return LAP_OK;
+}
 
 extern "C" int lap_attention_fwd(const lap_attn_fwd_args* a, void* stream) {
   if (!a || !check_common(a->B, a->NH, a->NKV, a->HD, a->q_len, a->k_len)) return LAP_ERR_ARG;

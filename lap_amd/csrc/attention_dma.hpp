@@ -1,0 +1,312 @@
+// HD = 256 attention kernels (the Gemma-2B / 300M head size of the LAP hot path): the streamed side of each kernel
+// arrives in 32-row tiles through LDS-DMA (`buffer_load ... lds`, no VGPR round trip) into a 2-stage ring, so the
+// loads of tile t+1 fly while tile t is multiplied and one barrier per tile is all the synchronisation there is.
+//
+// Included by attention.hip inside its anonymous namespace (shares AttnP, mask_ok, pack8, store4 ...).
+//
+// LDS image of a tile: 32 rows x 512 B (256 bf16 of d).  The DMA writes 1 KiB = 2 rows per wave instruction,
+// lane-linear, so the conflict-avoidance must be a permutation of the SOURCE addresses rather than padding: the
+// 16-byte chunk c of row r lives at chunk  c ^ ((r & 7) << 1).
+//   * ds_read_b128 fragments (16 rows x 4 chunks): the two half-groups of a 16-lane service group land on even / odd
+//     chunks, 8 distinct positions each -> all 64 banks once;
+//   * ds_read_b64_tr_b16 fragments (8 rows x 32 B per 32 lanes): the 32-byte block index becomes d ^ (r & 7) -> the 8
+//     rows hit 8 distinct blocks of the 256-byte bank window.
+// Rows past the end of a segment are fetched with an out-of-range buffer offset, which the hardware turns into zeros.
+
+constexpr int T32_TILE = 32 * 512;         // bytes of one 32 x 256 bf16 tile
+constexpr int T32_INFO_INTS = 48;          // 32 info words + and / or / index summaries (padded)
+constexpr unsigned DMA_OOB = 0x80000000u;
+
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Inclusive scan step inside a row of 16 lanes (DPP row_shr, no LDS round trip); lanes shifted in get `ident`.
+template <int SHR>
+__device__ __forceinline__ int dpp_shr(int v, int ident) {
+  return __builtin_amdgcn_update_dpp(ident, v, 0x110 + SHR, 0xf, 0xf, false);
+}
+// One wave publishes a 32-row tile of info words (lane < 32 holds row `lane`; rows past the end of the segment and
+// lanes >= 32 hold 0 = class 0 = matches nothing) and its summary {AND of class bits, OR of class bits, max (keys) /
+// min (queries) of the index field, number of valid rows}.
+__device__ __forceinline__ void put_infos32(int* words, int* sum, int v, int valid, int lane, bool want_min) {
+  const bool in = lane < valid;
+  int c_and = in ? (v >> 24) : (lane < 32 ? 0 : -1);
+  int c_or = v >> 24;
+  const int id_idx = want_min ? 0xffffff : 0;
+  int idx = in ? (v & 0xffffff) : (lane < 32 ? 0xffffff - id_idx : id_idx);   // an invalid row defeats "all ok"
+#define LAP_SCAN_STEP(SHR)                                                              \
+  c_and &= dpp_shr<SHR>(c_and, -1);                                                     \
+  c_or |= dpp_shr<SHR>(c_or, 0);                                                        \
+  { const int o = dpp_shr<SHR>(idx, id_idx); idx = want_min ? min(idx, o) : max(idx, o); }
+  LAP_SCAN_STEP(1) LAP_SCAN_STEP(2) LAP_SCAN_STEP(4) LAP_SCAN_STEP(8)
+#undef LAP_SCAN_STEP
+  // lanes 15 and 31 hold the totals of rows 0-15 / 16-31
+  const int a = __builtin_amdgcn_readlane(c_and, 15) & __builtin_amdgcn_readlane(c_and, 31);
+  const int o = __builtin_amdgcn_readlane(c_or, 15) | __builtin_amdgcn_readlane(c_or, 31);
+  const int x0 = __builtin_amdgcn_readlane(idx, 15), x1 = __builtin_amdgcn_readlane(idx, 31);
+  const int x = want_min ? min(x0, x1) : max(x0, x1);
+  if (lane < 32) words[lane] = v;
+  if (lane == 0) *reinterpret_cast<i32x4*>(sum) = i32x4{a, o, x, valid};
+}
+
+// max over the four lanes {i, i+16, i+32, i+48} (gfx950 v_permlane{32,16}_swap: pure VALU, no LDS round trip)
+__device__ __forceinline__ float max_over_groups(float v) {
+  unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u = __float_as_uint(fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])));
+  auto r2 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+}
+__device__ __forceinline__ float sum_over_groups(float v) {
+  unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u = __float_as_uint(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+  auto r2 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+}
+
+template <int V> struct IC { static constexpr int value = V; };
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+// Streamed-side cursor: the 32-row tiles of the two segments form one list.  `rs*` are buffer descriptors whose
+// num_records end right after the last valid row, so rows past the end of a segment read as zeros with no per-lane
+// range test.  K and V share the row stride, hence the per-lane offsets.
+struct StreamCursor {
+  int seg, tile;        // next tile to fetch
+};
+__device__ __forceinline__ int seg_records(int len, int row_stride) { return len > 0 ? ((len - 1) * row_stride + 256) * 2 : 0; }
+
+// =============================================================================== forward
+// Block = 4 waves x 16 queries of the JOINT query sequence (the two segments are tiled as one list, a lane resolves
+// the segment of its own row); two blocks per CU.  The loop body is written for a low instruction count -- the
+// kernel is issue bound (each wave issues at most one instruction every 4 cycles; 32 MFMAs per 32-key tile leave room
+// for ~250 others): LDS addresses are loop invariant registers + immediates (the two stages are unrolled), the
+// info words / tile summaries are staged once per block, the running-max exchange uses v_permlane swaps, the
+// accumulator rescale is skipped while no lane's maximum moves, and exp runs in the log2 domain (one FMA + v_exp).
+__global__ __launch_bounds__(256, 2) void attn256_fwd_kernel(AttnP p) {
+  constexpr int HD = 256, KS = 8, DF = 16, BQ = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x [K tile | V tile], info words, summaries
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int Tq = p.qlen[0] + p.qlen[1], Tk = p.klen[0] + p.klen[1];
+  const int ntq = (Tq + BQ - 1) / BQ;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qtile = bid % ntq, h = (bid / ntq) % p.NH, b = bid / (ntq * p.NH);
+  const int hk = h / (p.NH / p.NKV);
+  const int nt0 = (p.klen[0] + 31) >> 5, nt1 = (p.klen[1] + 31) >> 5, ntk = nt0 + nt1;
+  int* sWords = reinterpret_cast<int*>(smem + 4 * T32_TILE);
+  int* sSum = sWords + ntk * 32;
+  const int per = (ntk + p.nsplit - 1) / p.nsplit;
+  const int gt0 = blockIdx.y * per, gt1 = min(ntk, gt0 + per);
+
+  // ---- my query row
+  const int myq = qtile * BQ + w * 16 + i;   // joint row
+  const bool vq = myq < Tq;
+  const int qsg = myq >= p.qlen[0], qloc = myq - (qsg ? p.qlen[0] : 0);
+  bf16x8 qf[KS];
+  load_row_frags<HD>(p.q[qsg] + (b * (long long)p.qlen[qsg] + qloc) * p.q_rs[qsg] + h * HD, vq, lane, qf);
+  const int qi = !vq ? 0 : (p.qinfo ? p.qinfo[(long long)b * Tq + myq] : 0x7fffffff);   // invalid row: class 0
+  const int qcls = qi >> 24, qidx = qi & 0xffffff;
+
+  // ---- stage the info words + tile summaries of my share of the key tiles (once per block); all loads of a
+  // batch of 8 tiles per wave are in flight together
+  auto stage_infos = [&]() {
+    for (int base = gt0 + w; base < gt1; base += 32) {
+      int v[8], valid[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = base + 4 * u;
+        const int sg = t >= nt0, tl = sg ? t - nt0 : t;
+        valid[u] = t < gt1 ? min(32, p.klen[sg] - tl * 32) : 0;
+        v[u] = 0;
+        if (lane < valid[u]) v[u] = p.kinfo ? p.kinfo[(long long)b * Tk + (sg ? p.klen[0] : 0) + tl * 32 + lane] : 0x7f000000;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = base + 4 * u;
+        if (t < gt1) put_infos32(sWords + t * 32, sSum + t * 4, v[u], valid[u], lane, false);
+      }
+    }
+  };
+
+  // ---- streamed side
+  StreamCursor cur;
+  const int rowbytes0 = p.kv_rs[0] * 2, rowbytes1 = p.kv_rs[1] * 2;
+  cur.seg = gt0 >= nt0; cur.tile = cur.seg ? gt0 - nt0 : gt0;
+  const long long kvoff0 = (long long)b * p.klen[0] * p.kv_rs[0] + hk * HD, kvoff1 = (long long)b * p.klen[1] * p.kv_rs[1] + hk * HD;
+  const auto rsK0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k[0] + kvoff0), 0, seg_records(p.klen[0], p.kv_rs[0]), 0x00020000);
+  const auto rsV0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.v[0] + kvoff0), 0, seg_records(p.klen[0], p.kv_rs[0]), 0x00020000);
+  const auto rsK1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k[1] + kvoff1), 0, seg_records(p.klen[1], p.kv_rs[1]), 0x00020000);
+  const auto rsV1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.v[1] + kvoff1), 0, seg_records(p.klen[1], p.kv_rs[1]), 0x00020000);
+  // DMA piece j of this wave: tile row 8w + 2j + lane/32, physical chunk lane%32 holds logical chunk ^ swz(row)
+  int dma_row[4], dma_col[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    dma_row[j] = (w * 4 + j) * 2 + (lane >> 5);
+    dma_col[j] = ((lane & 31) ^ ((dma_row[j] & 7) << 1)) * 16;
+  }
+  auto issue = [&](int stage) {   // fetch tile `cur` into `stage`, advance the cursor
+    const int rb = cur.seg ? rowbytes1 : rowbytes0;
+    char* base = smem + stage * 2 * T32_TILE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned off = (unsigned)((cur.tile * 32 + dma_row[j]) * rb + dma_col[j]);
+      char* dst = base + (w * 4 + j) * 1024;
+      if (cur.seg == 0) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK0, (LDS_PTR(void))dst, 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV0, (LDS_PTR(void))(dst + T32_TILE), 16, off, 0, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK1, (LDS_PTR(void))dst, 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV1, (LDS_PTR(void))(dst + T32_TILE), 16, off, 0, 0, 0);
+      }
+    }
+    if (++cur.tile == (cur.seg ? nt1 : nt0)) { cur.seg = 1; cur.tile = 0; }
+  };
+
+  // ---- loop invariant LDS addresses
+  // K (ds_read_b128): row nf*16 + i, chunk (4 kk + g) ^ swz(i) = 16 (kk>>2) + ((4 (kk&3) + g) ^ swz)
+  const char* kp[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kp[c] = smem + i * 512 + (((4 * c + g) ^ ((i & 7) << 1)) << 4);
+  // V (transposing reads): row 4g + i/4 (+16), chunk (2 d + (i&3)/2) ^ swz(row) = 16 (d>>3) + ((2 (d&7)) ^ lane_swz)
+  unsigned va[8];
+  {
+    const int tr_row = 4 * g + (i >> 2);
+    const unsigned lane_swz = (unsigned)(((tr_row & 7) << 1) ^ ((i & 3) >> 1));
+    const unsigned lane_off = lds_addr_of(smem) + (unsigned)(tr_row * 512 + ((i & 1) << 3));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) va[c] = lane_off + (((unsigned)(2 * c) ^ lane_swz) << 4);
+  }
+
+  const float c2 = p.scale * LOG2E;     // logits in the log2 domain: s * c2
+  float m = NEG_BIG, l = 0.f;
+  f32x4 acc_o[DF];
+#pragma unroll
+  for (int d = 0; d < DF; ++d) acc_o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  unsigned long long skipmask = 0, fastmask = 0;   // per-wave tile decisions, filled in below
+  auto step = [&](auto STC, int gt) {
+    constexpr int ST = decltype(STC)::value;
+    constexpr int KOFF = ST * 2 * T32_TILE, VOFF = KOFF + T32_TILE;
+    wait_vm0();          // my pieces of tile gt have landed ...
+    __syncthreads();     // ... and everybody's; every wave is done with the stage refilled below
+    if (gt + 1 < gt1) issue(ST ^ 1);
+
+    // tile-level mask decision (wave uniform, precomputed): skip / no masking needed / per-element
+    if ((skipmask >> (gt - gt0)) & 1) return;       // nothing in this tile is visible to this wave's queries
+    const bool fast = (fastmask >> (gt - gt0)) & 1;
+
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + KOFF + (kk >> 2) * 256);
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + KOFF + 16 * 512 + (kk >> 2) * 256);
+      s0 = mfma16(k0, qf[kk], s0);
+      s1 = mfma16(k1, qf[kk], s1);
+    }
+    // online softmax in the log2 domain; lane owns query column i and keys 16 nf + 4 g + r.
+    // The running maximum is LAZY: it only moves (and the accumulators are only rescaled) when some row's new
+    // maximum exceeds the one in use by more than 2^8; until then p = exp2(s - m) is allowed to reach 256 -- the
+    // bf16 rounding of P is scale invariant and l / O carry the same factor, so the result is unchanged.
+    i32x4 kw0 = {0, 0, 0, 0}, kw1 = {0, 0, 0, 0};
+    bool ok0[4], ok1[4];
+    float mx;
+    if (fast) {
+      mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+    } else {
+      kw0 = *reinterpret_cast<const i32x4*>(sWords + gt * 32 + 4 * g);
+      kw1 = *reinterpret_cast<const i32x4*>(sWords + gt * 32 + 16 + 4 * g);
+      mx = NEG_BIG;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ok0[r] = (qcls & (kw0[r] >> 24)) != 0 && (kw0[r] & 0xffffff) <= qidx;
+        ok1[r] = (qcls & (kw1[r] >> 24)) != 0 && (kw1[r] & 0xffffff) <= qidx;
+        if (ok0[r]) mx = fmaxf(mx, s0[r]);
+        if (ok1[r]) mx = fmaxf(mx, s1[r]);
+      }
+    }
+    const float m_new = fmaxf(m, max_over_groups(mx) * c2);
+    if (__any(m_new > m + 8.0f)) {
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      l *= alpha;
+#pragma unroll
+      for (int d = 0; d < DF; ++d) acc_o[d] *= alpha;
+      m = m_new;
+    }
+    if (fast) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(s0[r] * c2 - m);
+        s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2 - m);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s0[r] = ok0[r] ? __builtin_amdgcn_exp2f(s0[r] * c2 - m) : 0.f;
+        s1[r] = ok1[r] ? __builtin_amdgcn_exp2f(s1[r] * c2 - m) : 0.f;
+      }
+    }
+    l += ((s0[0] + s0[1]) + (s0[2] + s0[3])) + ((s1[0] + s1[1]) + (s1[2] + s1[3]));
+    const bf16x8 pb = pack8(s0, s1);
+
+    // O^T += V^T P^T: V fragments through raw transposing reads, software pipelined in groups of 4 d-fragments
+    bf16x4 vr[2][8];
+#define LAP_ISSUE_V(GRP, R)                                                               \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
+    R[2 * j] = ds_read_tr_raw<VOFF + ((GRP) >> 1) * 256>(va[((GRP) & 1) * 4 + j]);        \
+    R[2 * j + 1] = ds_read_tr_raw<VOFF + ((GRP) >> 1) * 256 + 16 * 512>(va[((GRP) & 1) * 4 + j]); \
+  }
+#define LAP_PV(GRP, R)                                                                    \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
+    acc_o[(GRP) * 4 + j] = mfma16(join8(R[2 * j], R[2 * j + 1]), pb, acc_o[(GRP) * 4 + j]);
+    LAP_ISSUE_V(0, vr[0])
+    LAP_ISSUE_V(1, vr[1]) lds_wait8<8>(vr[0]); LAP_PV(0, vr[0])
+    LAP_ISSUE_V(2, vr[0]) lds_wait8<8>(vr[1]); LAP_PV(1, vr[1])
+    LAP_ISSUE_V(3, vr[1]) lds_wait8<8>(vr[0]); LAP_PV(2, vr[0])
+    lds_wait8<0>(vr[1]); LAP_PV(3, vr[1])
+#undef LAP_ISSUE_V
+#undef LAP_PV
+  };
+
+  if (gt0 < gt1) issue(0);
+  stage_infos();      // overlaps the first tile's DMA
+  __syncthreads();
+  // Tile-level mask decisions of this wave for its whole share of key tiles, as two scalar bit masks (lane t decides
+  // tile gt0 + t): skip = no query of the wave sees any key of the tile; fast = every query sees every key.
+  {
+    const int t = gt0 + lane;
+    i32x4 sm = {0, 0, 0, 0};
+    if (t < gt1) sm = *reinterpret_cast<const i32x4*>(sSum + t * 4);
+    bool f = sm[3] == 32;
+    int qor = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {   // lanes 0..15 hold the wave's 16 query rows
+      const int c = __builtin_amdgcn_readlane(qcls, r), x = __builtin_amdgcn_readlane(qidx, r);
+      qor |= c;
+      f = f && (c & sm[0]) != 0 && sm[2] <= x;
+    }
+    skipmask = __ballot((qor & sm[1]) == 0);
+    fastmask = __ballot(f);
+  }
+  for (int gt = gt0; gt < gt1; gt += 2) {
+    step(IC<0>{}, gt);
+    if (gt + 1 < gt1) step(IC<1>{}, gt + 1);
+  }
+
+  l = sum_over_groups(l);
+  if (!vq) return;
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  const float lse = (m + __builtin_amdgcn_logf(l)) * LN2;   // natural log-sum-exp of scale * q.k
+  if (p.nsplit > 1) {
+    // partial result of this key share: normalised O (f32) + its log-sum-exp; combined by attn_fwd_combine_kernel
+    const long long row = ((long long)blockIdx.y * p.B + b) * Tq + myq;
+    float* op = p.part + (row * p.NH + h) * HD;
+#pragma unroll
+    for (int d = 0; d < DF; ++d) *reinterpret_cast<f32x4*>(op + d * 16 + 4 * g) = acc_o[d] * inv;
+    if (g == 0) p.lpart[(((long long)blockIdx.y * p.B + b) * p.NH + h) * Tq + myq] = l > 0.f ? lse : NEG_BIG;
+    return;
+  }
+  bf16* orow = p.o[qsg] + (b * (long long)p.qlen[qsg] + qloc) * p.o_rs[qsg] + h * HD;
+#pragma unroll
+  for (int d = 0; d < DF; ++d) store4(orow + d * 16 + 4 * g, acc_o[d], inv);
+  if (p.lse && g == 0) p.lse[((long long)b * p.NH + h) * Tq + myq] = l > 0.f ? lse : LSE_EMPTY;
+}

@@ -108,6 +108,31 @@ __device__ __forceinline__ unsigned mc_tile_off(int krow, int chunk16) {
 __device__ __forceinline__ bf16x4 ds_read_tr(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(p));
 }
+// The same read issued from inline asm.  The compiler does not model it as an LDS access, which is the point: for
+// the builtin (an instruction without memory operand) it conservatively drains EVERY outstanding LDS-DMA prefetch
+// (`s_waitcnt vmcnt(0)`) before the first transposing read of a loop body, serialising prefetch and compute.  The
+// price: no automatic lgkmcnt wait either -- every result MUST pass through one of the lds_wait*() fences below
+// (which tie the registers to the wait) before it is used.  LDS operations retire in order, so a counted wait that
+// leaves the N youngest reads in flight is safe regardless of what else the compiler has outstanding.
+template <int OFFSET>
+__device__ __forceinline__ bf16x4 ds_read_tr_raw(unsigned lds_addr) {
+  bf16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFFSET));
+  return r;
+}
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) { return (unsigned)(uintptr_t)(LDS_PTR(const char))(p); }
+template <int LEFT>
+__device__ __forceinline__ void lds_wait4(bf16x4 (&r)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(LEFT));
+}
+template <int LEFT>
+__device__ __forceinline__ void lds_wait8(bf16x4 (&r)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+               : "n"(LEFT));
+}
+__device__ __forceinline__ bf16x8 join8(bf16x4 lo, bf16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+
 // Fragment for m columns [m0, m0+16) and k-step kk of a 64-deep tile.  A
 // 16-lane group reads a [4 k][16 m] block (lane i supplies row i/4, 8 bytes at
 // column 4*(i%4)) and receives column i, 4 consecutive k.

@@ -96,6 +96,7 @@ SIGNATURES: dict[str, list] = {
     "lap_add_posemb_cast_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],
     "lap_attention_bwd": [C.POINTER(AttnBwdArgs), _vp],
+    "lap_attention_set_variant": [_i],
     "lap_fused_reduce_rope_split": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "lap_fused_reduce_geglu": [_vp, _i, _vp, _i, _i, _vp],
     "lap_fused_reduce_residual_norm": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp],
@@ -383,6 +384,11 @@ def add_posemb_cast_bwd(dy, dpos, T):
 
 
 # ----------------------------------------------------------------------- attention
+def attention_set_variant(variant: int):
+    """Test / benchmark knob: -1 automatic, 0 generic kernels, 1 / 2 row groups of the HD = 256 LDS-DMA kernels."""
+    _chk(_fn["lap_attention_set_variant"](int(variant)), "lap_attention_set_variant")
+
+
 def attention_fwd(q, k, v, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None, need_lse=True, scale=1.0,
                   q_rs=(0, 0), kv_rs=(0, 0), nsplit_hint=None):
     """q/k/v: lists of up to two segment tensors (None for an empty segment).  q_rs / kv_rs: row strides in

@@ -382,6 +382,22 @@ def test_attention_lap_mask_two_segments(hip, HD, Tp, S, n_lang, n_pad, stop):
     assert rel_err(dv[0].view_as(vf0), vf0.grad) < 2e-2 and rel_err(dv[1].view_as(vf1), vf1.grad) < 2e-2
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attention_hd256_kernel_variants(hip, variant):
+    """HD = 256 has three kernel families (generic padded-LDS; LDS-DMA with 1 / 2 row groups per wave): each must pass
+    the same reference checks, including ragged tiles, the two-segment LAP mask, stop-gradient and key splits."""
+    hip.attention_set_variant(variant)
+    try:
+        test_attention_nomask(hip, 256, 8, 1, 2, 200)
+        test_attention_nomask(hip, 256, 4, 2, 1, 333)
+        test_attention_lap_mask_two_segments(hip, 256, 150, 50, 16, 5, False)
+        test_attention_lap_mask_two_segments(hip, 256, 100, 16, 9, 2, True)
+        test_attention_lap_mask_two_segments(hip, 256, 290, 50, 40, 7, False)
+        test_attention_suffix_only_queries(hip)
+    finally:
+        hip.attention_set_variant(-1)
+
+
 def test_attention_fused_qkv_strided(hip):
     # SigLIP layout: q|k|v are column slices of one [rows, 3*NH*HD] buffer; gradients land in a fused dqkv buffer
     B, T, NH, HD = 2, 100, 4, 72
