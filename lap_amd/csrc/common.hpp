@@ -131,6 +131,9 @@ __device__ __forceinline__ void lds_wait8(bf16x4 (&r)[8]) {
                : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
                : "n"(LEFT));
 }
+// Zero-instruction fence: pins `r` behind every earlier asm volatile (the wait) for the compiler's scheduler.
+template <typename T> __device__ __forceinline__ void lds_tie(T& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ bf16x8 join8(bf16x4 lo, bf16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
 // Fragment for m columns [m0, m0+16) and k-step kk of a 64-deep tile.  A
@@ -145,6 +148,18 @@ __device__ __forceinline__ bf16x8 mc_frag(const char* tile, int m0, int kk, int 
   bf16x4 lo = ds_read_tr(tile + mc_tile_off<MW>(kr, c16) + (half << 3));
   bf16x4 hi = ds_read_tr(tile + mc_tile_off<MW>(kr + 4, c16) + (half << 3));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// mc_frag through raw reads (see ds_read_tr_raw): results are valid only after lds_wait_all() + lds_tie().
+template <int MW>
+__device__ __forceinline__ void mc_frag_raw(const char* tile, int m0, int kk, int lane, bf16x4 (&r)[2]) {
+  const int i = lane & 15, g = lane >> 4;
+  const int kr = kk * 32 + 8 * g + (i >> 2);
+  const int mcol = m0 + (i & 3) * 4;
+  const int c16 = mcol >> 3, half = (mcol >> 2) & 1;
+  const unsigned a = lds_addr_of(tile) + mc_tile_off<MW>(kr, c16) + (half << 3);
+  r[0] = ds_read_tr_raw<0>(a);
+  r[1] = ds_read_tr_raw<4 * MW * 2>(a);   // k-row + 4: same swizzle
 }
 
 // XCD-aware block id remap (bijective for any grid size): consecutive logical

@@ -219,14 +219,38 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int kk = 0; kk < KSUB; ++kk) {
       bf16x8 fa[FM], fb[FN];
+      // M-contiguous operands: transposing reads issued raw (the builtin makes the compiler drain the LDS-DMA
+      // prefetch of the next tile first, see common.hpp), fenced once per k-step
+      bf16x4 ta[A_KC ? 1 : FM][2], tb[B_KC ? 1 : FN][2];
+      if (!A_KC) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
-        fa[i] = A_KC ? (BK == 64 ? kc_frag(tA, wm * WTM + i * 16, kk, lane) : kc32_frag(tA, wm * WTM + i * 16, lane))
-                     : mc_frag<BM>(tA, wm * WTM + i * 16, kk, lane);
+        for (int i = 0; i < FM; ++i) mc_frag_raw<BM>(tA, wm * WTM + i * 16, kk, lane, ta[i]);
+      }
+      if (!B_KC) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-        fb[j] = B_KC ? (BK == 64 ? kc_frag(tB, wn * WTN + j * 16, kk, lane) : kc32_frag(tB, wn * WTN + j * 16, lane))
-                     : mc_frag<BN>(tB, wn * WTN + j * 16, kk, lane);
+        for (int j = 0; j < FN; ++j) mc_frag_raw<BN>(tB, wn * WTN + j * 16, kk, lane, tb[j]);
+      }
+      if (A_KC) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          fa[i] = BK == 64 ? kc_frag(tA, wm * WTM + i * 16, kk, lane) : kc32_frag(tA, wm * WTM + i * 16, lane);
+      }
+      if (B_KC) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          fb[j] = BK == 64 ? kc_frag(tB, wn * WTN + j * 16, kk, lane) : kc32_frag(tB, wn * WTN + j * 16, lane);
+      }
+      if (!A_KC || !B_KC) {
+        lds_wait_all();
+        if (!A_KC) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) { lds_tie(ta[i][0]); lds_tie(ta[i][1]); fa[i] = join8(ta[i][0], ta[i][1]); }
+        }
+        if (!B_KC) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) { lds_tie(tb[j][0]); lds_tie(tb[j][1]); fb[j] = join8(tb[j][0], tb[j][1]); }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
