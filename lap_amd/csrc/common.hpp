@@ -150,6 +150,13 @@ __device__ __forceinline__ bf16x8 mc_frag(const char* tile, int m0, int kk, int 
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// kc_frag through a raw ds_read_b128 (valid after lds_wait_all() + lds_tie()).
+__device__ __forceinline__ bf16x8 kc_frag_raw(const char* tile, int row0, int kk, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(lds_addr_of(tile) + kc_tile_off(row0 + i, kk * 4 + g)));
+  return r;
+}
 // mc_frag through raw reads (see ds_read_tr_raw): results are valid only after lds_wait_all() + lds_tie().
 template <int MW>
 __device__ __forceinline__ void mc_frag_raw(const char* tile, int m0, int kk, int lane, bf16x4 (&r)[2]) {

@@ -230,25 +230,28 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) mc_frag_raw<BN>(tB, wn * WTN + j * 16, kk, lane, tb[j]);
       }
+      constexpr bool RAW_KC = BK == 64;   // K-contiguous operands through raw b128 reads as well (+1-3 %)
       if (A_KC) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
-          fa[i] = BK == 64 ? kc_frag(tA, wm * WTM + i * 16, kk, lane) : kc32_frag(tA, wm * WTM + i * 16, lane);
+          fa[i] = RAW_KC ? kc_frag_raw(tA, wm * WTM + i * 16, kk, lane) : kc32_frag(tA, wm * WTM + i * 16, lane);
       }
       if (B_KC) {
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          fb[j] = BK == 64 ? kc_frag(tB, wn * WTN + j * 16, kk, lane) : kc32_frag(tB, wn * WTN + j * 16, lane);
+          fb[j] = RAW_KC ? kc_frag_raw(tB, wn * WTN + j * 16, kk, lane) : kc32_frag(tB, wn * WTN + j * 16, lane);
       }
-      if (!A_KC || !B_KC) {
+      if (RAW_KC || !A_KC || !B_KC) {
         lds_wait_all();
-        if (!A_KC) {
 #pragma unroll
-          for (int i = 0; i < FM; ++i) { lds_tie(ta[i][0]); lds_tie(ta[i][1]); fa[i] = join8(ta[i][0], ta[i][1]); }
+        for (int i = 0; i < FM; ++i) {
+          if (!A_KC) { lds_tie(ta[i][0]); lds_tie(ta[i][1]); fa[i] = join8(ta[i][0], ta[i][1]); }
+          else if (RAW_KC) lds_tie(fa[i]);
         }
-        if (!B_KC) {
 #pragma unroll
-          for (int j = 0; j < FN; ++j) { lds_tie(tb[j][0]); lds_tie(tb[j][1]); fb[j] = join8(tb[j][0], tb[j][1]); }
+        for (int j = 0; j < FN; ++j) {
+          if (!B_KC) { lds_tie(tb[j][0]); lds_tie(tb[j][1]); fb[j] = join8(tb[j][0], tb[j][1]); }
+          else if (RAW_KC) lds_tie(fb[j]);
         }
       }
 #pragma unroll
