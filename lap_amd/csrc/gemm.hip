@@ -52,7 +52,20 @@ struct GemmParams {
   int gelu, accum;
   int ksplit, ktiles_per_split;
   float* part;           // split-K scratch: f32 [ksplit][M][N] partial products (null: atomic accumulate into C)
+  int tile_base;         // this launch covers the logical tiles [tile_base, tile_base + gridDim.x)
+  int tile_count;        // host side only: tiles of this launch (0 = all from tile_base)
+  int part_compact;      // partial slabs are [ksplit][gridDim.x][256][256] (tail split of the 256x256 kernel)
 };
+
+// logical tile -> (m-tile, n-tile): groups of GM m-tiles sweep n so that neighbouring tiles share operand panels
+template <int GM>
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int t, int& tm, int& tn) {
+  const int group_sz = GM * p.tiles_n;
+  const int first_m = (t / group_sz) * GM;
+  const int gm = min(p.tiles_m - first_m, GM);
+  tm = first_m + (t % group_sz) % gm;
+  tn = (t % group_sz) / gm;
+}
 
 // 64-byte-row K-contiguous tile (BK = 32): 16-byte chunk c of row r is stored at chunk c ^ ((-(r >> 2)) & 3), which
 // makes every 16-lane service group of ds_read_b128 cover all 64 banks once.
@@ -68,7 +81,12 @@ __device__ __forceinline__ bf16x8 kc32_frag(const char* tile, int row0, int lane
 template <bool OUT_F32>
 __device__ __forceinline__ void store_tile4(const GemmParams& p, int m, int n, f32x4 a) {
   if (p.part) {  // split-K partial: raw product, epilogue happens in splitk_reduce_kernel
-    *reinterpret_cast<f32x4*>(p.part + ((long long)blockIdx.y * p.M + m) * p.N + n) = a;
+    if (p.part_compact) {
+      const int slot = xcd_remap(blockIdx.x, gridDim.x);
+      *reinterpret_cast<f32x4*>(p.part + (((long long)blockIdx.y * gridDim.x + slot) << 16) + ((m & 255) << 8) + (n & 255)) = a;
+    } else {
+      *reinterpret_cast<f32x4*>(p.part + ((long long)blockIdx.y * p.M + m) * p.N + n) = a;
+    }
     return;
   }
   f32x4 v = a * p.alpha;
@@ -126,14 +144,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
   const int wm = w / WGN, wn = w % WGN;
 
   // Block -> tile mapping: XCD-aware remap, then groups of GM m-tiles sweep n.
-  const int nblk = p.tiles_m * p.tiles_n;
-  const int t = xcd_remap(blockIdx.x, nblk);
+  const int t = p.tile_base + xcd_remap(blockIdx.x, gridDim.x);
   constexpr int GM = (BM == 256) ? 4 : 8;
-  const int group_sz = GM * p.tiles_n;
-  const int first_m = (t / group_sz) * GM;
-  const int gm = min(p.tiles_m - first_m, GM);
-  const int tm = first_m + (t % group_sz) % gm;
-  const int tn = (t % group_sz) / gm;
+  int tm, tn;
+  tile_coords<GM>(p, t, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   auto rsA = __builtin_amdgcn_make_buffer_rsrc(
@@ -516,7 +530,8 @@ int launch(GemmParams p, hipStream_t s) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const int nkt = (p.K + BK - 1) / BK;
   p.ktiles_per_split = (nkt + p.ksplit - 1) / p.ksplit;
-  dim3 grid(p.tiles_m * p.tiles_n, p.ksplit);
+  const int count = p.tile_count > 0 ? p.tile_count : p.tiles_m * p.tiles_n - p.tile_base;
+  dim3 grid(count, p.ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), LDS, s, p);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
@@ -534,6 +549,47 @@ int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
     case 2: return launch<256, 256, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
     case 1: return launch<256, 128, 4, 2, 64, 3, A_KC, B_KC, OUT_F32>(p, s);
     default: return launch<128, 128, 2, 2, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
+  }
+}
+
+// Reduce + epilogue for the TAIL split of the 256x256 kernel: slabs [ksplit][count][256][256], slot s = logical tile
+// tile_base + s.  64 blocks per tile, 4 outputs per thread.
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void splitk_tail_reduce_kernel(GemmParams p, int count) {
+  const int slot = blockIdx.x >> 6;
+  const int within = ((blockIdx.x & 63) * 256 + threadIdx.x) * 4;
+  int tm, tn;
+  tile_coords<4>(p, p.tile_base + slot, tm, tn);
+  const int m = tm * 256 + (within >> 8), n = tn * 256 + (within & 255);
+  if (m >= p.M || n >= p.N) return;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < p.ksplit; ++sp) v += *reinterpret_cast<const f32x4*>(p.part + (((long long)sp * count + slot) << 16) + within);
+  v *= p.alpha;
+  if (p.bias_kind == 1) {
+    bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
+  } else if (p.bias_kind == 2) {
+    v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+  }
+  if (p.gelu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+  }
+  if (p.R) {
+    bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+  }
+  if (OUT_F32) {
+    float* c = (float*)p.C + (long long)m * p.ldc + n;
+    if (p.accum) v += *reinterpret_cast<const f32x4*>(c);
+    *reinterpret_cast<f32x4*>(c) = v;
+  } else {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+    *reinterpret_cast<bf16x4*>((bf16*)p.C + (long long)m * p.ldc + n) = o;
   }
 }
 
@@ -602,11 +658,26 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
   if (tile < -1 || tile > 8 || ksplit < 0) return LAP_ERR_ARG;
   if (tile < 0) tile = pick_tile(M, N, K);
-  if (ksplit == 0 && scratch != nullptr) ksplit = pick_ksplit(tile, M, N, K, scratch_bytes);
+  // Tail split (256x256 kernel, automatic split only): the full rounds of 256 tiles run unsplit; only the tiles of
+  // the last, poorly filled round are split along K so that they fill the chip for 1/sp of a round.
+  int tail_tiles = 0, tail_sp = 0;
+  if (ksplit == 0 && scratch != nullptr && tile == 5 && !(flags & LAP_GEMM_PARTIALS)) {
+    const long long t5 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    const int tail = (int)(t5 % 256), nkt = (K + 63) / 64;
+    if (t5 > 256 && tail > 0 && tail < 200) {
+      int sp = 256 / tail;
+      if (sp > 8) sp = 8;
+      if (sp > nkt / 8) sp = nkt / 8;
+      const long long cap = scratch_bytes / ((long long)tail * 65536 * 4);
+      if (sp > cap) sp = (int)cap;
+      if (sp >= 2) { tail_tiles = tail; tail_sp = sp; }
+    }
+  }
+  if (ksplit == 0 && scratch != nullptr && !tail_tiles) ksplit = pick_ksplit(tile, M, N, K, scratch_bytes);
   const bool two_phase = ksplit > 1 && scratch != nullptr;
   if (two_phase && scratch_bytes < (long long)ksplit * M * N * 4) return LAP_ERR_ARG;
   if (ksplit > 1 && !two_phase && (!f32 || !(flags & LAP_GEMM_ACCUM) || bias || residual)) return LAP_ERR_ARG;
-  GemmParams p;
+  GemmParams p = {};
   p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C; p.bias = bias; p.R = (const bf16*)residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.alpha = alpha;
   p.bias_kind = bias ? ((flags & LAP_GEMM_BIAS_F32) ? 2 : 1) : 0;
@@ -618,6 +689,36 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   if (flags & LAP_GEMM_PARTIALS) {
     if (!scratch || ksplit < 1 || scratch_bytes < (long long)(ksplit > 1 ? ksplit : 1) * M * N * 4) return LAP_ERR_ARG;
     p.part = (float*)scratch;   // also valid for ksplit == 1: one slab
+  }
+  if (tail_tiles) {
+    const int t5 = ((M + 255) / 256) * ((N + 255) / 256);
+    int rc;
+    // (a) the full rounds, straight to C
+    p.ksplit = 1; p.part = nullptr; p.tile_base = 0; p.tile_count = t5 - tail_tiles;
+    if (f32) {
+      if (a_kc && b_kc) rc = dispatch_tile<true, true, true>(p, 5, s);
+      else if (a_kc && !b_kc) rc = dispatch_tile<true, false, true>(p, 5, s);
+      else if (!a_kc && !b_kc) rc = dispatch_tile<false, false, true>(p, 5, s);
+      else rc = dispatch_tile<false, true, true>(p, 5, s);
+    } else {
+      if (a_kc && b_kc) rc = dispatch_tile<true, true, false>(p, 5, s);
+      else if (a_kc && !b_kc) rc = dispatch_tile<true, false, false>(p, 5, s);
+      else if (!a_kc && !b_kc) rc = dispatch_tile<false, false, false>(p, 5, s);
+      else rc = dispatch_tile<false, true, false>(p, 5, s);
+    }
+    if (rc) return rc;
+    // (b) the tail tiles, split along K into compact f32 slabs, then reduce + epilogue
+    p.ksplit = tail_sp; p.part = (float*)scratch; p.part_compact = 1; p.tile_base = t5 - tail_tiles; p.tile_count = tail_tiles;
+    if (a_kc && b_kc) rc = dispatch_tile<true, true, true>(p, 5, s);
+    else if (a_kc && !b_kc) rc = dispatch_tile<true, false, true>(p, 5, s);
+    else if (!a_kc && !b_kc) rc = dispatch_tile<false, false, true>(p, 5, s);
+    else rc = dispatch_tile<false, true, true>(p, 5, s);
+    if (rc) return rc;
+    p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+    if (f32) hipLaunchKernelGGL(splitk_tail_reduce_kernel<true>, dim3(tail_tiles * 64), dim3(256), 0, s, p, tail_tiles);
+    else hipLaunchKernelGGL(splitk_tail_reduce_kernel<false>, dim3(tail_tiles * 64), dim3(256), 0, s, p, tail_tiles);
+    LAP_CHECK_LAUNCH();
+    return LAP_OK;
   }
   if (two_phase || (flags & LAP_GEMM_PARTIALS)) {
     int rc;

@@ -182,14 +182,15 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, 
     return out
 
 
-def linear_fwd(x, wt, out=None, *, bias=None, residual=None, gelu=False, out_dtype=torch.bfloat16, tile=-1):
+def linear_fwd(x, wt, out=None, *, bias=None, residual=None, gelu=False, out_dtype=torch.bfloat16, tile=-1, ksplit=0):
     """y[M,out] = x[M,in] @ wt[out,in]^T (+bias)(gelu)(+residual)."""
     M, K = x.shape
     N = wt.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=x.device)
     return gemm(x, wt, out, M=M, N=N, K=K, lda=x.stride(0), ldb=wt.stride(0), ldc=out.stride(0), bias=bias,
-                residual=residual, ldr=(residual.stride(0) if residual is not None else 0), gelu=gelu, tile=tile)
+                residual=residual, ldr=(residual.stride(0) if residual is not None else 0), gelu=gelu, tile=tile,
+                ksplit=ksplit)
 
 
 def linear_dgrad(dy, wt, out=None, *, out_dtype=torch.bfloat16, accum=False, tile=-1):

@@ -69,6 +69,28 @@ def test_gemm_tiles_all_layouts(hip, tile):
     assert torch.equal(hip.linear_fwd(a2, w2, tile=tile), w2.t().contiguous())
 
 
+def test_gemm_tail_split(hip):
+    # more than one round of 256x256 tiles with a poorly filled last round: the full rounds run unsplit, the tail
+    # tiles are split along K into compact slabs and reduced (partial tiles in M and N included)
+    M, N, K = 4300, 4000, 1024   # 17 x 16 = 272 tiles -> tail of 16 tiles
+    a = rnd(M, K); wt = rnd(N, K, seed=1); res = rnd(M, N, seed=2); bias = rnd(N, dtype=torch.float32, seed=3)
+    base = a.float() @ wt.float().t()
+    assert rel_err(hip.linear_fwd(a, wt, tile=5), base) < 4e-3
+    assert rel_err(hip.linear_fwd(a, wt, bias=bias, residual=res, tile=5), base + bias + res.float()) < 4e-3
+    assert rel_err(hip.linear_fwd(a, wt, bias=bias, gelu=True, tile=5), torch.nn.functional.gelu(base + bias, approximate="tanh")) < 4e-3
+    # identical to the unsplit kernel up to the f32 summation order of the split tiles
+    assert rel_err(hip.linear_fwd(a, wt, tile=5), hip.linear_fwd(a, wt, tile=5, ksplit=1)) < 1e-3
+    dy = rnd(M, N, seed=4)
+    assert rel_err(hip.linear_dgrad(dy, wt, tile=5), dy.float() @ wt.float()) < 4e-3
+    Mw, Nw, Kw = 1024, 4296, 4000   # wgrad: output [Nw, Kw] = 17 x 16 tiles, contraction over Mw rows
+    dyw = rnd(Mw, Nw, seed=5); xw = rnd(Mw, Kw, seed=6)
+    g = torch.full((Nw, Kw), 2.0, device=DEV)
+    hip.linear_wgrad(dyw, xw, g, tile=5)
+    assert rel_err(g, dyw.float().t() @ xw.float()) < 1e-5
+    hip.linear_wgrad(dyw, xw, g, accum=True, tile=5)
+    assert rel_err(g, 2 * (dyw.float().t() @ xw.float())) < 1e-5
+
+
 def test_gemm_two_phase_splitk(hip):
     # skinny-M serving shapes take the automatic two-phase split-K path (f32 partials + reduce/epilogue kernel)
     for (M, N, K) in [(50, 1024, 4096), (50, 1024, 2048), (50, 2560, 1024), (560, 2048, 16384)]:
