@@ -614,8 +614,8 @@ int launch_fwd256(const AttnP& p, hipStream_t s) {
   const int nt = (p.qlen[0] + p.qlen[1] + 63) / 64;
   const int ntk = (p.klen[0] + 31) / 32 + (p.klen[1] + 31) / 32;
   const int lds = 4 * T32_TILE + ntk * 144;
-  if (int e = set_lds(attn256_fwd_kernel, lds)) return e;
-  hipLaunchKernelGGL(attn256_fwd_kernel, dim3(p.B * p.NH * nt, p.nsplit), dim3(256), lds, s, p);
+  if (int e = set_lds(attn256_q_kernel<0>, lds)) return e;
+  hipLaunchKernelGGL(attn256_q_kernel<0>, dim3(p.B * p.NH * nt, p.nsplit), dim3(256), lds, s, p);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
@@ -660,6 +660,17 @@ int launch_bwd(const AttnP& p, hipStream_t s) {
     const long long n4 = (long long)p.B * (p.klen[0] + p.klen[1]) * p.NKV * HD / 4;
     hipLaunchKernelGGL(attn_dkdv_reduce_kernel<HD>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
     LAP_CHECK_LAUNCH();
+  }
+  if constexpr (HD == 256) {
+    if (dma_path_ok(p)) {
+      const int nt = (p.qlen[0] + p.qlen[1] + 63) / 64;
+      const int ntk32 = (p.klen[0] + 31) / 32 + (p.klen[1] + 31) / 32;
+      const int lds2 = 4 * T32_TILE + ntk32 * 144;
+      if (int e = set_lds(attn256_q_kernel<1>, lds2)) return e;
+      hipLaunchKernelGGL(attn256_q_kernel<1>, dim3(p.B * p.NH * nt, 1), dim3(256), lds2, s, p);
+      LAP_CHECK_LAUNCH();
+      return LAP_OK;
+    }
   }
   const int ntq = (p.qlen[0] + 63) / 64 + (p.qlen[1] + 63) / 64;
   if (int e = set_lds(attn_bwd_dq_kernel<HD>, lds)) return e;
@@ -740,6 +751,7 @@ extern "C" int lap_attention_bwd(const lap_attn_bwd_args* a, void* stream) {
   p.qinfo = a->qinfo; p.kinfo = a->kinfo; p.lse = (float*)a->lse; p.delta = a->delta;
   p.scale = a->scale;
   p.B = a->B; p.NH = a->NH; p.NKV = a->NKV; p.stop = a->stop_q1_to_k0;
+  p.nsplit = 1;
   // grouped-query models: spread the query heads of a kv head over several blocks when scratch is provided
   p.hsplit = 1; p.part = nullptr;
   {

@@ -82,7 +82,12 @@ __device__ __forceinline__ int seg_records(int len, int row_stride) { return len
 // for ~250 others): LDS addresses are loop invariant registers + immediates (the two stages are unrolled), the
 // info words / tile summaries are staged once per block, the running-max exchange uses v_permlane swaps, the
 // accumulator rescale is skipped while no lane's maximum moves, and exp runs in the log2 domain (one FMA + v_exp).
-__global__ __launch_bounds__(256, 2) void attn256_fwd_kernel(AttnP p) {
+//
+// MODE 1 = backward dQ with the same skeleton: per key tile S^T = K Q^T and dP^T = V dO^T (V read K-contiguous like
+// K), dS^T = P^T o (dP^T - delta) * scale with P recomputed from the saved log-sum-exp, and dQ^T += K^T dS^T through
+// the transposing reads of the K tile.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
   constexpr int HD = 256, KS = 8, DF = 16, BQ = 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x [K tile | V tile], info words, summaries
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -106,6 +111,13 @@ __global__ __launch_bounds__(256, 2) void attn256_fwd_kernel(AttnP p) {
   load_row_frags<HD>(p.q[qsg] + (b * (long long)p.qlen[qsg] + qloc) * p.q_rs[qsg] + h * HD, vq, lane, qf);
   const int qi = !vq ? 0 : (p.qinfo ? p.qinfo[(long long)b * Tq + myq] : 0x7fffffff);   // invalid row: class 0
   const int qcls = qi >> 24, qidx = qi & 0xffffff;
+  bf16x8 dof[KS];   // MODE 1 only (dead otherwise)
+  float lse2 = 0.f, dl_q = 0.f;     // MODE 1: log2-domain log-sum-exp and delta = rowsum(dO o O) of my row
+  if constexpr (MODE == 1) {
+    load_row_frags<HD>(p.d_o[qsg] + (b * (long long)p.qlen[qsg] + qloc) * p.o_rs[qsg] + h * HD, vq, lane, dof);
+    lse2 = (vq ? p.lse[((long long)b * p.NH + h) * Tq + myq] : LSE_EMPTY) * LOG2E;
+    dl_q = vq ? p.delta[((long long)b * p.NH + h) * Tq + myq] : 0.f;
+  }
 
   // ---- stage the info words + tile summaries of my share of the key tiles (once per block); all loads of a
   // batch of 8 tiles per wave are in flight together
@@ -195,6 +207,56 @@ __global__ __launch_bounds__(256, 2) void attn256_fwd_kernel(AttnP p) {
     if ((skipmask >> (gt - gt0)) & 1) return;       // nothing in this tile is visible to this wave's queries
     const bool fast = (fastmask >> (gt - gt0)) & 1;
 
+    if constexpr (MODE == 1) {
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + KOFF + (kk >> 2) * 256);
+        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + KOFF + 16 * 512 + (kk >> 2) * 256);
+        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + VOFF + (kk >> 2) * 256);
+        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + VOFF + 16 * 512 + (kk >> 2) * 256);
+        s0 = mfma16(k0, qf[kk], s0);      // S^T[key][q]
+        s1 = mfma16(k1, qf[kk], s1);
+        d0 = mfma16(v0, dof[kk], d0);     // dP^T[key][q]
+        d1 = mfma16(v1, dof[kk], d1);
+      }
+      if (fast) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          d0[r] = __builtin_amdgcn_exp2f(s0[r] * c2 - lse2) * (d0[r] - dl_q) * p.scale;
+          d1[r] = __builtin_amdgcn_exp2f(s1[r] * c2 - lse2) * (d1[r] - dl_q) * p.scale;
+        }
+      } else {
+        const i32x4 kw0 = *reinterpret_cast<const i32x4*>(sWords + gt * 32 + 4 * g);
+        const i32x4 kw1 = *reinterpret_cast<const i32x4*>(sWords + gt * 32 + 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool a0 = (qcls & (kw0[r] >> 24)) != 0 && (kw0[r] & 0xffffff) <= qidx;
+          const bool a1 = (qcls & (kw1[r] >> 24)) != 0 && (kw1[r] & 0xffffff) <= qidx;
+          d0[r] = a0 ? __builtin_amdgcn_exp2f(s0[r] * c2 - lse2) * (d0[r] - dl_q) * p.scale : 0.f;
+          d1[r] = a1 ? __builtin_amdgcn_exp2f(s1[r] * c2 - lse2) * (d1[r] - dl_q) * p.scale : 0.f;
+        }
+      }
+      const bf16x8 pb = pack8(d0, d1);
+      // dQ^T += K^T dS^T: K fragments through raw transposing reads, software pipelined in groups of 4 d-fragments
+      bf16x4 vr[2][8];
+#define LAP_ISSUE_K(GRP, R)                                                               \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
+    R[2 * j] = ds_read_tr_raw<KOFF + ((GRP) >> 1) * 256>(va[((GRP) & 1) * 4 + j]);        \
+    R[2 * j + 1] = ds_read_tr_raw<KOFF + ((GRP) >> 1) * 256 + 16 * 512>(va[((GRP) & 1) * 4 + j]); \
+  }
+#define LAP_DQ(GRP, R)                                                                    \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
+    acc_o[(GRP) * 4 + j] = mfma16(join8(R[2 * j], R[2 * j + 1]), pb, acc_o[(GRP) * 4 + j]);
+      LAP_ISSUE_K(0, vr[0])
+      LAP_ISSUE_K(1, vr[1]) lds_wait8<8>(vr[0]); LAP_DQ(0, vr[0])
+      LAP_ISSUE_K(2, vr[0]) lds_wait8<8>(vr[1]); LAP_DQ(1, vr[1])
+      LAP_ISSUE_K(3, vr[1]) lds_wait8<8>(vr[0]); LAP_DQ(2, vr[0])
+      lds_wait8<0>(vr[1]); LAP_DQ(3, vr[1])
+#undef LAP_ISSUE_K
+#undef LAP_DQ
+      return;
+    }
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
@@ -292,6 +354,13 @@ __global__ __launch_bounds__(256, 2) void attn256_fwd_kernel(AttnP p) {
     if (gt + 1 < gt1) step(IC<1>{}, gt + 1);
   }
 
+  if (MODE == 1) {
+    if (!vq) return;
+    bf16* dqrow = p.dq[qsg] + (b * (long long)p.qlen[qsg] + qloc) * p.q_rs[qsg] + h * HD;
+#pragma unroll
+    for (int d = 0; d < DF; ++d) store4(dqrow + d * 16 + 4 * g, acc_o[d], 1.0f);
+    return;
+  }
   l = sum_over_groups(l);
   if (!vq) return;
   const float inv = l > 0.f ? 1.0f / l : 0.f;
