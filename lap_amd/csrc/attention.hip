@@ -653,9 +653,21 @@ int launch_bwd(const AttnP& p, hipStream_t s) {
   hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p);
   LAP_CHECK_LAUNCH();
   const int ntk = (p.klen[0] + 63) / 64 + (p.klen[1] + 63) / 64;
-  if (int e = set_lds(attn_bwd_dkdv_kernel<HD>, lds)) return e;
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HD>, dim3(p.B * p.NKV * p.hsplit * ntk), dim3(256), lds, s, p);
-  LAP_CHECK_LAUNCH();
+  bool kv_dma = false;
+  if constexpr (HD == 256) kv_dma = dma_path_ok(p);
+  if (kv_dma) {
+    if constexpr (HD == 256) {
+      const int ntq32 = (p.qlen[0] + 31) / 32 + (p.qlen[1] + 31) / 32;
+      const int lds2 = 4 * T32_TILE + 1024 + ntq32 * 144;
+      if (int e = set_lds(attn256_kv_kernel, lds2)) return e;
+      hipLaunchKernelGGL(attn256_kv_kernel, dim3(p.B * p.NKV * p.hsplit * ntk), dim3(256), lds2, s, p);
+      LAP_CHECK_LAUNCH();
+    }
+  } else {
+    if (int e = set_lds(attn_bwd_dkdv_kernel<HD>, lds)) return e;
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HD>, dim3(p.B * p.NKV * p.hsplit * ntk), dim3(256), lds, s, p);
+    LAP_CHECK_LAUNCH();
+  }
   if (p.hsplit > 1) {
     const long long n4 = (long long)p.B * (p.klen[0] + p.klen[1]) * p.NKV * HD / 4;
     hipLaunchKernelGGL(attn_dkdv_reduce_kernel<HD>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);

@@ -379,3 +379,221 @@ __global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
   for (int d = 0; d < DF; ++d) store4(orow + d * 16 + 4 * g, acc_o[d], inv);
   if (p.lse && g == 0) p.lse[((long long)b * p.NH + h) * Tq + myq] = l > 0.f ? lse : LSE_EMPTY;
 }
+
+// ======================================================================== backward: dK, dV
+// Block = (b, kv head, head group, 64-key tile of one key segment); wave owns 16 keys (lane column i) whose K and V
+// rows live in registers.  The streamed side is the list of (query head of the group) x (32-row query tile): the Q
+// and dO tiles arrive through the 2-stage LDS-DMA ring, the 32 log-sum-exp / delta values of the tile through two
+// dword DMAs of wave 0.  Per tile:  S = Q K^T, dP = dO V^T (Q / dO read K-contiguous),  P = exp2(S c2 - lse),
+// dS = P o (dP - delta) scale,  dV^T += dO^T P,  dK^T += Q^T dS (Q / dO read through raw transposing reads).
+__global__ __launch_bounds__(256, 2) void attn256_kv_kernel(AttnP p) {
+  constexpr int HD = 256, KS = 8, DF = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x [Q tile | dO tile], 2 x [lse | delta], q infos
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const BlockId id = decode_block(p.klen[0], p.klen[1], p.NKV * p.hsplit);
+  const int b = id.b, hk = id.h / p.hsplit, hg = id.h % p.hsplit, kseg = id.seg;
+  const int klen = p.klen[kseg];
+  const int Tq = p.qlen[0] + p.qlen[1], Tk = p.klen[0] + p.klen[1];
+  const int mykey = id.tile * 64 + w * 16 + i;
+  const bool vk = mykey < klen;
+  const long long koff = (b * (long long)klen + mykey) * p.kv_rs[kseg] + hk * HD;
+  const int nq0 = (p.qlen[0] + 31) >> 5, nq1 = (p.stop && kseg == 0) ? 0 : (p.qlen[1] + 31) >> 5, ntq = nq0 + nq1;
+  float* sLD = reinterpret_cast<float*>(smem + 4 * T32_TILE);          // per stage: 64 floats lse(+pad), 64 floats delta(+pad)
+  int* sWords = reinterpret_cast<int*>(smem + 4 * T32_TILE + 1024);
+  int* sSum = sWords + ntq * 32;
+
+  bf16x8 kf[KS], vf[KS];
+  load_row_frags<HD>(p.k[kseg] + koff, vk, lane, kf);
+  load_row_frags<HD>(p.v[kseg] + koff, vk, lane, vf);
+  const int ki = !vk ? 0 : (p.kinfo ? p.kinfo[(long long)b * Tk + (kseg ? p.klen[0] : 0) + mykey] : 0x7f000000);
+  const int kcls = ki >> 24, kidx = ki & 0xffffff;
+
+  // ---- query info words + tile summaries (once per block; the same for every head)
+  for (int base = w; base < ntq; base += 32) {
+    int v[8], valid[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = base + 4 * u;
+      const int sg = t >= nq0, tl = sg ? t - nq0 : t;
+      valid[u] = t < ntq ? min(32, p.qlen[sg] - tl * 32) : 0;
+      v[u] = 0;
+      if (lane < valid[u]) v[u] = p.qinfo ? p.qinfo[(long long)b * Tq + (sg ? p.qlen[0] : 0) + tl * 32 + lane] : 0x7fffffff;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = base + 4 * u;
+      if (t < ntq) put_infos32(sWords + t * 32, sSum + t * 4, v[u], valid[u], lane, true);
+    }
+  }
+
+  // ---- streamed side: items = (head of my group) x (query tile)
+  const int hpk = p.NH / p.NKV, hpg = hpk / p.hsplit;
+  const int h_first = hk * hpk + hg * hpg;
+  const int items = hpg * ntq;
+  int cur_h = h_first, cur_t = 0;   // next item to fetch
+  int dma_row[4], dma_col[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    dma_row[j] = (w * 4 + j) * 2 + (lane >> 5);
+    dma_col[j] = ((lane & 31) ^ ((dma_row[j] & 7) << 1)) * 16;
+  }
+  auto issue = [&](int stage) {
+    const int sg = cur_t >= nq0, tl = sg ? cur_t - nq0 : cur_t;
+    const int qlen = p.qlen[sg], qrs = p.q_rs[sg], ors = p.o_rs[sg];
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q[sg] + (long long)b * qlen * qrs + cur_h * HD), 0, seg_records(qlen, qrs), 0x00020000);
+    const auto rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(p.d_o[sg] + (long long)b * qlen * ors + cur_h * HD), 0, seg_records(qlen, ors), 0x00020000);
+    char* base = smem + stage * 2 * T32_TILE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      char* dst = base + (w * 4 + j) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (LDS_PTR(void))dst, 16, (unsigned)((tl * 32 + dma_row[j]) * qrs * 2 + dma_col[j]), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (LDS_PTR(void))(dst + T32_TILE), 16, (unsigned)((tl * 32 + dma_row[j]) * ors * 2 + dma_col[j]), 0, 0, 0);
+    }
+    if (w == 0) {   // lse / delta of the tile's rows: lanes 0..31 fetch, lanes 32..63 (and rows past the end) write zeros
+      const long long roff = ((long long)b * p.NH + cur_h) * Tq + (sg ? p.qlen[0] : 0);
+      const auto rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + roff), 0, qlen * 4, 0x00020000);
+      const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.delta + roff), 0, qlen * 4, 0x00020000);
+      const unsigned off = lane < 32 ? (unsigned)((tl * 32 + lane) * 4) : DMA_OOB;
+      float* dst = sLD + stage * 128;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (LDS_PTR(void))dst, 4, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (LDS_PTR(void))(dst + 64), 4, off, 0, 0, 0);
+    }
+    if (++cur_t == ntq) { cur_t = 0; ++cur_h; }
+  };
+
+  // ---- loop invariant LDS addresses (same tile image as the forward kernel)
+  const char* kp[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kp[c] = smem + i * 512 + (((4 * c + g) ^ ((i & 7) << 1)) << 4);
+  unsigned va[8];
+  {
+    const int tr_row = 4 * g + (i >> 2);
+    const unsigned lane_swz = (unsigned)(((tr_row & 7) << 1) ^ ((i & 3) >> 1));
+    const unsigned lane_off = lds_addr_of(smem) + (unsigned)(tr_row * 512 + ((i & 1) << 3));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) va[c] = lane_off + (((unsigned)(2 * c) ^ lane_swz) << 4);
+  }
+
+  const float c2 = p.scale * LOG2E;
+  f32x4 acc_dk[DF], acc_dv[DF];
+#pragma unroll
+  for (int d = 0; d < DF; ++d) { acc_dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  unsigned long long skipmask = 0, fastmask = 0;   // per query tile, the same for every head
+  auto step = [&](auto STC, int qt) {
+    constexpr int ST = decltype(STC)::value;
+    constexpr int QOFF = ST * 2 * T32_TILE, DOFF = QOFF + T32_TILE;
+    wait_vm0();
+    __syncthreads();
+    if (cur_h < h_first + hpg) issue(ST ^ 1);
+    if ((skipmask >> qt) & 1) return;      // no query of this tile sees this wave's keys
+    const bool fast = (fastmask >> qt) & 1;
+
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + QOFF + (kk >> 2) * 256);
+      const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + QOFF + 16 * 512 + (kk >> 2) * 256);
+      const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + DOFF + (kk >> 2) * 256);
+      const bf16x8 o1 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + DOFF + 16 * 512 + (kk >> 2) * 256);
+      s0 = mfma16(q0, kf[kk], s0);      // S[q][key]
+      s1 = mfma16(q1, kf[kk], s1);
+      d0 = mfma16(o0, vf[kk], d0);      // dP[q][key]
+      d1 = mfma16(o1, vf[kk], d1);
+    }
+    // lane: key column i, query rows 16 f + 4 g + r
+    const float* ld = sLD + ST * 128;
+    const f32x4 l0 = *reinterpret_cast<const f32x4*>(ld + 4 * g) * LOG2E, l1 = *reinterpret_cast<const f32x4*>(ld + 16 + 4 * g) * LOG2E;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(ld + 64 + 4 * g), x1 = *reinterpret_cast<const f32x4*>(ld + 80 + 4 * g);
+    if (fast) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(s0[r] * c2 - l0[r]);
+        s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2 - l1[r]);
+        d0[r] = s0[r] * (d0[r] - x0[r]) * p.scale;
+        d1[r] = s1[r] * (d1[r] - x1[r]) * p.scale;
+      }
+    } else {
+      const i32x4 qw0 = *reinterpret_cast<const i32x4*>(sWords + qt * 32 + 4 * g);
+      const i32x4 qw1 = *reinterpret_cast<const i32x4*>(sWords + qt * 32 + 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool a0 = ((qw0[r] >> 24) & kcls) != 0 && kidx <= (qw0[r] & 0xffffff);
+        const bool a1 = ((qw1[r] >> 24) & kcls) != 0 && kidx <= (qw1[r] & 0xffffff);
+        s0[r] = a0 ? __builtin_amdgcn_exp2f(s0[r] * c2 - l0[r]) : 0.f;
+        s1[r] = a1 ? __builtin_amdgcn_exp2f(s1[r] * c2 - l1[r]) : 0.f;
+        d0[r] = s0[r] * (d0[r] - x0[r]) * p.scale;
+        d1[r] = s1[r] * (d1[r] - x1[r]) * p.scale;
+      }
+    }
+    const bf16x8 pb = pack8(s0, s1), db = pack8(d0, d1);
+    // dV^T += dO^T P, dK^T += Q^T dS: raw transposing reads, double buffered in groups of 2 d-fragments x 2 tiles
+    bf16x4 tr[2][8];
+#define LAP_ISSUE_T(GRP, R)                                                               \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                         \
+    R[4 * j] = ds_read_tr_raw<DOFF + ((GRP) >> 2) * 256>(va[((GRP) & 3) * 2 + j]);        \
+    R[4 * j + 1] = ds_read_tr_raw<DOFF + ((GRP) >> 2) * 256 + 16 * 512>(va[((GRP) & 3) * 2 + j]); \
+    R[4 * j + 2] = ds_read_tr_raw<QOFF + ((GRP) >> 2) * 256>(va[((GRP) & 3) * 2 + j]);    \
+    R[4 * j + 3] = ds_read_tr_raw<QOFF + ((GRP) >> 2) * 256 + 16 * 512>(va[((GRP) & 3) * 2 + j]); \
+  }
+#define LAP_DKDV(GRP, R)                                                                  \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                         \
+    acc_dv[(GRP) * 2 + j] = mfma16(join8(R[4 * j], R[4 * j + 1]), pb, acc_dv[(GRP) * 2 + j]);      \
+    acc_dk[(GRP) * 2 + j] = mfma16(join8(R[4 * j + 2], R[4 * j + 3]), db, acc_dk[(GRP) * 2 + j]);  \
+  }
+    LAP_ISSUE_T(0, tr[0])
+    LAP_ISSUE_T(1, tr[1]) lds_wait8<8>(tr[0]); LAP_DKDV(0, tr[0])
+    LAP_ISSUE_T(2, tr[0]) lds_wait8<8>(tr[1]); LAP_DKDV(1, tr[1])
+    LAP_ISSUE_T(3, tr[1]) lds_wait8<8>(tr[0]); LAP_DKDV(2, tr[0])
+    LAP_ISSUE_T(4, tr[0]) lds_wait8<8>(tr[1]); LAP_DKDV(3, tr[1])
+    LAP_ISSUE_T(5, tr[1]) lds_wait8<8>(tr[0]); LAP_DKDV(4, tr[0])
+    LAP_ISSUE_T(6, tr[0]) lds_wait8<8>(tr[1]); LAP_DKDV(5, tr[1])
+    LAP_ISSUE_T(7, tr[1]) lds_wait8<8>(tr[0]); LAP_DKDV(6, tr[0])
+    lds_wait8<0>(tr[1]); LAP_DKDV(7, tr[1])
+#undef LAP_ISSUE_T
+#undef LAP_DKDV
+  };
+
+  if (items > 0) issue(0);
+  __syncthreads();   // query info table complete
+  {
+    i32x4 sm = {0, 0, 0, 0};
+    if (lane < ntq) sm = *reinterpret_cast<const i32x4*>(sSum + lane * 4);
+    bool f = sm[3] == 32;
+    int kor = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {   // lanes 0..15 hold the wave's 16 keys
+      const int c = __builtin_amdgcn_readlane(kcls, r), x = __builtin_amdgcn_readlane(kidx, r);
+      kor |= c;
+      f = f && (c & sm[0]) != 0 && x <= sm[2];
+    }
+    skipmask = __ballot((kor & sm[1]) == 0);
+    fastmask = __ballot(f);
+  }
+  for (int it = 0; it < items; it += 2) {
+    // the parity of the stage follows the item index; the query tile index is item % ntq
+    step(IC<0>{}, it % ntq);
+    if (it + 1 < items) step(IC<1>{}, (it + 1) % ntq);
+  }
+
+  if (!vk) return;
+  if (p.hsplit > 1) {
+    // f32 partial of this head group: packed [b][joint key][kv head][HD]
+    const long long n_all = (long long)p.B * Tk * p.NKV * HD;
+    const long long row = ((long long)b * Tk + (kseg ? p.klen[0] : 0) + mykey) * p.NKV + hk;
+    float* pk = p.part + (long long)hg * n_all + row * HD;
+    float* pv = pk + (long long)p.hsplit * n_all;
+#pragma unroll
+    for (int d = 0; d < DF; ++d) {
+      *reinterpret_cast<f32x4*>(pk + d * 16 + 4 * g) = acc_dk[d];
+      *reinterpret_cast<f32x4*>(pv + d * 16 + 4 * g) = acc_dv[d];
+    }
+    return;
+  }
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+    store4(p.dk[kseg] + koff + d * 16 + 4 * g, acc_dk[d], 1.0f);
+    store4(p.dv[kseg] + koff + d * 16 + 4 * g, acc_dv[d], 1.0f);
+  }
+}
