@@ -657,6 +657,19 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
   if (tile < -1 || tile > 8 || ksplit < 0) return LAP_ERR_ARG;
+  // Few output tiles but a very long contraction (LM-head dgrad: 1504 x 2048 over K = 257152; prefill down
+  // projection): the big tile with enough K splits to cover the chip beats the small tile walking all of K.
+  if (tile < 0 && ksplit == 0 && scratch != nullptr && K >= 16384 && !(flags & LAP_GEMM_PARTIALS)) {
+    const long long t5 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    if (t5 <= 128) {
+      long long sp = 256 / t5;
+      const long long cap = scratch_bytes / ((long long)M * N * 4);
+      if (sp > 8) sp = 8;
+      if (sp > (K + 63) / 64 / 16) sp = (K + 63) / 64 / 16;
+      if (sp > cap) sp = cap;
+      if (sp >= 2) { tile = 5; ksplit = (int)sp; }
+    }
+  }
   if (tile < 0) tile = pick_tile(M, N, K);
   // Tail split (256x256 kernel, automatic split only): the full rounds of 256 tiles run unsplit; only the tiles of
   // the last, poorly filled round are split along K so that they fill the chip for 1/sp of a round.

@@ -28,6 +28,7 @@ def bench_gemms():
     shapes = [
         ("qkv   fwd", "fwd", M, 2560, 2048), ("out   fwd", "fwd", M, 2048, 2048),
         ("gateup fwd", "fwd", M, 32768, 2048), ("down  fwd", "fwd", M, 2048, 16384),
+        ("lm head dgrad", "dgrad", 1504, 2048, 257152), ("prefill down", "fwd", 816, 2048, 16384),
         ("gateup dgrad", "dgrad", M, 2048, 32768), ("down  dgrad", "dgrad", M, 16384, 2048),
         ("gateup wgrad", "wgrad", M, 32768, 2048), ("down  wgrad", "wgrad", M, 2048, 16384),
         ("siglip fc1", "fwd", 16384, 4304, 1152), ("siglip qkv", "fwd", 16384, 3456, 1152),
@@ -45,7 +46,7 @@ def bench_gemms():
             dy = rnd(m, n); x = rnd(m, k); out = torch.empty(n, k, dtype=torch.float32, device=dev)
             fn = lambda: hip.linear_wgrad(dy, x, out)
         res = []
-        for tile in (5, 6, 8):
+        for tile in (5, 6, -1):
             if kind == "fwd":
                 fn = lambda: hip.linear_fwd(a, w, out, tile=tile)
             elif kind == "dgrad":
