@@ -220,6 +220,8 @@ int lap_ce_chunk_grad(const float* logits, int ldl, const int32_t* target, const
 /* ------------------------------------------------------------ optimizer --- */
 /* sumsq[0] += sum x^2 (f32 atomics; caller zeroes). */
 int lap_sumsq_f32(const float* x, long long n, float* sumsq, void* stream);
+/* Greedy decode step of sample_tokens (lap.py:719-724): out[r] = argmax_c x[r][c], lowest index among ties (jnp.argmax). */
+int lap_argmax_rows_f32(const float* x, int rows, int n, int ld, int* out, void* stream);
 /* Fused clip-by-global-norm + AdamW + EMA + bf16 weight refresh (train.py:363-396).
  * scalars (device f32[8]): [0]=sum of squared grads (global), [1]=lr, [2]=bias_corr1, [3]=bias_corr2,
  * [4]=ema_decay, [5]=ema_enabled (0/1).  clip = min(1, max_norm / (sqrt(s0)+1e-6)).

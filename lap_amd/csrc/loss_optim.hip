@@ -76,6 +76,34 @@ __global__ __launch_bounds__(256) void ce_grad_kernel(const float* __restrict__ 
   }
 }
 
+// Greedy token choice: index of the row maximum, lowest index among ties (jnp.argmax, lap.py:723).  One block per row.
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int ld, int n, int* __restrict__ out) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const float* row = x + (long long)blockIdx.x * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = threadIdx.x; c < n; c += 256) {
+    const float v = row[c];
+    if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sv[w] = best; si[w] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+    out[blockIdx.x] = bi;
+  }
+}
+
 // -------------------------------------------------------------------- optimizer
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
   __shared__ float red[4];
@@ -249,6 +277,12 @@ extern "C" int lap_ce_chunk_grad(const float* logits, int ldl, const int32_t* ta
   if (rows <= 0 || vc <= 0) return LAP_ERR_ARG;
   dim3 grid((vc + 1023) / 1024, rows);
   hipLaunchKernelGGL(ce_grad_kernel, grid, dim3(256), 0, S_, logits, ldl, target, m, l, w, (bf16*)dlogits, ldd, v0, vc);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_argmax_rows_f32(const float* x, int rows, int n, int ld, int* out, void* stream) {
+  if (rows <= 0 || n <= 0 || ld < n || !x || !out) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, S_, x, ld, n, out);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

@@ -103,6 +103,7 @@ SIGNATURES: dict[str, list] = {
     "lap_ce_chunk_update": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_ce_chunk_grad": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lap_sumsq_f32": [_vp, _ll, _vp, _vp],
+    "lap_argmax_rows_f32": [_vp, _i, _i, _i, _vp, _vp],
     "lap_adamw_ema": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _vp],
     "lap_fm_mix": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "lap_posemb_sincos": [_vp, _vp, _i, _i, _f, _f, _vp],
@@ -209,6 +210,15 @@ def linear_wgrad(dy, x, out, *, accum=False, ksplit=0, tile=-1):
     Kin = x.shape[1]
     return gemm(dy, x, out, M=Nout, N=Kin, K=Mrows, lda=dy.stride(0), ldb=x.stride(0), ldc=out.stride(0), a_kc=False,
                 b_kc=False, accum=accum, ksplit=ksplit, tile=tile)
+
+
+def argmax_rows(x, out=None):
+    """x f32 [rows, n] (row stride x.stride(0)) -> int32 [rows], lowest index among ties."""
+    _req(x, torch.float32, "x")
+    if out is None:
+        out = torch.empty((x.shape[0],), dtype=torch.int32, device=x.device)
+    call("lap_argmax_rows_f32", _p(x), x.shape[0], x.shape[1], x.stride(0), _p(out))
+    return out
 
 
 def gemm_f32(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, alpha=1.0, accum=False):

@@ -614,5 +614,97 @@ class LAP:
             hip.axpy_f32(x_t, v_t, dt)
         return x_t
 
-    def sample_tokens(self, *a, **k):
-        raise NotImplementedError("AR token sampling (lap.py:678-766) is a 'next' row of SURVEY.md §8(f)")
+    EOS_TOKEN = 1   # PaliGemma <eos> (lap.py: self.EOS_TOKEN)
+
+    def _vlm_decode_step(self, token, pos, step, cache, gen, qinfo_d, kinfo_prefix, B, Pn):
+        """One expert-0 decode step (lap.py:734-752): embed the sampled token, run the 18 VLM layers on that single row
+        per sample with keys = [prefilled prefix cache | generated tokens incl. this one], return f32 logits [B, V].
+        The reference appends into a fixed-size cache by index (gemma.py:597-605); here the generated keys are a second
+        key segment that grows by one row per step."""
+        v = self.v
+        NH, HD, KV, Dv = v.num_heads, v.head_dim, v.num_kv_heads, v.width
+        dev = self.device
+        x = torch.empty((B, Dv), dtype=torch.bfloat16, device=dev)
+        rows, lo, hi = self.ps.embed_rows()
+        hip.embed_gather(rows, token.view(B, 1).contiguous(), x, B, 1, Dv, 1, 0, math.sqrt(Dv), lo, hi)
+        kinfo = torch.cat([kinfo_prefix, torch.full((B, step + 1), 1 << 24, dtype=torch.int32, device=dev)], 1).contiguous()
+        for l in range(v.depth):
+            p = f"llm/{l}/"
+            h, _ = hip.rmsnorm_fwd(x, scale=self.F(p + "n_attn"), save_rstd=False)
+            qkv = hip.linear_fwd(h, self.W(p + "wqkv0"))
+            q, k, vv = hip.rope_split_fwd(qkv, pos, B, 1, 1, 0, NH, HD, HD ** -0.5)
+            gk, gv = gen[l]
+            gk = k.view(B, 1, -1) if gk is None else torch.cat([gk, k.view(B, 1, -1)], 1)
+            gv = vv.view(B, 1, -1) if gv is None else torch.cat([gv, vv.view(B, 1, -1)], 1)
+            gen[l] = (gk, gv)
+            ck, cv = cache[l]
+            o, _ = hip.attention_fwd([None, q], [ck, gk.view(B * (step + 1), -1)], [cv, gv.view(B * (step + 1), -1)], [0, 1],
+                                     [Pn, step + 1], B, NH, KV, HD, qinfo_d, kinfo, need_lse=False)
+            xa = hip.linear_fwd(o[1], self.W(p + "wo0"), residual=x)
+            hf, _ = hip.rmsnorm_fwd(xa, scale=self.F(p + "n_ffw"), save_rstd=False)
+            act = hip.geglu_fwd(hip.linear_fwd(hf, self.W(p + "wgu0")))
+            x = hip.linear_fwd(act, self.W(p + "wd0"), residual=xa)
+        return self._lm_logits(x)
+
+    def _lm_logits(self, rows):
+        """final norm + Embedder.decode (gemma.py:153-154, 525-527): f32 logits [R, V]."""
+        pl, _ = hip.rmsnorm_fwd(rows, scale=self.F("llm/final_norm"), save_rstd=False)
+        V, Dv = self.config.vocab_size, self.v.width
+        lg = torch.empty((rows.shape[0], V), dtype=torch.float32, device=self.device)
+        hip.gemm(pl, self.W("llm/embed"), lg, M=rows.shape[0], N=V, K=Dv, lda=Dv, ldb=Dv, ldc=V)
+        return lg
+
+    def sample_tokens(self, rng, observation, *, max_decoding_steps: int = 390, temperature: float = 0.0, collect=None):
+        """lap.py:678-766 (LAP_AR serving mode): VLM-only prefill, then single-token decode until every sample has emitted
+        EOS or `max_decoding_steps` tokens; returns int32 [B, max_decoding_steps] (zeros after the stop).
+
+        The reference right-aligns the prefix (`left_to_right_align`) so that a fixed-size cache can be addressed by
+        `prefix_start`; rolling changes neither the attention pattern nor `cumsum(mask) - 1` positions of valid tokens,
+        so the engine keeps the tokens in place and expresses the decode mask `[prefix_start, prefill_size + step]` in
+        un-rolled coordinates: prefix keys `seqlen - prefill_len <= j < seqlen` (seqlen = last valid index + 1) plus every
+        generated key.  Known deviation: with a hole inside the prefix (a masked-out image followed by valid tokens) the
+        reference's range mask covers the hole's tokens, whose prefill activations above layer 0 are softmax outputs of
+        fully masked rows (uniform averages, "never consumed" elsewhere); the engine's attention writes zeros for such
+        rows, so decode logits differ from the reference in that case only (prefill logits still agree; tested).
+        temperature > 0 samples with the Gumbel-max trick from a torch generator seeded by `rng` (the JAX PRNG stream of
+        `jax.random.categorical` cannot be reproduced)."""
+        cfg = self.config
+        dev = self.device
+        if self.comm.world_size != 1:
+            raise NotImplementedError("sample_tokens is a serving path: replicas only (SURVEY.md §8e)")
+        self.comm.wait_unit("small")
+        obs = preprocess_observation(observation, train=False, image_keys=cfg.image_keys, image_resolution=cfg.image_resolution)
+        B = obs.tokenized_prompt.shape[0]
+        x0, Pn, _ = self._embed_prefix(obs, False)
+        qinfo_p, kinfo_p, ppos = self._serve_infos(obs, 1)[:3]
+        prefix_mask, _ = self._prefix_masks(obs)
+        ar = torch.arange(Pn, device=dev)
+        seqlen = (prefix_mask.to(torch.int64) * ar).max(-1).values + 1          # left_to_right_align's roll amount
+        plen = prefix_mask.sum(-1)                                               # prefill_len
+        in_range = (ar[None] >= (seqlen - plen)[:, None]) & (ar[None] < seqlen[:, None])
+        kinfo_prefix = (in_range.to(torch.int32) << 24).contiguous()
+        qinfo_d = torch.full((B, 1), (1 << 24) | 0xFFFFFF, dtype=torch.int32, device=dev)
+        cache = []
+        xf0, _, _ = self._llm_fwd(x0, None, None, ppos, qinfo_p, kinfo_p, B, Pn, 0, False, cache_out=cache)
+        last = (torch.arange(B, device=dev) * Pn + seqlen - 1)
+        logits = self._lm_logits(xf0.index_select(0, last).contiguous())        # decodes the first token (lap.py:716)
+        out = torch.zeros((B, max_decoding_steps), dtype=torch.int32, device=dev)
+        eos = torch.zeros((B,), dtype=torch.bool, device=dev)
+        gen = [(None, None)] * self.v.depth
+        g = _gen(rng, dev) if temperature > 0.0 else None
+        step = 0
+        while step < max_decoding_steps:
+            if temperature > 0.0:
+                u = torch.rand(logits.shape, generator=g, device=dev, dtype=torch.float32).clamp_(1e-20, 1.0)
+                logits = logits / temperature - torch.log(-torch.log(u))
+            token = hip.argmax_rows(logits)
+            if collect is not None:
+                collect[f"logit/{step}"] = logits.clone()
+            out[:, step] = token
+            eos |= token == self.EOS_TOKEN
+            step += 1
+            if step >= max_decoding_steps or bool(eos.all()):   # lap.py:754-756 loop condition (the unused last decode is skipped)
+                break
+            pos = (plen + (step - 1)).to(torch.int32).view(B, 1).contiguous()
+            logits = self._vlm_decode_step(token, pos, step - 1, cache, gen, qinfo_d, kinfo_prefix, B, Pn)
+        return out

@@ -92,3 +92,38 @@ class Policy:
             a = self.model.sample_actions(0, o, num_steps=self.num_steps, noise=noise)
         actions = a[0].cpu().numpy()  # device sync
         return {"actions": actions, "policy_timing": {"infer_ms": (time.perf_counter() - t0) * 1e3}}
+
+
+class ARPolicy:
+    """policies/policy_adapter.py:13-61: the autoregressive serving mode (LAP_AR).  `infer` returns the generated token
+    ids of `LAP.sample_tokens` (+ the model-level state) instead of an action chunk; decoding them to text / actions is
+    the job of the output transforms, which take exactly this dict."""
+
+    def __init__(self, base: Policy, *, sample_kwargs: dict | None = None):
+        if not hasattr(base.model, "sample_tokens"):
+            raise AssertionError("Model must have a sample_tokens method")
+        self._base = base
+        self._sample_kwargs = dict(sample_kwargs or {})
+        self._calls = 0
+
+    def __getattr__(self, name):
+        return getattr(self._base, name)
+
+    def infer_reasoning(self, obs: dict) -> dict:
+        t0 = time.perf_counter()
+        dev = self._base.model.device
+        raw_state = np.array(obs["state"], copy=True) if obs.get("state") is not None else None
+        batched = {k: ({kk: np.asarray(vv)[None] for kk, vv in v.items()} if isinstance(v, dict) else np.asarray(v)[None])
+                   for k, v in obs.items() if v is not None}
+        o = CoTObservation.from_dict(batched, device=dev)
+        self._calls += 1
+        tokens = self._base.model.sample_tokens(self._calls, o, **self._sample_kwargs)
+        out = {"state": batched.get("state"), "tokens": tokens.cpu().numpy(), "raw_state": raw_state}
+        out["policy_timing"] = {"infer_ms": (time.perf_counter() - t0) * 1e3}
+        return out
+
+    def infer(self, obs: dict, *, noise=None) -> dict:
+        return self.infer_reasoning(obs)
+
+    def vqa_infer(self, obs: dict) -> dict:
+        return self.infer_reasoning(obs)

@@ -528,6 +528,59 @@ def sample_actions(P, cfg: OracleCfg, obs, noise, num_steps: int = 10, collect=N
     return x_t
 
 
+def left_to_right_align(x, input_mask, attn_mask):
+    """[UPSTREAM-RECALL] openpi pi0_fast.left_to_right_align (vmapped per sample): roll every sequence so that the
+    span up to its last valid token ends at the right edge; padding ends up on the left."""
+    xs, ms, as_ = [], [], []
+    T = input_mask.shape[1]
+    for b in range(x.shape[0]):
+        seqlen = int((input_mask[b].long() * torch.arange(T)).max().item()) + 1
+        xs.append(torch.roll(x[b], -seqlen, 0))
+        ms.append(torch.roll(input_mask[b], -seqlen, 0))
+        as_.append(torch.roll(attn_mask[b], (-seqlen, -seqlen), (0, 1)))
+    return torch.stack(xs), torch.stack(ms), torch.stack(as_)
+
+
+EOS_TOKEN = 1  # lap.py: `self.EOS_TOKEN` (PaliGemma tokenizer <eos>)
+
+
+def sample_tokens(P, cfg: OracleCfg, obs, max_decoding_steps: int = 390, temperature: float = 0.0, collect=None,
+                  eos_token: int = EOS_TOKEN):
+    """lap.py:678-766: right-aligned VLM prefill -> KV cache -> greedy single-token decode with expert 0 only until every
+    sample has produced EOS or `max_decoding_steps` tokens.  temperature > 0 (categorical sampling with the JAX PRNG)
+    is not restated: it cannot be reproduced bit for bit without that generator."""
+    if temperature > 0.0:
+        raise NotImplementedError("temperature sampling depends on the JAX PRNG stream")
+    table = P["PaliGemma/llm/embedder/input_embedding"]
+    r = _mk_round(cfg)
+    prefix_tokens, prefix_mask, prefix_ar = embed_prefix(P, cfg, obs)
+    prefix_attn = make_attn_mask(prefix_mask, prefix_ar)
+    prefix_tokens, prefix_mask, prefix_attn = left_to_right_align(prefix_tokens, prefix_mask, prefix_attn)
+    B, prefill_size = prefix_mask.shape
+    prefill_len = prefix_mask.long().sum(-1)
+    prefix_start = prefill_size - prefill_len
+    positions = torch.cumsum(prefix_mask.long(), -1) - 1
+    (pre, _), cache = gemma_forward(P, cfg, [prefix_tokens, None], positions, prefix_attn, [None, None])
+    last_logit = pre[:, -1:] @ table.t()                      # Embedder.decode (gemma.py:153-154), f32
+    out = torch.zeros(B, max_decoding_steps, dtype=torch.int32)
+    eos = torch.zeros(B, dtype=torch.bool)
+    step = 0
+    while (not bool(eos.all())) and step < max_decoding_steps:
+        token = torch.argmax(last_logit, dim=-1).to(torch.int32)          # [B, 1]
+        if collect is not None:
+            collect[f"logit/{step}"] = last_logit[:, 0]
+        out[:, step] = token[:, 0]
+        eos = eos | (token[:, 0] == eos_token)
+        emb = r(table[token.long()] * math.sqrt(cfg.vlm.width))           # llm(token, method="embed")
+        pos = prefill_len[:, None] + step
+        ar = torch.arange(prefill_size + step + 1)                        # cached keys + the fresh one
+        mask = (ar[None, None, :] >= prefix_start[:, None, None]) & (ar[None, None, :] < prefill_size + step + 1)
+        (pre, _), cache = gemma_forward(P, cfg, [emb, None], pos, mask, [None, None], kv_cache=cache)
+        last_logit = pre @ table.t()
+        step += 1
+    return out
+
+
 # --------------------------------------------------------------------------- optimizer / schedules
 def adamw_step(p, g, m, v, step, lr, b1=0.9, b2=0.95, eps=1e-8, wd=1e-4, clip_scale=1.0):
     """optax.chain(clip_by_global_norm, adamw) for one tensor, step counted from 1
