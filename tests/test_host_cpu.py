@@ -93,3 +93,37 @@ def test_info_words_reproduce_reference_masks_and_positions(ragged):
     full = torch.cat([pm[:, None, :].expand(3, S, -1), torch.ones(3, S, S, dtype=torch.bool)], -1)
     assert torch.equal(_mask_from_info(qs, kall), full)
     assert torch.equal(pall[:, -S:].long(), pm.long().sum(-1)[:, None] + torch.arange(S)[None])
+
+
+@pytest.mark.parametrize("hole", [False, True])
+def test_sample_tokens_right_alignment_is_a_relabelling(hole):
+    """The engine's sample_tokens keeps the prefix in place; the reference rolls it to the right edge (lap.py:696-704).
+    On the oracle: prefill logits and the first decode step computed WITHOUT the roll, with the decode range mask
+    `[prefix_start, prefill_size + step]` rewritten as `seqlen - prefill_len <= j < seqlen`, equal the literal
+    restatement - also with a hole in the prefix (masked image), where both formulations attend the same tokens."""
+    import math
+
+    cfg = debug_model_cfg()
+    oc = oracle_cfg(cfg)
+    P = O.init_params(oc, seed=13)
+    obs, _, _, _ = make_inputs(cfg, B=3, ragged=True)
+    so = {k: v for k, v in obs.items() if k != "tokenized_langact_mask"}
+    if not hole:
+        so["image_masks"] = {k: torch.ones_like(m) for k, m in so["image_masks"].items()}
+    c = {}
+    O.sample_tokens(P, oc, so, max_decoding_steps=2, collect=c)
+    table = P["PaliGemma/llm/embedder/input_embedding"]
+    pt, pm, par = O.embed_prefix(P, oc, so)
+    B, size = pm.shape
+    ar = torch.arange(size)
+    seqlen = (pm.long() * ar).max(-1).values + 1
+    plen = pm.long().sum(-1)
+    assert hole == bool((seqlen != plen).any())
+    (pre, _), cache = O.gemma_forward(P, oc, [pt, None], torch.cumsum(pm.long(), -1) - 1, O.make_attn_mask(pm, par), [None, None])
+    lg0 = pre[torch.arange(B), seqlen - 1] @ table.t()
+    assert (lg0 - c["logit/0"]).abs().max() < 1e-4
+    emb = table[lg0.argmax(-1)][:, None] * math.sqrt(oc.vlm.width)
+    in_range = (ar[None] >= (seqlen - plen)[:, None]) & (ar[None] < seqlen[:, None])
+    mask = torch.cat([in_range, torch.ones(B, 1, dtype=torch.bool)], 1)[:, None, :]
+    (pre1, _), _ = O.gemma_forward(P, oc, [emb, None], plen[:, None], mask, [None, None], kv_cache=cache)
+    assert ((pre1 @ table.t())[:, 0] - c["logit/1"]).abs().max() < 1e-4
