@@ -258,8 +258,13 @@ class ParamStore:
         for u in self.units:
             buf = src[u.name]
             if self.sharded(u):
-                full = torch.empty(self.padded(u), dtype=torch.float32, device=self.device)
-                dist.all_gather_into_tensor(full, buf)
+                if dist.get_backend() == "nccl":
+                    full = torch.empty(self.padded(u), dtype=torch.float32, device=self.device)
+                    dist.all_gather_into_tensor(full, buf)
+                else:   # gloo (CPU tests) has no fused tensor collective
+                    parts = [torch.empty_like(buf) for _ in range(self.world_size)]
+                    dist.all_gather(parts, buf.contiguous())
+                    full = torch.cat(parts)
                 buf = full
             for t in u.tensors:
                 out[t.name] = buf[t.offset:t.offset + t.numel].view(t.shape).cpu()

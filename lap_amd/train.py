@@ -100,3 +100,107 @@ class TrainingStepRunner:
             if _is_kernel_param(name, spec.shape) and not ps.sharded(ps.tensor_unit[name]):
                 hip.sumsq_f32(ps.f32(name).reshape(-1), acc)
         return acc.sqrt().view(())
+
+
+# ====================================================================================== training entry point
+class SyntheticDataLoader:
+    """Stand-in for datasets/data_loader.py: seeded batches of the benchmark shape (§8d) with
+    the protocol the train loop and the checkpoint code use (`__iter__`, `get_state`, `set_state`).  Rank r of N draws
+    batch `N * i + r`, so a resumed run continues with the batches the interrupted run would have seen."""
+
+    def __init__(self, cfg, per_rank_batch: int, device, *, seed: int = 0, rank: int = 0, world_size: int = 1):
+        self.cfg, self.B, self.device = cfg, per_rank_batch, device
+        self.seed, self.rank, self.world = seed, rank, world_size
+        self.index = 0
+
+    def get_state(self) -> dict:
+        return {"index": self.index, "seed": self.seed}
+
+    def set_state(self, s: dict):
+        self.index, self.seed = int(s["index"]), int(s["seed"])
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        from lap_amd.observation import CoTObservation
+
+        cfg, B, dev = self.cfg, self.B, self.device
+        g = torch.Generator(device="cpu").manual_seed(self.seed * 1_000_003 + self.index * self.world + self.rank)
+        self.index += 1
+        L, H = cfg.max_token_len, cfg.image_size
+        la = torch.zeros(B, L, dtype=torch.bool)
+        la[:, L - min(16, L // 2):] = True
+        obs = CoTObservation(
+            images={k: (torch.rand(B, H, H, 3, generator=g) * 2 - 1).to(dev) for k in cfg.image_keys},
+            image_masks={k: torch.ones(B, dtype=torch.bool, device=dev) for k in cfg.image_keys},
+            state=(torch.rand(B, cfg.action_dim, generator=g) * 2 - 1).to(dev),
+            tokenized_prompt=torch.randint(0, cfg.vocab_size, (B, L), generator=g, dtype=torch.int32).to(dev),
+            tokenized_prompt_mask=torch.ones(B, L, dtype=torch.bool, device=dev),
+            tokenized_langact_mask=la.to(dev), token_loss_mask=torch.ones(B, L, dtype=torch.bool, device=dev),
+            sample_mask=torch.ones(B, dtype=torch.bool, device=dev))
+        return obs, torch.randn(B, cfg.action_horizon, cfg.action_dim, generator=g).to(dev)
+
+
+def main(config: TrainConfig, *, data_loader=None, device: str | None = None, log=print) -> TrainState:
+    """scripts/train.py:422-640 (main): distributed init, train state (+ resume), the step loop with interval logging
+    and checkpointing.  One process per GPU; under `torch.distributed.run` the parameters / optimizer / EMA are ZeRO-3
+    sharded over all ranks and `batch_size` is the GLOBAL batch (config.py:783)."""
+    import os
+    import time as _time
+
+    import torch.distributed as dist
+
+    from lap_amd import checkpoints as ck
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if device is None:
+        device = f"cuda:{local % max(torch.cuda.device_count(), 1)}"
+    if torch.device(device).type == "cuda":
+        torch.cuda.set_device(torch.device(device))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if torch.device(device).type == "cuda" else "gloo", rank=rank, world_size=world)
+    if config.batch_size % world:
+        raise ValueError(f"batch_size {config.batch_size} must be divisible by the number of ranks {world}")
+    mngr, resuming = ck.initialize_checkpoint_dir(config.checkpoint_dir, keep_period=config.keep_period,
+                                                  overwrite=config.overwrite and rank == 0, resume=config.resume)
+    if world > 1:
+        dist.barrier()
+    state = init_train_state(config, device=device, world_size=world, rank=rank, use_fsdp=world > 1)
+    if data_loader is None:
+        data_loader = SyntheticDataLoader(config.model, config.batch_size // world, device, seed=config.seed, rank=rank, world_size=world)
+    if resuming:
+        state = ck.restore_state(mngr, state, data_loader)
+        log(f"resumed from step {state.step} ({mngr.directory})")
+    runner = TrainingStepRunner(config)
+    it = iter(data_loader)
+    infos, t_last, start = [], _time.perf_counter(), state.step
+    for step in range(start, config.num_train_steps):
+        state, info = runner(config.seed, state, next(it), step)
+        infos.append(info)
+        last = step == config.num_train_steps - 1
+        if (step + 1) % config.log_interval == 0 or last:   # mean of the interval's step infos (metrics_logging.py:181-237)
+            keys = [k for k, v in infos[0].items() if torch.is_tensor(v) and v.numel() == 1]
+            mean = {k: float(torch.stack([i[k].float().reshape(()) for i in infos]).mean()) for k in keys}
+            if world > 1:
+                t = torch.tensor([mean[k] for k in keys], device=device)
+                dist.all_reduce(t)
+                mean = {k: float(v) / world for k, v in zip(keys, t)}
+            mean["param_norm"] = float(runner.param_norm(state)) if world == 1 else float("nan")
+            dt = _time.perf_counter() - t_last
+            if rank == 0:
+                log(f"step {step + 1}: " + ", ".join(f"{k}={v:.4f}" for k, v in mean.items()) +
+                    f" | {len(infos) * config.batch_size / dt:.1f} samples/s")
+            infos, t_last = [], _time.perf_counter()
+        if ((step + 1) % config.save_interval == 0 and step + 1 > start) or last:
+            ck.save_state(mngr, state, data_loader, step + 1)
+    return state
+
+
+if __name__ == "__main__":
+    from lap_amd.config import cli
+
+    main(cli())

@@ -87,6 +87,107 @@ def test_fsdp_world2_gloo():
     assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
 
 
+def _ckpt_worker(rank, world, port, ret, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = _checkpoint_round_trip(tmp, world, rank)
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+class _Stub:   # what the checkpoint code needs from a LAP model: the store and the pipeline
+    def __init__(self, ps, comm):
+        self.ps, self.comm = ps, comm
+
+
+def _checkpoint_round_trip(tmp, world, rank):
+    import lap_amd.checkpoints as ck
+    from lap_amd.train import TrainState
+
+    cfg = get_config("debug").model
+
+    def fresh(seed):
+        ps = ParamStore(cfg, "cpu", world_size=world, rank=rank)
+        ps.load_reference_tree(O.init_params(oracle_cfg(cfg), seed=seed))
+        g = torch.Generator().manual_seed(100 + seed)
+        for u in ps.units:   # distinct optimizer / EMA contents, identical on every rank before slicing
+            a, b = ps.shard_range(u)
+            for buf in (ps.m, ps.v, ps.ema):
+                full = torch.zeros(ps.padded(u))   # alignment padding between / after tensors carries no state
+                for t in u.tensors:
+                    full[t.offset:t.offset + t.numel] = torch.randn(t.numel, generator=g)
+                buf[u.name].copy_(full[a:b])
+        comm = None
+        if world > 1:
+            from lap_amd.fsdp import FsdpComm
+
+            comm = FsdpComm(ps)
+        return TrainState(step=0, model=_Stub(ps, comm), ema_decay=0.999)
+
+    class Loader:
+        def __init__(self): self.pos = 0
+        def get_state(self): return {"pos": self.pos}
+        def set_state(self, s): self.pos = s["pos"]
+
+    mngr, resuming = ck.initialize_checkpoint_dir(tmp, keep_period=4, overwrite=False, resume=True)
+    assert not resuming                      # exists (or was just created) but holds no checkpoint
+    a = fresh(1)
+    a = TrainState(step=3, model=a.model, ema_decay=0.999)
+    ld = Loader(); ld.pos = 17
+    for step in (2, 3, 4, 5):
+        ck.save_state(mngr, TrainState(step=step, model=a.model, ema_decay=0.999), ld, step, norm_stats={"state": {"mean": [0.0], "std": [1.0]}})
+    if world > 1:
+        dist.barrier()
+    assert mngr.all_steps() == (4, 5)        # max_to_keep=1 + multiples of keep_period
+    ck.save_state(mngr, a, ld, 3, preserve_checkpoint=True)
+    assert (mngr.directory / "additional" / "3" / "_COMMITTED").exists() or rank != 0
+    _, resuming = ck.initialize_checkpoint_dir(tmp, keep_period=4, overwrite=False, resume=True)
+    assert resuming
+    b = fresh(2)
+    ld2 = Loader()
+    b = ck.restore_state(mngr, b, ld2)
+    assert b.step == 5 and ld2.pos == 17
+    pa, pb = a.model.ps, b.model.ps
+    for u in pa.units:
+        for name in ("master", "m", "v", "ema"):
+            assert torch.equal(getattr(pa, name)[u.name], getattr(pb, name)[u.name]), (u.name, name)
+        if u.big:
+            assert torch.equal(pb.full16[u.name], pa.full16[u.name] if world == 1 else pb.full16[u.name])
+    # the params item is the EMA tree in the reference's names, loadable for any world size
+    tree = ck.restore_params(mngr)
+    ref = ParamStore(cfg, "cpu", world_size=1, rank=0)
+    ref.load_reference_tree(tree)
+    for u in pa.units:
+        x, y = pa.shard_range(u)
+        assert torch.equal(ref.master[u.name][x:y], pa.ema[u.name]), u.name
+    assert ck.load_norm_stats(mngr.step_dir(5) / "assets")["state"]["std"] == [1.0]
+    with pytest.raises(FileExistsError):
+        ck.initialize_checkpoint_dir(tmp, keep_period=None, overwrite=False, resume=False)
+    return "ok"
+
+
+def test_checkpoint_round_trip_single(tmp_path):
+    assert _checkpoint_round_trip(tmp_path / "ck", 1, 0) == "ok"
+
+
+def test_checkpoint_round_trip_world2_gloo(tmp_path):
+    world = 2
+    port = 30100 + os.getpid() % 500
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    procs = [mp.get_context("spawn").Process(target=_ckpt_worker, args=(r, world, port, ret, str(tmp_path / "ck"))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
+
+
 def test_config_surface():
     """training/config.py registry + EMA / LR schedule semantics."""
     lib = get_config("lap_libero")
