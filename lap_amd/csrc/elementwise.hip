@@ -23,6 +23,8 @@ inline dim3 flat_grid(long long n, int per_block = 256) { return dim3((unsigned)
 // ------------------------------------------------------------------------ RoPE
 // gemma.py:548-564: radians = pos / 10000^(2i/HD); [x1 c - x2 s, x2 c + x1 s] in f32 -> bf16;
 // gemma.py:216: q *= HD^-0.5 as a bf16 multiply.
+// One thread per (row, 8-wide frequency chunk): sin / cos are evaluated once and reused for the NH query heads and the
+// key head of the row (they only depend on the position and the frequency index), then the value head is copied.
 template <bool BWD>
 __global__ __launch_bounds__(256) void rope_split_kernel(const bf16* __restrict__ a0, const bf16* __restrict__ a1,
                                                          const bf16* __restrict__ a2, const int32_t* __restrict__ pos,
@@ -30,60 +32,60 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const bf16* __restrict_
                                                          bf16* __restrict__ o2, int rows, int T_seg, int T_total,
                                                          int seg_off, int NH, int HD, float q_scale) {
   // FWD: a0 = qkv, outputs o0 = q, o1 = k, o2 = v.   BWD: a0 = dq, a1 = dk, a2 = dv, output o0 = dqkv.
-  const int cph = HD / 16;               // 8-wide frequency chunks per head
-  const int tpr = (NH + 2) * cph;        // threads per row
+  const int cph = HD / 16;               // 8-wide frequency chunks per head = threads per row
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long long)rows * tpr) return;
-  const int row = (int)(gid / tpr);
-  const int rem = (int)(gid % tpr);
-  const int h = rem / cph, c = rem % cph;
+  if (gid >= (long long)rows * cph) return;
+  const int row = (int)(gid / cph);
+  const int c = (int)(gid % cph);
   const int b = row / T_seg, t = row % T_seg;
   const int W = (NH + 2) * HD;
   const int half = HD / 2;
-
-  float x1[8], x2[8];
-  const bf16* src;
-  if (!BWD) src = a0 + (long long)row * W + h * HD;
-  else if (h < NH) src = a0 + (long long)row * NH * HD + h * HD;
-  else if (h == NH) src = a1 + (long long)row * HD;
-  else src = a2 + (long long)row * HD;
-  ld8(src + c * 8, x1);
-  ld8(src + half + c * 8, x2);
-
-  float y1[8], y2[8];
-  if (h <= NH) {
-    const float p = (float)pos[(long long)b * T_total + seg_off + t];
+  const float p = (float)pos[(long long)b * T_total + seg_off + t];
+  float sn[8], cs[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int i = c * 8 + e;
-      const float fe = (2.0f / (float)HD) * (float)i;
-      const float ts = powf(10000.0f, fe);
-      const float rad = p / ts;
-      float sn, cs;
-      sincosf(rad, &sn, &cs);
-      if (!BWD) {
-        float r1 = bf2f(f2bf(x1[e] * cs - x2[e] * sn));
-        float r2 = bf2f(f2bf(x2[e] * cs + x1[e] * sn));
-        if (h < NH) { r1 *= q_scale; r2 *= q_scale; }
-        y1[e] = r1; y2[e] = r2;
-      } else {
-        float d1 = x1[e], d2 = x2[e];
-        if (h < NH) { d1 *= q_scale; d2 *= q_scale; }
-        y1[e] = d1 * cs + d2 * sn;
-        y2[e] = d2 * cs - d1 * sn;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { y1[e] = x1[e]; y2[e] = x2[e]; }
+  for (int e = 0; e < 8; ++e) {
+    const int i = c * 8 + e;
+    const float fe = (2.0f / (float)HD) * (float)i;
+    const float ts = powf(10000.0f, fe);
+    sincosf(p / ts, &sn[e], &cs[e]);
   }
-  bf16* dst;
-  if (BWD) dst = o0 + (long long)row * W + h * HD;
-  else if (h < NH) dst = o0 + (long long)row * NH * HD + h * HD;
-  else if (h == NH) dst = o1 + (long long)row * HD;
-  else dst = o2 + (long long)row * HD;
-  st8(dst + c * 8, y1);
-  st8(dst + half + c * 8, y2);
+#pragma unroll 2
+  for (int h = 0; h < NH + 2; ++h) {
+    const bf16* src;
+    if (!BWD) src = a0 + (long long)row * W + h * HD;
+    else if (h < NH) src = a0 + (long long)row * NH * HD + h * HD;
+    else if (h == NH) src = a1 + (long long)row * HD;
+    else src = a2 + (long long)row * HD;
+    float x1[8], x2[8], y1[8], y2[8];
+    ld8(src + c * 8, x1);
+    ld8(src + half + c * 8, x2);
+    if (h <= NH) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (!BWD) {
+          float r1 = bf2f(f2bf(x1[e] * cs[e] - x2[e] * sn[e]));
+          float r2 = bf2f(f2bf(x2[e] * cs[e] + x1[e] * sn[e]));
+          if (h < NH) { r1 *= q_scale; r2 *= q_scale; }
+          y1[e] = r1; y2[e] = r2;
+        } else {
+          float d1 = x1[e], d2 = x2[e];
+          if (h < NH) { d1 *= q_scale; d2 *= q_scale; }
+          y1[e] = d1 * cs[e] + d2 * sn[e];
+          y2[e] = d2 * cs[e] - d1 * sn[e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { y1[e] = x1[e]; y2[e] = x2[e]; }
+    }
+    bf16* dst;
+    if (BWD) dst = o0 + (long long)row * W + h * HD;
+    else if (h < NH) dst = o0 + (long long)row * NH * HD + h * HD;
+    else if (h == NH) dst = o1 + (long long)row * HD;
+    else dst = o2 + (long long)row * HD;
+    st8(dst + c * 8, y1);
+    st8(dst + half + c * 8, y2);
+  }
 }
 
 // ----------------------------------------------------------------------- GeGLU
@@ -450,7 +452,7 @@ extern "C" int lap_abi_version(void) { return LAP_ABI_VERSION; }
 extern "C" int lap_rope_split_fwd(const void* qkv, const int32_t* pos, void* q, void* k, void* v, int B, int T_seg,
                                   int T_total, int seg_off, int NH, int HD, float q_scale, void* stream) {
   if (B <= 0 || T_seg <= 0 || (HD & 15) || NH <= 0) return LAP_ERR_ARG;
-  const long long n = (long long)B * T_seg * (NH + 2) * (HD / 16);
+  const long long n = (long long)B * T_seg * (HD / 16);
   hipLaunchKernelGGL(rope_split_kernel<false>, flat_grid(n), dim3(256), 0, S_, (const bf16*)qkv, nullptr, nullptr, pos,
                      (bf16*)q, (bf16*)k, (bf16*)v, B * T_seg, T_seg, T_total, seg_off, NH, HD, q_scale);
   LAP_CHECK_LAUNCH();
@@ -459,7 +461,7 @@ extern "C" int lap_rope_split_fwd(const void* qkv, const int32_t* pos, void* q, 
 extern "C" int lap_rope_split_bwd(const void* dq, const void* dk, const void* dv, const int32_t* pos, void* dqkv, int B,
                                   int T_seg, int T_total, int seg_off, int NH, int HD, float q_scale, void* stream) {
   if (B <= 0 || T_seg <= 0 || (HD & 15) || NH <= 0) return LAP_ERR_ARG;
-  const long long n = (long long)B * T_seg * (NH + 2) * (HD / 16);
+  const long long n = (long long)B * T_seg * (HD / 16);
   hipLaunchKernelGGL(rope_split_kernel<true>, flat_grid(n), dim3(256), 0, S_, (const bf16*)dq, (const bf16*)dk,
                      (const bf16*)dv, pos, (bf16*)dqkv, nullptr, nullptr, B * T_seg, T_seg, T_total, seg_off, NH, HD,
                      q_scale);
