@@ -610,21 +610,23 @@ bool dma_path_ok(const AttnP& p) {
   return attn_variant() != 0 && max(ntk, ntq) * 144 <= DMA_MAX_INFO_BYTES && per <= 64 && ntq <= 64 && p.scale > 0.f;
 }
 
-int launch_fwd256(const AttnP& p, hipStream_t s) {
+template <int HD>
+int launch_fwd_dma(const AttnP& p, hipStream_t s) {
   const int nt = (p.qlen[0] + p.qlen[1] + 63) / 64;
   const int ntk = (p.klen[0] + 31) / 32 + (p.klen[1] + 31) / 32;
-  const int lds = 4 * T32_TILE + ntk * 144;
-  if (int e = set_lds(attn256_q_kernel<0>, lds)) return e;
-  hipLaunchKernelGGL(attn256_q_kernel<0>, dim3(p.B * p.NH * nt, p.nsplit), dim3(256), lds, s, p);
+  const int lds = 4 * DmaCfg<HD>::TILE + ntk * 144;
+  auto kern = attn_dma_q_kernel<HD, 0>;
+  if (int e = set_lds(kern, lds)) return e;
+  hipLaunchKernelGGL(kern, dim3(p.B * p.NH * nt, p.nsplit), dim3(256), lds, s, p);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
 
 template <int HD>
 int launch_fwd(const AttnP& p, hipStream_t s) {
-  if constexpr (HD == 256) {
+  if constexpr (HD == 256 || HD == 72) {
     if (dma_path_ok(p)) {
-      if (int e = launch_fwd256(p, s)) return e;
+      if (int e = launch_fwd_dma<HD>(p, s)) return e;
       if (p.nsplit > 1) {
         const long long n4 = (long long)p.B * (p.qlen[0] + p.qlen[1]) * p.NH * HD / 4;
         hipLaunchKernelGGL(attn_fwd_combine_kernel<HD>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
@@ -654,13 +656,14 @@ int launch_bwd(const AttnP& p, hipStream_t s) {
   LAP_CHECK_LAUNCH();
   const int ntk = (p.klen[0] + 63) / 64 + (p.klen[1] + 63) / 64;
   bool kv_dma = false;
-  if constexpr (HD == 256) kv_dma = dma_path_ok(p);
+  if constexpr (HD == 256 || HD == 72) kv_dma = dma_path_ok(p);
   if (kv_dma) {
-    if constexpr (HD == 256) {
+    if constexpr (HD == 256 || HD == 72) {
       const int ntq32 = (p.qlen[0] + 31) / 32 + (p.qlen[1] + 31) / 32;
-      const int lds2 = 4 * T32_TILE + 1024 + ntq32 * 144;
-      if (int e = set_lds(attn256_kv_kernel, lds2)) return e;
-      hipLaunchKernelGGL(attn256_kv_kernel, dim3(p.B * p.NKV * p.hsplit * ntk), dim3(256), lds2, s, p);
+      const int lds2 = 4 * DmaCfg<HD>::TILE + 1024 + ntq32 * 144;
+      auto kern = attn_dma_kv_kernel<HD>;
+      if (int e = set_lds(kern, lds2)) return e;
+      hipLaunchKernelGGL(kern, dim3(p.B * p.NKV * p.hsplit * ntk), dim3(256), lds2, s, p);
       LAP_CHECK_LAUNCH();
     }
   } else {
@@ -673,13 +676,14 @@ int launch_bwd(const AttnP& p, hipStream_t s) {
     hipLaunchKernelGGL(attn_dkdv_reduce_kernel<HD>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
     LAP_CHECK_LAUNCH();
   }
-  if constexpr (HD == 256) {
+  if constexpr (HD == 256 || HD == 72) {
     if (dma_path_ok(p)) {
       const int nt = (p.qlen[0] + p.qlen[1] + 63) / 64;
       const int ntk32 = (p.klen[0] + 31) / 32 + (p.klen[1] + 31) / 32;
-      const int lds2 = 4 * T32_TILE + ntk32 * 144;
-      if (int e = set_lds(attn256_q_kernel<1>, lds2)) return e;
-      hipLaunchKernelGGL(attn256_q_kernel<1>, dim3(p.B * p.NH * nt, 1), dim3(256), lds2, s, p);
+      const int lds2 = 4 * DmaCfg<HD>::TILE + ntk32 * 144;
+      auto kern = attn_dma_q_kernel<HD, 1>;
+      if (int e = set_lds(kern, lds2)) return e;
+      hipLaunchKernelGGL(kern, dim3(p.B * p.NH * nt, 1), dim3(256), lds2, s, p);
       LAP_CHECK_LAUNCH();
       return LAP_OK;
     }

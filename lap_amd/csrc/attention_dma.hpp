@@ -13,7 +13,49 @@
 //     rows hit 8 distinct blocks of the 256-byte bank window.
 // Rows past the end of a segment are fetched with an out-of-range buffer offset, which the hardware turns into zeros.
 
-constexpr int T32_TILE = 32 * 512;         // bytes of one 32 x 256 bf16 tile
+constexpr int T32_TILE = 32 * 512;         // bytes of one 32 x 256 bf16 tile (head size 256)
+
+// Per head size: k-steps of the contraction over d (KS), 16-wide output fragments along d (DF), LDS row pitch, real
+// 16-byte chunks per row, and the source-address swizzle.  Head size 72 (SigLIP) uses a 256-byte pitch: one bank
+// window per row, chunk c of row r at  c ^ (((r & 7) << 1) | ((r >> 3) & 1)) - the 16 rows of a ds_read_b128 service
+// group hit 16 distinct chunks, the 8 rows of a transposing read 8 distinct 32-byte blocks; chunks 9..15 of a row
+// (d >= 72) are fetched with an out-of-range offset, i.e. as zeros.
+template <int HD> struct DmaCfg;
+template <> struct DmaCfg<256> {
+  static constexpr int KS = 8, DF = 16, PITCH = 512, REAL_CHUNKS = 32, TILE = 32 * 512, PIECES = 4, KREGS = 4, VREGS = 8, BLOCKS = 2, KV_BLOCKS = 2;
+  __device__ static __forceinline__ int swz(int row) { return (row & 7) << 1; }
+};
+template <> struct DmaCfg<72> {
+  static constexpr int KS = 3, DF = 5, PITCH = 256, REAL_CHUNKS = 9, TILE = 32 * 256, PIECES = 2, KREGS = 3, VREGS = 5, BLOCKS = 4, KV_BLOCKS = 3;
+  __device__ static __forceinline__ int swz(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
+};
+// DMA piece j of wave w (1 KiB = 1024 / PITCH rows): tile row and byte column of the lane's 16-byte chunk, or col < 0
+// for a padding chunk that must read as zeros.
+template <int HD>
+__device__ __forceinline__ void dma_lane(int w, int j, int lane, int& row, int& col) {
+  using C = DmaCfg<HD>;
+  constexpr int CPR = C::PITCH / 16;          // chunks per row
+  const int piece = w * C::PIECES + j;
+  row = piece * (1024 / C::PITCH) + lane / CPR;
+  const int c = (lane % CPR) ^ C::swz(row);
+  col = c < C::REAL_CHUNKS ? c * 16 : -1;
+}
+// Loop invariant per-lane LDS offsets.  K-contiguous fragment (ds_read_b128) of tile row nf*16 + i, k-step kk:
+// kbase[kreg(kk)] + kimm(kk) + nf * 16 * PITCH;  transposing read of d-fragment d: vbase[vreg(d)] + vimm(d) (+ 16 rows).
+template <int HD>
+__device__ __forceinline__ void dma_frag_bases(const char* smem, int lane, const char* (&kbase)[DmaCfg<HD>::KREGS], unsigned (&vbase)[DmaCfg<HD>::VREGS]) {
+  using C = DmaCfg<HD>;
+  const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < C::KREGS; ++c) kbase[c] = smem + i * C::PITCH + (((4 * c + g) ^ C::swz(i)) << 4);
+  const int tr_row = 4 * g + (i >> 2);
+  const unsigned lane_swz = (unsigned)(C::swz(tr_row) ^ ((i & 3) >> 1));
+  const unsigned lane_off = lds_addr_of(smem) + (unsigned)(tr_row * C::PITCH + ((i & 1) << 3));
+#pragma unroll
+  for (int c = 0; c < C::VREGS; ++c) vbase[c] = lane_off + (((unsigned)(2 * c) ^ lane_swz) << 4);
+}
+template <int HD> __device__ __forceinline__ constexpr int kreg(int kk) { return HD == 256 ? (kk & 3) : kk; }
+template <int HD> __device__ __forceinline__ constexpr int kimm(int kk) { return HD == 256 ? (kk >> 2) * 256 : 0; }
 constexpr int T32_INFO_INTS = 48;          // 32 info words + and / or / index summaries (padded)
 constexpr unsigned DMA_OOB = 0x80000000u;
 
@@ -73,7 +115,21 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 struct StreamCursor {
   int seg, tile;        // next tile to fetch
 };
-__device__ __forceinline__ int seg_records(int len, int row_stride) { return len > 0 ? ((len - 1) * row_stride + 256) * 2 : 0; }
+__device__ __forceinline__ int seg_records(int len, int row_stride, int hd) { return len > 0 ? ((len - 1) * row_stride + hd) * 2 : 0; }
+
+// All DF transposing fragment reads of one tile (LDS byte offset OFF) in one burst + fence; for small head sizes.
+template <int HD, int OFF>
+__device__ __forceinline__ void tr_burst(const unsigned (&va)[DmaCfg<HD>::VREGS], bf16x4 (&r)[2 * DmaCfg<HD>::DF]) {
+  static_assert(DmaCfg<HD>::VREGS == DmaCfg<HD>::DF, "one address register per d-fragment");
+#pragma unroll
+  for (int d = 0; d < DmaCfg<HD>::DF; ++d) {
+    r[2 * d] = ds_read_tr_raw<OFF>(va[d]);
+    r[2 * d + 1] = ds_read_tr_raw<OFF + 16 * DmaCfg<HD>::PITCH>(va[d]);
+  }
+  lds_wait_all();
+#pragma unroll
+  for (int d = 0; d < 2 * DmaCfg<HD>::DF; ++d) lds_tie(r[d]);
+}
 
 // =============================================================================== forward
 // Block = 4 waves x 16 queries of the JOINT query sequence (the two segments are tiled as one list, a lane resolves
@@ -86,9 +142,10 @@ __device__ __forceinline__ int seg_records(int len, int row_stride) { return len
 // MODE 1 = backward dQ with the same skeleton: per key tile S^T = K Q^T and dP^T = V dO^T (V read K-contiguous like
 // K), dS^T = P^T o (dP^T - delta) * scale with P recomputed from the saved log-sum-exp, and dQ^T += K^T dS^T through
 // the transposing reads of the K tile.
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
-  constexpr int HD = 256, KS = 8, DF = 16, BQ = 64;
+template <int HD, int MODE>
+__global__ __launch_bounds__(256, DmaCfg<HD>::BLOCKS) void attn_dma_q_kernel(AttnP p) {
+  using C = DmaCfg<HD>;
+  constexpr int KS = C::KS, DF = C::DF, BQ = 64, TILE = C::TILE, PITCH = C::PITCH;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x [K tile | V tile], info words, summaries
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -98,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
   const int qtile = bid % ntq, h = (bid / ntq) % p.NH, b = bid / (ntq * p.NH);
   const int hk = h / (p.NH / p.NKV);
   const int nt0 = (p.klen[0] + 31) >> 5, nt1 = (p.klen[1] + 31) >> 5, ntk = nt0 + nt1;
-  int* sWords = reinterpret_cast<int*>(smem + 4 * T32_TILE);
+  int* sWords = reinterpret_cast<int*>(smem + 4 * TILE);
   int* sSum = sWords + ntk * 32;
   const int per = (ntk + p.nsplit - 1) / p.nsplit;
   const int gt0 = blockIdx.y * per, gt1 = min(ntk, gt0 + per);
@@ -145,49 +202,36 @@ __global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
   const int rowbytes0 = p.kv_rs[0] * 2, rowbytes1 = p.kv_rs[1] * 2;
   cur.seg = gt0 >= nt0; cur.tile = cur.seg ? gt0 - nt0 : gt0;
   const long long kvoff0 = (long long)b * p.klen[0] * p.kv_rs[0] + hk * HD, kvoff1 = (long long)b * p.klen[1] * p.kv_rs[1] + hk * HD;
-  const auto rsK0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k[0] + kvoff0), 0, seg_records(p.klen[0], p.kv_rs[0]), 0x00020000);
-  const auto rsV0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.v[0] + kvoff0), 0, seg_records(p.klen[0], p.kv_rs[0]), 0x00020000);
-  const auto rsK1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k[1] + kvoff1), 0, seg_records(p.klen[1], p.kv_rs[1]), 0x00020000);
-  const auto rsV1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.v[1] + kvoff1), 0, seg_records(p.klen[1], p.kv_rs[1]), 0x00020000);
+  const auto rsK0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k[0] + kvoff0), 0, seg_records(p.klen[0], p.kv_rs[0], HD), 0x00020000);
+  const auto rsV0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.v[0] + kvoff0), 0, seg_records(p.klen[0], p.kv_rs[0], HD), 0x00020000);
+  const auto rsK1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k[1] + kvoff1), 0, seg_records(p.klen[1], p.kv_rs[1], HD), 0x00020000);
+  const auto rsV1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.v[1] + kvoff1), 0, seg_records(p.klen[1], p.kv_rs[1], HD), 0x00020000);
   // DMA piece j of this wave: tile row 8w + 2j + lane/32, physical chunk lane%32 holds logical chunk ^ swz(row)
-  int dma_row[4], dma_col[4];
+  int dma_row[C::PIECES], dma_col[C::PIECES];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    dma_row[j] = (w * 4 + j) * 2 + (lane >> 5);
-    dma_col[j] = ((lane & 31) ^ ((dma_row[j] & 7) << 1)) * 16;
-  }
+  for (int j = 0; j < C::PIECES; ++j) dma_lane<HD>(w, j, lane, dma_row[j], dma_col[j]);
   auto issue = [&](int stage) {   // fetch tile `cur` into `stage`, advance the cursor
     const int rb = cur.seg ? rowbytes1 : rowbytes0;
-    char* base = smem + stage * 2 * T32_TILE;
+    char* base = smem + stage * 2 * TILE;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned off = (unsigned)((cur.tile * 32 + dma_row[j]) * rb + dma_col[j]);
-      char* dst = base + (w * 4 + j) * 1024;
+    for (int j = 0; j < C::PIECES; ++j) {
+      const unsigned off = dma_col[j] < 0 ? DMA_OOB : (unsigned)((cur.tile * 32 + dma_row[j]) * rb + dma_col[j]);
+      char* dst = base + (w * C::PIECES + j) * 1024;
       if (cur.seg == 0) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK0, (LDS_PTR(void))dst, 16, off, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV0, (LDS_PTR(void))(dst + T32_TILE), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV0, (LDS_PTR(void))(dst + TILE), 16, off, 0, 0, 0);
       } else {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK1, (LDS_PTR(void))dst, 16, off, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV1, (LDS_PTR(void))(dst + T32_TILE), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV1, (LDS_PTR(void))(dst + TILE), 16, off, 0, 0, 0);
       }
     }
     if (++cur.tile == (cur.seg ? nt1 : nt0)) { cur.seg = 1; cur.tile = 0; }
   };
 
-  // ---- loop invariant LDS addresses
-  // K (ds_read_b128): row nf*16 + i, chunk (4 kk + g) ^ swz(i) = 16 (kk>>2) + ((4 (kk&3) + g) ^ swz)
-  const char* kp[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) kp[c] = smem + i * 512 + (((4 * c + g) ^ ((i & 7) << 1)) << 4);
-  // V (transposing reads): row 4g + i/4 (+16), chunk (2 d + (i&3)/2) ^ swz(row) = 16 (d>>3) + ((2 (d&7)) ^ lane_swz)
-  unsigned va[8];
-  {
-    const int tr_row = 4 * g + (i >> 2);
-    const unsigned lane_swz = (unsigned)(((tr_row & 7) << 1) ^ ((i & 3) >> 1));
-    const unsigned lane_off = lds_addr_of(smem) + (unsigned)(tr_row * 512 + ((i & 1) << 3));
-#pragma unroll
-    for (int c = 0; c < 8; ++c) va[c] = lane_off + (((unsigned)(2 * c) ^ lane_swz) << 4);
-  }
+  // ---- loop invariant LDS addresses (dma_frag_bases)
+  const char* kp[C::KREGS];
+  unsigned va[C::VREGS];
+  dma_frag_bases<HD>(smem, lane, kp, va);
 
   const float c2 = p.scale * LOG2E;     // logits in the log2 domain: s * c2
   float m = NEG_BIG, l = 0.f;
@@ -198,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
   unsigned long long skipmask = 0, fastmask = 0;   // per-wave tile decisions, filled in below
   auto step = [&](auto STC, int gt) {
     constexpr int ST = decltype(STC)::value;
-    constexpr int KOFF = ST * 2 * T32_TILE, VOFF = KOFF + T32_TILE;
+    constexpr int KOFF = ST * 2 * TILE, VOFF = KOFF + TILE;
     wait_vm0();          // my pieces of tile gt have landed ...
     __syncthreads();     // ... and everybody's; every wave is done with the stage refilled below
     if (gt + 1 < gt1) issue(ST ^ 1);
@@ -211,10 +255,10 @@ __global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
-        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + KOFF + (kk >> 2) * 256);
-        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + KOFF + 16 * 512 + (kk >> 2) * 256);
-        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + VOFF + (kk >> 2) * 256);
-        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + VOFF + 16 * 512 + (kk >> 2) * 256);
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kp[kreg<HD>(kk)] + KOFF + kimm<HD>(kk));
+        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kp[kreg<HD>(kk)] + KOFF + 16 * PITCH + kimm<HD>(kk));
+        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(kp[kreg<HD>(kk)] + VOFF + kimm<HD>(kk));
+        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(kp[kreg<HD>(kk)] + VOFF + 16 * PITCH + kimm<HD>(kk));
         s0 = mfma16(k0, qf[kk], s0);      // S^T[key][q]
         s1 = mfma16(k1, qf[kk], s1);
         d0 = mfma16(v0, dof[kk], d0);     // dP^T[key][q]
@@ -238,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
         }
       }
       const bf16x8 pb = pack8(d0, d1);
+      if constexpr (HD == 256) {
       // dQ^T += K^T dS^T: K fragments through raw transposing reads, software pipelined in groups of 4 d-fragments
       bf16x4 vr[2][8];
 #define LAP_ISSUE_K(GRP, R)                                                               \
@@ -255,13 +300,20 @@ __global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
       lds_wait8<0>(vr[1]); LAP_DQ(3, vr[1])
 #undef LAP_ISSUE_K
 #undef LAP_DQ
+      } else {
+        // few d-fragments (head size 72: 5): all transposing reads in one burst, one fence, then the MFMAs
+        bf16x4 vr[2 * DF];
+        tr_burst<HD, KOFF>(va, vr);
+#pragma unroll
+        for (int d = 0; d < DF; ++d) acc_o[d] = mfma16(join8(vr[2 * d], vr[2 * d + 1]), pb, acc_o[d]);
+      }
       return;
     }
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + KOFF + (kk >> 2) * 256);
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + KOFF + 16 * 512 + (kk >> 2) * 256);
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kp[kreg<HD>(kk)] + KOFF + kimm<HD>(kk));
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kp[kreg<HD>(kk)] + KOFF + 16 * PITCH + kimm<HD>(kk));
       s0 = mfma16(k0, qf[kk], s0);
       s1 = mfma16(k1, qf[kk], s1);
     }
@@ -310,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
     l += ((s0[0] + s0[1]) + (s0[2] + s0[3])) + ((s1[0] + s1[1]) + (s1[2] + s1[3]));
     const bf16x8 pb = pack8(s0, s1);
 
+    if constexpr (HD == 256) {
     // O^T += V^T P^T: V fragments through raw transposing reads, software pipelined in groups of 4 d-fragments
     bf16x4 vr[2][8];
 #define LAP_ISSUE_V(GRP, R)                                                               \
@@ -327,6 +380,12 @@ __global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
     lds_wait8<0>(vr[1]); LAP_PV(3, vr[1])
 #undef LAP_ISSUE_V
 #undef LAP_PV
+    } else {
+      bf16x4 vr[2 * DF];
+      tr_burst<HD, VOFF>(va, vr);
+#pragma unroll
+      for (int d = 0; d < DF; ++d) acc_o[d] = mfma16(join8(vr[2 * d], vr[2 * d + 1]), pb, acc_o[d]);
+    }
   };
 
   if (gt0 < gt1) issue(0);
@@ -358,7 +417,8 @@ __global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
     if (!vq) return;
     bf16* dqrow = p.dq[qsg] + (b * (long long)p.qlen[qsg] + qloc) * p.q_rs[qsg] + h * HD;
 #pragma unroll
-    for (int d = 0; d < DF; ++d) store4(dqrow + d * 16 + 4 * g, acc_o[d], 1.0f);
+    for (int d = 0; d < DF; ++d)
+      if (d * 16 + 4 * g < HD) store4(dqrow + d * 16 + 4 * g, acc_o[d], 1.0f);
     return;
   }
   l = sum_over_groups(l);
@@ -370,13 +430,15 @@ __global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
     const long long row = ((long long)blockIdx.y * p.B + b) * Tq + myq;
     float* op = p.part + (row * p.NH + h) * HD;
 #pragma unroll
-    for (int d = 0; d < DF; ++d) *reinterpret_cast<f32x4*>(op + d * 16 + 4 * g) = acc_o[d] * inv;
+    for (int d = 0; d < DF; ++d)
+      if (d * 16 + 4 * g < HD) *reinterpret_cast<f32x4*>(op + d * 16 + 4 * g) = acc_o[d] * inv;
     if (g == 0) p.lpart[(((long long)blockIdx.y * p.B + b) * p.NH + h) * Tq + myq] = l > 0.f ? lse : NEG_BIG;
     return;
   }
   bf16* orow = p.o[qsg] + (b * (long long)p.qlen[qsg] + qloc) * p.o_rs[qsg] + h * HD;
 #pragma unroll
-  for (int d = 0; d < DF; ++d) store4(orow + d * 16 + 4 * g, acc_o[d], inv);
+  for (int d = 0; d < DF; ++d)
+    if (d * 16 + 4 * g < HD) store4(orow + d * 16 + 4 * g, acc_o[d], inv);
   if (p.lse && g == 0) p.lse[((long long)b * p.NH + h) * Tq + myq] = l > 0.f ? lse : LSE_EMPTY;
 }
 
@@ -386,8 +448,10 @@ __global__ __launch_bounds__(256, 2) void attn256_q_kernel(AttnP p) {
 // and dO tiles arrive through the 2-stage LDS-DMA ring, the 32 log-sum-exp / delta values of the tile through two
 // dword DMAs of wave 0.  Per tile:  S = Q K^T, dP = dO V^T (Q / dO read K-contiguous),  P = exp2(S c2 - lse),
 // dS = P o (dP - delta) scale,  dV^T += dO^T P,  dK^T += Q^T dS (Q / dO read through raw transposing reads).
-__global__ __launch_bounds__(256, 2) void attn256_kv_kernel(AttnP p) {
-  constexpr int HD = 256, KS = 8, DF = 16;
+template <int HD>
+__global__ __launch_bounds__(256, DmaCfg<HD>::KV_BLOCKS) void attn_dma_kv_kernel(AttnP p) {
+  using C = DmaCfg<HD>;
+  constexpr int KS = C::KS, DF = C::DF, TILE = C::TILE, PITCH = C::PITCH;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x [Q tile | dO tile], 2 x [lse | delta], q infos
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -399,8 +463,8 @@ __global__ __launch_bounds__(256, 2) void attn256_kv_kernel(AttnP p) {
   const bool vk = mykey < klen;
   const long long koff = (b * (long long)klen + mykey) * p.kv_rs[kseg] + hk * HD;
   const int nq0 = (p.qlen[0] + 31) >> 5, nq1 = (p.stop && kseg == 0) ? 0 : (p.qlen[1] + 31) >> 5, ntq = nq0 + nq1;
-  float* sLD = reinterpret_cast<float*>(smem + 4 * T32_TILE);          // per stage: 64 floats lse(+pad), 64 floats delta(+pad)
-  int* sWords = reinterpret_cast<int*>(smem + 4 * T32_TILE + 1024);
+  float* sLD = reinterpret_cast<float*>(smem + 4 * TILE);          // per stage: 64 floats lse(+pad), 64 floats delta(+pad)
+  int* sWords = reinterpret_cast<int*>(smem + 4 * TILE + 1024);
   int* sSum = sWords + ntq * 32;
 
   bf16x8 kf[KS], vf[KS];
@@ -432,23 +496,22 @@ __global__ __launch_bounds__(256, 2) void attn256_kv_kernel(AttnP p) {
   const int h_first = hk * hpk + hg * hpg;
   const int items = hpg * ntq;
   int cur_h = h_first, cur_t = 0;   // next item to fetch
-  int dma_row[4], dma_col[4];
+  int dma_row[C::PIECES], dma_col[C::PIECES];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    dma_row[j] = (w * 4 + j) * 2 + (lane >> 5);
-    dma_col[j] = ((lane & 31) ^ ((dma_row[j] & 7) << 1)) * 16;
-  }
+  for (int j = 0; j < C::PIECES; ++j) dma_lane<HD>(w, j, lane, dma_row[j], dma_col[j]);
   auto issue = [&](int stage) {
     const int sg = cur_t >= nq0, tl = sg ? cur_t - nq0 : cur_t;
     const int qlen = p.qlen[sg], qrs = p.q_rs[sg], ors = p.o_rs[sg];
-    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q[sg] + (long long)b * qlen * qrs + cur_h * HD), 0, seg_records(qlen, qrs), 0x00020000);
-    const auto rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(p.d_o[sg] + (long long)b * qlen * ors + cur_h * HD), 0, seg_records(qlen, ors), 0x00020000);
-    char* base = smem + stage * 2 * T32_TILE;
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q[sg] + (long long)b * qlen * qrs + cur_h * HD), 0, seg_records(qlen, qrs, HD), 0x00020000);
+    const auto rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(p.d_o[sg] + (long long)b * qlen * ors + cur_h * HD), 0, seg_records(qlen, ors, HD), 0x00020000);
+    char* base = smem + stage * 2 * TILE;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      char* dst = base + (w * 4 + j) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (LDS_PTR(void))dst, 16, (unsigned)((tl * 32 + dma_row[j]) * qrs * 2 + dma_col[j]), 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (LDS_PTR(void))(dst + T32_TILE), 16, (unsigned)((tl * 32 + dma_row[j]) * ors * 2 + dma_col[j]), 0, 0, 0);
+    for (int j = 0; j < C::PIECES; ++j) {
+      char* dst = base + (w * C::PIECES + j) * 1024;
+      const unsigned oq = dma_col[j] < 0 ? DMA_OOB : (unsigned)((tl * 32 + dma_row[j]) * qrs * 2 + dma_col[j]);
+      const unsigned od = dma_col[j] < 0 ? DMA_OOB : (unsigned)((tl * 32 + dma_row[j]) * ors * 2 + dma_col[j]);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (LDS_PTR(void))dst, 16, oq, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (LDS_PTR(void))(dst + TILE), 16, od, 0, 0, 0);
     }
     if (w == 0) {   // lse / delta of the tile's rows: lanes 0..31 fetch, lanes 32..63 (and rows past the end) write zeros
       const long long roff = ((long long)b * p.NH + cur_h) * Tq + (sg ? p.qlen[0] : 0);
@@ -463,17 +526,9 @@ __global__ __launch_bounds__(256, 2) void attn256_kv_kernel(AttnP p) {
   };
 
   // ---- loop invariant LDS addresses (same tile image as the forward kernel)
-  const char* kp[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) kp[c] = smem + i * 512 + (((4 * c + g) ^ ((i & 7) << 1)) << 4);
-  unsigned va[8];
-  {
-    const int tr_row = 4 * g + (i >> 2);
-    const unsigned lane_swz = (unsigned)(((tr_row & 7) << 1) ^ ((i & 3) >> 1));
-    const unsigned lane_off = lds_addr_of(smem) + (unsigned)(tr_row * 512 + ((i & 1) << 3));
-#pragma unroll
-    for (int c = 0; c < 8; ++c) va[c] = lane_off + (((unsigned)(2 * c) ^ lane_swz) << 4);
-  }
+  const char* kp[C::KREGS];
+  unsigned va[C::VREGS];
+  dma_frag_bases<HD>(smem, lane, kp, va);
 
   const float c2 = p.scale * LOG2E;
   f32x4 acc_dk[DF], acc_dv[DF];
@@ -483,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void attn256_kv_kernel(AttnP p) {
   unsigned long long skipmask = 0, fastmask = 0;   // per query tile, the same for every head
   auto step = [&](auto STC, int qt) {
     constexpr int ST = decltype(STC)::value;
-    constexpr int QOFF = ST * 2 * T32_TILE, DOFF = QOFF + T32_TILE;
+    constexpr int QOFF = ST * 2 * TILE, DOFF = QOFF + TILE;
     wait_vm0();
     __syncthreads();
     if (cur_h < h_first + hpg) issue(ST ^ 1);
@@ -493,10 +548,10 @@ __global__ __launch_bounds__(256, 2) void attn256_kv_kernel(AttnP p) {
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-      const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + QOFF + (kk >> 2) * 256);
-      const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + QOFF + 16 * 512 + (kk >> 2) * 256);
-      const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + DOFF + (kk >> 2) * 256);
-      const bf16x8 o1 = *reinterpret_cast<const bf16x8*>(kp[kk & 3] + DOFF + 16 * 512 + (kk >> 2) * 256);
+      const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(kp[kreg<HD>(kk)] + QOFF + kimm<HD>(kk));
+      const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(kp[kreg<HD>(kk)] + QOFF + 16 * PITCH + kimm<HD>(kk));
+      const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(kp[kreg<HD>(kk)] + DOFF + kimm<HD>(kk));
+      const bf16x8 o1 = *reinterpret_cast<const bf16x8*>(kp[kreg<HD>(kk)] + DOFF + 16 * PITCH + kimm<HD>(kk));
       s0 = mfma16(q0, kf[kk], s0);      // S[q][key]
       s1 = mfma16(q1, kf[kk], s1);
       d0 = mfma16(o0, vf[kk], d0);      // dP[q][key]
@@ -528,6 +583,7 @@ __global__ __launch_bounds__(256, 2) void attn256_kv_kernel(AttnP p) {
       }
     }
     const bf16x8 pb = pack8(s0, s1), db = pack8(d0, d1);
+    if constexpr (HD == 256) {
     // dV^T += dO^T P, dK^T += Q^T dS: raw transposing reads, double buffered in groups of 2 d-fragments x 2 tiles
     bf16x4 tr[2][8];
 #define LAP_ISSUE_T(GRP, R)                                                               \
@@ -553,6 +609,16 @@ __global__ __launch_bounds__(256, 2) void attn256_kv_kernel(AttnP p) {
     lds_wait8<0>(tr[1]); LAP_DKDV(7, tr[1])
 #undef LAP_ISSUE_T
 #undef LAP_DKDV
+    } else {
+      bf16x4 rd[2 * DF], rq[2 * DF];
+      tr_burst<HD, DOFF>(va, rd);
+      tr_burst<HD, QOFF>(va, rq);    // (the second burst's fence also covers the first)
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        acc_dv[d] = mfma16(join8(rd[2 * d], rd[2 * d + 1]), pb, acc_dv[d]);
+        acc_dk[d] = mfma16(join8(rq[2 * d], rq[2 * d + 1]), db, acc_dk[d]);
+      }
+    }
   };
 
   if (items > 0) issue(0);
@@ -586,6 +652,7 @@ __global__ __launch_bounds__(256, 2) void attn256_kv_kernel(AttnP p) {
     float* pv = pk + (long long)p.hsplit * n_all;
 #pragma unroll
     for (int d = 0; d < DF; ++d) {
+      if (d * 16 + 4 * g >= HD) continue;
       *reinterpret_cast<f32x4*>(pk + d * 16 + 4 * g) = acc_dk[d];
       *reinterpret_cast<f32x4*>(pv + d * 16 + 4 * g) = acc_dv[d];
     }
@@ -593,6 +660,7 @@ __global__ __launch_bounds__(256, 2) void attn256_kv_kernel(AttnP p) {
   }
 #pragma unroll
   for (int d = 0; d < DF; ++d) {
+    if (d * 16 + 4 * g >= HD) continue;
     store4(p.dk[kseg] + koff + d * 16 + 4 * g, acc_dk[d], 1.0f);
     store4(p.dv[kseg] + koff + d * 16 + 4 * g, acc_dv[d], 1.0f);
   }

@@ -406,7 +406,7 @@ def test_attention_lap_mask_two_segments(hip, HD, Tp, S, n_lang, n_pad, stop):
 
 @pytest.mark.parametrize("variant", [0, 1])
 def test_attention_hd256_kernel_variants(hip, variant):
-    """HD = 256 has three kernel families (generic padded-LDS; LDS-DMA with 1 / 2 row groups per wave): each must pass
+    """HD = 256 / 72 have two kernel families (generic padded-LDS; LDS-DMA with 1 / 2 row groups per wave): each must pass
     the same reference checks, including ragged tiles, the two-segment LAP mask, stop-gradient and key splits."""
     hip.attention_set_variant(variant)
     try:
@@ -416,6 +416,12 @@ def test_attention_hd256_kernel_variants(hip, variant):
         test_attention_lap_mask_two_segments(hip, 256, 100, 16, 9, 2, True)
         test_attention_lap_mask_two_segments(hip, 256, 290, 50, 40, 7, False)
         test_attention_suffix_only_queries(hip)
+        # head size 72 (SigLIP) has the same two families
+        test_attention_nomask(hip, 72, 16, 16, 2, 256)
+        test_attention_nomask(hip, 72, 4, 2, 1, 333)
+        test_attention_lap_mask_two_segments(hip, 72, 150, 50, 16, 5, False)
+        test_attention_lap_mask_two_segments(hip, 72, 100, 16, 9, 2, True)
+        test_attention_fused_qkv_strided(hip)
     finally:
         hip.attention_set_variant(-1)
 

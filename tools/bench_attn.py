@@ -28,3 +28,18 @@ for var in (0, 1, 1):
         (o0, o1), lse = hip.attention_fwd([q0, q1], [k0, k1], [v0, v1], [Tp, S], [Tp, S], B, NH, 1, HD, *a)
         tb = timeit(lambda: hip.attention_bwd([q0, q1], [k0, k1], [v0, v1], [o0, o1], [q0, q1], lse, [Tp, S], [Tp, S], B, NH, 1, HD, *a))
         print(f"variant {var} masked={masked}: fwd {t*1e6:.0f} us {fl/t/1e12:.0f} TF | bwd {tb*1e6:.0f} us {2.5*fl/tb/1e12:.0f} TF", flush=True)
+
+# SigLIP: 64 images x 256 tokens, 16 heads of 72, no mask, fused qkv buffer
+B, NH, HD, T = 64, 16, 72, 256
+W = NH * HD
+qkv = rnd(B * T, 3 * W)
+q, k, v = qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:]
+fl = 4 * B * NH * T * T * HD
+for var in (0, 1, 1):
+    hip.attention_set_variant(var)
+    kw = dict(scale=HD ** -0.5, q_rs=(3 * W, 0), kv_rs=(3 * W, 0))
+    t = timeit(lambda: hip.attention_fwd([q], [k], [v], [T], [T], B, NH, NH, HD, **kw))
+    (o, _), lse = hip.attention_fwd([q], [k], [v], [T], [T], B, NH, NH, HD, **kw)
+    dqkv = torch.zeros_like(qkv)
+    tb = timeit(lambda: hip.attention_bwd([q], [k], [v], [o], [o], lse, [T], [T], B, NH, NH, HD, dq_out=[dqkv[:, :W]], dk_out=[dqkv[:, W:2 * W]], dv_out=[dqkv[:, 2 * W:]], **kw))
+    print(f"siglip hd72 variant {var}: fwd {t*1e6:.0f} us {fl/t/1e12:.0f} TF | bwd {tb*1e6:.0f} us {2.5*fl/tb/1e12:.0f} TF", flush=True)
