@@ -79,42 +79,45 @@ class GemmMeter:
 
 
 def cpu_baseline(cores: int):
-    """CPU oracle (f32, torch CPU autograd) on a bounded slice: LAP-3B widths, batch 1, BASELINE shapes, 2 of 18 joint
-    Gemma layers + 2 of 27 SigLIP blocks + a 16k-row vocabulary slice; forward + backward; samples/s extrapolated by
-    the FLOP ratio of the full model to the slice."""
-    import dataclasses
-
+    """CPU oracle (f32, torch CPU autograd) on a bounded slice: LAP-3B widths, BASELINE shapes, NL of 18 joint Gemma
+    layers + NL of 27 SigLIP blocks + a 16k-row vocabulary slice; forward + backward; samples/s extrapolated by the FLOP
+    ratio of the full model to the slice.  The slice grows (2 layers x batch 1 -> 6 layers x batch 2) until the timed
+    region is of the order of 10 s on the host at hand."""
     from oracle import lap_oracle as O
 
     torch.set_num_threads(cores)
-    O.GEMMA["gemma_2b_d2"] = O.GemmaCfg(2048, 2, 16384, 8, 1, 256)
-    O.GEMMA["gemma_300m_d2"] = O.GemmaCfg(1024, 2, 4096, 8, 1, 256)
-    O.SIGLIP["So400m/14_d2"] = O.SiglipCfg(1152, 2, 4304, 16)
     V = 16384
-    oc = O.OracleCfg(paligemma_variant="gemma_2b_d2", action_expert_variant="gemma_300m_d2", siglip_variant="So400m/14_d2",
-                     action_horizon=50, max_token_len=48, vocab_size=V, language_loss_weight=0.4)
-    P = O.init_params(oc, 0)
-    g = torch.Generator().manual_seed(0)
-    B, L = 1, 48
-    la = torch.zeros(B, L, dtype=torch.bool); la[:, L - 16:] = True
-    obs = dict(images={k: torch.rand(B, 224, 224, 3, generator=g) * 2 - 1 for k in oc.image_keys},
-               image_masks={k: torch.ones(B, dtype=torch.bool) for k in oc.image_keys},
-               tokenized_prompt=torch.randint(0, V, (B, L), generator=g), tokenized_prompt_mask=torch.ones(B, L, dtype=torch.bool),
-               tokenized_langact_mask=la, token_loss_mask=torch.ones(B, L, dtype=torch.bool), sample_mask=torch.ones(B, dtype=torch.bool))
-    actions = torch.randn(B, 50, 7, generator=g); noise = torch.randn(B, 50, 7, generator=g); t = torch.rand(B, generator=g) * 0.999 + 0.001
-    Pg = {k: v.requires_grad_(True) for k, v in P.items()}
-    t0 = time.perf_counter()
-    loss, _ = O.compute_loss(Pg, oc, obs, actions, noise, t)
-    loss.backward()
-    dt = time.perf_counter() - t0
-    # forward FLOPs of the slice vs the full model (SURVEY.md §8d formula)
     Tp, S = 560, 50
     w_sig_l, w_vlm_l, w_exp_l = 412.4e6 / 27, 1.982e9 / 18, 0.311e9 / 18
-    f_slice = 2 * (2 * 256 * 2 * w_sig_l + 2 * 4 * 256 ** 2 * 1152) + 2 * Tp * 2 * w_vlm_l + 2 * 4 * Tp ** 2 * 2048 \
-        + 2 * S * 2 * w_exp_l + 2 * 4 * S * (Tp + S) * 2048 + 2 * 47 * 2048 * V
     f_full = 2.792e12
-    return {"value": round(1.0 / (dt * f_full / f_slice), 6), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle f32 fwd+bwd, batch 1, LAP-3B widths, 2/18 Gemma layers + 2/27 SigLIP blocks + 16k-row vocab slice "
+    for NL, B in ((2, 1), (6, 2)):
+        O.GEMMA["gemma_2b_slice"] = O.GemmaCfg(2048, NL, 16384, 8, 1, 256)
+        O.GEMMA["gemma_300m_slice"] = O.GemmaCfg(1024, NL, 4096, 8, 1, 256)
+        O.SIGLIP["So400m/14_slice"] = O.SiglipCfg(1152, NL, 4304, 16)
+        oc = O.OracleCfg(paligemma_variant="gemma_2b_slice", action_expert_variant="gemma_300m_slice", siglip_variant="So400m/14_slice",
+                         action_horizon=50, max_token_len=48, vocab_size=V, language_loss_weight=0.4)
+        P = O.init_params(oc, 0)
+        g = torch.Generator().manual_seed(0)
+        L = 48
+        la = torch.zeros(B, L, dtype=torch.bool); la[:, L - 16:] = True
+        obs = dict(images={k: torch.rand(B, 224, 224, 3, generator=g) * 2 - 1 for k in oc.image_keys},
+                   image_masks={k: torch.ones(B, dtype=torch.bool) for k in oc.image_keys},
+                   tokenized_prompt=torch.randint(0, V, (B, L), generator=g), tokenized_prompt_mask=torch.ones(B, L, dtype=torch.bool),
+                   tokenized_langact_mask=la, token_loss_mask=torch.ones(B, L, dtype=torch.bool), sample_mask=torch.ones(B, dtype=torch.bool))
+        actions = torch.randn(B, 50, 7, generator=g); noise = torch.randn(B, 50, 7, generator=g); t = torch.rand(B, generator=g) * 0.999 + 0.001
+        Pg = {k: v.requires_grad_(True) for k, v in P.items()}
+        t0 = time.perf_counter()
+        loss, _ = O.compute_loss(Pg, oc, obs, actions, noise, t)
+        loss.backward()
+        dt = time.perf_counter() - t0
+        del P, Pg, loss
+        if dt >= 6.0:
+            break
+    # forward FLOPs per sample of the slice vs the full model (SURVEY.md 8d formula)
+    f_slice = 2 * (2 * 256 * NL * w_sig_l + NL * 4 * 256 ** 2 * 1152) + 2 * Tp * NL * w_vlm_l + NL * 4 * Tp ** 2 * 2048 \
+        + 2 * S * NL * w_exp_l + NL * 4 * S * (Tp + S) * 2048 + 2 * 47 * 2048 * V
+    return {"value": round(B / (dt * f_full / f_slice), 6), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle f32 fwd+bwd, batch {B}, LAP-3B widths, {NL}/18 Gemma layers + {NL}/27 SigLIP blocks + 16k-row vocab slice "
                       f"({dt:.1f} s), extrapolated by forward-FLOP ratio {f_full / f_slice:.1f}x; stand-in for the reference's JAX-CPU "
                       f"path, which cannot be installed offline"}
 
