@@ -164,10 +164,11 @@ def main():
     meter = GemmMeter(hip)
     meter.install()
 
-    def sync():
+    def sync():   # barrier + device synchronize (all streams: compute, optimizer / collective side stream)
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         state, info = runner(0, state, batches[i % 2], state.step)
