@@ -37,6 +37,15 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }  // RNE
+// A bf16 rounding that the reference performs between two f32 operations (bf16 products, bf16 adds ...).  The value
+// is passed through an empty asm so that the compiler cannot fold the fptrunc/fpext pair into the surrounding
+// arithmetic: left to itself it contracted `x + bf16(y * g)` into fma(y, g, x) in one kernel and not in another,
+// which breaks bit-identity between the fused serving kernels and the generic layer path.
+__device__ __forceinline__ float round_bf16(float x) {
+  float r = (float)(bf16)x;
+  asm("" : "+v"(r));
+  return r;
+}
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   // jax.nn.gelu(approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
@@ -50,6 +59,17 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
   float t = tanhf(u);
   float du = k0 * (1.0f + 3.0f * k1 * x * x);
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+
+// RoPE (gemma.py:548-564) building blocks shared by every kernel that rotates, written with explicitly rounded
+// operations so that all of them produce the same bits regardless of how the compiler would contract a*b - c*d.
+__device__ __forceinline__ void rope_sincos(float pos, int i, int HD, float& sn, float& cs) {
+  const float ts = powf(10000.0f, (2.0f / (float)HD) * (float)i);   // timescale of frequency index i
+  sincosf(__fdiv_rn(pos, ts), &sn, &cs);
+}
+__device__ __forceinline__ void rope_rotate(float x1, float x2, float sn, float cs, float& r1, float& r2) {
+  r1 = __fsub_rn(__fmul_rn(x1, cs), __fmul_rn(x2, sn));
+  r2 = __fadd_rn(__fmul_rn(x2, cs), __fmul_rn(x1, sn));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

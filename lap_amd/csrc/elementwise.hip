@@ -43,12 +43,7 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const bf16* __restrict_
   const float p = (float)pos[(long long)b * T_total + seg_off + t];
   float sn[8], cs[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int i = c * 8 + e;
-    const float fe = (2.0f / (float)HD) * (float)i;
-    const float ts = powf(10000.0f, fe);
-    sincosf(p / ts, &sn[e], &cs[e]);
-  }
+  for (int e = 0; e < 8; ++e) rope_sincos(p, c * 8 + e, HD, sn[e], cs[e]);
 #pragma unroll 2
   for (int h = 0; h < NH + 2; ++h) {
     const bf16* src;
@@ -63,15 +58,15 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const bf16* __restrict_
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         if (!BWD) {
-          float r1 = bf2f(f2bf(x1[e] * cs[e] - x2[e] * sn[e]));
-          float r2 = bf2f(f2bf(x2[e] * cs[e] + x1[e] * sn[e]));
+          float r1, r2;
+          rope_rotate(x1[e], x2[e], sn[e], cs[e], r1, r2);
+          r1 = round_bf16((r1)); r2 = round_bf16((r2));
           if (h < NH) { r1 *= q_scale; r2 *= q_scale; }
           y1[e] = r1; y2[e] = r2;
-        } else {
+        } else {   // transpose of the rotation
           float d1 = x1[e], d2 = x2[e];
           if (h < NH) { d1 *= q_scale; d2 *= q_scale; }
-          y1[e] = d1 * cs[e] + d2 * sn[e];
-          y2[e] = d2 * cs[e] - d1 * sn[e];
+          rope_rotate(d1, d2, -sn[e], cs[e], y1[e], y2[e]);
         }
       }
     } else {
@@ -100,7 +95,7 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16* __restrict__
   ld8(gu + row * 2 * H + c, g);
   ld8(gu + row * 2 * H + H + c, u);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(gelu_tanh_f(g[e]))) * u[e];  // gelu output is a bf16 tensor upstream
+  for (int e = 0; e < 8; ++e) o[e] = round_bf16((gelu_tanh_f(g[e]))) * u[e];  // gelu output is a bf16 tensor upstream
   st8(act + row * H + c, o);
 }
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16* __restrict__ gu, const bf16* __restrict__ dact,
@@ -117,7 +112,7 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16* __restrict__
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     dg[e] = d[e] * u[e] * gelu_tanh_grad_f(g[e]);
-    du[e] = d[e] * bf2f(f2bf(gelu_tanh_f(g[e])));
+    du[e] = d[e] * round_bf16((gelu_tanh_f(g[e])));
   }
   st8(dgu + row * 2 * H + c, dg);
   st8(dgu + row * 2 * H + H + c, du);
@@ -193,7 +188,7 @@ __global__ __launch_bounds__(256) void gated_res_fwd_kernel(const bf16* __restri
     float gv[8];
     ld8(gate + (long long)(r / rps) * ldg + c, gv);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = xv[e] + bf2f(f2bf(uv[e] * gv[e]));  // y*gate is a bf16 product upstream
+    for (int e = 0; e < 8; ++e) o[e] = xv[e] + round_bf16((uv[e] * gv[e]));  // y*gate is a bf16 product upstream
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = xv[e] + uv[e];

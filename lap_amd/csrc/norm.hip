@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16* __restrict
         load8(mrow + c, sc);
         load8(mrow + D + c, sh);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = xv[p][e] * r * bf2f(f2bf(1.0f + sc[e])) + sh[e];  // (1 + scale) is a bf16 op in the reference
+        for (int e = 0; e < 8; ++e) o[e] = xv[p][e] * r * round_bf16((1.0f + sc[e])) + sh[e];  // (1 + scale) is a bf16 op in the reference
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = xv[p][e] * r * (1.0f + scale[c + e]);
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
         float sc[8];
         load8(mrow + c, sc);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) wgt[p][e] = bf2f(f2bf(1.0f + sc[e]));
+        for (int e = 0; e < 8; ++e) wgt[p][e] = round_bf16((1.0f + sc[e]));
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) wgt[p][e] = 1.0f + scale[c + e];

@@ -27,14 +27,28 @@ __device__ __forceinline__ void ld8(const bf16* p, float (&v)[8]) {
 __device__ __forceinline__ void sum8(const float* part, long long off, int ks, long long slab, float (&v)[8]) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = 0.f;
-  for (int s = 0; s < ks; ++s) {
+  // loads of 4 slabs in flight at a time; the additions keep the slab order (bit-identical to splitk_reduce_kernel)
+  int s = 0;
+  for (; s + 4 <= ks; s += 4) {
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = *reinterpret_cast<const f32x4*>(part + (s + u) * slab + off);
+      b[u] = *reinterpret_cast<const f32x4*>(part + (s + u) * slab + off + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += a[u][e]; v[4 + e] += b[u][e]; }
+  }
+  for (; s < ks; ++s) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(part + s * slab + off);
     const f32x4 b = *reinterpret_cast<const f32x4*>(part + s * slab + off + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+  for (int e = 0; e < 8; ++e) v[e] = round_bf16((v[e]));
 }
 
 // ---------------------------------------------------------------- reduce + RoPE + split
@@ -57,12 +71,10 @@ __global__ __launch_bounds__(256) void reduce_rope_kernel(const float* __restric
     const float p = (float)pos[(long long)b * T_total + seg_off + t];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float fe = (2.0f / (float)HD) * (float)(c * 8 + e);
-      const float rad = p / powf(10000.0f, fe);
-      float sn, cs;
-      sincosf(rad, &sn, &cs);
-      float r1 = bf2f(f2bf(x1[e] * cs - x2[e] * sn));
-      float r2 = bf2f(f2bf(x2[e] * cs + x1[e] * sn));
+      float sn, cs, r1, r2;
+      rope_sincos(p, c * 8 + e, HD, sn, cs);
+      rope_rotate(x1[e], x2[e], sn, cs, r1, r2);
+      r1 = round_bf16((r1)); r2 = round_bf16((r2));
       if (h < NH) { r1 *= q_scale; r2 *= q_scale; }
       y1[e] = r1; y2[e] = r2;
     }
@@ -87,7 +99,7 @@ __global__ __launch_bounds__(256) void reduce_geglu_kernel(const float* __restri
   sum8(part, row * 2 * H + c, ks, slab, g);
   sum8(part, row * 2 * H + H + c, ks, slab, u);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(gelu_tanh_f(g[e]))) * u[e];
+  for (int e = 0; e < 8; ++e) o[e] = round_bf16((gelu_tanh_f(g[e]))) * u[e];
   st8(act + row * H + c, o);
 }
 
@@ -116,10 +128,10 @@ __global__ __launch_bounds__(256) void reduce_residual_norm_kernel(const float* 
       if (gate) {
         ld8(gate + (long long)b * ldg + c, gv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[p][e] = bf2f(f2bf(xv[e] + bf2f(f2bf(y[e] * gv[e]))));
+        for (int e = 0; e < 8; ++e) v[p][e] = round_bf16((xv[e] + round_bf16((y[e] * gv[e]))));
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[p][e] = bf2f(f2bf(xv[e] + y[e]));
+        for (int e = 0; e < 8; ++e) v[p][e] = round_bf16((xv[e] + y[e]));
       }
       st8(xn + (long long)row * D + c, v[p]);
 #pragma unroll
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(256) void reduce_residual_norm_kernel(const float* 
       ld8(mrow + c, sc);
       ld8(mrow + D + c, sh);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = v[p][e] * r * bf2f(f2bf(1.0f + sc[e])) + sh[e];
+      for (int e = 0; e < 8; ++e) o[e] = v[p][e] * r * round_bf16((1.0f + sc[e])) + sh[e];
       st8(hout + (long long)row * D + c, o);
     }
   }
