@@ -131,6 +131,10 @@ int lap_colsum_f32(const float* x, float* out, int rows, int cols, int ld, void*
 
 /* Generic casts / copies / fills. */
 int lap_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream);
+/* hi = bf16(x), lo = bf16(x - hi) for x f32 [rows][cols] (row stride ld); outputs [rows][ld_out], ld_out % 8 == 0, zero
+   padded beyond `cols`.  Feeding (hi, lo) pairs to the bf16 MFMA GEMM with f32 accumulation reproduces the f32 SigLIP
+   stem (siglip_gemma3.py:398-408: conv + bias in f32) to ~2^-17 relative at MFMA speed. */
+int lap_split_f32_hilo(const float* x, int rows, int cols, int ld, void* hi, void* lo, int ld_out, void* stream);
 int lap_cast_bf16_to_f32(const void* x, float* y, long long n, void* stream);
 int lap_add_bf16(const void* a, const void* b, void* y, long long n, void* stream);
 /* Strided 2-D copy of bf16 rows: dst[r*ldd + c] = src[r*lds + c], c < cols. */

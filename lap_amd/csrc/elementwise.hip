@@ -233,6 +233,25 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     for (long long j = i; j < n; ++j) y[j] = f2bf(x[j]);
   }
 }
+// x f32 [rows][cols] (row stride ld) -> hi = bf16(x), lo = bf16(x - hi), both [rows][ld_out] with zero padding in the
+// columns [cols, ld_out).  hi + lo carries 16 mantissa bits of x: products of such pairs on the bf16 MFMA path, f32
+// accumulated, reproduce an f32 GEMM to ~2^-17 relative (used for the f32 SigLIP stem, siglip_gemma3.py:398-408).
+__global__ __launch_bounds__(256) void split_hilo_kernel(const float* __restrict__ x, int rows, int cols, int ld,
+                                                         bf16* __restrict__ hi, bf16* __restrict__ lo, int ld_out) {
+  const int cpr = ld_out / 8;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * cpr) return;
+  const int r = (int)(gid / cpr), c0 = (int)(gid % cpr) * 8;
+  float h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = (c0 + e < cols) ? x[(long long)r * ld + c0 + e] : 0.f;
+    h[e] = round_bf16(v);
+    l[e] = v - h[e];
+  }
+  st8(hi + (long long)r * ld_out + c0, h);
+  st8(lo + (long long)r * ld_out + c0, l);
+}
 __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, long long n) {
   const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
   if (i + 8 <= n) {
@@ -547,6 +566,13 @@ extern "C" int lap_colsum_f32(const float* x, float* out, int rows, int cols, in
 extern "C" int lap_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream) {
   if (n <= 0) return LAP_ERR_ARG;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, flat_grid((n + 7) / 8), dim3(256), 0, S_, x, (bf16*)y, n);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_split_f32_hilo(const float* x, int rows, int cols, int ld, void* hi, void* lo, int ld_out, void* stream) {
+  if (rows <= 0 || cols <= 0 || ld < cols || ld_out < cols || (ld_out & 7) || !x || !hi || !lo) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(split_hilo_kernel, flat_grid((long long)rows * (ld_out / 8)), dim3(256), 0, S_, x, rows, cols, ld, (bf16*)hi,
+                     (bf16*)lo, ld_out);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

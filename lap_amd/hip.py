@@ -87,6 +87,7 @@ SIGNATURES: dict[str, list] = {
     "lap_colsum_bf16": [_vp, _vp, _i, _i, _i, _vp],
     "lap_colsum_f32": [_vp, _vp, _i, _i, _i, _vp],
     "lap_cast_f32_to_bf16": [_vp, _vp, _ll, _vp],
+    "lap_split_f32_hilo": [_vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "lap_cast_bf16_to_f32": [_vp, _vp, _ll, _vp],
     "lap_add_bf16": [_vp, _vp, _vp, _ll, _vp],
     "lap_copy2d_bf16": [_vp, _vp, _i, _i, _i, _i, _vp],
@@ -210,6 +211,17 @@ def linear_wgrad(dy, x, out, *, accum=False, ksplit=0, tile=-1):
     Kin = x.shape[1]
     return gemm(dy, x, out, M=Nout, N=Kin, K=Mrows, lda=dy.stride(0), ldb=x.stride(0), ldc=out.stride(0), a_kc=False,
                 b_kc=False, accum=accum, ksplit=ksplit, tile=tile)
+
+
+def split_f32_hilo(x, ld_out=None):
+    """x f32 [rows, cols] -> (hi, lo) bf16 [rows, ld_out] with hi + lo ~ x (16 mantissa bits), zero padded columns."""
+    _req(x, torch.float32, "x")
+    rows, cols = x.shape
+    ld_out = (cols + 7) // 8 * 8 if ld_out is None else ld_out
+    hi = torch.empty((rows, ld_out), dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty_like(hi)
+    call("lap_split_f32_hilo", _p(x), rows, cols, x.stride(0), _p(hi), _p(lo), ld_out)
+    return hi, lo
 
 
 def argmax_rows(x, out=None):

@@ -110,13 +110,22 @@ class LAP:
         hd = W // s.num_heads
         ctx = {"blocks": []} if save else None
         patches = hip.im2col_patch(images.contiguous(), s.patch)
-        stem = self._lin32(patches, "img/stem_w", "img/stem_b")
+        # f32 stem (siglip_gemma3.py:398-408) on the MFMA path: x = hi + lo (2 x bf16, 16 mantissa bits), products exact
+        # in the f32 accumulator, the lo.lo term (2^-18 relative) dropped
+        p_hi, p_lo = hip.split_f32_hilo(patches)
+        w_hi, w_lo = hip.split_f32_hilo(self.F("img/stem_w"))
+        del patches
+        stem = torch.empty((p_hi.shape[0], W), dtype=torch.float32, device=p_hi.device)
+        R, Kp = p_hi.shape
+        hip.gemm(p_hi, w_hi, stem, M=R, N=W, K=Kp, lda=Kp, ldb=Kp, ldc=W, bias=self.F("img/stem_b"))
+        hip.gemm(p_hi, w_lo, stem, M=R, N=W, K=Kp, lda=Kp, ldb=Kp, ldc=W, accum=True)
+        hip.gemm(p_lo, w_hi, stem, M=R, N=W, K=Kp, lda=Kp, ldb=Kp, ldc=W, accum=True)
         x = hip.add_posemb_cast(stem, self.F("img/pos"), T)
         del stem
         if collect is not None:
             collect["img/stem"] = x
         if save:
-            ctx["patches"] = patches
+            ctx["patches"] = (p_hi, p_lo)
         for l in range(s.depth):
             self.comm.wait_unit(f"img{l}")
             p = f"img/{l}/"
@@ -180,8 +189,14 @@ class LAP:
             hip.layernorm_bwd(x, dy, self.F(p + "ln1_g"), mean1, rstd1, self.G(p + "ln1_g"), self.G(p + "ln1_b"), dx=dx, accum_dx=True)
             ctx["blocks"][l] = None
             self.comm.grads_ready(f"img{l}")
-        dstem = hip.add_posemb_cast_bwd(dx, self.G("img/pos"), T)
-        self._lin32_bwd(ctx["patches"], dstem, "img/stem_w", "img/stem_b", need_dx=False)
+        dstem = hip.add_posemb_cast_bwd(dx, self.G("img/pos"), T)     # f32 copy of a bf16 gradient: exact in bf16
+        p_hi, p_lo = ctx["patches"]
+        gw = self.G("img/stem_w")
+        tmp = torch.empty((gw.shape[0], p_hi.shape[1]), dtype=torch.float32, device=gw.device)   # [W, 592]
+        hip.linear_wgrad(dx, p_hi, tmp)
+        hip.linear_wgrad(dx, p_lo, tmp, accum=True)
+        gw.add_(tmp[:, :gw.shape[1]])
+        hip.colsum(dstem, self.G("img/stem_b"))
 
     # ================================================================== token info words / positions
     def _prefix_masks(self, obs: CoTObservation):

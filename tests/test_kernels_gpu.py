@@ -445,6 +445,22 @@ def test_attention_fused_qkv_strided(hip):
     assert rel_err(dqkv.view(B, T, 3, NH, HD), x.grad) < 2e-2
 
 
+def test_split_hilo_reproduces_f32_gemm(hip):
+    # the f32 SigLIP stem on the MFMA path: x = hi + lo; hi.hi + hi.lo + lo.hi with f32 accumulation ~ f32 GEMM
+    R, K, N = 300, 588, 96
+    x = rnd(R, K, dtype=torch.float32, seed=1); w = rnd(N, K, dtype=torch.float32, seed=2)
+    xh, xl = hip.split_f32_hilo(x); wh, wl = hip.split_f32_hilo(w)
+    assert xh.shape == (R, 592) and torch.equal(xh[:, K:], torch.zeros_like(xh[:, K:])) and torch.equal(xl[:, K:], torch.zeros_like(xl[:, K:]))
+    assert torch.equal(xh[:, :K], x.bfloat16()) and rel_err(xh[:, :K].float() + xl[:, :K].float(), x) < 2e-5
+    out = torch.empty(R, N, dtype=torch.float32, device=DEV)
+    hip.gemm(xh, wh, out, M=R, N=N, K=592, lda=592, ldb=592, ldc=N)
+    hip.gemm(xh, wl, out, M=R, N=N, K=592, lda=592, ldb=592, ldc=N, accum=True)
+    hip.gemm(xl, wh, out, M=R, N=N, K=592, lda=592, ldb=592, ldc=N, accum=True)
+    ref = x.double() @ w.double().t()
+    assert rel_err(out, ref) < 3e-5                      # vs 4e-3 for a plain bf16 GEMM
+    assert rel_err(xh[:, :K].float() @ wh[:, :K].float().t(), ref) > 1e-3
+
+
 def test_colsum(hip):
     x = rnd(300, 200); out = torch.zeros(136, device=DEV)
     hip.colsum(x[:, 8:144], out)
