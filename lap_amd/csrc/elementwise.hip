@@ -317,19 +317,38 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
   const int r0 = blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool vec = (c0 + 8 <= cols) && ((ld * (int)sizeof(T)) % 16 == 0) && ((((uintptr_t)x) & 15) == 0) && (c0 * (int)sizeof(T)) % 16 == 0;
-  for (int r = r0 + w; r < r1; r += 4) {
-    const T* row = x + (long long)r * ld;
-    if (vec) {
+  if (vec) {
+    // 8 row loads in flight per wave (rows r, r+4, .. r+28), then the adds: the plain loop had one load in flight
+    for (int r = r0 + w; r < r1; r += 32) {
       if constexpr (sizeof(T) == 2) {
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(row + c0);
+        bf16x8 v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        for (int u = 0; u < 8; ++u) {
+          const int rr = r + 4 * u;
+          v[u] = rr < r1 ? *reinterpret_cast<const bf16x8*>(x + (long long)rr * ld + c0) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += (float)v[u][e];
       } else {
-        f32x4 a = *reinterpret_cast<const f32x4*>(row + c0), b = *reinterpret_cast<const f32x4*>(row + c0 + 4);
+        f32x4 a[8], b[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { acc[e] += a[e]; acc[4 + e] += b[e]; }
+        for (int u = 0; u < 8; ++u) {
+          const int rr = r + 4 * u;
+          const bool ok = rr < r1;
+          a[u] = ok ? *reinterpret_cast<const f32x4*>(x + (long long)rr * ld + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+          b[u] = ok ? *reinterpret_cast<const f32x4*>(x + (long long)rr * ld + c0 + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { acc[e] += a[u][e]; acc[4 + e] += b[u][e]; }
       }
-    } else {
+    }
+  } else {
+    for (int r = r0 + w; r < r1; r += 4) {
+      const T* row = x + (long long)r * ld;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         if (c0 + e < cols) acc[e] += (float)row[c0 + e];
