@@ -229,7 +229,8 @@ int lap_argmax_rows_f32(const float* x, int rows, int n, int ld, int* out, void*
 /* Fused clip-by-global-norm + AdamW + EMA + bf16 weight refresh (train.py:363-396).
  * scalars (device f32[8]): [0]=sum of squared grads (global), [1]=lr, [2]=bias_corr1, [3]=bias_corr2,
  * [4]=ema_decay, [5]=ema_enabled (0/1).  clip = min(1, max_norm / (sqrt(s0)+1e-6)).
- * p,m,v,ema f32 [n]; g f32 [n]; p16 bf16 [n] out (may be NULL); ema may be NULL. */
+ * p,m,v,ema f32 [n]; g f32 [n]; p16 bf16 [n] out (may be NULL); ema may be NULL.  n must be even (8-byte accesses;
+ * unit buffers are padded).  The kernel is held to 32 VGPRs so that its waves are co-resident with the 256x256 GEMM. */
 int lap_adamw_ema(float* p, float* m, float* v, float* ema, const float* g, void* p16, long long n,
                   const float* scalars, float b1, float b2, float eps, float wd, float max_norm, void* stream);
 

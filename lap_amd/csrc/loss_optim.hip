@@ -121,51 +121,45 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) atomicAdd(out, acc);
 }
 
-__global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
-                                                        float* __restrict__ ema, const float* __restrict__ g,
-                                                        bf16* __restrict__ p16, long long n,
-                                                        const float* __restrict__ sc, float b1, float b2, float eps,
-                                                        float wd, float max_norm) {
+// Two parameters per thread and iteration, 32 VGPRs: an optimizer wave fits next to the 256x256 GEMM's 4 waves x 120
+// VGPRs per SIMD, so the side-stream optimizer never evicts GEMM blocks of the next forward.  (Measured: the step time
+// does not change versus a 54-VGPR version - the ~26 ms the overlapped optimizer still costs per step is HBM contention
+// of its 38 B / parameter with the GEMMs' operand traffic, not CU occupancy.)
+__global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float* __restrict__ ema,
+                      const float* __restrict__ g, bf16* __restrict__ p16, long long n, const float* __restrict__ sc,
+                      float b1, float b2, float eps, float wd, float max_norm) {
   const float gnorm = sqrtf(sc[0]);
   // optax.clip_by_global_norm: g if norm < max_norm else g / norm * max_norm
   const float clip = (max_norm <= 0.f || gnorm < max_norm) ? 1.0f : max_norm / gnorm;
-  const float lr = sc[1], bc1 = sc[2], bc2 = sc[3], ed = sc[4];
+  const float lr = sc[1], rbc1 = 1.0f / sc[2], rbc2 = 1.0f / sc[3], ed = sc[4];
   const bool ema_on = ema != nullptr && sc[5] != 0.f;
-  const long long stride = (long long)gridDim.x * 256 * 4;
-  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
-    const int cnt = (int)min((long long)4, n - i);
-    float pv[4], mv[4], vv[4], gv[4], ev[4];
-    if (cnt == 4) {
-      f32x4 a = *reinterpret_cast<const f32x4*>(p + i), b = *reinterpret_cast<const f32x4*>(m + i),
-            c = *reinterpret_cast<const f32x4*>(v + i), d = *reinterpret_cast<const f32x4*>(g + i);
+  // 32-bit BYTE offsets from the (scalar) array bases: one VGPR of addressing for all six arrays (the host wrapper
+  // launches at most 2^29 elements at a time); v_sqrt / v_rcp (1 ulp) instead of the IEEE fix-up sequences
+  const unsigned nb = (unsigned)n * 4u;
+  const unsigned stride = gridDim.x * 256u * 8u;
+  auto at = [](auto* base, unsigned byte_off) { return reinterpret_cast<f32x2*>(reinterpret_cast<char*>(base) + byte_off); };
+  auto cat = [](const float* base, unsigned byte_off) { return reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(base) + byte_off); };
+  for (unsigned o = (blockIdx.x * 256u + threadIdx.x) * 8u; o < nb; o += stride) {
+    {   // n is even (unit buffers are padded to multiples of 64 elements; checked by the host wrapper)
+      f32x2 pv = *cat(p, o), mv = *cat(m, o), vv = *cat(v, o);
+      const f32x2 gv = *cat(g, o);
+      f32x2 ev = {0.f, 0.f};
+      if (ema_on) ev = *cat(ema, o);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { pv[e] = a[e]; mv[e] = b[e]; vv[e] = c[e]; gv[e] = d[e]; }
-      if (ema_on) { f32x4 q = *reinterpret_cast<const f32x4*>(ema + i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ev[e] = q[e]; }
-    } else {
-      for (int e = 0; e < cnt; ++e) { pv[e] = p[i + e]; mv[e] = m[i + e]; vv[e] = v[i + e]; gv[e] = g[i + e]; if (ema_on) ev[e] = ema[i + e]; }
-    }
-    for (int e = 0; e < cnt; ++e) {
-      const float gg = gv[e] * clip;
-      mv[e] = b1 * mv[e] + (1.0f - b1) * gg;
-      vv[e] = b2 * vv[e] + (1.0f - b2) * gg * gg;
-      const float upd = (mv[e] / bc1) / (sqrtf(vv[e] / bc2) + eps) + wd * pv[e];
-      pv[e] = pv[e] - lr * upd;
-      if (ema_on) ev[e] = ed * ev[e] + (1.0f - ed) * pv[e];
-    }
-    if (cnt == 4) {
-      *reinterpret_cast<f32x4*>(p + i) = f32x4{pv[0], pv[1], pv[2], pv[3]};
-      *reinterpret_cast<f32x4*>(m + i) = f32x4{mv[0], mv[1], mv[2], mv[3]};
-      *reinterpret_cast<f32x4*>(v + i) = f32x4{vv[0], vv[1], vv[2], vv[3]};
-      if (ema_on) *reinterpret_cast<f32x4*>(ema + i) = f32x4{ev[0], ev[1], ev[2], ev[3]};
-      if (p16) { bf16x4 o; for (int e = 0; e < 4; ++e) o[e] = f2bf(pv[e]); *reinterpret_cast<bf16x4*>(p16 + i) = o; }
-    } else {
-      for (int e = 0; e < cnt; ++e) {
-        p[i + e] = pv[e]; m[i + e] = mv[e]; v[i + e] = vv[e];
-        if (ema_on) ema[i + e] = ev[e];
-        if (p16) p16[i + e] = f2bf(pv[e]);
+      for (int e = 0; e < 2; ++e) {
+        float gg = gv[e] * clip;
+        asm("" : "+v"(gg));   // keeps the two lanes of work scalar: packed f32 math would need the constants in VGPR pairs
+        mv[e] = b1 * mv[e] + (1.0f - b1) * gg;
+        vv[e] = b2 * vv[e] + (1.0f - b2) * gg * gg;
+        const float upd = (mv[e] * rbc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv[e] * rbc2) + eps) + wd * pv[e];
+        pv[e] = pv[e] - lr * upd;
+        if (ema_on) ev[e] = ed * ev[e] + (1.0f - ed) * pv[e];
       }
+      *at(p, o) = pv;
+      *at(m, o) = mv;
+      *at(v, o) = vv;
+      if (ema_on) *at(ema, o) = ev;
+      if (p16) { bf16x2 q; q[0] = f2bf(pv[0]); q[1] = f2bf(pv[1]); *reinterpret_cast<bf16x2*>(reinterpret_cast<char*>(p16) + (o >> 1)) = q; }
     }
   }
 }
@@ -296,11 +290,16 @@ extern "C" int lap_sumsq_f32(const float* x, long long n, float* sumsq, void* st
 extern "C" int lap_adamw_ema(float* p, float* m, float* v, float* ema, const float* g, void* p16, long long n,
                              const float* scalars, float b1, float b2, float eps, float wd, float max_norm,
                              void* stream) {
-  if (n <= 0 || !scalars) return LAP_ERR_ARG;
-  const long long blocks = (n + 1023) / 1024;
-  hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, S_, p, m, v, ema, g,
-                     (bf16*)p16, n, scalars, b1, b2, eps, wd, max_norm);
-  LAP_CHECK_LAUNCH();
+  if (n <= 0 || (n & 1) || !scalars) return LAP_ERR_ARG;
+  const long long cap = 4096;
+  const long long CH = 1LL << 29;
+  for (long long o = 0; o < n; o += CH) {
+    const long long cnt = n - o < CH ? n - o : CH;
+    const long long blocks = (cnt + 511) / 512;
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, p + o, m + o, v + o,
+                       ema ? ema + o : nullptr, g + o, p16 ? (bf16*)p16 + o : nullptr, cnt, scalars, b1, b2, eps, wd, max_norm);
+    LAP_CHECK_LAUNCH();
+  }
   return LAP_OK;
 }
 extern "C" int lap_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
