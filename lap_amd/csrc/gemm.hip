@@ -297,79 +297,74 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 // Ping-pong 256x256x64 kernel: 8 waves (2 x 4), 128x64 per wave, one block per CU.  Each k-tile is cut into four
 // phases (one 64x32 quadrant of the wave's output x K = 64 = 16 MFMAs); a phase is
-//     [ds_read the fragments this quadrant needs | issue the next k-tile's LDS-DMA]  barrier  [16 MFMAs]  barrier
+//     [ds_read the fragments this quadrant needs | issue ONE half-tile of LDS-DMA | counted vmcnt]  barrier
+//     [16 MFMAs]  barrier
 // and the second wave row runs one barrier behind the first, so on every SIMD one wave is in its MFMA segment while
 // its partner is in its LDS segment: the matrix pipe and the LDS port work concurrently by construction instead of
 // by luck of the wave scheduler.  Quadrant order (0,0) (0,1) (1,1) (1,0) reuses the A half for two phases and keeps
-// both B halves in registers: 12 / 4 / 8 / 0 ds_read_b128 per phase.  The next tile's loads are issued in phase 1
-// and waited for (vmcnt(0)) in phase 4's LDS segment, one barrier before they are read.
+// both B halves in registers: 12 / 4 / 8 / 0 ds_read_b128 per phase.
+// Staging granularity is the HALF tile (the 128 rows of A, or 128 columns of B, that one quadrant row / column
+// reads: a 16 KiB image, 2 LDS-DMA pieces per wave), 8 slots = 2 k-tiles.  A half is dead as soon as its quadrant
+// has been read, so it is refilled with the k-tile after next: phase 1 issues B1(kt+1), phase 2 A1(kt+1), phase 3
+// A0(kt+2), phase 4 B0(kt+2) - every half is requested five phases (1.25 k-tiles) before its first reader and four
+// halves (64 KiB per block) are in flight at every wait, which is always the same `s_waitcnt vmcnt(8)` (never 0
+// inside the loop; past the end of K the pieces are out-of-range buffer loads, i.e. zero fills without traffic).
+// Ordering: a wait in the LDS segment of phase p makes the half visible to readers from phase p + 1 on (one barrier
+// more than usual because the two groups are a barrier apart); a half is refilled at the earliest two phases after
+// its last read.  All fragment reads are raw (common.hpp), fenced by the lgkmcnt(0) that opens the MFMA segment.
 template <bool A_KC, bool B_KC, bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
-  constexpr int BM = 256, BN = 256, BK = 64, NW = 8;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 256, BN = 256, BK = 64, HALF = 128 * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // slot (buf, h): h = 0 A0, 1 A1, 2 B0, 3 B1
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 2, wn = w & 3;   // waves 0-3: row 0 (leading group), waves 4-7: row 1 (one barrier behind)
 
-  const int nblk = p.tiles_m * p.tiles_n;
-  const int t = xcd_remap(blockIdx.x, nblk);
-  constexpr int GM = 4;
-  const int group_sz = GM * p.tiles_n;
-  const int first_m = (t / group_sz) * GM;
-  const int gm = min(p.tiles_m - first_m, GM);
-  const int tm = first_m + (t % group_sz) % gm;
-  const int tn = (t % group_sz) / gm;
+  const int t = p.tile_base + xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  tile_coords<4>(p, t, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   auto rsA = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.A, 0, (int)min((long long)(A_KC ? p.M : p.K) * p.lda * 2, 0x7fffffffLL), 0x00020000);
   auto rsB = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.B, 0, (int)min((long long)(B_KC ? p.N : p.K) * p.ldb * 2, 0x7fffffffLL), 0x00020000);
-  unsigned offA[PA], offB[PB];
-  int kidxA[PA], kidxB[PB];
+  // Half images.  A half mh holds the rows {wm' * 128 + mh * 64 + r} at local index wm' * 64 + r; B half nh holds the
+  // columns {wn' * 64 + nh * 32 + c} at local index wn' * 32 + c.  K-contiguous: [128 rows][64 k]; M-contiguous:
+  // [64 k][128 m].  Piece q = 2 w + j covers linear 16-byte chunks [64 q, 64 q + 64) of the image.
+  unsigned off[4][2];
+  int kidxA[2], kidxB[2];
 #pragma unroll
-  for (int j = 0; j < PA; ++j) {
-    const int ci = (w * PA + j) * 64 + lane;
-    if (A_KC) {
-      const int row = ci >> 3, pc = ci & 7, c = pc ^ ((row >> 1) & 7);
-      kidxA[j] = c * 8;
-      offA[j] = (m0 + row < p.M) ? (unsigned)(((long long)(m0 + row) * p.lda + c * 8) * 2) : OOB;
-    } else {
-      const int kr = ci / (BM / 8), pc = ci % (BM / 8), c = pc ^ (mc_swz(kr) << 1);
-      kidxA[j] = kr;
-      offA[j] = (m0 + c * 8 < p.M) ? (unsigned)(((long long)kr * p.lda + m0 + c * 8) * 2) : OOB;
-    }
-  }
+  for (int j = 0; j < 2; ++j) {
+    const int ci = (w * 2 + j) * 64 + lane;
+    int la, ca, lb, cb;   // local row / column index, logical 16-byte chunk
+    if (A_KC) { la = ci >> 3; ca = (ci & 7) ^ ((la >> 1) & 7); kidxA[j] = ca * 8; }
+    else { const int kr = ci >> 4; ca = (ci & 15) ^ (mc_swz(kr) << 1); la = ca * 8; kidxA[j] = kr; }
+    if (B_KC) { lb = ci >> 3; cb = (ci & 7) ^ ((lb >> 1) & 7); kidxB[j] = cb * 8; }
+    else { const int kr = ci >> 4; cb = (ci & 15) ^ (mc_swz(kr) << 1); lb = cb * 8; kidxB[j] = kr; }
 #pragma unroll
-  for (int j = 0; j < PB; ++j) {
-    const int ci = (w * PB + j) * 64 + lane;
-    if (B_KC) {
-      const int row = ci >> 3, pc = ci & 7, c = pc ^ ((row >> 1) & 7);
-      kidxB[j] = c * 8;
-      offB[j] = (n0 + row < p.N) ? (unsigned)(((long long)(n0 + row) * p.ldb + c * 8) * 2) : OOB;
-    } else {
-      const int kr = ci / (BN / 8), pc = ci % (BN / 8), c = pc ^ (mc_swz(kr) << 1);
-      kidxB[j] = kr;
-      offB[j] = (n0 + c * 8 < p.N) ? (unsigned)(((long long)kr * p.ldb + n0 + c * 8) * 2) : OOB;
+    for (int h = 0; h < 2; ++h) {
+      const int gm = m0 + (la >> 6) * 128 + h * 64 + (la & 63);
+      const int gn = n0 + (lb >> 5) * 64 + h * 32 + (lb & 31);
+      off[h][j] = gm < p.M ? (unsigned)((A_KC ? (long long)gm * p.lda + ca * 8 : (long long)kidxA[j] * p.lda + gm) * 2) : OOB;
+      off[2 + h][j] = gn < p.N ? (unsigned)((B_KC ? (long long)gn * p.ldb + cb * 8 : (long long)kidxB[j] * p.ldb + gn) * 2) : OOB;
     }
   }
   const unsigned stepA = A_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.lda * 2);
   const unsigned stepB = B_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.ldb * 2);
-  auto stage = [&](int buf, int kt) {
-    const int k0 = kt * BK;
-    char* base = smem + buf * STAGE;
+
+  const int nkt_all = (p.K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * p.ktiles_per_split;
+  const int kt1 = min(nkt_all, kt0 + p.ktiles_per_split);
+  const int kend = min(p.K, kt1 * BK);
+  auto issue = [&](int buf, int h, int kt) {
+    char* base = smem + (buf * 4 + h) * HALF + w * 2048;
 #pragma unroll
-    for (int j = 0; j < PA; ++j) {
-      unsigned va = (offA[j] != OOB && k0 + kidxA[j] < p.K) ? offA[j] + (unsigned)kt * stepA : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(base + (w * PA + j) * 1024), 16, va, 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-      unsigned vb = (offB[j] != OOB && k0 + kidxB[j] < p.K) ? offB[j] + (unsigned)kt * stepB : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(base + A_BYTES + (w * PB + j) * 1024), 16, vb, 0, 0, 0);
+    for (int j = 0; j < 2; ++j) {
+      const int kidx = h < 2 ? kidxA[j] : kidxB[j];
+      const unsigned v = (off[h][j] != OOB && kt * BK + kidx < kend) ? off[h][j] + (unsigned)kt * (h < 2 ? stepA : stepB) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(h < 2 ? rsA : rsB, (LDS_PTR(void))(base + j * 1024), 16, v, 0, 0, 0);
     }
   };
 
@@ -379,70 +374,105 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nkt_all = (p.K + BK - 1) / BK;
-  const int kt0 = blockIdx.y * p.ktiles_per_split;
-  const int kt1 = min(nkt_all, kt0 + p.ktiles_per_split);
-
-  bf16x8 fa[4][2], fb[2][2][2];   // A half: [m-frag][kk]; B: [n-half][n-frag][kk]
-  auto load_a = [&](const char* tA, int mh) {
+  bf16x8 fa[4][2], fb[2][2][2];                               // A half: [m-frag][kk]; B: [n-half][n-frag][kk]
+  bf16x4 ra[A_KC ? 1 : 4][2][2], rb[B_KC ? 1 : 2][2][2][2];   // transposing reads arrive as two 64-bit halves
+  auto read_a = [&](const char* img) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        fa[i][kk] = A_KC ? kc_frag(tA, wm * 128 + mh * 64 + i * 16, kk, lane) : mc_frag<BM>(tA, wm * 128 + mh * 64 + i * 16, kk, lane);
+      for (int kk = 0; kk < 2; ++kk) {
+        if (A_KC) fa[i][kk] = kc_frag_raw(img, wm * 64 + i * 16, kk, lane);
+        else mc_frag_raw<128>(img, wm * 64 + i * 16, kk, lane, ra[A_KC ? 0 : i][kk]);
+      }
   };
-  auto load_b = [&](const char* tB, int nh) {
+  auto read_b = [&](const char* img, int nh) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        fb[nh][j][kk] = B_KC ? kc_frag(tB, wn * 64 + nh * 32 + j * 16, kk, lane) : mc_frag<BN>(tB, wn * 64 + nh * 32 + j * 16, kk, lane);
+      for (int kk = 0; kk < 2; ++kk) {
+        if (B_KC) fb[nh][j][kk] = kc_frag_raw(img, wn * 32 + j * 16, kk, lane);
+        else mc_frag_raw<128>(img, wn * 32 + j * 16, kk, lane, rb[B_KC ? 0 : nh][j][kk]);
+      }
   };
+  auto tie_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if (A_KC) lds_tie(fa[i][kk]);
+        else { lds_tie(ra[A_KC ? 0 : i][kk][0]); lds_tie(ra[A_KC ? 0 : i][kk][1]); fa[i][kk] = join8(ra[A_KC ? 0 : i][kk][0], ra[A_KC ? 0 : i][kk][1]); }
+      }
+  };
+  auto tie_b = [&](int nh) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if (B_KC) lds_tie(fb[nh][j][kk]);
+        else {
+          lds_tie(rb[B_KC ? 0 : nh][j][kk][0]); lds_tie(rb[B_KC ? 0 : nh][j][kk][1]);
+          fb[nh][j][kk] = join8(rb[B_KC ? 0 : nh][j][kk][0], rb[B_KC ? 0 : nh][j][kk][1]);
+        }
+      }
+  };
+#define PP_BAR() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
 #define PP_MMA(MH, NH)                                                                         \
   {                                                                                            \
-    __builtin_amdgcn_s_barrier();                                                              \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
     __builtin_amdgcn_s_setprio(1);                                                             \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                           \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
           acc[MH * 4 + i][NH * 2 + j] = mfma16(fb[NH][j][kk], fa[i][kk], acc[MH * 4 + i][NH * 2 + j]); \
     __builtin_amdgcn_s_setprio(0);                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    __builtin_amdgcn_s_barrier();                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
   }
 
-  if (kt0 < kt1) {
-    stage(0, kt0);
-    wait_vmcnt<0>();
-  }
-  __builtin_amdgcn_s_barrier();               // tile kt0 visible to everybody
+  // prologue: the six halves the steady state would already have requested, in its order
+  issue(0, 0, kt0); issue(0, 2, kt0); issue(0, 3, kt0); issue(0, 1, kt0); issue(1, 0, kt0 + 1); issue(1, 2, kt0 + 1);
+  wait_vmcnt<8>();                            // A0, B0 of the first k-tile
+  PP_BAR()
   if (wm == 1) __builtin_amdgcn_s_barrier();  // second wave row drops one barrier behind
   __builtin_amdgcn_sched_barrier(0);
-  int cur = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
-    const char* tA = smem + cur * STAGE;
-    const char* tB = tA + A_BYTES;
+    const int buf = (kt - kt0) & 1;
+    const char* img = smem + buf * 4 * HALF;
     // phase 1: quadrant (0,0)
-    load_a(tA, 0);
-    load_b(tB, 0);
-    if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
+    read_a(img);
+    read_b(img + 2 * HALF, 0);
+    issue(buf ^ 1, 3, kt + 1);
+    wait_vmcnt<8>();                          // B1(kt) for phase 2
+    PP_BAR()
+    lds_wait_all();
+    tie_a(); tie_b(0);
     PP_MMA(0, 0)
+    PP_BAR()
     // phase 2: quadrant (0,1)
-    load_b(tB, 1);
+    read_b(img + 3 * HALF, 1);
+    issue(buf ^ 1, 1, kt + 1);
+    wait_vmcnt<8>();                          // A1(kt) for phase 3
+    PP_BAR()
+    lds_wait_all();
+    tie_b(1);
     PP_MMA(0, 1)
+    PP_BAR()
     // phase 3: quadrant (1,1)
-    load_a(tA, 1);
+    read_a(img + HALF);
+    issue(buf, 0, kt + 2);
+    PP_BAR()
+    lds_wait_all();
+    tie_a();
     PP_MMA(1, 1)
-    // phase 4: quadrant (1,0) — nothing to read; retire the prefetch one barrier before its first reader
-    wait_vmcnt<0>();
+    PP_BAR()
+    // phase 4: quadrant (1,0): nothing to read
+    issue(buf, 2, kt + 2);
+    wait_vmcnt<8>();                          // A0, B0 of the next k-tile
+    PP_BAR()
     PP_MMA(1, 0)
-    cur ^= 1;
+    PP_BAR()
   }
+  wait_vmcnt<0>();
   if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
 #undef PP_MMA
+#undef PP_BAR
 
   const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
@@ -472,7 +502,8 @@ int launch_pp(GemmParams p, hipStream_t s) {
   p.tiles_n = (p.N + 255) / 256;
   const int nkt = (p.K + 63) / 64;
   p.ktiles_per_split = (nkt + p.ksplit - 1) / p.ksplit;
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.ksplit), dim3(512), LDS, s, p);
+  const int count = p.tile_count > 0 ? p.tile_count : p.tiles_m * p.tiles_n - p.tile_base;
+  hipLaunchKernelGGL(kern, dim3(count, p.ksplit), dim3(512), LDS, s, p);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

@@ -447,7 +447,7 @@ def attention_fwd(q, k, v, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None,
     if nsplit_hint is not None:
         nsplit = nsplit_hint
     elif blocks < 128 and ntk > 1:
-        nsplit = min(ntk, max(1, 256 // blocks))
+        nsplit = min((ntk + 1) // 2, max(1, 256 // blocks))   # >= 128 keys per split: the combine cost grows with the split count
     a.nsplit = nsplit
     if nsplit > 1:
         scratch = torch.empty(nsplit * B * Tq * NH * (HD + 1), dtype=torch.float32, device=dev)

@@ -69,6 +69,21 @@ def test_gemm_tiles_all_layouts(hip, tile):
     assert torch.equal(hip.linear_fwd(a2, w2, tile=tile), w2.t().contiguous())
 
 
+def test_gemm_pingpong_matches_single_phase_bitwise(hip):
+    """Tile 8 (ping-pong, half-tile staging with counted waits) accumulates in the same order as tile 2: any race in
+    its LDS-DMA / read ordering shows up as a bit difference.  Shapes with 1, 2, 3 and many k-tiles, all layouts."""
+    for rep in range(2):
+        for (m, n, k) in [(2048, 2304, 4096), (2000, 3000, 1096), (256, 256, 64), (256, 256, 128), (304, 264, 192)]:
+            a = rnd(m, k, seed=rep); w = rnd(n, k, seed=rep + 10)
+            assert torch.equal(hip.linear_fwd(a, w, tile=8), hip.linear_fwd(a, w, tile=2))
+            w2 = rnd(k, n, seed=rep + 20)
+            assert torch.equal(hip.linear_dgrad(a, w2, tile=8), hip.linear_dgrad(a, w2, tile=2))
+            dy = rnd(k, m, seed=rep + 30); x = rnd(k, n, seed=rep + 40)
+            g8 = torch.empty(m, n, device=DEV); g2 = torch.empty(m, n, device=DEV)
+            hip.linear_wgrad(dy, x, g8, tile=8); hip.linear_wgrad(dy, x, g2, tile=2)
+            assert torch.equal(g8, g2)
+
+
 def test_gemm_tail_split(hip):
     # more than one round of 256x256 tiles with a poorly filled last round: the full rounds run unsplit, the tail
     # tiles are split along K into compact slabs and reduced (partial tiles in M and N included)

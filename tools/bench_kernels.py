@@ -46,7 +46,7 @@ def bench_gemms():
             dy = rnd(m, n); x = rnd(m, k); out = torch.empty(n, k, dtype=torch.float32, device=dev)
             fn = lambda: hip.linear_wgrad(dy, x, out)
         res = []
-        for tile in (5, 6, -1):
+        for tile in (5, 2, 8):
             if kind == "fwd":
                 fn = lambda: hip.linear_fwd(a, w, out, tile=tile)
             elif kind == "dgrad":
@@ -55,6 +55,16 @@ def bench_gemms():
                 fn = lambda: hip.linear_wgrad(dy, x, out, tile=tile)
             t = timeit(fn, iters=10)
             res.append(f"t{tile}: {t*1e3:7.3f} ms {2*m*n*k/t/1e12:6.0f} TF")
+        # calibration only: the vendor library (torch.matmul -> hipBLASLt) on the same product
+        if kind == "fwd":
+            vf = lambda: torch.matmul(a, w.t(), out=out)
+        elif kind == "dgrad":
+            vf = lambda: torch.matmul(a, w, out=out)
+        else:
+            o16 = torch.empty(n, k, dtype=torch.bfloat16, device=dev)
+            vf = lambda: torch.matmul(dy.t(), x, out=o16)
+        t = timeit(vf, iters=10)
+        res.append(f"hipBLASLt: {t*1e3:7.3f} ms {2*m*n*k/t/1e12:6.0f} TF")
         print(f"gemm {name:14s} {kind:5s} M={m} N={n} K={k}: " + " | ".join(res), flush=True)
 
 
