@@ -195,14 +195,14 @@ def linear_fwd(x, wt, out=None, *, bias=None, residual=None, gelu=False, out_dty
                 ksplit=ksplit)
 
 
-def linear_dgrad(dy, wt, out=None, *, out_dtype=torch.bfloat16, accum=False, tile=-1):
+def linear_dgrad(dy, wt, out=None, *, out_dtype=torch.bfloat16, accum=False, tile=-1, ksplit=0):
     """dx[M,in] = dy[M,out] @ wt[out,in]."""
     M, K = dy.shape
     N = wt.shape[1]
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=dy.device)
     return gemm(dy, wt, out, M=M, N=N, K=K, lda=dy.stride(0), ldb=wt.stride(0), ldc=out.stride(0), a_kc=True,
-                b_kc=False, accum=accum, tile=tile)
+                b_kc=False, accum=accum, tile=tile, ksplit=ksplit)
 
 
 def linear_wgrad(dy, x, out, *, accum=False, ksplit=0, tile=-1):

@@ -75,12 +75,12 @@ def test_gemm_pingpong_matches_single_phase_bitwise(hip):
     for rep in range(2):
         for (m, n, k) in [(2048, 2304, 4096), (2000, 3000, 1096), (256, 256, 64), (256, 256, 128), (304, 264, 192)]:
             a = rnd(m, k, seed=rep); w = rnd(n, k, seed=rep + 10)
-            assert torch.equal(hip.linear_fwd(a, w, tile=8), hip.linear_fwd(a, w, tile=2))
+            assert torch.equal(hip.linear_fwd(a, w, tile=8, ksplit=1), hip.linear_fwd(a, w, tile=2, ksplit=1))
             w2 = rnd(k, n, seed=rep + 20)
-            assert torch.equal(hip.linear_dgrad(a, w2, tile=8), hip.linear_dgrad(a, w2, tile=2))
+            assert torch.equal(hip.linear_dgrad(a, w2, tile=8, ksplit=1), hip.linear_dgrad(a, w2, tile=2, ksplit=1))
             dy = rnd(k, m, seed=rep + 30); x = rnd(k, n, seed=rep + 40)
             g8 = torch.empty(m, n, device=DEV); g2 = torch.empty(m, n, device=DEV)
-            hip.linear_wgrad(dy, x, g8, tile=8); hip.linear_wgrad(dy, x, g2, tile=2)
+            hip.linear_wgrad(dy, x, g8, tile=8, ksplit=1); hip.linear_wgrad(dy, x, g2, tile=2, ksplit=1)
             assert torch.equal(g8, g2)
 
 
