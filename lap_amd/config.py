@@ -258,6 +258,7 @@ class RLDSDataConfig:
     val_fraction: float = 0.02
     random_base_prob: float = 0.0
     max_samples: int | None = None
+    action_proprio_normalization_type: str = "bounds_q99"   # config.py:98-99 (normal | bounds | bounds_q99)
 
 
 @dataclasses.dataclass(frozen=True)

@@ -85,9 +85,32 @@ class CoTObservation:
         return CoTObservation(**{k: (v if k in ("images", "image_masks") else mv(v)) for k, v in d.items()})
 
 
+def resize_with_pad(images: torch.Tensor, height: int, width: int) -> torch.Tensor:
+    """openpi.shared.image_tools.resize_with_pad ([UPSTREAM-RECALL], called at model_adapter.py:113-116): aspect-preserving
+    bilinear resize (jax.image.resize semantics: half-pixel centres, anti-aliased when shrinking) of [b, h, w, c] images,
+    then centred padding to (height, width) with the "black" value of the dtype's range (-1 for [-1, 1] floats, 0 for uint8).
+    A request-time preprocessing step on a few hundred KB: torch ops, not a kernel of the hot path."""
+    b, h, w, c = images.shape
+    if (h, w) == (height, width):
+        return images
+    ratio = max(w / width, h / height)
+    rh, rw = int(h / ratio), int(w / ratio)
+    x = images.permute(0, 3, 1, 2).to(torch.float32)
+    x = torch.nn.functional.interpolate(x, size=(rh, rw), mode="bilinear", align_corners=False, antialias=True)
+    if images.dtype == torch.uint8:
+        x = x.round().clamp(0, 255).to(torch.uint8)
+        fill = 0
+    else:
+        x = x.clamp(-1.0, 1.0)
+        fill = -1.0
+    ph0, pw0 = (height - rh) // 2, (width - rw) // 2
+    x = torch.nn.functional.pad(x, (pw0, width - rw - pw0, ph0, height - rh - ph0), value=fill)
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
 def preprocess_observation(observation: CoTObservation, *, train: bool, image_keys, image_resolution,
                            enable_image_augmentation: bool = True) -> CoTObservation:
-    """model_adapter.py:83-181 without augmax: selects the image keys, checks the resolution and fills default
+    """model_adapter.py:83-181 without augmax: selects the image keys, resizes to the model resolution and fills default
     image masks.  Train-time augmentation (RandomCrop 95% / Resize / Rotate +-5 deg / ColorJitter) is a listed
     'next' item (SURVEY.md §8 a-bis); asking for it raises instead of silently skipping it."""
     if train and enable_image_augmentation:
@@ -99,7 +122,7 @@ def preprocess_observation(observation: CoTObservation, *, train: bool, image_ke
             raise ValueError(f"images dict missing key {key}; got {list(observation.images)}")
         img = observation.images[key]
         if tuple(img.shape[1:3]) != tuple(image_resolution):
-            raise NotImplementedError(f"resize_with_pad {tuple(img.shape[1:3])} -> {image_resolution} is not implemented")
+            img = resize_with_pad(img, *image_resolution)
         images[key] = img
         batch = img.shape[0]
         m = observation.image_masks.get(key)

@@ -69,29 +69,95 @@ class GraphedSampler:
 
 
 class Policy:
-    """Model-level stand-in for openpi's Policy: `infer(obs)` with un-batched numpy inputs -> {"actions", "policy_timing"}."""
+    """openpi's Policy surface: `infer(obs)` -> {"actions", ..., "policy_timing"}.
 
-    def __init__(self, model: LAP, *, num_steps: int = 10, use_graph: bool = True, seed: int = 0, metadata: dict | None = None):
+    With `transforms` / `output_transforms` (lap_amd/policy_io.py, assembled by `create_trained_policy`) `obs` is the raw
+    client request ({"observation": {image keys, "state"}, "prompt", ...}) and the result carries un-normalised actions, as
+    in policies/policy_config_adapter.py:139-153.  Without them `obs` is already model-level (un-batched numpy arrays)."""
+
+    def __init__(self, model: LAP, *, num_steps: int = 10, use_graph: bool = True, seed: int = 0, metadata: dict | None = None,
+                 transforms=(), output_transforms=(), sample_kwargs: dict | None = None):
+        from lap_amd.policy_io import compose
+
         self.model = model
         self.metadata = metadata or {}
-        self.num_steps = num_steps
-        self._sampler = GraphedSampler(model, 1, num_steps) if use_graph else None
+        self._sample_kwargs = dict(sample_kwargs or {})
+        self.num_steps = self._sample_kwargs.pop("num_steps", num_steps)
+        self._sampler = GraphedSampler(model, 1, self.num_steps) if use_graph else None
         self._gen = torch.Generator(device=model.device).manual_seed(seed)
+        self._has_transforms = bool(transforms) or bool(output_transforms)
+        self._transforms = list(transforms)
+        self._input_transform = compose(self._transforms)
+        self._output_transform = compose(list(output_transforms))
 
-    def infer(self, obs: dict) -> dict:
+    def _to_observation(self, inputs: dict) -> tuple[CoTObservation, dict]:
+        batched = {k: ({kk: np.asarray(vv)[None] for kk, vv in v.items()} if isinstance(v, dict) else np.asarray(v)[None])
+                   for k, v in inputs.items() if v is not None and not isinstance(v, str)}
+        return CoTObservation.from_dict(batched, device=self.model.device), batched
+
+    def infer(self, obs: dict, *, noise=None) -> dict:
         t0 = time.perf_counter()
         dev = self.model.device
-        batched = {k: ({kk: np.asarray(vv)[None] for kk, vv in v.items()} if isinstance(v, dict) else np.asarray(v)[None])
-                   for k, v in obs.items() if v is not None}
-        o = CoTObservation.from_dict(batched, device=dev)
+        inputs = self._input_transform(dict(obs))
+        o, batched = self._to_observation(inputs)
         cfg = self.model.config
-        noise = torch.randn((1, cfg.action_horizon, cfg.action_dim), generator=self._gen, device=dev)
-        if self._sampler is not None:
+        if noise is None:
+            noise = torch.randn((1, cfg.action_horizon, cfg.action_dim), generator=self._gen, device=dev)
+        else:
+            noise = torch.as_tensor(np.asarray(noise), dtype=torch.float32, device=dev).reshape(1, cfg.action_horizon, cfg.action_dim)
+        if self._sampler is not None and self._graph_compatible(o):
             a = self._sampler(o, noise)
         else:
             a = self.model.sample_actions(0, o, num_steps=self.num_steps, noise=noise)
         actions = a[0].cpu().numpy()  # device sync
-        return {"actions": actions, "policy_timing": {"infer_ms": (time.perf_counter() - t0) * 1e3}}
+        model_ms = (time.perf_counter() - t0) * 1e3
+        if not self._has_transforms:
+            return {"actions": actions, "policy_timing": {"infer_ms": model_ms}}
+        outputs = self._output_transform({"state": batched["state"][0], "actions": actions})
+        outputs["policy_timing"] = {"infer_ms": model_ms}
+        return outputs
+
+    def _graph_compatible(self, o: CoTObservation) -> bool:
+        """The captured graph is tied to the model's native image resolution and prompt length."""
+        g = self._sampler.obs
+        return (all(tuple(o.images[k].shape) == tuple(g.images[k].shape) for k in g.images)
+                and tuple(o.tokenized_prompt.shape) == tuple(g.tokenized_prompt.shape))
+
+
+def create_trained_policy(train_config, checkpoint_dir, *, tokenizer_model_path=None, tokenizer=None, repack_transforms=(),
+                          sample_kwargs: dict | None = None, default_prompt: str | None = None, norm_stats: dict | None = None,
+                          device="cuda", use_graph: bool = True) -> Policy:
+    """policies/policy_config_adapter.py:85-154: model from `<checkpoint_dir>/params`, norm stats from
+    `<checkpoint_dir>/assets/<asset_id>/norm_stats.json`, and the standard transform stack
+        [repack.inputs, InjectDefaultPrompt, CoTInputs, Normalize, InjectDefaultPrompt, Tokenize, PadStatesAndActions]
+        -> model -> [Unnormalize, CoTOutputs, repack.outputs].
+    `repack_transforms` = (inputs, outputs) lists.  The PaliGemma SentencePiece model cannot be downloaded here: pass
+    `tokenizer_model_path` (or a ready `tokenizer`)."""
+    import pathlib
+
+    from lap_amd import checkpoints as _ckpt
+    from lap_amd import policy_io as pio
+
+    checkpoint_dir = pathlib.Path(checkpoint_dir)
+    mc = train_config.model
+    model = mc.load(_ckpt.restore_params(checkpoint_dir), device=device, with_grads=False)
+    if norm_stats is None:
+        if getattr(train_config.data, "asset_id", None) is None:
+            raise ValueError("Asset id is required to load norm stats.")
+        norm_stats = _ckpt.load_norm_stats(checkpoint_dir / "assets")
+    ntype = getattr(train_config.data, "action_proprio_normalization_type", "bounds_q99")
+    if tokenizer is None:
+        tokenizer = pio.PaligemmaTokenizer(tokenizer_model_path, mc.max_token_len, prompt_format=mc.prompt_format,
+                                           reasoning_mask_prob=0.0)
+    rin, rout = (list(repack_transforms[0]), list(repack_transforms[1])) if repack_transforms else ([], [])
+    transforms = [*rin, pio.InjectDefaultPrompt(default_prompt), pio.CoTInputs(action_dim=mc.action_dim),
+                  pio.Normalize(norm_stats, normalization_type=ntype), pio.InjectDefaultPrompt(None),
+                  pio.TokenizePromptAndReasoning(tokenizer, discrete_state_input=mc.discrete_state_input, verbose_mode=mc.verbose_mode,
+                                                 state_dropout=0.0),
+                  pio.PadStatesAndActions(mc.action_dim)]
+    outputs = [pio.Unnormalize(norm_stats, normalization_type=ntype), pio.CoTOutputs(), *rout]
+    return Policy(model, transforms=transforms, output_transforms=outputs, sample_kwargs=sample_kwargs, use_graph=use_graph,
+                  metadata=getattr(train_config, "policy_metadata", None))
 
 
 class ARPolicy:
@@ -111,15 +177,21 @@ class ARPolicy:
 
     def infer_reasoning(self, obs: dict) -> dict:
         t0 = time.perf_counter()
-        dev = self._base.model.device
-        raw_state = np.array(obs["state"], copy=True) if obs.get("state") is not None else None
-        batched = {k: ({kk: np.asarray(vv)[None] for kk, vv in v.items()} if isinstance(v, dict) else np.asarray(v)[None])
-                   for k, v in obs.items() if v is not None}
-        o = CoTObservation.from_dict(batched, device=dev)
+        base = self._base
+        if base._has_transforms:   # raw client request (policy_adapter.py:25-31)
+            raw_state = np.array(obs["observation"]["state"], copy=True)
+            inputs = base._input_transform(dict(obs))
+        else:
+            raw_state = np.array(obs["state"], copy=True) if obs.get("state") is not None else None
+            inputs = obs
+        o, batched = base._to_observation(inputs)
         self._calls += 1
-        tokens = self._base.model.sample_tokens(self._calls, o, **self._sample_kwargs)
+        tokens = base.model.sample_tokens(self._calls, o, **self._sample_kwargs)
         out = {"state": batched.get("state"), "tokens": tokens.cpu().numpy(), "raw_state": raw_state}
-        out["policy_timing"] = {"infer_ms": (time.perf_counter() - t0) * 1e3}
+        model_ms = (time.perf_counter() - t0) * 1e3
+        if base._has_transforms:
+            out = base._output_transform(out)
+        out["policy_timing"] = {"infer_ms": model_ms}
         return out
 
     def infer(self, obs: dict, *, noise=None) -> dict:
@@ -127,3 +199,14 @@ class ARPolicy:
 
     def vqa_infer(self, obs: dict) -> dict:
         return self.infer_reasoning(obs)
+
+
+def create_trained_policy_ar(*args, sample_kwargs: dict | None = None, **kwargs) -> ARPolicy:
+    """policy_config_adapter.py:157-160.  The output stack of the AR mode stops at the decoded text (`reasoning`): parsing
+    language actions back into end-effector deltas (lang_action_formats.py) is not implemented."""
+    from lap_amd import policy_io as pio
+
+    base = create_trained_policy(*args, use_graph=False, **kwargs)
+    tok = next(t.tokenizer for t in base._transforms if isinstance(t, pio.TokenizePromptAndReasoning))
+    base._output_transform = pio.compose([pio.DetokenizeReasoning(tok)])
+    return ARPolicy(base, sample_kwargs=sample_kwargs)

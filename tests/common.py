@@ -62,3 +62,19 @@ def to_observation(obs, device):
 def rel(a, b):
     a = a.detach().float().cpu(); b = b.detach().float().cpu()
     return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def tiny_sentencepiece_proto(vocab_size=150) -> bytes:
+    """A throw-away SentencePiece model with PaliGemma's special ids (pad 0, eos 1, bos 2, unk 3) for the tokenizer tests:
+    the real paligemma_tokenizer.model cannot be fetched offline."""
+    import io
+
+    import sentencepiece as spm
+    corpus = ["Task: pick up the block, predict the robot's action in the robot base frame; State: 12 200 7 0 255 128; Answer: ",
+              "move right 3 cm and move up 2 cm and rotate clockwise 10 degrees and open gripper",
+              "move left 5 cm move forward 1 cm move back 4 cm close gripper end-effector frame"] * 40
+    buf = io.BytesIO()
+    spm.SentencePieceTrainer.train(sentence_iterator=iter(corpus), model_writer=buf, vocab_size=vocab_size, model_type="bpe",
+                                   user_defined_symbols=["right", "left"], pad_id=0, eos_id=1, bos_id=2, unk_id=3,
+                                   character_coverage=1.0, minloglevel=2)
+    return buf.getvalue()
