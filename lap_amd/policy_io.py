@@ -12,8 +12,9 @@ fixtures (lap_amd/prompt.py); the arithmetic here is pinned only by the cited li
 tests/test_policy_io_cpu.py ("parity unpinned": the reference modules import openpi and cannot run here).
 
 Scope: the inference path of robot samples (what a LIBERO / DROID client sends) plus the training-time tokenisation with
-language actions.  Dataset-time sample handlers (VQA / prediction question synthesis, language-action summarisation from
-raw trajectories, wrist-image dropout) belong to the data path (§8f rank 4) and raise NotImplementedError.
+language actions; text <-> delta conversion lives in lap_amd/lang_actions.py.  Dataset-time sample handlers (VQA / prediction
+question synthesis, per-dataset language-action summarisation inside CoTInputs, wrist-image dropout) belong to the data path
+(§8f rank 4) and raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -427,14 +428,49 @@ class DetokenizeReasoning:
 # ------------------------------------------------------------------------------------------------ outputs
 @dataclasses.dataclass(frozen=True)
 class CoTOutputs:
-    """policies/transforms/output_transforms.py:20-73 for the flow-matching policies: actions pass through, `reasoning` None.
-    Decoding generated text back into end-effector deltas (lang_action_formats.parse_language_to_deltas) belongs to the
-    LAP_AR text pipeline and is refused here rather than approximated."""
+    """policies/transforms/output_transforms.py:20-214.  Flow-matching policies: actions pass through, `reasoning` None.
+    LAP_AR: the decoded text is parsed back into [dx, dy, dz, droll, dpitch, dyaw (, gripper)] with the configured language
+    action format (end-effector-frame formats are rotated into the base frame with the request's `raw_state`); the VLA-0
+    strategy returns the full [horizon, dim] grid, un-normalised with `norm_stats["actions"]`."""
+    language_action_format: Any = None
+    norm_stats: Any = None
+    normalization_type: str = "bounds_q99"
+    transform_strategy: str = "standard"
+
+    def __post_init__(self):
+        from lap_amd import lang_actions as la
+        f = self.language_action_format
+        if f is not None and not isinstance(f, la.LanguageActionFormat):
+            object.__setattr__(self, "language_action_format", la.get_language_action_format(f))
+        object.__setattr__(self, "norm_stats", as_norm_stats(self.norm_stats))
 
     def __call__(self, data: dict) -> dict:
+        from lap_amd import lang_actions as la
         if "reasoning" not in data:
             return {"actions": np.asarray(data["actions"]), "reasoning": None}
-        raise NotImplementedError("language-action text -> deltas parsing (lang_action_formats.py) is not implemented")
+        reasoning, fmt = data.get("reasoning"), self.language_action_format
+        assert fmt is not None
+        assert reasoning is not None
+        if self.transform_strategy == "vla0" and isinstance(fmt, la.VLA0ActionFormat):
+            return {"actions": self._unnormalize_vla0(fmt.parse_to_full_actions(reasoning)), "reasoning": reasoning}
+        state = np.asarray(data["raw_state"]) if (self.transform_strategy != "vla0" and fmt.use_eef_frame and "raw_state" in data) else None
+        movement, gripper = fmt.parse_language_to_deltas(reasoning, initial_state=state) if self.transform_strategy != "vla0" \
+            else fmt.parse_language_to_deltas(reasoning)
+        return {"actions": movement if gripper is None else np.concatenate([movement, [gripper]]), "reasoning": reasoning}
+
+    def _unnormalize_vla0(self, actions: np.ndarray) -> np.ndarray:
+        """output_transforms.py:106-190: only the recorded leading dimensions are mapped back; unknown types pass through."""
+        st = None if self.norm_stats is None else self.norm_stats.get("actions")
+        if st is None:
+            return actions
+        lo, hi, eps = {"bounds_q99": (st.q01, st.q99, 1e-6), "bounds": (st.min, st.max, 1e-8), "normal": (st.mean, st.std, None)}.get(
+            self.normalization_type, (None, None, None))
+        if lo is None or hi is None:
+            return actions
+        d = min(lo.shape[-1], actions.shape[-1])
+        head = actions[..., :d]
+        head = head * (hi[..., :d] + 1e-6) + lo[..., :d] if eps is None else (head + 1.0) / 2.0 * (hi[..., :d] - lo[..., :d] + eps) + lo[..., :d]
+        return head if actions.shape[-1] <= d else np.concatenate([head, actions[..., d:]], axis=-1)
 
 
 def compose(transforms: Sequence[Callable[[dict], dict]]) -> Callable[[dict], dict]:

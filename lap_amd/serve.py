@@ -201,12 +201,14 @@ class ARPolicy:
         return self.infer_reasoning(obs)
 
 
-def create_trained_policy_ar(*args, sample_kwargs: dict | None = None, **kwargs) -> ARPolicy:
-    """policy_config_adapter.py:157-160.  The output stack of the AR mode stops at the decoded text (`reasoning`): parsing
-    language actions back into end-effector deltas (lang_action_formats.py) is not implemented."""
+def create_trained_policy_ar(*args, sample_kwargs: dict | None = None, language_action_format="verbose_eef_with_rotation", **kwargs) -> ARPolicy:
+    """policy_config_adapter.py:157-160 with the AR output stack [DetokenizeReasoning, CoTOutputs(language_action_format)]:
+    generated ids -> text -> [dx, dy, dz, droll, dpitch, dyaw, gripper] (the language action describes the whole chunk as
+    one delta, output_transforms.py:75-104; `Unnormalize` has no `actions` statistics to apply to such deltas and is left out
+    as in the reference's standard stack it would act on the normalised `state` only)."""
     from lap_amd import policy_io as pio
 
     base = create_trained_policy(*args, use_graph=False, **kwargs)
     tok = next(t.tokenizer for t in base._transforms if isinstance(t, pio.TokenizePromptAndReasoning))
-    base._output_transform = pio.compose([pio.DetokenizeReasoning(tok)])
+    base._output_transform = pio.compose([pio.DetokenizeReasoning(tok), pio.CoTOutputs(language_action_format=language_action_format)])
     return ARPolicy(base, sample_kwargs=sample_kwargs)

@@ -248,3 +248,68 @@ def test_websocket_policy_server_round_trip():
     np.testing.assert_allclose(pio.unpackb(b[1][1])["actions"], r1["actions"])
     assert c[1][0] == W.OP_TEXT and b"RuntimeError: policy failed" in c[1][1] and c[2] == "closed"
     assert health.startswith(b"HTTP/1.1 200 OK") and health.endswith(b"OK\n")
+
+
+def test_language_actions_match_reference_fixture():
+    """Numbers <-> text and the frame transforms against outputs of the reference's own modules (tests/golden/make_lang_action_golden.py)."""
+    from lap_amd import lang_actions as LA
+    G = json.loads((pathlib.Path(__file__).parent / "golden" / "lang_action_v1.json").read_text())
+    T = LA.case_tables()
+    texts = G["texts"]
+    assert texts[:len(T["texts"])] == T["texts"]
+    for c in G["summaries"]:
+        assert LA.summarize_numeric_actions(T["chunks"][c["chunk"]], c["sum_decimal"], c["rot"]) == c["expected"], c
+    for c in G["bimanual"]:
+        ch = np.asarray(T["chunks"][c["chunk"]])
+        two = np.concatenate([ch, ch[::-1] * 0.5], axis=1)
+        assert LA.summarize_bimanual_numeric_actions(two, c["sum_decimal"], True) == c["expected"], c
+    for c in G["scale"]:
+        assert LA.describe_language_action_scale(texts[c["text"]]) == c["expected"], c
+    for c in G["idle"]:
+        assert LA.is_idle_language_action(texts[c["text"]], c["sum_decimal"], c["rot"]) == c["expected"], (texts[c["text"]], c)
+    fmts = {"verbose_with_rotation": LA.VERBOSE_WITH_ROTATION_FORMAT, "verbose_eef_with_rotation": LA.VERBOSE_EEF_WITH_ROTATION_FORMAT,
+            "compact_rot": LA.LanguageActionFormat(name="c", style="compact", include_rotation=True)}
+    for c in G["parse"]:
+        st = None if c["state"] is None else np.asarray(T["states"][c["state"]])
+        mv, g = fmts[c["format"]].parse_language_to_deltas(texts[c["text"]], initial_state=st)
+        np.testing.assert_allclose(mv, c["movement"], rtol=0, atol=1e-12, err_msg=str(c))
+        assert g == c["gripper"], c
+    for c in G["vla0"]:
+        mv, g = LA.VLA0_CHUNKED_FORMAT.parse_language_to_deltas(texts[c["text"]])
+        np.testing.assert_allclose(mv, c["movement"], atol=1e-15)
+        assert g == c["gripper"]
+        np.testing.assert_allclose(LA.VLA0_CHUNKED_FORMAT.parse_to_full_actions(texts[c["text"]]), c["full"], atol=1e-15)
+    acts = np.asarray(T["chunks"][2])[:, :7]
+    assert LA.VLA0_CHUNKED_FORMAT.summarize_actions(acts * 20) == G["vla0_summary"]["expected"]
+    assert LA.VLA0ActionFormat().summarize_actions(acts[0] * 20) == G["vla0_summary"]["single"]
+    for c in G["frames"]:
+        a, st = np.asarray(T["frame_actions"][c["action"]]), np.asarray(T["states"][c["state"]])
+        np.testing.assert_allclose(LA.transform_actions_from_eef_frame(a, st, c["dataset"]), c["from_eef"], atol=1e-12, err_msg=str(c))
+        for wrist in (0, 1):
+            if f"to_eef_{wrist}" in c:
+                np.testing.assert_allclose(LA.transform_actions_to_eef_frame(a, st, c["dataset"], bool(wrist)), c[f"to_eef_{wrist}"], atol=1e-12)
+    np.testing.assert_allclose(LA.transform_actions_from_eef_frame(np.asarray(T["frame_actions"]), np.asarray([T["states"][0]])), G["from_eef_chunk"], atol=1e-12)
+    np.testing.assert_allclose(LA.rot6d_to_rotmat(np.asarray(T["states"][1])[3:9]), G["rot6d"], atol=1e-14)
+    assert LA.get_language_action_format("vla0_chunked").get_sum_decimal() == "vla0" and LA.VERBOSE_WITH_ROTATION_FORMAT.get_sum_decimal() == "0f"
+    with pytest.raises(ValueError, match="Unknown language action format"):
+        LA.get_language_action_format("nope")
+
+
+def test_cot_outputs_text_to_actions():
+    from lap_amd import lang_actions as LA
+    text = "move forward 3 cm, move left 2 cm, tilt left 10 degrees, open gripper"
+    out = pio.CoTOutputs(language_action_format="verbose_with_rotation")({"reasoning": text, "tokens": np.zeros(3)})
+    np.testing.assert_allclose(out["actions"], [0.03, 0.02, 0.0, np.deg2rad(10), 0.0, 0.0, 1.0])
+    assert out["reasoning"] == text
+    # end-effector-frame format: rotated into the base frame with the request's raw state ([xyz, euler, gripper])
+    state = np.array([0.1, 0.2, 0.3, 0.0, 0.0, np.pi / 2, 0.5])     # yaw 90 degrees
+    eef = pio.CoTOutputs(language_action_format="verbose_eef_with_rotation")({"reasoning": "move forward 10 cm", "raw_state": state})
+    np.testing.assert_allclose(eef["actions"][:3], [0.0, 0.1, 0.0], atol=1e-12)      # eef x is base y after the yaw
+    assert eef["actions"].shape == (6,)                                                # no gripper phrase -> no 7th value
+    v = pio.CoTOutputs(language_action_format="vla0_chunked", transform_strategy="vla0", normalization_type="bounds_q99",
+                       norm_stats={"actions": {"mean": [0.0] * 7, "std": [1.0] * 7, "q01": [-1.0] * 7, "q99": [3.0] * 7}})
+    full = v({"reasoning": "500 0 1000 " * 30})["actions"]
+    assert full.shape == (10, 7)
+    np.testing.assert_allclose(full[0, :3], [(0.0 + 1) / 2 * (4 + 1e-6) - 1, -1.0, 3.0 + 1e-6], atol=1e-9)   # bins 500, 0, 1000 -> 0, -1, +1 -> [q01, q99]
+    with pytest.raises(AssertionError):
+        pio.CoTOutputs()({"reasoning": "move up 1 cm"})
