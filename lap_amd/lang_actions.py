@@ -346,6 +346,47 @@ def get_language_action_format(name: str) -> LanguageActionFormat:
     return LANGUAGE_ACTION_FORMAT_REGISTRY[name]
 
 
+# ------------------------------------------------------------------------------------------------ training labels
+@dataclasses.dataclass
+class ActionProcessor:
+    """policies/transforms/action_processor.py:19-193: raw language actions of a trajectory chunk -> (label text, frame
+    description).  End-effector-frame formats rotate the (single, already summed) delta into the gripper camera's frame first;
+    `random_base_prob` keeps a share of the wrist-camera samples in the base frame."""
+    language_action_format: LanguageActionFormat
+    random_base_prob: float = 0.0
+
+    def _frame(self, initial_state, has_wrist_image: bool) -> tuple[bool, str]:
+        import random
+        eef = self.language_action_format.use_eef_frame and initial_state is not None
+        if self.random_base_prob > 0.0:
+            eef = eef and has_wrist_image and random.random() < (1 - self.random_base_prob)
+        return eef, ("end-effector frame" if eef else "robot base frame")
+
+    def transform_to_frame(self, raw_actions, initial_state, dataset_name: str, rotation_applied: bool, has_wrist_image: bool):
+        eef, frame = self._frame(initial_state, has_wrist_image)
+        return (transform_actions_to_eef_frame(raw_actions, initial_state, dataset_name, rotation_applied) if eef else raw_actions), frame
+
+    def summarize_language_actions(self, data: dict, lang_action_key: str = "language_actions", initial_state=None,
+                                   dataset_name: str | None = None, rotation_applied: bool = False):
+        acts, frame = self.transform_to_frame(data[lang_action_key], initial_state, dataset_name, rotation_applied,
+                                              data.get("has_wrist_image", False))
+        f = self.language_action_format
+        if data.get("is_bimanual", False):
+            return summarize_bimanual_numeric_actions(acts, f.get_sum_decimal(), f.include_rotation), frame
+        if data.get("is_navigation", False):
+            return summarize_numeric_actions(acts, "nearest_10", include_rotation=True, rotation_precision=10), frame
+        return summarize_numeric_actions(acts, sum_decimal=f.get_sum_decimal(), include_rotation=f.include_rotation), frame
+
+    @staticmethod
+    def extract_motion_components(language_actions) -> dict:
+        """[dx, dy, dz, droll, dpitch, dyaw, gripper] in m / rad (first row of a chunk) -> cm / degrees."""
+        a = np.asarray(language_actions, dtype=float)
+        a = a[0] if a.ndim == 2 else a
+        deg = lambda i: a[i] * 180.0 / np.pi if len(a) > i else 0.0
+        return {"dx_cm": a[0] * 100.0, "dy_cm": a[1] * 100.0, "dz_cm": a[2] * 100.0, "droll_deg": deg(3), "dpitch_deg": deg(4),
+                "dyaw_deg": deg(5), "gripper": a[6] if len(a) > 6 else 0.5}
+
+
 # ------------------------------------------------------------------------------------------------ golden case tables
 def case_tables() -> dict:
     """Inputs shared by the golden generator (reference side) and the parity test (this module)."""
@@ -370,3 +411,20 @@ def case_tables() -> dict:
     frame_actions = np.round(np.concatenate([rs.uniform(-0.05, 0.05, (3, 3)), rs.uniform(-0.3, 0.3, (3, 3)), rs.uniform(0, 1, (3, 1))], 1), 5).tolist()
     return {"chunks": chunks, "texts": texts, "states": states, "datasets": datasets, "frame_actions": frame_actions,
             "sum_decimals": ["0f", "1f", "2f", "nearest_10", "no_number", "compact"]}
+
+
+def processor_cases() -> list[dict]:
+    rs = np.random.RandomState(11)
+    state = np.round(np.concatenate([rs.uniform(-0.5, 0.5, 3), rs.normal(size=6), [0.4]]), 4).tolist()
+    one = lambda: np.round(np.concatenate([rs.uniform(-0.06, 0.06, 3), rs.uniform(-0.5, 0.5, 3), rs.uniform(0, 1, 1)]), 5).tolist()
+    cases = []
+    for fmt in ("verbose_with_rotation", "verbose_eef_with_rotation"):
+        for ds in ("droid", "jaco_play", "berkeley_autolab_ur5", "viola", "fmb"):
+            for rot_applied in (False, True):
+                cases.append({"format": fmt, "dataset": ds, "rotation_applied": rot_applied, "actions": one(), "state": state, "flags": {}})
+        cases.append({"format": fmt, "dataset": "droid", "rotation_applied": False, "actions": one(), "state": None, "flags": {}})
+    chunk = [one() for _ in range(5)]
+    cases.append({"format": "verbose_with_rotation", "dataset": "x", "rotation_applied": False, "actions": chunk, "state": state, "flags": {"is_navigation": True}})
+    two = np.concatenate([np.asarray(chunk), np.asarray(chunk)[::-1]], axis=1).tolist()
+    cases.append({"format": "verbose_with_rotation", "dataset": "x", "rotation_applied": False, "actions": two, "state": state, "flags": {"is_bimanual": True}})
+    return cases

@@ -259,25 +259,51 @@ def _text(value, default: str = "") -> str:
 @dataclasses.dataclass(frozen=True)
 class CoTInputs:
     """policies/transforms/input_transforms.py:22-249 for robot samples: base image (+ wrist images, zeros and mask False
-    when absent or all-zero; image_handler.py:22-107,149-166), state, prompt (text_utils.py:37-63, incl. the r1_lite
-    `@` rule), frame description, actions padded to action_dim, `sample_mask` True.  VQA / prediction samples and the
-    language-action summarisation of training trajectories are dataset-time work and are refused."""
+    when absent or all-zero; image_handler.py:22-166 incl. the training-time wrist dropout / random un-masking), state, prompt
+    (text_utils.py:37-63, incl. the r1_lite `@` rule), frame description, actions padded to action_dim.  With raw
+    `language_actions` in the sample (training) the label text is produced by `lang_actions.ActionProcessor`, the frame
+    description follows the frame actually used, and idle labels clear `sample_mask` (sample_handlers.py:372-431).
+    VQA / prediction samples (question synthesis) are dataset-time work of the data path and are refused."""
     action_dim: int
+    language_action_format: Any = "verbose_eef_with_rotation"
+    wrist_image_dropout_prob: float = 0.0
+    enable_langact_training: bool = True
+    use_rough_scale: bool = False
+    random_base_prob: float = 0.0
+    random_mask_prob: float = 0.0
     image_keys: tuple[str, ...] = IMAGE_KEYS
 
+    def __post_init__(self):
+        from lap_amd import lang_actions as la
+        f = self.language_action_format
+        if f is not None and not isinstance(f, la.LanguageActionFormat):
+            object.__setattr__(self, "language_action_format", la.get_language_action_format(f))
+
+    def _mask(self, image, random_mask_prob: float = 0.0):
+        if np.all(image == 0.0):
+            return np.True_ if (random_mask_prob > 0.0 and np.random.rand() < random_mask_prob) else np.False_
+        return np.True_
+
+    def _wrist(self, obs: dict, key: str, base):
+        if key not in obs:
+            return np.zeros_like(base)
+        image = parse_image(obs[key])
+        if self.wrist_image_dropout_prob > 0.0 and np.random.rand() < float(self.wrist_image_dropout_prob):
+            return np.zeros_like(base)
+        return image
+
     def __call__(self, data: dict) -> dict:
+        from lap_amd import lang_actions as la
         assert "observation" in data
         if data.get("is_vqa_sample", False) or data.get("is_prediction_sample", False):
             raise NotImplementedError("VQA / prediction sample handlers are part of the data path (SURVEY.md 8f rank 4)")
-        if "language_actions" in data:
-            raise NotImplementedError("language-action summarisation of raw trajectories is part of the data path")
         obs = data["observation"]
         raw = obs.get(self.image_keys[0])
         base = None if (isinstance(raw, (str, bytes)) and len(raw) == 0) else parse_image(raw)
         if base is None:
             base = np.zeros((224, 224, 3), dtype=np.uint8)   # masked out below: an all-zero image
-        images = [base] + [parse_image(obs[k]) if k in obs else np.zeros_like(base) for k in self.image_keys[1:]]
-        masks = [np.False_ if np.all(im == 0.0) else np.True_ for im in images]
+        images = [base] + [self._wrist(obs, k, base) for k in self.image_keys[1:]]
+        masks = [self._mask(base)] + [self._mask(im, self.random_mask_prob) for im in images[1:]]
         dataset_name = _text(data.get("dataset_name"))
         prompt = data.get("prompt")
         assert prompt is not None, "Prompt missing from data"
@@ -300,7 +326,17 @@ class CoTInputs:
         out["is_vqa_sample"] = False
         out["time_horizon_seconds"] = data.get("time_horizon_seconds")
         out["vqa_dataset_id"] = data.get("vqa_dataset_id", 0)
-        out["sample_mask"] = True
+        fmt = self.language_action_format
+        if "language_actions" in data and self.enable_langact_training:
+            proc = la.ActionProcessor(language_action_format=fmt, random_base_prob=self.random_base_prob)
+            text, frame = proc.summarize_language_actions(data, "language_actions", np.asarray(data["raw_state"]), dataset_name,
+                                                          data.get("rotation_applied", False))
+            out["frame_description"] = frame
+            out["language_actions"] = la.describe_language_action_scale(text) if self.use_rough_scale else text
+            out["sample_mask"] = True if self.use_rough_scale else \
+                not la.is_idle_language_action(out["language_actions"], fmt.get_sum_decimal(), fmt.include_rotation)
+        else:
+            out["sample_mask"] = True
         return out
 
 

@@ -20,6 +20,7 @@ sys.modules["lap.policies"] = _pkg
 from lap.policies import lang_action_formats as ref_fmt                      # noqa: E402
 from lap.policies.transforms import action_text as ref_text                  # noqa: E402
 from lap.policies.transforms import frame_transforms as ref_frame            # noqa: E402
+from lap.policies.transforms.action_processor import ActionProcessor as RefProcessor   # noqa: E402
 
 from lap_amd import lang_actions as mine                                     # noqa: E402  (case tables only)
 
@@ -62,6 +63,12 @@ for ds in T["datasets"]:
                 for wrist in (False, True):
                     rec[f"to_eef_{int(wrist)}"] = js(ref_frame.transform_actions_to_eef_frame(np.asarray(a), np.asarray(st), ds, wrist))
             out["frames"].append(rec)
+out["processor"] = []
+for c in mine.processor_cases():
+    proc = RefProcessor(language_action_format=ref_fmt.get_language_action_format(c["format"]))
+    text, frame = proc.summarize_language_actions({"language_actions": np.asarray(c["actions"]), **c["flags"]}, "language_actions",
+                                                  None if c["state"] is None else np.asarray(c["state"]), c["dataset"], c["rotation_applied"])
+    out["processor"].append({"text": text, "frame": frame, "motion": {k: float(v) for k, v in RefProcessor.extract_motion_components(np.asarray(c["actions"])).items()}})
 out["from_eef_chunk"] = js(ref_frame.transform_actions_from_eef_frame(np.asarray(T["frame_actions"]), np.asarray([T["states"][0]])))
 out["rot6d"] = js(ref_frame.rot6d_to_rotmat(np.asarray(T["states"][1])[3:9]))
 path = pathlib.Path(__file__).with_name("lang_action_v1.json")

@@ -313,3 +313,41 @@ def test_cot_outputs_text_to_actions():
     np.testing.assert_allclose(full[0, :3], [(0.0 + 1) / 2 * (4 + 1e-6) - 1, -1.0, 3.0 + 1e-6], atol=1e-9)   # bins 500, 0, 1000 -> 0, -1, +1 -> [q01, q99]
     with pytest.raises(AssertionError):
         pio.CoTOutputs()({"reasoning": "move up 1 cm"})
+
+
+def test_action_processor_and_training_inputs(tiny_tokenizer):
+    from lap_amd import lang_actions as LA
+    G = json.loads((pathlib.Path(__file__).parent / "golden" / "lang_action_v1.json").read_text())
+    cases = LA.processor_cases()
+    assert len(cases) == len(G["processor"])
+    for c, g in zip(cases, G["processor"]):
+        proc = LA.ActionProcessor(language_action_format=LA.get_language_action_format(c["format"]))
+        text, frame = proc.summarize_language_actions({"language_actions": np.asarray(c["actions"]), **c["flags"]}, "language_actions",
+                                                      None if c["state"] is None else np.asarray(c["state"]), c["dataset"], c["rotation_applied"])
+        assert (text, frame) == (g["text"], g["frame"]), c
+        m = LA.ActionProcessor.extract_motion_components(np.asarray(c["actions"]))
+        assert {k: float(v) for k, v in m.items()} == pytest.approx(g["motion"], abs=1e-12)
+    # training sample through the input stack: label text from raw deltas, frame description of the frame used, EOS-terminated
+    c = cases[0]
+    sample = {"observation": {"base_0_rgb": np.ones((224, 224, 3), np.uint8), "left_wrist_0_rgb": np.ones((224, 224, 3), np.uint8),
+                              "state": np.zeros(8)}, "prompt": "stack the cups", "dataset_name": c["dataset"], "raw_state": np.asarray(c["state"]),
+              "language_actions": np.asarray(c["actions"]), "actions": np.zeros((10, 7)), "has_wrist_image": True}
+    tin = pio.CoTInputs(action_dim=32, language_action_format="verbose_eef_with_rotation")(sample)
+    proc = LA.ActionProcessor(language_action_format=LA.VERBOSE_EEF_WITH_ROTATION_FORMAT)
+    want, frame = proc.summarize_language_actions(sample, "language_actions", np.asarray(c["state"]), c["dataset"], False)
+    assert tin["language_actions"] == want and tin["frame_description"] == frame == "end-effector frame" and tin["sample_mask"] is True
+    tk = pio.PaligemmaTokenizer(model_proto=tiny_tokenizer._tokenizer.serialized_model_proto(), max_len=200)
+    out = pio.TokenizePromptAndReasoning(tk, discrete_state_input=True)(tin)
+    assert out["tokenized_langact_mask"].sum() == len(tk.encode(want, add_eos=True)) and "language_actions" not in out
+    idle = dict(sample, language_actions=np.array([0.001, 0.0, 0.0, 0.01, 0.0, 0.0, 1.0]))
+    assert pio.CoTInputs(action_dim=32)(idle)["sample_mask"] is False                       # < 1 cm and < 10 degrees
+    rough = pio.CoTInputs(action_dim=32, use_rough_scale=True)(sample)
+    assert rough["sample_mask"] is True and not any(ch.isdigit() for ch in rough["language_actions"])
+    base = pio.CoTInputs(action_dim=32, language_action_format="verbose_with_rotation")(sample)
+    assert base["frame_description"] == "robot base frame"
+    off = pio.CoTInputs(action_dim=32, enable_langact_training=False)(sample)
+    assert "language_actions" not in off and off["sample_mask"] is True
+    np.random.seed(0)
+    dropped = pio.CoTInputs(action_dim=32, wrist_image_dropout_prob=1.0)(sample)
+    assert not dropped["image"]["left_wrist_0_rgb"].any() and not dropped["image_mask"]["left_wrist_0_rgb"]
+    assert pio.CoTInputs(action_dim=32, wrist_image_dropout_prob=1.0, random_mask_prob=1.0)(sample)["image_mask"]["left_wrist_0_rgb"]
