@@ -1,0 +1,181 @@
+"""Host-side data path: episodes on disk -> transformed, batched `(CoTObservation, actions)`.
+
+The reference reads RLDS / TFDS shards through TensorFlow (`src/lap/datasets/**`, `datasets/data_loader.py:97-326`), applies
+the per-sample transform stack to every element of a TF batch and yields `CoTObservation.from_dict(batch), batch["actions"]`
+(`data_loader.py:286-326`).  TensorFlow and the RLDS corpora do not exist here, so the STORAGE format is our own (one `.npz`
+per episode, below); everything after a raw sample dict exists is the reference's pipeline: `CoTInputs` (label text, frame,
+idle mask) -> `Normalize` (per-dataset q01/q99) -> `TokenizePromptAndReasoning` -> `PadStatesAndActions` -> stack ->
+`CoTObservation`.  The loader keeps the contract the train loop and the checkpoint code rely on: endless iteration for
+`split="train"`, one pass for `"val"`, `get_state` / `set_state` resume with the batches the interrupted run would have seen
+(the reference skips `batches_seen` batches of the host's shard, data_loader.py:289-306), per-rank shards of every epoch's
+permutation, `get_norm_stats_for_checkpoint`.
+
+Episode file (`np.savez`): `base_0_rgb` / `left_wrist_0_rgb` uint8 [T, H, W, 3] (wrist optional), `state` f32 [T, >= 9]
+([xyz, rot6d, gripper, ...]; 7 values = [xyz, euler, gripper] also work for base-frame labels), `actions` f32 [T, 7]
+per-step deltas [dx, dy, dz, droll, dpitch, dyaw, gripper] in m / rad, `prompt` str, `dataset_name` str.
+A sample at step t carries the action chunk `actions[t : t + action_horizon]` (the last row repeated past the episode end,
+with zero motion) and, as raw language action, the summed delta of the next `summation_steps` steps with the last gripper
+value — what the label text describes (`action_text.py:47-141` sums a chunk the same way).
+"""
+from __future__ import annotations
+
+import pathlib
+from typing import Callable, Sequence
+
+import numpy as np
+import torch
+
+from lap_amd import policy_io as pio
+from lap_amd.observation import CoTObservation
+
+IMAGE_KEYS = pio.IMAGE_KEYS
+
+
+class EpisodeDataset:
+    """Random access over (episode, step) pairs of a list of episode dicts or of `*.npz` files in a directory."""
+
+    def __init__(self, episodes: Sequence[dict] | str | pathlib.Path, *, action_horizon: int, summation_steps: int | None = None):
+        if isinstance(episodes, (str, pathlib.Path)):
+            files = sorted(pathlib.Path(episodes).glob("*.npz"))
+            if not files:
+                raise FileNotFoundError(f"no episode files (*.npz) under {episodes}")
+            episodes = [dict(np.load(f, allow_pickle=False)) for f in files]
+        self.episodes = [self._check(e, i) for i, e in enumerate(episodes)]
+        self.action_horizon = action_horizon
+        self.summation_steps = summation_steps or action_horizon
+        self._starts = np.cumsum([0] + [len(e["actions"]) for e in self.episodes])
+
+    @staticmethod
+    def _check(e: dict, i: int) -> dict:
+        for k in ("base_0_rgb", "state", "actions", "prompt"):
+            if k not in e:
+                raise KeyError(f"episode {i} has no '{k}'")
+        T = len(e["actions"])
+        if len(e["state"]) != T or len(e["base_0_rgb"]) != T or np.asarray(e["actions"]).shape[-1] < 7:
+            raise ValueError(f"episode {i}: state / images / actions must share T and actions need >= 7 columns")
+        return e
+
+    def __len__(self) -> int:
+        return int(self._starts[-1])
+
+    def __getitem__(self, index: int) -> dict:
+        ep = int(np.searchsorted(self._starts, index, side="right") - 1)
+        t = int(index - self._starts[ep])
+        e = self.episodes[ep]
+        acts = np.asarray(e["actions"], dtype=np.float32)
+        T = len(acts)
+        rows = np.minimum(np.arange(t, t + self.action_horizon), T - 1)
+        chunk = acts[rows].copy()
+        chunk[np.arange(t, t + self.action_horizon) >= T, :6] = 0.0          # past the end: hold still, keep the gripper
+        window = acts[t:min(T, t + self.summation_steps)]
+        lang = np.concatenate([window[:, :6].sum(0), window[-1:, 6]]).astype(np.float32)
+        obs = {"base_0_rgb": e["base_0_rgb"][t], "state": np.asarray(e["state"][t], dtype=np.float32)}
+        if "left_wrist_0_rgb" in e:
+            obs["left_wrist_0_rgb"] = e["left_wrist_0_rgb"][t]
+        return {"observation": obs, "prompt": str(np.asarray(e["prompt"]).item()) if not isinstance(e["prompt"], str) else e["prompt"],
+                "dataset_name": str(np.asarray(e.get("dataset_name", "")).item()) if not isinstance(e.get("dataset_name", ""), str) else e.get("dataset_name", ""),
+                "actions": chunk, "language_actions": lang, "raw_state": np.asarray(e["state"][t], dtype=np.float32),
+                "has_wrist_image": "left_wrist_0_rgb" in e}
+
+
+def compute_norm_stats(dataset: EpisodeDataset, *, action_pad_to: int | None = None) -> dict:
+    """scripts/compute_norm_stats.py equivalent over the whole store: mean / std / q01 / q99 / min / max of `state` and of the
+    per-step `actions` (norm_stats.json layout, openpi NormStats fields).  The reference computes them AFTER the data
+    transforms, i.e. on actions already zero-padded to the model's action_dim (`action_pad_to`): `Normalize` cuts statistics
+    to the data's width but cannot widen them, and all-zero columns normalise to 0 by the q01 == q99 rule."""
+    out = {}
+    for key in ("state", "actions"):
+        x = np.concatenate([np.asarray(e[key], dtype=np.float64).reshape(len(e["actions"]), -1) for e in dataset.episodes], 0)
+        if key == "actions" and action_pad_to is not None:
+            x = pio.pad_to_dim(x, action_pad_to, axis=-1)
+        out[key] = {"mean": x.mean(0).tolist(), "std": x.std(0).tolist(), "q01": np.quantile(x, 0.01, axis=0).tolist(),
+                    "q99": np.quantile(x, 0.99, axis=0).tolist(), "min": x.min(0).tolist(), "max": x.max(0).tolist()}
+    return out
+
+
+def _stack(samples: list[dict]) -> dict:
+    """jax.tree.map(np.stack) over per-sample dicts (data_loader.py:111-121); None leaves must be None everywhere."""
+    first = samples[0]
+    out = {}
+    for k, v in first.items():
+        if isinstance(v, dict):
+            out[k] = _stack([s[k] for s in samples])
+        elif v is None:
+            if any(s[k] is not None for s in samples):
+                raise ValueError(f"field '{k}' is None in some samples of the batch only")
+            out[k] = None
+        elif isinstance(v, str):
+            continue
+        else:
+            out[k] = np.stack([np.asarray(s[k]) for s in samples], axis=0)
+    return out
+
+
+class DataLoader:
+    """Iterates `(CoTObservation, actions f32 [b, action_horizon, action_dim])`; see the module docstring for the contract."""
+
+    def __init__(self, dataset, transform: Callable[[dict], dict], batch_size: int, *, shuffle: bool = True, seed: int = 0,
+                 rank: int = 0, world_size: int = 1, num_batches: int | None = None, split: str = "train", device=None,
+                 norm_stats: dict | None = None):
+        if batch_size <= 0 or len(dataset) < batch_size * world_size:
+            raise ValueError(f"dataset of {len(dataset)} samples cannot fill a global batch of {batch_size} x {world_size}")
+        self.dataset, self.transform, self.batch_size = dataset, transform, batch_size
+        self.shuffle, self.seed, self.rank, self.world = shuffle, seed, rank, world_size
+        self.num_batches, self.split, self.device, self._norm_stats = num_batches, split, device, norm_stats
+        self._seen_batches = 0
+        self.per_epoch = len(dataset) // (batch_size * world_size)    # full global batches only (ragged tail dropped)
+
+    # ---- checkpoint protocol (train.main / checkpoints.save_state)
+    def get_state(self) -> dict:
+        return {"batches_seen": self._seen_batches, "seed": self.seed, "world_size": self.world}
+
+    def set_state(self, s: dict):
+        if int(s.get("world_size", self.world)) != self.world:
+            raise ValueError("dataloader state was saved with a different world size")
+        self._seen_batches, self.seed = int(s["batches_seen"]), int(s["seed"])
+
+    def get_batches_seen(self) -> int:
+        return self._seen_batches
+
+    def get_norm_stats_for_checkpoint(self):
+        return (self._norm_stats, "per-dataset") if self._norm_stats is not None else (None, "none")
+
+    # ---- iteration
+    def _indices(self, batch_index: int) -> np.ndarray:
+        epoch, within = divmod(batch_index, self.per_epoch)
+        order = np.random.RandomState(self.seed + 7919 * epoch).permutation(len(self.dataset)) if self.shuffle else np.arange(len(self.dataset))
+        g0 = within * self.batch_size * self.world + self.rank * self.batch_size
+        return order[g0:g0 + self.batch_size]
+
+    def __iter__(self):
+        produced = 0
+        while True:
+            if self.num_batches is not None and produced >= self.num_batches:
+                return
+            if self.split == "val" and self._seen_batches >= self.per_epoch:
+                return
+            batch = _stack([self.transform(self.dataset[int(i)]) for i in self._indices(self._seen_batches)])
+            self._seen_batches += 1
+            produced += 1
+            actions = torch.as_tensor(batch["actions"], dtype=torch.float32, device=self.device)
+            yield CoTObservation.from_dict(batch, device=self.device), actions
+
+
+def create_data_loader(config, dataset: EpisodeDataset, tokenizer, *, norm_stats: dict | None = None, shuffle: bool = True, seed: int = 0,
+                       rank: int = 0, world_size: int = 1, num_batches: int | None = None, split: str = "train", device=None) -> DataLoader:
+    """datasets/data_loader.py:126-198: per-rank batch = config.batch_size // world_size; the transform stack of
+    `training/config.py` (data transforms + Normalize + model transforms) for the LAP model type."""
+    mc = config.model
+    if norm_stats is None:
+        norm_stats = compute_norm_stats(dataset, action_pad_to=mc.action_dim)
+    ntype = getattr(config.data, "action_proprio_normalization_type", "bounds_q99")
+    stack = pio.compose([
+        pio.CoTInputs(action_dim=mc.action_dim, random_base_prob=getattr(config.data, "random_base_prob", 0.0),
+                      enable_langact_training=mc.enable_langact_training),
+        pio.Normalize(norm_stats, normalization_type=ntype),
+        pio.TokenizePromptAndReasoning(tokenizer, discrete_state_input=mc.discrete_state_input, verbose_mode=mc.verbose_mode,
+                                       state_dropout=mc.state_dropout if split == "train" else 0.0),
+        pio.PadStatesAndActions(mc.action_dim),
+    ])
+    return DataLoader(dataset, stack, max(1, config.batch_size // world_size), shuffle=shuffle, seed=seed, rank=rank,
+                      world_size=world_size, num_batches=num_batches, split=split, device=device, norm_stats=norm_stats)

@@ -158,7 +158,7 @@ def main(config: TrainConfig, *, data_loader=None, device: str | None = None, lo
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if device is None:
         device = f"cuda:{local % max(torch.cuda.device_count(), 1)}"
-    if torch.device(device).type == "cuda":
+    if torch.device(device).type == "cuda" and torch.device(device).index is not None:
         torch.cuda.set_device(torch.device(device))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -196,7 +196,12 @@ def main(config: TrainConfig, *, data_loader=None, device: str | None = None, lo
                     f" | {len(infos) * config.batch_size / dt:.1f} samples/s")
             infos, t_last = [], _time.perf_counter()
         if ((step + 1) % config.save_interval == 0 and step + 1 > start) or last:
-            ck.save_state(mngr, state, data_loader, step + 1)
+            # save_assets callback (training/checkpoints.py:216-285): the loader's normalisation statistics travel with the
+            # checkpoint, so the policy built from it un-normalises with the training-time numbers
+            stats = data_loader.get_norm_stats_for_checkpoint()[0] if hasattr(data_loader, "get_norm_stats_for_checkpoint") else None
+            ck.save_state(mngr, state, data_loader, step + 1, norm_stats=stats, asset_id=getattr(config.data, "asset_id", None) or "combined")
+            if rank == 0:
+                log(f"saved checkpoint {step + 1}")
     return state
 
 

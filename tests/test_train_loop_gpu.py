@@ -2,6 +2,7 @@
 resume from the latest checkpoint with the data position, and equivalence of "6 steps + resume + 2 steps" with an
 uninterrupted 8-step run (up to the f32 atomics order of the small-unit gradients)."""
 import dataclasses
+import json
 
 import pytest
 import torch
@@ -18,7 +19,7 @@ def test_train_resume_matches_uninterrupted_run(hip, tmp_path):
                                save_interval=3, keep_period=None, seed=3)
     lines = []
     a = main(dataclasses.replace(base, exp_name="full", num_train_steps=8), log=lines.append)
-    assert a.step == 8 and any(l.startswith("step 8:") for l in lines) and "samples/s" in lines[-1]
+    assert a.step == 8 and any(l.startswith("step 8:") for l in lines) and "samples/s" in lines[-2] and lines[-1] == "saved checkpoint 8"
     assert ck.CheckpointManager(base.checkpoint_base_dir and (tmp_path / base.name / "full")).all_steps() == (8,)
     b = main(dataclasses.replace(base, exp_name="split", num_train_steps=6), log=lambda s: None)
     assert b.step == 6
@@ -41,3 +42,39 @@ def test_train_resume_matches_uninterrupted_run(hip, tmp_path):
     assert worst(a.model.ps, c.model.ps) <= max(5 * noise, 1e-3), (worst(a.model.ps, c.model.ps), noise)
     with pytest.raises(FileExistsError):
         main(dataclasses.replace(base, exp_name="split", num_train_steps=8, resume=False), log=lambda s: None)
+
+
+def test_train_from_episode_store_then_serve(hip, tmp_path):
+    """Data path end to end (SURVEY 8f rank 4 -> train -> rank 1): episodes -> transform stack -> train.main steps with a
+    checkpoint carrying the loader's norm stats -> policy assembled from that checkpoint answers a raw request."""
+    import dataclasses
+
+    import numpy as np
+
+    from lap_amd import data as D, policy_io as pio
+    from lap_amd.config import get_config
+    from lap_amd.serve import create_trained_policy
+    from lap_amd.train import main
+    from tests.common import tiny_sentencepiece_proto
+    from tests.test_data_cpu import _episodes
+
+    cfg = get_config("debug")
+    cfg = dataclasses.replace(cfg, model=dataclasses.replace(cfg.model, action_dim=16), num_train_steps=4, save_interval=4, log_interval=2,
+                              checkpoint_base_dir=str(tmp_path), exp_name="episodes", overwrite=True, resume=False,
+                              data=dataclasses.replace(cfg.data, asset_id="toy"))
+    tok = pio.PaligemmaTokenizer(model_proto=tiny_sentencepiece_proto(), max_len=cfg.model.max_token_len)
+    ds = D.EpisodeDataset(_episodes(3, 12, hw=(56, 56)), action_horizon=cfg.model.action_horizon)
+    loader = D.create_data_loader(cfg, ds, tok, seed=0, device="cuda")
+    lines = []
+    state = main(cfg, data_loader=loader, device="cuda", log=lines.append)
+    assert state.step == 4 and loader.get_batches_seen() == 4 and any("saved checkpoint 4" in str(l) for l in lines)
+    losses = [float(str(l).split(": loss=")[1].split(",")[0]) for l in lines if "loss=" in str(l)]
+    assert losses and all(np.isfinite(losses))
+    ckpt = next(p for p in tmp_path.rglob("4") if p.is_dir())
+    stats = json.loads((ckpt / "assets" / "toy" / "norm_stats.json").read_text())["norm_stats"]
+    assert len(stats["actions"]["q99"]) == 16
+    policy = create_trained_policy(cfg, ckpt, tokenizer=tok, use_graph=False, device="cuda")
+    e = ds.episodes[2]
+    out = policy.infer({"observation": {"base_0_rgb": e["base_0_rgb"][0], "left_wrist_0_rgb": e["left_wrist_0_rgb"][0], "state": e["state"][0]},
+                        "prompt": e["prompt"]})
+    assert out["actions"].shape == (cfg.model.action_horizon, 16) and np.isfinite(out["actions"]).all()
