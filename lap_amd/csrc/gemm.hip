@@ -709,11 +709,20 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
     const long long t5 = (long long)((M + 255) / 256) * ((N + 255) / 256);
     const int tail = (int)(t5 % 256), nkt = (K + 63) / 64;
     if (t5 > 256 && tail > 0 && tail < 200) {
-      int sp = 256 / tail;
-      if (sp > 8) sp = 8;
-      if (sp > nkt / 8) sp = nkt / 8;
+      // Cost model (microseconds, calibrated on in-situ traces): a tile costs ~6 + 1.9 per 64-deep k-tile; splitting the
+      // tail sp ways shortens that to nkt / sp k-tiles but adds a reduce pass over sp f32 slabs + the output
+      // (~25 us of launch + latency + bytes at ~2.5 TB/s).  Short contractions (K <= 2048) are cheaper unsplit
+      // (measured: tools/bench_tail.py).
+      int smax = 256 / tail;
+      if (smax > 8) smax = 8;
       const long long cap = scratch_bytes / ((long long)tail * 65536 * 4);
-      if (sp > cap) sp = (int)cap;
+      if (smax > cap) smax = (int)cap;
+      double best = 6.0 + 1.9 * nkt;
+      int sp = 1;
+      for (int c = 2; c <= smax; ++c) {
+        const double cost = 6.0 + 1.9 * ((nkt + c - 1) / c) + 25.0 + (double)tail * 65536.0 * (4.0 * c + 2.0) / 2.5e6;
+        if (cost < best - 4.0) { best = cost; sp = c; }   // (a split has to pay for its extra launch clearly)
+      }
       if (sp >= 2) { tail_tiles = tail; tail_sp = sp; }
     }
   }

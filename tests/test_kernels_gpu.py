@@ -87,17 +87,20 @@ def test_gemm_pingpong_matches_single_phase_bitwise(hip):
 def test_gemm_tail_split(hip):
     # more than one round of 256x256 tiles with a poorly filled last round: the full rounds run unsplit, the tail
     # tiles are split along K into compact slabs and reduced (partial tiles in M and N included)
-    M, N, K = 4300, 4000, 1024   # 17 x 16 = 272 tiles -> tail of 16 tiles
+    M, N, K = 4300, 4000, 8192   # 17 x 16 = 272 tiles -> tail of 16 tiles; K long enough for the cost model to split them
     a = rnd(M, K); wt = rnd(N, K, seed=1); res = rnd(M, N, seed=2); bias = rnd(N, dtype=torch.float32, seed=3)
     base = a.float() @ wt.float().t()
     assert rel_err(hip.linear_fwd(a, wt, tile=5), base) < 4e-3
     assert rel_err(hip.linear_fwd(a, wt, bias=bias, residual=res, tile=5), base + bias + res.float()) < 4e-3
     assert rel_err(hip.linear_fwd(a, wt, bias=bias, gelu=True, tile=5), torch.nn.functional.gelu(base + bias, approximate="tanh")) < 4e-3
     # identical to the unsplit kernel up to the f32 summation order of the split tiles
-    assert rel_err(hip.linear_fwd(a, wt, tile=5), hip.linear_fwd(a, wt, tile=5, ksplit=1)) < 1e-3
+    split, unsplit = hip.linear_fwd(a, wt, tile=5), hip.linear_fwd(a, wt, tile=5, ksplit=1)
+    assert rel_err(split, unsplit) < 1e-3 and not torch.equal(split, unsplit)   # (the split path really ran: another summation order)
+    short = rnd(M, 1024, seed=7), rnd(N, 1024, seed=8)                           # K = 1024: cheaper unsplit, the model must not split
+    assert torch.equal(hip.linear_fwd(*short, tile=5), hip.linear_fwd(*short, tile=5, ksplit=1))
     dy = rnd(M, N, seed=4)
     assert rel_err(hip.linear_dgrad(dy, wt, tile=5), dy.float() @ wt.float()) < 4e-3
-    Mw, Nw, Kw = 1024, 4296, 4000   # wgrad: output [Nw, Kw] = 17 x 16 tiles, contraction over Mw rows
+    Mw, Nw, Kw = 8192, 4296, 4000   # wgrad: output [Nw, Kw] = 17 x 16 tiles, contraction over Mw rows
     dyw = rnd(Mw, Nw, seed=5); xw = rnd(Mw, Kw, seed=6)
     g = torch.full((Nw, Kw), 2.0, device=DEV)
     hip.linear_wgrad(dyw, xw, g, tile=5)
