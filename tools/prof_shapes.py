@@ -2,7 +2,7 @@
 import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
-print(cols)
+# print(cols)
 gx = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else None)
 pat = sys.argv[2] if len(sys.argv) > 2 else "gemm"
 q = f"select name, {gx}, grid_y, workgroup_x, count(*), sum(end-start), avg(end-start) from kernels where name like '%{pat}%' group by name, {gx}, grid_y order by 6 desc limit {int(sys.argv[3]) if len(sys.argv)>3 else 60}"
