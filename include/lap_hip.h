@@ -204,8 +204,11 @@ int lap_attention_set_variant(int variant);
 /* ---------------------------------------- fused consumers of GEMM partials (serving) -- */
 /* partials: f32 [ksplit][rows][cols] from lap_gemm_bf16_ex(LAP_GEMM_PARTIALS).  Each kernel sums the slabs, rounds to
  * bf16 like the GEMM would have, and applies the ops that follow the projection in gemma.py:336-387. */
-int lap_fused_reduce_rope_split(const float* partials, int ksplit, const int32_t* pos, void* q, void* k, void* v,
-                                int B, int T_seg, int T_total, int seg_off, int NH, int HD, float q_scale, void* stream);
+/* table (optional, else NULL): sin / cos per (row, frequency), f32 [B*T_seg][HD/2][2] from lap_rope_table — the positions
+ * of the action tokens are the same for all 10 x 18 projections of a denoise loop, so the transcendental work is hoisted. */
+int lap_rope_table(const int32_t* pos, float* table, int B, int T_seg, int T_total, int seg_off, int HD, void* stream);
+int lap_fused_reduce_rope_split(const float* partials, int ksplit, const int32_t* pos, const float* table, void* q, void* k,
+                                void* v, int B, int T_seg, int T_total, int seg_off, int NH, int HD, float q_scale, void* stream);
 int lap_fused_reduce_geglu(const float* partials, int ksplit, void* act, int rows, int H, void* stream);
 /* xn = x + bf16(y * gate[sample]) (gate NULL: plain add); h = adaptive RMSNorm(xn; mod) when mod != NULL. */
 int lap_fused_reduce_residual_norm(const float* partials, int ksplit, const void* x, const void* gate, int ldg,

@@ -27,8 +27,21 @@ __device__ __forceinline__ void ld8(const bf16* p, float (&v)[8]) {
 __device__ __forceinline__ void sum8(const float* part, long long off, int ks, long long slab, float (&v)[8]) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = 0.f;
-  // loads of 4 slabs in flight at a time; the additions keep the slab order (bit-identical to splitk_reduce_kernel)
+  // loads of 8 (then 4) slabs in flight at a time: these kernels are pure latency chains at batch 1; the additions keep
+  // the slab order (bit-identical to splitk_reduce_kernel)
   int s = 0;
+  for (; s + 8 <= ks; s += 8) {
+    f32x4 a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = *reinterpret_cast<const f32x4*>(part + (s + u) * slab + off);
+      b[u] = *reinterpret_cast<const f32x4*>(part + (s + u) * slab + off + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += a[u][e]; v[4 + e] += b[u][e]; }
+  }
   for (; s + 4 <= ks; s += 4) {
     f32x4 a[4], b[4];
 #pragma unroll
@@ -52,7 +65,22 @@ __device__ __forceinline__ void sum8(const float* part, long long off, int ks, l
 }
 
 // ---------------------------------------------------------------- reduce + RoPE + split
+// sin / cos of every (row, frequency) of a segment, f32 [rows][HD / 2][2]: the suffix positions of a denoise loop do not
+// change between its 10 x 18 projections, so the powf / sincosf work is done once (same rope_sincos => same bits)
+__global__ __launch_bounds__(256) void rope_table_kernel(const int32_t* __restrict__ pos, float* __restrict__ tab, int rows, int T_seg,
+                                                         int T_total, int seg_off, int HD) {
+  const int half = HD / 2;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= rows * half) return;
+  const int row = gid / half, i = gid % half;
+  float sn, cs;
+  rope_sincos((float)pos[(long long)(row / T_seg) * T_total + seg_off + row % T_seg], i, HD, sn, cs);
+  tab[2 * gid] = sn;
+  tab[2 * gid + 1] = cs;
+}
+
 __global__ __launch_bounds__(256) void reduce_rope_kernel(const float* __restrict__ part, int ks, const int32_t* __restrict__ pos,
+                                                          const float* __restrict__ tab,
                                                           bf16* __restrict__ q, bf16* __restrict__ k, bf16* __restrict__ v,
                                                           int rows, int T_seg, int T_total, int seg_off, int NH, int HD,
                                                           float q_scale) {
@@ -68,11 +96,18 @@ __global__ __launch_bounds__(256) void reduce_rope_kernel(const float* __restric
   sum8(part, (long long)row * W + h * HD + c * 8, ks, slab, x1);
   sum8(part, (long long)row * W + h * HD + half + c * 8, ks, slab, x2);
   if (h <= NH) {
-    const float p = (float)pos[(long long)b * T_total + seg_off + t];
+    const float p = tab ? 0.f : (float)pos[(long long)b * T_total + seg_off + t];
+    float sc[16];
+    if (tab) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        *reinterpret_cast<f32x4*>(sc + 4 * u) = *reinterpret_cast<const f32x4*>(tab + ((long long)row * half + c * 8) * 2 + 4 * u);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float sn, cs, r1, r2;
-      rope_sincos(p, c * 8 + e, HD, sn, cs);
+      if (tab) { sn = sc[2 * e]; cs = sc[2 * e + 1]; }
+      else rope_sincos(p, c * 8 + e, HD, sn, cs);
       rope_rotate(x1[e], x2[e], sn, cs, r1, r2);
       r1 = round_bf16((r1)); r2 = round_bf16((r2));
       if (h < NH) { r1 *= q_scale; r2 *= q_scale; }
@@ -160,12 +195,20 @@ __global__ __launch_bounds__(256) void reduce_residual_norm_kernel(const float* 
 
 #define S_ ((hipStream_t)stream)
 
-extern "C" int lap_fused_reduce_rope_split(const float* partials, int ksplit, const int32_t* pos, void* q, void* k, void* v,
-                                           int B, int T_seg, int T_total, int seg_off, int NH, int HD, float q_scale,
-                                           void* stream) {
-  if (!partials || ksplit < 1 || B <= 0 || T_seg <= 0 || (HD & 15) || NH <= 0) return LAP_ERR_ARG;
+extern "C" int lap_rope_table(const int32_t* pos, float* table, int B, int T_seg, int T_total, int seg_off, int HD, void* stream) {
+  if (!pos || !table || B <= 0 || T_seg <= 0 || (HD & 15)) return LAP_ERR_ARG;
+  const int n = B * T_seg * (HD / 2);
+  hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, S_, pos, table, B * T_seg, T_seg, T_total, seg_off, HD);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_fused_reduce_rope_split(const float* partials, int ksplit, const int32_t* pos, const float* table, void* q,
+                                           void* k, void* v, int B, int T_seg, int T_total, int seg_off, int NH, int HD,
+                                           float q_scale, void* stream) {
+  if (!partials || ksplit < 1 || B <= 0 || T_seg <= 0 || (HD & 15) || NH <= 0 || (!pos && !table)) return LAP_ERR_ARG;
   const long long n = (long long)B * T_seg * (NH + 2) * (HD / 16);
-  hipLaunchKernelGGL(reduce_rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_, partials, ksplit, pos, (bf16*)q,
+  hipLaunchKernelGGL(reduce_rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_, partials, ksplit, pos, table, (bf16*)q,
                      (bf16*)k, (bf16*)v, B * T_seg, T_seg, T_total, seg_off, NH, HD, q_scale);
   LAP_CHECK_LAUNCH();
   return LAP_OK;

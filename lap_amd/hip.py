@@ -98,7 +98,8 @@ SIGNATURES: dict[str, list] = {
     "lap_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],
     "lap_attention_bwd": [C.POINTER(AttnBwdArgs), _vp],
     "lap_attention_set_variant": [_i],
-    "lap_fused_reduce_rope_split": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "lap_rope_table": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "lap_fused_reduce_rope_split": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "lap_fused_reduce_geglu": [_vp, _i, _vp, _i, _i, _vp],
     "lap_fused_reduce_residual_norm": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp],
     "lap_ce_chunk_update": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -563,7 +564,7 @@ def linear_partials(x, wt, scratch, ksplit=None):
     N = wt.shape[0]
     if ksplit is None:
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        ksplit = max(1, min(K // 256, 256 // max(tiles, 1), 16))
+        ksplit = max(1, min(K // 256, 256 // max(tiles, 1), 16))   # (K // 128, 384-512 blocks, K // 512 measured: no better)
     need = ksplit * M * N
     if scratch.numel() < need:
         raise ValueError("scratch too small for the requested split")
@@ -572,13 +573,20 @@ def linear_partials(x, wt, scratch, ksplit=None):
     return scratch[:need].view(ksplit, M, N), ksplit
 
 
-def fused_reduce_rope_split(part, ksplit, pos, B, T_seg, T_total, seg_off, NH, HD, q_scale):
+def rope_table(pos, B, T_seg, T_total, seg_off, HD):
+    """sin / cos of a segment's positions, f32 [B*T_seg, HD/2, 2] (hoisted out of the denoise loop's RoPE kernels)."""
+    tab = torch.empty((B * T_seg, HD // 2, 2), dtype=torch.float32, device=pos.device)
+    call("lap_rope_table", _p(pos), _p(tab), B, T_seg, T_total, seg_off, HD)
+    return tab
+
+
+def fused_reduce_rope_split(part, ksplit, pos, B, T_seg, T_total, seg_off, NH, HD, q_scale, table=None):
     rows = B * T_seg
     dev = part.device
     q = torch.empty((rows, NH * HD), dtype=torch.bfloat16, device=dev)
     k = torch.empty((rows, HD), dtype=torch.bfloat16, device=dev)
     v = torch.empty((rows, HD), dtype=torch.bfloat16, device=dev)
-    call("lap_fused_reduce_rope_split", _p(part), ksplit, _p(pos), _p(q), _p(k), _p(v), B, T_seg, T_total, seg_off, NH, HD,
+    call("lap_fused_reduce_rope_split", _p(part), ksplit, _p(pos), _p(table), _p(q), _p(k), _p(v), B, T_seg, T_total, seg_off, NH, HD,
          float(q_scale))
     return q, k, v
 

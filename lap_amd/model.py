@@ -433,7 +433,7 @@ class LAP:
             self.comm.grads_ready(f"llm{l}")
         return dx0, dx1
 
-    def _expert_denoise_fwd(self, x1, mod, pos, qinfo, kinfo, B, Pn, S, cache):
+    def _expert_denoise_fwd(self, x1, mod, pos, qinfo, kinfo, B, Pn, S, cache, rope_tab=None):
         """The 18 action-expert layers of one denoise step (gemma.py:336-387 with xs = [None, suffix], kv_cache given)
         on the fused serving kernels: every projection is a split-K GEMM that leaves f32 partials, and the reduction
         happens inside the consumer (RoPE+split / GeGLU / gated residual + next adaptive RMSNorm).  `mod` is the single
@@ -450,7 +450,7 @@ class LAP:
             self.comm.wait_unit(f"llm{l}")
             p = f"llm/{l}/"
             part, ks = hip.linear_partials(h, self.W(p + "wqkv1"), scratch)
-            q, k, vv = hip.fused_reduce_rope_split(part, ks, pos, B, S, Ttot, Ttot - S, NH, HD, HD ** -0.5)
+            q, k, vv = hip.fused_reduce_rope_split(part, ks, pos, B, S, Ttot, Ttot - S, NH, HD, HD ** -0.5, table=rope_tab)
             ck, cv = cache[l]
             o, _ = hip.attention_fwd([None, q], [ck, k], [cv, vv], [0, S], [Pn, S], B, NH, KV, HD, qinfo, kinfo, need_lse=False)
             part, ks = hip.linear_partials(o[1], self.W(p + "wo1"), scratch)
@@ -615,11 +615,13 @@ class LAP:
         # built on the device (no host->device copy: the sampler is captured into a HIP graph and replayed)
         tvec = 1.0 + dt * torch.arange(len(times), dtype=torch.float32, device=dev)
         mods, _ = self._time_mod(tvec, False)
+        # ... and so are the action tokens' positions: one sin / cos table serves the 10 x 18 fused RoPE kernels
+        rope_tab = hip.rope_table(pos_all, B, S, pos_all.shape[1], pos_all.shape[1] - S, self.v.head_dim) if fused else None
         for step in range(len(times)):
             mod = mods[step:step + 1]
             x1, _ = self._embed_actions(x_t)
             if fused:
-                pre1 = self._expert_denoise_fwd(x1, mod, pos_all, qinfo_s, kinfo_all, B, Pn, S, cache)
+                pre1 = self._expert_denoise_fwd(x1, mod, pos_all, qinfo_s, kinfo_all, B, Pn, S, cache, rope_tab)
             else:  # generic path (same numerics; kept for A/B tests)
                 _, xf1, _ = self._llm_fwd(None, x1, mod, pos_all, qinfo_s, kinfo_all, B, Pn, S, False, kv_cache=cache, mod_shared=True)
                 pre1, _ = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=False, mod_ld=0)
