@@ -55,6 +55,7 @@ struct GemmParams {
   int tile_base;         // this launch covers the logical tiles [tile_base, tile_base + gridDim.x)
   int tile_count;        // host side only: tiles of this launch (0 = all from tile_base)
   int part_compact;      // partial slabs are [ksplit][gridDim.x][256][256] (tail split of the 256x256 kernel)
+  int epi_lds;           // bf16 output of the 256x256 kernel goes out through LDS in full 512-byte rows (set by the host)
 };
 
 // logical tile -> (m-tile, n-tile): groups of GM m-tiles sweep n so that neighbouring tiles share operand panels
@@ -281,6 +282,60 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
 
   // Epilogue. Lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + 4*(lane>>4).
   const int li = lane & 15, lg = lane >> 4;
+  if constexpr (!OUT_F32 && BM == 256 && BN == 256 && NW == 16) {
+    // bf16 output staged through LDS: straight from the accumulators a lane owns 8-byte pieces of 16 different rows
+    // (32-byte runs per row: 64 narrow stores per wave instruction, store-issue bound, and with one block per CU nothing
+    // overlaps them - ~7 us per tile, 11-18 % of a K <= 2048 tile).  The operand tiles are dead after the k-loop, so the
+    // finished bf16 tile is written to LDS (row pitch 544 B: the 16 rows x 4 column groups of a ds_write_b64 land on
+    // distinct even banks) and leaves as 16-byte stores, two full 512-byte rows per wave instruction.  Same values:
+    // alpha / bias / GELU / residual are applied in registers exactly as in the direct path.
+    if (p.epi_lds) {
+      constexpr int CP = BN * 2 + 32;
+      __syncthreads();   // every wave is done reading the operand tiles (no LDS-DMA in flight after the last k-tile)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int ml = wm * WTM + i * 16 + li;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int nl = wn * WTN + j * 16 + 4 * lg;
+          const int m = m0 + ml, n = n0 + nl;
+          f32x4 v = acc[i][j] * p.alpha;
+          if (m < p.M && n < p.N) {
+            if (p.bias_kind == 1) {
+              bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
+            } else if (p.bias_kind == 2) {
+              v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+            }
+            if (p.gelu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+            }
+            if (p.R) {
+              bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+            }
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+          *reinterpret_cast<bf16x4*>(smem + ml * CP + nl * 2) = o;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < BM * BN / 8 / (NW * 64); ++it) {
+        const int id = tid + NW * 64 * it;
+        const int r = id >> 5, c = id & 31;
+        const int m = m0 + r, n = n0 + c * 8;
+        if (m < p.M && n < p.N)   // N % 8 == 0 on this path: a 16-byte piece is inside or outside as a whole
+          *reinterpret_cast<bf16x8*>((bf16*)p.C + (long long)m * p.ldc + n) = *reinterpret_cast<const bf16x8*>(smem + r * CP + c * 16);
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int m = m0 + wm * WTM + i * 16 + li;
@@ -547,8 +602,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 
 template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool A_KC, bool B_KC, bool OUT_F32>
 int launch(GemmParams p, hipStream_t s) {
-  constexpr int LDS = NS * (BM + BN) * BK * 2;
+  constexpr int EPI = (!OUT_F32 && BM == 256 && BN == 256 && WGM * WGN == 16) ? BM * (BN * 2 + 32) : 0;   // staged bf16 tile
+  constexpr int LDS = NS * (BM + BN) * BK * 2 > EPI ? NS * (BM + BN) * BK * 2 : EPI;
   auto kern = gemm_kernel<BM, BN, WGM, WGN, BK, NS, A_KC, B_KC, OUT_F32>;
+  p.epi_lds = (EPI > 0 && !p.part && !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) ? 1 : 0;
   if (LDS > 65536) {
     static bool done = false;  // benign race: the attribute is idempotent
     if (!done) {

@@ -69,6 +69,23 @@ def test_gemm_tiles_all_layouts(hip, tile):
     assert torch.equal(hip.linear_fwd(a2, w2, tile=tile), w2.t().contiguous())
 
 
+def test_gemm_staged_epilogue_matches_direct_stores(hip):
+    """Tile 5 writes bf16 outputs through LDS in full rows when N % 8 == 0 and falls back to per-lane stores otherwise;
+    both must give the bits of the 8-wave kernel (tile 2, always direct) with every epilogue option, ragged M / N included."""
+    for (M, N, K) in [(777, 1000, 320), (520, 396, 200), (256, 264, 64), (1030, 2056, 192)]:   # 396 = 4 * 99: direct path
+        a = rnd(M, K); wt = rnd(N, K, seed=1); res = rnd(M, N, seed=2); bias = rnd(N, dtype=torch.float32, seed=3)
+        for kw in ({}, {"bias": bias}, {"bias": bias, "gelu": True}, {"bias": bias, "residual": res}, {"residual": res}):
+            assert torch.equal(hip.linear_fwd(a, wt, tile=5, ksplit=1, **kw), hip.linear_fwd(a, wt, tile=2, ksplit=1, **kw)), (M, N, K, list(kw))
+        if N % 8 == 0:   # (the contraction axis of the dgrad needs 16-byte rows)
+            dy = rnd(M, N, seed=4)
+            assert torch.equal(hip.linear_dgrad(dy, wt, tile=5, ksplit=1), hip.linear_dgrad(dy, wt, tile=2, ksplit=1))
+    # a view into a wider buffer: ldc != N
+    wide = torch.zeros(520, 1024, dtype=torch.bfloat16, device=DEV)
+    a = rnd(520, 128); wt = rnd(512, 128, seed=1)
+    hip.linear_fwd(a, wt, out=wide[:, 256:768], tile=5, ksplit=1)
+    assert torch.equal(wide[:, 256:768], hip.linear_fwd(a, wt, tile=2, ksplit=1)) and not wide[:, :256].any() and not wide[:, 768:].any()
+
+
 def test_gemm_pingpong_matches_single_phase_bitwise(hip):
     """Tile 8 (ping-pong, half-tile staging with counted waits) accumulates in the same order as tile 2: any race in
     its LDS-DMA / read ordering shows up as a bit difference.  Shapes with 1, 2, 3 and many k-tiles, all layouts."""
