@@ -22,8 +22,8 @@
 //   128x128x64 /  8 waves (64x32 per wave): 64 FLOP/B, two blocks per CU — small or
 //            awkward shapes (a 128x128 tile at the 2.5 PF MFMA peak would need
 //            39 TB/s from L2, more than the ~35 TB/s the XCD L2s deliver).
-// Other instantiations (8-wave 256x256, BK=32 4-stage rings, 256x128) are kept
-// selectable through lap_gemm_bf16_ex for A/B measurements; they measured slower.
+// Other instantiations (8-wave 256x256, BK=32 4-stage rings, 256x128, the two ping-pong
+// kernels = tiles 8 / 9) are kept selectable through lap_gemm_bf16_ex for A/B measurements.
 // HBM -> LDS staging is buffer_load_dwordx4 ... lds (LDS-DMA, no VGPR round trip),
 // double buffered: tile t+1 streams in while tile t is multiplied, one barrier
 // per k-tile.  The LDS image is lane-linear per wave instruction, so the
@@ -543,6 +543,167 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 16-wave ping-pong (tile 9): the 256x256 / 64x64-per-wave geometry of the production kernel, but the k-loop advances in
+// 32-deep SUB-TILES (one MFMA k-step: 8 fragment reads, 16 MFMAs per wave) and the wave rows alternate between two
+// groups one barrier apart (rows 0, 2 lead; rows 1, 3 trail), so that each SIMD always has two waves in their MFMA
+// segment (512 pipe cycles) while its other two are in their LDS segment (reads of the next sub-tile, 2 LDS-DMA pieces,
+// counted wait).  The lockstep kernel pays a matrix-pipe bubble after every barrier (all 16 waves issue DMA + reads and
+// wait for LDS at the same time); here that segment of one group hides under the other group's MFMAs.
+// Ring of 4 sub-tile slots (32 KiB each: A [256][32] | B [256][32], the BK = 32 images of common.hpp / kc32_*): phase st
+// reads slot st, issues sub-tile st + 2 into the slot last read two phases ago, and `s_waitcnt vmcnt(2)` makes sub-tile
+// st + 1 visible for the next phase (wait in phase p -> read in phase p + 1, as for tile 8).
+__device__ __forceinline__ bf16x8 kc32_frag_raw(const char* tile, int row0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(lds_addr_of(tile) + kc32_tile_off(row0 + i, g)));
+  return r;
+}
+
+template <bool A_KC, bool B_KC, bool OUT_F32>
+__global__ __launch_bounds__(1024) void gemm_pp16_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, SK = 32, OPB = 256 * SK * 2, SLOT = 2 * OPB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 slots: [A sub-tile | B sub-tile]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  const int trailing = wm & 1;
+
+  const int t = p.tile_base + xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  tile_coords<4>(p, t, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  auto rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.A, 0, (int)min((long long)(A_KC ? p.M : p.K) * p.lda * 2, 0x7fffffffLL), 0x00020000);
+  auto rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.B, 0, (int)min((long long)(B_KC ? p.N : p.K) * p.ldb * 2, 0x7fffffffLL), 0x00020000);
+  // one 1 KiB piece per wave and operand: linear 16-byte chunks [64 w, 64 w + 64) of the sub-tile image
+  unsigned offA, offB;
+  int kidxA, kidxB;
+  {
+    const int ci = w * 64 + lane;
+    if (A_KC) {
+      const int row = ci >> 2, c = (ci & 3) ^ ((-(row >> 2)) & 3);
+      kidxA = c * 8;
+      offA = (m0 + row < p.M) ? (unsigned)(((long long)(m0 + row) * p.lda + c * 8) * 2) : OOB;
+    } else {
+      const int kr = ci >> 5, c = (ci & 31) ^ (mc_swz(kr) << 1);
+      kidxA = kr;
+      offA = (m0 + c * 8 < p.M) ? (unsigned)(((long long)kr * p.lda + m0 + c * 8) * 2) : OOB;
+    }
+    if (B_KC) {
+      const int row = ci >> 2, c = (ci & 3) ^ ((-(row >> 2)) & 3);
+      kidxB = c * 8;
+      offB = (n0 + row < p.N) ? (unsigned)(((long long)(n0 + row) * p.ldb + c * 8) * 2) : OOB;
+    } else {
+      const int kr = ci >> 5, c = (ci & 31) ^ (mc_swz(kr) << 1);
+      kidxB = kr;
+      offB = (n0 + c * 8 < p.N) ? (unsigned)(((long long)kr * p.ldb + n0 + c * 8) * 2) : OOB;
+    }
+  }
+  const unsigned stepA = A_KC ? (unsigned)(SK * 2) : (unsigned)((long long)SK * p.lda * 2);
+  const unsigned stepB = B_KC ? (unsigned)(SK * 2) : (unsigned)((long long)SK * p.ldb * 2);
+  const int st0 = blockIdx.y * p.ktiles_per_split * 2;
+  const int st1 = min((p.K + SK - 1) / SK, st0 + p.ktiles_per_split * 2);
+  const int kend = min(p.K, st1 * SK);
+  auto issue = [&](int st) {   // past the end: out-of-range pieces (zero fill, no traffic) keep the wait counts uniform
+    char* base = smem + (st & 3) * SLOT + w * 1024;
+    const unsigned va = (offA != OOB && st * SK + kidxA < kend) ? offA + (unsigned)st * stepA : OOB;
+    const unsigned vb = (offB != OOB && st * SK + kidxB < kend) ? offB + (unsigned)st * stepB : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(base), 16, va, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(base + OPB), 16, vb, 0, 0, 0);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[4], fb[4];
+  bf16x4 ra[A_KC ? 1 : 4][2], rb[B_KC ? 1 : 4][2];
+
+#define P16_BAR() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+  issue(st0); issue(st0 + 1);
+  wait_vmcnt<2>();                                // sub-tile st0 landed
+  P16_BAR()
+  if (trailing) __builtin_amdgcn_s_barrier();     // rows 1, 3 drop one barrier behind
+  __builtin_amdgcn_sched_barrier(0);
+  for (int st = st0; st < st1; ++st) {
+    const char* tA = smem + (st & 3) * SLOT;
+    const char* tB = tA + OPB;
+    // ---- LDS segment
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (A_KC) fa[i] = kc32_frag_raw(tA, wm * 64 + i * 16, lane);
+      else mc_frag_raw<BM>(tA, wm * 64 + i * 16, 0, lane, ra[A_KC ? 0 : i]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (B_KC) fb[j] = kc32_frag_raw(tB, wn * 64 + j * 16, lane);
+      else mc_frag_raw<BN>(tB, wn * 64 + j * 16, 0, lane, rb[B_KC ? 0 : j]);
+    }
+    issue(st + 2);
+    wait_vmcnt<2>();                              // sub-tile st + 1 (read in the next phase)
+    P16_BAR()
+    // ---- MFMA segment
+    lds_wait_all();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (A_KC) lds_tie(fa[i]);
+      else { lds_tie(ra[A_KC ? 0 : i][0]); lds_tie(ra[A_KC ? 0 : i][1]); fa[i] = join8(ra[A_KC ? 0 : i][0], ra[A_KC ? 0 : i][1]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (B_KC) lds_tie(fb[j]);
+      else { lds_tie(rb[B_KC ? 0 : j][0]); lds_tie(rb[B_KC ? 0 : j][1]); fb[j] = join8(rb[B_KC ? 0 : j][0], rb[B_KC ? 0 : j][1]); }
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    P16_BAR()
+  }
+  wait_vmcnt<0>();
+  if (!trailing) __builtin_amdgcn_s_barrier();    // balance the stagger
+#undef P16_BAR
+
+  const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * lg;
+      if (n >= p.N) continue;
+      store_tile4<OUT_F32>(p, m, n, acc[i][j]);
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC, bool OUT_F32>
+int launch_pp16(GemmParams p, hipStream_t s) {
+  constexpr int LDS = 4 * 2 * 256 * 32 * 2;
+  auto kern = gemm_pp16_kernel<A_KC, B_KC, OUT_F32>;
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  const int nkt = (p.K + 63) / 64;
+  p.ktiles_per_split = (nkt + p.ksplit - 1) / p.ksplit;
+  const int count = p.tile_count > 0 ? p.tile_count : p.tiles_m * p.tiles_n - p.tile_base;
+  hipLaunchKernelGGL(kern, dim3(count, p.ksplit), dim3(1024), LDS, s, p);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
 template <bool A_KC, bool B_KC, bool OUT_F32>
 int launch_pp(GemmParams p, hipStream_t s) {
   constexpr int LDS = 2 * (256 + 256) * 64 * 2;
@@ -628,6 +789,7 @@ int launch(GemmParams p, hipStream_t s) {
 template <bool A_KC, bool B_KC, bool OUT_F32>
 int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
   switch (tile) {
+    case 9: return launch_pp16<A_KC, B_KC, OUT_F32>(p, s);
     case 8: return launch_pp<A_KC, B_KC, OUT_F32>(p, s);
     case 7: return launch<256, 128, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
     case 6: return launch<128, 128, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
@@ -744,7 +906,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   const bool f32 = flags & LAP_GEMM_OUT_F32;
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
-  if (tile < -1 || tile > 8 || ksplit < 0) return LAP_ERR_ARG;
+  if (tile < -1 || tile > 9 || ksplit < 0) return LAP_ERR_ARG;
   // Few output tiles but a very long contraction (LM-head dgrad: 1504 x 2048 over K = 257152; prefill down
   // projection): the big tile with enough K splits to cover the chip beats the small tile walking all of K.
   if (tile < 0 && ksplit == 0 && scratch != nullptr && K >= 16384 && !(flags & LAP_GEMM_PARTIALS)) {
