@@ -26,7 +26,53 @@ def _engine(cfg, P):
 
 @pytest.mark.parametrize("B,ragged,stop", [(2, False, False), (3, True, False), (3, True, True)])
 def test_loss_activations_and_grads(hip, B, ragged, stop):
-    cfg = debug_model_cfg(stop_action_to_vlm_grad=stop)
+    _check_loss_activations_and_grads(debug_model_cfg(stop_action_to_vlm_grad=stop), B, ragged)
+
+
+def _full_width_cfg(monkeypatch):
+    """LAP-3B WIDTHS (Gemma-2B 2048 / 16384, expert 1024 / 4096, SigLIP So400m 1152 / 4304, head sizes 256 and 72, 224 x 224
+    images, 48-token prompt, 50-step chunk, action_dim 32) with 2 layers per tower and a 16k-word vocabulary, so that the
+    oracle finishes in seconds."""
+    from lap_amd import config as C
+    from lap_amd.config import LAPConfig
+
+    monkeypatch.setitem(C._GEMMA, "gemma_2b_x2", C.GemmaConfig(2048, 2, 16384, 8, 1, 256))
+    monkeypatch.setitem(C._GEMMA, "gemma_300m_x2", C.GemmaConfig(1024, 2, 4096, 8, 1, 256))
+    monkeypatch.setitem(C._SIGLIP, "So400m/14_x2", C.SiglipConfig(1152, 2, 4304, 16))
+    monkeypatch.setitem(O.GEMMA, "gemma_2b_x2", O.GemmaCfg(2048, 2, 16384, 8, 1, 256))
+    monkeypatch.setitem(O.GEMMA, "gemma_300m_x2", O.GemmaCfg(1024, 2, 4096, 8, 1, 256))
+    monkeypatch.setitem(O.SIGLIP, "So400m/14_x2", O.SiglipCfg(1152, 2, 4304, 16))
+    return LAPConfig(paligemma_variant="gemma_2b_x2", action_expert_variant="gemma_300m_x2", siglip_variant="So400m/14_x2",
+                     image_size=224, vocab_size=16384, action_dim=32, action_horizon=50, max_token_len=48,
+                     language_loss_weight=0.4, enable_image_augmentation=False, enable_action_training=True)
+
+
+def test_full_width_two_layer_slice_matches_oracle(hip, monkeypatch):
+    """Loss, activations and every gradient at the LAP-3B widths: this drives the production code paths the tiny debug model
+    never reaches (256x256 tiles with staged epilogue and tail split, LDS-DMA attention for both head sizes, the hi/lo f32
+    stem, vocabulary-chunked cross entropy at width 2048)."""
+    _check_loss_activations_and_grads(_full_width_cfg(monkeypatch), B=2, ragged=True)
+
+
+def test_full_width_sample_actions_matches_oracle(hip, monkeypatch):
+    """Batch-1 serving at the LAP-3B widths: prefill + 10 denoise steps through the fused split-K consumers, the hoisted
+    sin / cos table and the key-split attention, against the oracle and against the generic layer path (bit for bit)."""
+    cfg = _full_width_cfg(monkeypatch)
+    oc = oracle_cfg(cfg)
+    P = O.init_params(oc, seed=5)
+    obs, _, noise, _ = make_inputs(cfg, B=1, ragged=False)
+    so = {k: v for k, v in obs.items() if k != "tokenized_langact_mask"}
+    ref = O.sample_actions(P, oc, so, noise, num_steps=10)
+    ref16 = O.sample_actions(P, dataclasses.replace(oc, emulate_bf16=True), so, noise, num_steps=10)
+    model = _engine(cfg, P)
+    o = to_observation(so | {"tokenized_langact_mask": None}, DEV)
+    out = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV))
+    assert torch.equal(out, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused=False))
+    err, base = rel(out, ref), rel(ref16, ref)
+    assert out.shape == (1, 50, 32) and err < max(3 * base, 1e-2), (err, base)
+
+
+def _check_loss_activations_and_grads(cfg, B, ragged):
     oc = oracle_cfg(cfg)
     P = O.init_params(oc, seed=7)
     obs, actions, noise, time = make_inputs(cfg, B=B, ragged=ragged)
