@@ -55,6 +55,7 @@ struct GemmParams {
   int tile_base;         // this launch covers the logical tiles [tile_base, tile_base + gridDim.x)
   int tile_count;        // host side only: tiles of this launch (0 = all from tile_base)
   int part_compact;      // partial slabs are [ksplit][gridDim.x][256][256] (tail split of the 256x256 kernel)
+  int sub256;            // 128x128 launch that covers tiles [tile_base, ..) of the 256x256 grid, 4 blocks (quadrants) per tile
   int epi_lds;           // bf16 output of the 256x256 kernel goes out through LDS in full 512-byte rows (set by the host)
 };
 
@@ -145,10 +146,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
   const int wm = w / WGN, wn = w % WGN;
 
   // Block -> tile mapping: XCD-aware remap, then groups of GM m-tiles sweep n.
-  const int t = p.tile_base + xcd_remap(blockIdx.x, gridDim.x);
   constexpr int GM = (BM == 256) ? 4 : 8;
   int tm, tn;
-  tile_coords<GM>(p, t, tm, tn);
+  if (BM == 128 && BN == 128 && p.sub256) {
+    // last round of a 256x256 grid re-tiled: 4 consecutive blocks (same XCD) are the quadrants of one 256x256 tile
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    tile_coords<4>(p, p.tile_base + (b >> 2), tm, tn);   // (p.tiles_m / tiles_n describe the 256x256 grid here)
+    tm = 2 * tm + ((b >> 1) & 1);
+    tn = 2 * tn + (b & 1);
+    if (tm * BM >= p.M || tn * BN >= p.N) return;   // quadrant outside the matrix (uniform per block)
+  } else {
+    tile_coords<GM>(p, p.tile_base + xcd_remap(blockIdx.x, gridDim.x), tm, tn);
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
   auto rsA = __builtin_amdgcn_make_buffer_rsrc(
@@ -775,11 +784,12 @@ int launch(GemmParams p, hipStream_t s) {
       done = true;
     }
   }
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + BN - 1) / BN;
+  const bool sub = BM == 128 && BN == 128 && p.sub256;
+  p.tiles_m = sub ? (p.M + 255) / 256 : (p.M + BM - 1) / BM;
+  p.tiles_n = sub ? (p.N + 255) / 256 : (p.N + BN - 1) / BN;
   const int nkt = (p.K + BK - 1) / BK;
   p.ktiles_per_split = (nkt + p.ksplit - 1) / p.ksplit;
-  const int count = p.tile_count > 0 ? p.tile_count : p.tiles_m * p.tiles_n - p.tile_base;
+  const int count = sub ? 4 * p.tile_count : (p.tile_count > 0 ? p.tile_count : p.tiles_m * p.tiles_n - p.tile_base);
   dim3 grid(count, p.ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), LDS, s, p);
   LAP_CHECK_LAUNCH();
@@ -936,13 +946,18 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
       if (smax > 8) smax = 8;
       const long long cap = scratch_bytes / ((long long)tail * 65536 * 4);
       if (smax > cap) smax = (int)cap;
-      double best = 6.0 + 1.9 * nkt;
+      const double whole = 6.0 + 1.9 * nkt;
+      double best = whole;
       int sp = 1;
       for (int c = 2; c <= smax; ++c) {
         const double cost = 6.0 + 1.9 * ((nkt + c - 1) / c) + 25.0 + (double)tail * 65536.0 * (4.0 * c + 2.0) / 2.5e6;
         if (cost < best - 4.0) { best = cost; sp = c; }   // (a split has to pay for its extra launch clearly)
       }
-      if (sp >= 2) { tail_tiles = tail; tail_sp = sp; }
+      // third option, for short contractions: the tail as 4 x tail quadrants on the 128x128 kernel (one round of it when
+      // tail <= 128), modelled as 0.64 of a 256x256 tile time + its launch.  Measured gain is small: 4-9 us per GEMM
+      // isolated (tools/bench_tail.py), 345.0 -> 344.1 ms per train step in an interleaved A/B (within noise)
+      if (tail <= 128 && 0.64 * whole + 6.0 < best - 4.0) { tail_tiles = tail; tail_sp = 1; }
+      else if (sp >= 2) { tail_tiles = tail; tail_sp = sp; }
     }
   }
   if (ksplit == 0 && scratch != nullptr && !tail_tiles) ksplit = pick_ksplit(tile, M, N, K, scratch_bytes);
@@ -979,6 +994,20 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
       else rc = dispatch_tile<false, true, false>(p, 5, s);
     }
     if (rc) return rc;
+    if (tail_sp == 1) {
+      // (b') the tail tiles as quadrants on the 128x128 kernel, straight to C with the caller's epilogue
+      p.sub256 = 1; p.tile_base = t5 - tail_tiles; p.tile_count = tail_tiles;
+      if (f32) {
+        if (a_kc && b_kc) return dispatch_tile<true, true, true>(p, 6, s);
+        if (a_kc && !b_kc) return dispatch_tile<true, false, true>(p, 6, s);
+        if (!a_kc && !b_kc) return dispatch_tile<false, false, true>(p, 6, s);
+        return dispatch_tile<false, true, true>(p, 6, s);
+      }
+      if (a_kc && b_kc) return dispatch_tile<true, true, false>(p, 6, s);
+      if (a_kc && !b_kc) return dispatch_tile<true, false, false>(p, 6, s);
+      if (!a_kc && !b_kc) return dispatch_tile<false, false, false>(p, 6, s);
+      return dispatch_tile<false, true, false>(p, 6, s);
+    }
     // (b) the tail tiles, split along K into compact f32 slabs, then reduce + epilogue
     p.ksplit = tail_sp; p.part = (float*)scratch; p.part_compact = 1; p.tile_base = t5 - tail_tiles; p.tile_count = tail_tiles;
     if (a_kc && b_kc) rc = dispatch_tile<true, true, true>(p, 5, s);

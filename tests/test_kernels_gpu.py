@@ -116,8 +116,17 @@ def test_gemm_tail_split(hip):
     # identical to the unsplit kernel up to the f32 summation order of the split tiles
     split, unsplit = hip.linear_fwd(a, wt, tile=5), hip.linear_fwd(a, wt, tile=5, ksplit=1)
     assert rel_err(split, unsplit) < 1e-3 and not torch.equal(split, unsplit)   # (the split path really ran: another summation order)
-    short = rnd(M, 1024, seed=7), rnd(N, 1024, seed=8)                           # K = 1024: cheaper unsplit, the model must not split
-    assert torch.equal(hip.linear_fwd(*short, tile=5), hip.linear_fwd(*short, tile=5, ksplit=1))
+    # K = 1024: splitting does not pay; the tail runs as quadrants on the 128x128 kernel instead (same accumulation order:
+    # bit-identical), with every epilogue option, ragged edges and in the dgrad / wgrad layouts
+    a1, w1 = rnd(M, 1024, seed=7), rnd(N, 1024, seed=8)
+    for kw in ({}, {"bias": bias, "gelu": True}, {"bias": bias, "residual": res}):
+        assert torch.equal(hip.linear_fwd(a1, w1, **kw), hip.linear_fwd(a1, w1, tile=5, ksplit=1, **kw)), list(kw)
+    dy1, wt1 = rnd(M, 1024, seed=9), rnd(1024, N, seed=10)
+    assert torch.equal(hip.linear_dgrad(dy1, wt1), hip.linear_dgrad(dy1, wt1, tile=5, ksplit=1))
+    dyw1, xw1 = rnd(1024, 4296, seed=11), rnd(1024, 4000, seed=12)
+    g1, g2 = torch.empty(4296, 4000, device=DEV), torch.empty(4296, 4000, device=DEV)
+    hip.linear_wgrad(dyw1, xw1, g1); hip.linear_wgrad(dyw1, xw1, g2, tile=5, ksplit=1)
+    assert torch.equal(g1, g2)
     dy = rnd(M, N, seed=4)
     assert rel_err(hip.linear_dgrad(dy, wt, tile=5), dy.float() @ wt.float()) < 4e-3
     Mw, Nw, Kw = 8192, 4296, 4000   # wgrad: output [Nw, Kw] = 17 x 16 tiles, contraction over Mw rows
