@@ -149,6 +149,11 @@ int lap_copy_rows_bf16(const void* src, void* dst, int rows, int T, int D,
 /* SigLIP stem helpers (siglip_gemma3.py:398-418): NHWC f32 image -> patch matrix f32 [B*GH*GW][P*P*C]
  * (row-major over (ph, pw, c) to match a Flax conv kernel reshaped [P,P,C,W]). */
 int lap_im2col_patch(const float* img, float* out, int B, int H, int W, int C, int P, void* stream);
+/* Train-time augmentation of f32 [B][H][W][3] images in [-1, 1] (model_adapter.py:118-151: augmax RandomCrop 95 % -> Resize
+ * -> Rotate +-5 deg -> ColorJitter 0.2/0.2/0.2, [UPSTREAM-RECALL]) as one gather + per-pixel colour pass.  params f32 [B][12]:
+ * crop offset x, y (pixels), crop width, height, cos, sin of the rotation, brightness, contrast, saturation in [-0.2, 0.2],
+ * skip flag (non-zero: copy the sample unchanged), 2 unused.  out must not alias img. */
+int lap_augment_images(const float* img, float* out, const float* params, int B, int H, int W, void* stream);
 /* y[bf16] = x[f32] + posemb[f32][r % T]  (stem output + learned posemb, cast to bf16). */
 int lap_add_posemb_cast(const float* x, const float* pos, void* y, int rows, int T, int D, void* stream);
 /* Backward of the above: dx f32 = dy; dpos[t] += sum_b dy[b,t]. */

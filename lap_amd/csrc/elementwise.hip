@@ -476,6 +476,69 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ x, const 
   if (i < n) x[i] += dt * v[i];
 }
 
+// ---------------------------------------------------------------- train-time image augmentation
+// models/model_adapter.py:118-151: augmax.Chain(RandomCrop(95 %), Resize(full), Rotate(+-5 deg), ColorJitter(0.2, 0.2, 0.2))
+// per sample, on [0, 1] images.  augmax composes the geometric transforms into ONE coordinate map and samples the source
+// once with bilinear interpolation; so does this kernel: output pixel -> rotation about the image centre -> scale of the
+// crop window -> crop offset -> 4-tap gather (outside the source: 0).  Colour on the sampled pixel: brightness, contrast
+// (piecewise-linear tone curve around 0.5), saturation (S channel of HSV).  [UPSTREAM-RECALL]: augmax is not in the image;
+// the random parameters come from the caller.  par[b] = {ox, oy, cw, ch, cos, sin, brightness, contrast, saturation, skip, -, -}.
+__device__ __forceinline__ float aug_brightness(float v, float b) { return b < 0.f ? v * (1.f + b) : v * (1.f - b) + b; }
+__device__ __forceinline__ float aug_contrast(float v, float c) {
+  const float slant = tanf((c + 1.f) * 0.78539816339744831f);
+  if (fabsf(slant - 1.f) < 1e-6f) return v;
+  const float p1 = (slant - slant * slant) / (2.f * (1.f - slant * slant)), p2 = 1.f - p1;
+  if (v < p1) return v / slant;
+  if (v > p2) return v / slant + 1.f - 1.f / slant;
+  return slant * (v - 0.5f) + 0.5f;
+}
+__global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ img, float* __restrict__ out,
+                                                      const float* __restrict__ par, int B, int H, int W) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)B * H * W) return;
+  const int x = (int)(gid % W), y = (int)((gid / W) % H), b = (int)(gid / ((long long)W * H));
+  const float* q = par + b * 12;
+  const float* src = img + (long long)b * H * W * 3;
+  float* dst = out + gid * 3;
+  if (q[9] != 0.f) {   // sample excluded from augmentation (VQA samples): copy
+    const float* s3 = src + ((long long)y * W + x) * 3;
+    dst[0] = s3[0]; dst[1] = s3[1]; dst[2] = s3[2];
+    return;
+  }
+  const float xc = (float)x + 0.5f - 0.5f * (float)W, yc = (float)y + 0.5f - 0.5f * (float)H;
+  const float xr = q[4] * xc - q[5] * yc, yr = q[5] * xc + q[4] * yc;
+  const float xs = q[0] + 0.5f * q[2] + xr * (q[2] / (float)W) - 0.5f;
+  const float ys = q[1] + 0.5f * q[3] + yr * (q[3] / (float)H) - 0.5f;
+  const float xf = floorf(xs), yf = floorf(ys);
+  const int x0 = (int)xf, y0 = (int)yf;
+  const float ax = xs - xf, ay = ys - yf;
+  float px[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int xx = x0 + dx, yy = y0 + dy;
+      if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+      const float wgt = (dx ? ax : 1.f - ax) * (dy ? ay : 1.f - ay);
+      const float* s3 = src + ((long long)yy * W + xx) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) px[c] += wgt * (s3[c] * 0.5f + 0.5f);   // [-1, 1] -> [0, 1]
+    }
+  float r = px[0], g = px[1], bl = px[2];
+  r = aug_brightness(r, q[6]); g = aug_brightness(g, q[6]); bl = aug_brightness(bl, q[6]);
+  r = aug_contrast(r, q[7]); g = aug_contrast(g, q[7]); bl = aug_contrast(bl, q[7]);
+  {   // saturation: scale S of HSV, i.e. move every channel towards / away from the maximum channel
+    const float mx = fmaxf(r, fmaxf(g, bl)), mn = fminf(r, fminf(g, bl));
+    const float sat = mx > 0.f ? (mx - mn) / mx : 0.f;
+    const float s2 = fminf(fmaxf(aug_brightness(sat, q[8]), 0.f), 1.f);
+    const float k = sat > 0.f ? s2 / sat : 0.f;
+    r = mx - (mx - r) * k; g = mx - (mx - g) * k; bl = mx - (mx - bl) * k;
+  }
+  dst[0] = fminf(fmaxf(r, 0.f), 1.f) * 2.f - 1.f;
+  dst[1] = fminf(fmaxf(g, 0.f), 1.f) * 2.f - 1.f;
+  dst[2] = fminf(fmaxf(bl, 0.f), 1.f) * 2.f - 1.f;
+}
+
 }  // namespace
 
 #define S_ ((hipStream_t)stream)
@@ -628,6 +691,12 @@ extern "C" int lap_im2col_patch(const float* img, float* out, int B, int H, int 
   if (B <= 0 || P <= 0 || H % P || W % P) return LAP_ERR_ARG;
   const long long n = (long long)B * H * W * C;
   hipLaunchKernelGGL(im2col_kernel, flat_grid(n), dim3(256), 0, S_, img, out, B, H, W, C, P);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_augment_images(const float* img, float* out, const float* params, int B, int H, int W, void* stream) {
+  if (!img || !out || !params || img == out || B <= 0 || H <= 0 || W <= 0) return LAP_ERR_ARG;
+  hipLaunchKernelGGL(augment_kernel, flat_grid((long long)B * H * W), dim3(256), 0, S_, img, out, params, B, H, W);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

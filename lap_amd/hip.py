@@ -93,6 +93,7 @@ SIGNATURES: dict[str, list] = {
     "lap_copy2d_bf16": [_vp, _vp, _i, _i, _i, _i, _vp],
     "lap_copy_rows_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "lap_im2col_patch": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "lap_augment_images": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_add_posemb_cast": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_add_posemb_cast_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],
@@ -571,6 +572,17 @@ def linear_partials(x, wt, scratch, ksplit=None):
     call("lap_gemm_bf16_ex", _p(x), _p(wt), None, None, None, M, N, K, x.stride(0), wt.stride(0), N, 0, 1.0, 1, 1,
          GEMM_OUT_F32 | GEMM_PARTIALS, 6, ksplit, _p(scratch), scratch.numel() * 4)
     return scratch[:need].view(ksplit, M, N), ksplit
+
+
+def augment_images(img, params):
+    """img f32 [B, H, W, 3] in [-1, 1], params f32 [B, 12] (include/lap_hip.h) -> augmented copy."""
+    _req(img, torch.float32, "img"); _req(params, torch.float32, "params")
+    B, H, W, C = img.shape
+    if C != 3 or params.shape != (B, 12) or not img.is_contiguous() or not params.is_contiguous():
+        raise ValueError("augment_images: img [B, H, W, 3] and params [B, 12], both contiguous")
+    out = torch.empty_like(img)
+    call("lap_augment_images", _p(img), _p(out), _p(params), B, H, W)
+    return out
 
 
 def rope_table(pos, B, T_seg, T_total, seg_off, HD):

@@ -471,14 +471,14 @@ class LAP:
             raise NotImplementedError("VQA / prediction loss mixing is not on the benchmarked path")
         dev = self.device
         self.comm.wait_unit("small")
+        g = _gen(rng, dev)
         obs = preprocess_observation(observation, train=train, image_keys=cfg.image_keys, image_resolution=cfg.image_resolution,
-                                     enable_image_augmentation=cfg.enable_image_augmentation)
+                                     enable_image_augmentation=cfg.enable_image_augmentation, rng=g)
         actions = actions.to(dev, torch.float32).contiguous()
         B, S, ad = actions.shape
         if S != self.action_horizon:
             raise ValueError(f"actions horizon {S} != action_horizon {self.action_horizon}")
         # lap.py:185-207 prepare_suffix — noise ~ N(0,1), time ~ Beta(1.5, 1) * 0.999 + 0.001
-        g = _gen(rng, dev)
         if noise is None:
             noise = torch.randn(actions.shape, generator=g, device=dev, dtype=torch.float32)
         if time is None:

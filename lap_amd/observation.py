@@ -5,6 +5,7 @@ openpi.models.model.Observation), as a plain dataclass of torch tensors, plus pr
 from __future__ import annotations
 
 import dataclasses
+import math
 
 import numpy as np
 import torch
@@ -108,13 +109,32 @@ def resize_with_pad(images: torch.Tensor, height: int, width: int) -> torch.Tens
     return x.permute(0, 2, 3, 1).contiguous()
 
 
+def augmentation_params(batch: int, height: int, width: int, generator: torch.Generator, device, skip=None) -> torch.Tensor:
+    """Random parameters of the train-time augmentation chain, f32 [batch, 12] in the layout of lap_augment_images:
+    RandomCrop(95 %) offset uniform over the valid range, Rotate uniform in [-5, 5] degrees, ColorJitter brightness /
+    contrast / saturation uniform in [-0.2, 0.2] (model_adapter.py:126-141)."""
+    u = torch.rand((batch, 6), generator=generator, device=device, dtype=torch.float32)
+    cw, ch = int(width * 0.95), int(height * 0.95)
+    ang = (u[:, 2] * 10.0 - 5.0) * (math.pi / 180.0)
+    par = torch.zeros((batch, 12), dtype=torch.float32, device=device)
+    par[:, 0] = u[:, 0] * (width - cw)
+    par[:, 1] = u[:, 1] * (height - ch)
+    par[:, 2], par[:, 3] = float(cw), float(ch)
+    par[:, 4], par[:, 5] = torch.cos(ang), torch.sin(ang)
+    par[:, 6:9] = u[:, 3:6] * 0.4 - 0.2
+    if skip is not None:
+        par[:, 9] = skip.to(device=device, dtype=torch.float32)
+    return par
+
+
 def preprocess_observation(observation: CoTObservation, *, train: bool, image_keys, image_resolution,
-                           enable_image_augmentation: bool = True) -> CoTObservation:
-    """model_adapter.py:83-181 without augmax: selects the image keys, resizes to the model resolution and fills default
-    image masks.  Train-time augmentation (RandomCrop 95% / Resize / Rotate +-5 deg / ColorJitter) is a listed
-    'next' item (SURVEY.md §8 a-bis); asking for it raises instead of silently skipping it."""
-    if train and enable_image_augmentation:
-        raise NotImplementedError("image augmentation is not implemented; use a config with enable_image_augmentation=False")
+                           enable_image_augmentation: bool = True, rng: torch.Generator | None = None) -> CoTObservation:
+    """model_adapter.py:83-181: selects the image keys, resizes to the model resolution, applies the train-time augmentation
+    chain (RandomCrop 95 % / Resize / Rotate +-5 deg / ColorJitter 0.2; augmax restated from memory, see lap_augment_images)
+    and fills default image masks."""
+    augment = train and enable_image_augmentation
+    if augment and rng is None:
+        raise ValueError("image augmentation needs a random generator (preprocess_observation(..., rng=...))")
     images, masks = {}, {}
     batch = None
     for key in image_keys:
@@ -123,6 +143,11 @@ def preprocess_observation(observation: CoTObservation, *, train: bool, image_ke
         img = observation.images[key]
         if tuple(img.shape[1:3]) != tuple(image_resolution):
             img = resize_with_pad(img, *image_resolution)
+        if augment:   # one fused gather + colour kernel per camera (csrc/elementwise.hip); VQA samples pass unchanged
+            from lap_amd import hip
+            img = img.to(torch.float32).contiguous()
+            par = augmentation_params(img.shape[0], img.shape[1], img.shape[2], rng, img.device, skip=observation.is_vqa_sample)
+            img = hip.augment_images(img, par)
         images[key] = img
         batch = img.shape[0]
         m = observation.image_masks.get(key)

@@ -622,3 +622,44 @@ def ema_decay_for_step(kind, step, ema_decay, start_step, num_train_steps):
             return ema_decay, True
         return 0.0, False
     raise ValueError(kind)
+
+
+# ------------------------------------------------------------------------------ train-time image augmentation
+def augment_images(img: torch.Tensor, par: torch.Tensor) -> torch.Tensor:
+    """models/model_adapter.py:118-151 [UPSTREAM-RECALL of augmax]: Chain(RandomCrop 95 %, Resize, Rotate, ColorJitter) on
+    f32 [B,H,W,3] images in [-1,1] with the random parameters given (layout of lap_augment_images: crop offset x, y, crop
+    width, height, cos, sin, brightness, contrast, saturation, skip).  One composed coordinate map + bilinear sampling with
+    zero fill, then brightness / contrast tone curve / HSV saturation per pixel."""
+    B, H, W, _ = img.shape
+    par = par.to(torch.float32)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    xc, yc = (xs + 0.5 - 0.5 * W)[None], (ys + 0.5 - 0.5 * H)[None]
+    q = lambda i: par[:, i].view(B, 1, 1)
+    xr, yr = q(4) * xc - q(5) * yc, q(5) * xc + q(4) * yc
+    sx = q(0) + 0.5 * q(2) + xr * (q(2) / W) - 0.5
+    sy = q(1) + 0.5 * q(3) + yr * (q(3) / H) - 0.5
+    x0, y0 = torch.floor(sx), torch.floor(sy)
+    ax, ay = (sx - x0)[..., None], (sy - y0)[..., None]
+    unit = img.to(torch.float32) * 0.5 + 0.5
+    out = torch.zeros_like(unit)
+    bidx = torch.arange(B).view(B, 1, 1).expand(B, H, W)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            xx, yy = (x0 + dx).long(), (y0 + dy).long()
+            ok = ((xx >= 0) & (xx < W) & (yy >= 0) & (yy < H))[..., None]
+            wgt = (ax if dx else 1 - ax) * (ay if dy else 1 - ay)
+            out = out + torch.where(ok, wgt * unit[bidx, yy.clamp(0, H - 1), xx.clamp(0, W - 1)], torch.zeros(()))
+    bri = lambda v, b: torch.where(b < 0, v * (1 + b), v * (1 - b) + b)
+    b_, c_, s_ = (par[:, i].view(B, 1, 1, 1) for i in (6, 7, 8))
+    v = bri(out, b_)
+    slant = torch.tan((c_ + 1.0) * (math.pi / 4))
+    safe = torch.where((slant - 1).abs() < 1e-6, torch.full_like(slant, 2.0), slant)
+    p1 = (safe - safe * safe) / (2 * (1 - safe * safe))
+    curve = torch.where(v < p1, v / safe, torch.where(v > 1 - p1, v / safe + 1 - 1 / safe, safe * (v - 0.5) + 0.5))
+    v = torch.where((slant - 1).abs() < 1e-6, v, curve)
+    mx, mn = v.max(-1, keepdim=True).values, v.min(-1, keepdim=True).values
+    sat = torch.where(mx > 0, (mx - mn) / mx.clamp_min(1e-30), torch.zeros(()))
+    k = torch.where(sat > 0, bri(sat, s_).clamp(0, 1) / sat.clamp_min(1e-30), torch.zeros(()))
+    v = (mx - (mx - v) * k).clamp(0, 1) * 2 - 1
+    skip = (par[:, 9] != 0).view(B, 1, 1, 1)
+    return torch.where(skip, img.to(torch.float32), v)

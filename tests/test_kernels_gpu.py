@@ -613,3 +613,35 @@ def test_flow_matching_bits(hip):
     f = rnd(1003, dtype=torch.float32, seed=8)
     assert torch.equal(hip.cast_f32_to_bf16(f), f.bfloat16())
     assert torch.equal(hip.cast_bf16_to_f32(a16), a16.float())
+
+
+# ------------------------------------------------------------------ train-time image augmentation
+def test_augment_images_matches_oracle_and_identity(hip):
+    from oracle import lap_oracle as O
+    from lap_amd.observation import augmentation_params
+    g = torch.Generator(device=DEV).manual_seed(3)
+    B, H, W = 5, 224, 224
+    img = (torch.rand(B, H, W, 3, generator=g, device=DEV) * 2 - 1).contiguous()
+    par = augmentation_params(B, H, W, g, DEV, skip=torch.tensor([False, False, True, False, False]))
+    assert par.shape == (B, 12) and float(par[:, 2].min()) == int(W * 0.95) and par[:, 0].max() <= W - int(W * 0.95)
+    assert par[:, 6:9].abs().max() <= 0.2 and torch.allclose(par[:, 4] ** 2 + par[:, 5] ** 2, torch.ones(B, device=DEV), atol=1e-6)
+    assert (torch.atan2(par[:, 5], par[:, 4]).abs() <= 5.0001 * 3.14159265 / 180).all()
+    out = hip.augment_images(img, par)
+    ref = O.augment_images(img.cpu(), par.cpu())
+    d = (out.cpu() - ref).abs()                                       # same formulas; the f32 coordinate map rounds differently (FMA
+    assert d.max() < 5e-4 and d.mean() < 1e-5                         # contraction), i.e. 1e-5 px of sampling position on random images
+    assert torch.equal(out[2], img[2])                                # skipped (VQA) sample untouched
+    assert out.min() >= -1 and out.max() <= 1 and (out[0] - img[0]).abs().mean() > 0.01
+    # neutral parameters (full-size crop, no rotation, zero jitter) reproduce the input
+    ident = torch.zeros(B, 12, device=DEV); ident[:, 2], ident[:, 3], ident[:, 4] = W, H, 1.0
+    assert (hip.augment_images(img, ident) - img).abs().max() < 1e-6
+    # pure brightness +0.2 on a grey image: v -> v * 0.8 + 0.2 in [0, 1]
+    grey = torch.full((1, 8, 8, 3), 0.0, device=DEV)                   # 0.5 in [0, 1]
+    pb = torch.zeros(1, 12, device=DEV); pb[:, 2], pb[:, 3], pb[:, 4], pb[:, 6] = 8, 8, 1.0, 0.2
+    assert torch.allclose(hip.augment_images(grey, pb), torch.full_like(grey, (0.5 * 0.8 + 0.2) * 2 - 1), atol=1e-6)
+    # a 5 degree rotation leaves the centre in place and brings zero fill (black, -1) only into the corners
+    white = torch.ones(1, 64, 64, 3, device=DEV)
+    pr = torch.zeros(1, 12, device=DEV); pr[:, 2], pr[:, 3] = 64, 64
+    pr[:, 4], pr[:, 5] = float(torch.cos(torch.tensor(0.0873))), float(torch.sin(torch.tensor(0.0873)))
+    rot = hip.augment_images(white, pr)
+    assert torch.allclose(rot[0, 24:40, 24:40], torch.ones(16, 16, 3, device=DEV), atol=1e-6) and rot[0, 0, 0, 0] < 0.0

@@ -78,3 +78,23 @@ def test_train_from_episode_store_then_serve(hip, tmp_path):
     out = policy.infer({"observation": {"base_0_rgb": e["base_0_rgb"][0], "left_wrist_0_rgb": e["left_wrist_0_rgb"][0], "state": e["state"][0]},
                         "prompt": e["prompt"]})
     assert out["actions"].shape == (cfg.model.action_horizon, 16) and np.isfinite(out["actions"]).all()
+
+
+def test_train_step_with_image_augmentation(hip):
+    """The reference's main config trains with augmentation on (config.py:608-619): the step must run, be reproducible for
+    a fixed rng and differ from the un-augmented loss."""
+    import dataclasses
+
+    from lap_amd.config import get_config
+    from lap_amd.model import LAP
+    from tests.common import make_inputs, to_observation
+
+    cfg = dataclasses.replace(get_config("debug").model, enable_image_augmentation=True)
+    obs, actions, noise, time = make_inputs(cfg, B=3, ragged=True)
+    model = LAP(cfg, seed=2, device="cuda")
+    o = to_observation(obs, "cuda")
+    l1, _ = model.loss_and_grad(7, o, actions.cuda(), noise=noise.cuda(), time=time.cuda(), train=True)
+    l2, _ = model.loss_and_grad(7, o, actions.cuda(), noise=noise.cuda(), time=time.cuda(), train=True)
+    l3, _ = model.loss_and_grad(8, o, actions.cuda(), noise=noise.cuda(), time=time.cuda(), train=True)
+    l0, _ = model.compute_loss(7, o, actions.cuda(), noise=noise.cuda(), time=time.cuda(), train=False)
+    assert torch.isfinite(l1) and float(l1) == float(l2) and float(l1) != float(l3) and float(l1) != float(l0)
