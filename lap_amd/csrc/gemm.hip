@@ -345,6 +345,54 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
       return;
     }
   }
+  if constexpr (OUT_F32 && BM == 256 && BN == 256 && NW == 16) {
+    // f32 output (weight gradients, logits): the same staging in two halves of 128 rows (a 256 x 256 f32 tile does not fit):
+    // the two wave rows of a half write their accumulators to LDS (1088-byte pitch), then all 16 waves move the half out in
+    // 16-byte pieces, four full 1 KiB rows per wave instruction - with beta = 1 the old values come in the same way.
+    if (p.epi_lds) {
+      constexpr int CP = BN * 4 + 64;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        __syncthreads();   // operand tiles dead (first pass) / previous half moved out (second pass)
+        if ((wm >> 1) == half) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            const int ml = (wm & 1) * WTM + i * 16 + li;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              const int nl = wn * WTN + j * 16 + 4 * lg;
+              const int n = n0 + nl;
+              f32x4 v = acc[i][j] * p.alpha;
+              if (n < p.N) {
+                if (p.bias_kind == 1) {
+                  bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
+                } else if (p.bias_kind == 2) {
+                  v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+                }
+              }
+              *reinterpret_cast<f32x4*>(smem + ml * CP + nl * 4) = v;
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 128 * BN / 4 / (NW * 64); ++it) {
+          const int id = tid + NW * 64 * it;
+          const int r = id >> 6, c = id & 63;
+          const int m = m0 + half * 128 + r, n = n0 + c * 4;
+          if (m < p.M && n < p.N) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CP + c * 16);
+            float* dst = (float*)p.C + (long long)m * p.ldc + n;
+            if (p.accum) v += *reinterpret_cast<const f32x4*>(dst);
+            *reinterpret_cast<f32x4*>(dst) = v;
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int m = m0 + wm * WTM + i * 16 + li;
@@ -772,10 +820,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 
 template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool A_KC, bool B_KC, bool OUT_F32>
 int launch(GemmParams p, hipStream_t s) {
-  constexpr int EPI = (!OUT_F32 && BM == 256 && BN == 256 && WGM * WGN == 16) ? BM * (BN * 2 + 32) : 0;   // staged bf16 tile
+  // staged epilogue of the 256x256 kernel: a bf16 tile (544-byte rows) or half an f32 tile (128 rows of 1088 bytes)
+  constexpr int EPI = (BM == 256 && BN == 256 && WGM * WGN == 16) ? (OUT_F32 ? 128 * (BN * 4 + 64) : BM * (BN * 2 + 32)) : 0;
   constexpr int LDS = NS * (BM + BN) * BK * 2 > EPI ? NS * (BM + BN) * BK * 2 : EPI;
   auto kern = gemm_kernel<BM, BN, WGM, WGN, BK, NS, A_KC, B_KC, OUT_F32>;
-  p.epi_lds = (EPI > 0 && !p.part && !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) ? 1 : 0;
+  p.epi_lds = (EPI > 0 && !p.part && p.ksplit == 1 && !(OUT_F32 && p.R) && !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) ? 1 : 0;
   if (LDS > 65536) {
     static bool done = false;  // benign race: the attribute is idempotent
     if (!done) {

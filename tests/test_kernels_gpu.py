@@ -79,6 +79,19 @@ def test_gemm_staged_epilogue_matches_direct_stores(hip):
         if N % 8 == 0:   # (the contraction axis of the dgrad needs 16-byte rows)
             dy = rnd(M, N, seed=4)
             assert torch.equal(hip.linear_dgrad(dy, wt, tile=5, ksplit=1), hip.linear_dgrad(dy, wt, tile=2, ksplit=1))
+    # f32 outputs (weight gradients, f32 projections) leave in two staged halves: beta = 0 and beta = 1, f32 bias, ragged edges
+    for (rows, out_f, in_f) in [(320, 777 * 8, 1000), (192, 520, 264)]:
+        dy = rnd(rows, out_f, seed=5); x = rnd(rows, in_f, seed=6)
+        g5 = torch.full((out_f, in_f), 0.5, device=DEV); g2 = g5.clone()
+        hip.linear_wgrad(dy, x, g5, tile=5, ksplit=1); hip.linear_wgrad(dy, x, g2, tile=2, ksplit=1)
+        assert torch.equal(g5, g2)
+        hip.linear_wgrad(dy, x, g5, tile=5, ksplit=1, accum=True); hip.linear_wgrad(dy, x, g2, tile=2, ksplit=1, accum=True)
+        assert torch.equal(g5, g2)
+    a = rnd(300, 128); wt = rnd(520, 128, seed=1); b32 = rnd(520, dtype=torch.float32, seed=2)
+    o5 = torch.empty(300, 520, device=DEV); o2 = torch.empty(300, 520, device=DEV)
+    hip.gemm(a, wt, o5, M=300, N=520, K=128, lda=128, ldb=128, ldc=520, bias=b32, tile=5, ksplit=1)
+    hip.gemm(a, wt, o2, M=300, N=520, K=128, lda=128, ldb=128, ldc=520, bias=b32, tile=2, ksplit=1)
+    assert torch.equal(o5, o2) and rel_err(o5, a.float() @ wt.float().t() + b32) < 1e-5
     # a view into a wider buffer: ldc != N
     wide = torch.zeros(520, 1024, dtype=torch.bfloat16, device=DEV)
     a = rnd(520, 128); wt = rnd(512, 128, seed=1)
