@@ -104,10 +104,27 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
       }
     }
   }
+  // one row ahead: the loads of the wave's next row are issued before the reductions / stores of the current one
+  bf16x8 nx[NCH], ndy[NCH];
+  float nr = 0.f;
+  auto fetch = [&](int row) {
+#pragma unroll
+    for (int p = 0; p < NCH; ++p) {
+      const int c = (lane + 64 * p) * 8;
+      if (c < D) {
+        nx[p] = *reinterpret_cast<const bf16x8*>(x + (long long)row * D + c);
+        ndy[p] = *reinterpret_cast<const bf16x8*>(dy + (long long)row * D + c);
+      }
+    }
+    nr = rstd[row];
+  };
+  if (r0 + w < r1) fetch(r0 + w);
   for (int row = r0 + w; row < r1; row += NWAVE) {
-    const bf16* xr = x + (long long)row * D;
-    const bf16* dyr = dy + (long long)row * D;
-    const float r = rstd[row];
+    bf16x8 cx[NCH], cdy[NCH];
+#pragma unroll
+    for (int p = 0; p < NCH; ++p) { cx[p] = nx[p]; cdy[p] = ndy[p]; }
+    const float r = nr;
+    if (row + NWAVE < r1) fetch(row + NWAVE);
     float xv[NCH][8], gv[NCH][8];
     float dot = 0.f;
 #pragma unroll
@@ -115,8 +132,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
       const int c = (lane + 64 * p) * 8;
       if (c < D) {
         float dyv[8];
-        load8(xr + c, xv[p]);
-        load8(dyr + c, dyv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xv[p][e] = (float)cx[p][e]; dyv[e] = (float)cdy[p][e]; }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           gv[p][e] = dyv[e] * wgt[p][e];
@@ -234,10 +251,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dg[p][e] = 0.f; db[p][e] = 0.f; gm[p][e] = (c < D) ? gamma[c + e] : 0.f; }
   }
+  bf16x8 nx[NCH], ndy[NCH];   // one row ahead, as in rmsnorm_bwd_kernel
+  float nmu = 0.f, nr = 0.f;
+  auto fetch = [&](int row) {
+#pragma unroll
+    for (int p = 0; p < NCH; ++p) {
+      const int c = (lane + 64 * p) * 8;
+      if (c < D) {
+        nx[p] = *reinterpret_cast<const bf16x8*>(x + (long long)row * D + c);
+        ndy[p] = *reinterpret_cast<const bf16x8*>(dy + (long long)row * D + c);
+      }
+    }
+    nmu = mean[row]; nr = rstd[row];
+  };
+  if (r0 + w < r1) fetch(r0 + w);
   for (int row = r0 + w; row < r1; row += NWAVE) {
-    const bf16* xr = x + (long long)row * D;
-    const bf16* dyr = dy + (long long)row * D;
-    const float mu = mean[row], r = rstd[row];
+    bf16x8 cx[NCH], cdy[NCH];
+#pragma unroll
+    for (int p = 0; p < NCH; ++p) { cx[p] = nx[p]; cdy[p] = ndy[p]; }
+    const float mu = nmu, r = nr;
+    if (row + NWAVE < r1) fetch(row + NWAVE);
     float xh[NCH][8], gv[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -245,8 +278,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
       const int c = (lane + 64 * p) * 8;
       if (c < D) {
         float xv[8], dyv[8];
-        load8(xr + c, xv);
-        load8(dyr + c, dyv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xv[e] = (float)cx[p][e]; dyv[e] = (float)cdy[p][e]; }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           xh[p][e] = (xv[e] - mu) * r;

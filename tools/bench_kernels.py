@@ -96,6 +96,13 @@ def bench_mem():
     y, rstd = hip.rmsnorm_fwd(x, scale=sc); ds = torch.zeros(D, device=dev)
     t = timeit(lambda: hip.rmsnorm_bwd(x, x, rstd, scale=sc, dscale=ds))
     print(f"rmsnorm bwd: {t*1e6:.1f} us {3*rows*D*2/t/1e9:.0f} GB/s")
+    xs = rnd(16384, 1152); gam = torch.ones(1152, device=dev); bet = torch.zeros(1152, device=dev)
+    t = timeit(lambda: hip.layernorm_fwd(xs, gam, bet))
+    print(f"layernorm fwd (16384 x 1152): {t*1e6:.1f} us {2*16384*1152*2/t/1e9:.0f} GB/s")
+    ys, mean_, rstd_ = hip.layernorm_fwd(xs, gam, bet)
+    dg = torch.zeros(1152, device=dev); db = torch.zeros(1152, device=dev)
+    t = timeit(lambda: hip.layernorm_bwd(xs, xs, gam, mean_, rstd_, dg, db))
+    print(f"layernorm bwd: {t*1e6:.1f} us {3*16384*1152*2/t/1e9:.0f} GB/s")
     gu = rnd(rows, 32768)
     t = timeit(lambda: hip.geglu_fwd(gu))
     print(f"geglu fwd: {t*1e6:.1f} us {rows*16384*2*3/t/1e9:.0f} GB/s")
