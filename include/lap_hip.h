@@ -50,7 +50,8 @@ int lap_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const
 /* Same with explicit scheduling knobs: tile = -1 (heuristic: 5 or 6) | 0 (128x128x64, 4 waves) | 1 (256x128x64, 3 stages)
  * | 2 (256x256x64, 8 waves) | 3 (256x256x32, 4 stages) | 4 (128x128x32, 4 stages) | 5 (256x256x64, 16 waves: production,
  * with the tail split of a poorly filled last round and the LDS-staged bf16 epilogue) | 6 (128x128x64, 8 waves, 2 blocks
- * per CU: production for small shapes) | 7 (256x128x64, 16 waves) | 8, 9 (8- / 16-wave ping-pong probes).  All tiles give
+ * per CU: production for small shapes) | 7 (256x128x64, 16 waves) | 8, 9 (8- / 16-wave ping-pong probes) | 10 (256x256x64,
+ * 8 waves, software-pipelined with two fragment register sets; K % 64 == 0; stands in for 5 in production).  All tiles give
  * the same bits for the same ksplit (k is accumulated in the same order).  ksplit > 1 splits K over grid.y:
  *  - with `scratch` (>= ksplit*M*N*4 bytes): f32 partials + a reduce/epilogue kernel, any output / epilogue
  *    (deterministic; used for GEMMs with too few output tiles to fill 256 CUs: skinny-M serving, small weights);

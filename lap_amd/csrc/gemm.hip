@@ -14,7 +14,9 @@
 //   dgrad    dx = dy . Wt        -> a_kc=1, b_kc=0
 //   wgrad    dWt = dy^T . x      -> a_kc=0, b_kc=0
 //
-// Structure: BM x BN x BK block tile, WGM x WGN waves, each wave a (BM/WGM) x
+// Production kernels: the software-pipelined 8-wave 256x256 kernel (gemm_sp_kernel, "tile 10") for K % 64 == 0, the
+// 16-wave lockstep kernel below ("tile 5") otherwise, the 128x128 kernel ("tile 6") for small shapes and short-K tails.
+// Structure of the generic kernel: BM x BN x BK block tile, WGM x WGN waves, each wave a (BM/WGM) x
 // (BN/WGN) sub-tile of v_mfma_f32_16x16x32_bf16 fragments.  Production shapes:
 //   256x256x64 / 16 waves (64x64 per wave): 128 FLOP per L2 byte, one block per CU
 //            (128 KiB LDS), 4 waves per SIMD hide the ds_read -> MFMA latency and the
@@ -122,6 +124,107 @@ __device__ __forceinline__ void store_tile4(const GemmParams& p, int m, int n, f
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
     *reinterpret_cast<bf16x4*>((bf16*)p.C + (long long)m * p.ldc + n) = o;
+  }
+}
+
+// Epilogue of the 256x256 kernels through LDS (set by the host: p.epi_lds).  bf16: straight from the accumulators a lane
+// owns 8-byte pieces of 16 different rows (32-byte runs per row: 64 narrow stores per wave instruction, store-issue bound,
+// and with one block per CU nothing overlaps them - ~7 us per tile, 11-18 % of a K <= 2048 tile).  The operand tiles are
+// dead after the k-loop, so the finished bf16 tile is written to LDS (row pitch 544 B: the 16 rows x 4 column groups of a
+// ds_write_b64 land on distinct even banks) and leaves as 16-byte stores, two full 512-byte rows per wave instruction.
+// alpha / bias / GELU / residual are applied in registers exactly as in the direct path: same bits.  f32 (weight gradients,
+// logits): the same in two halves of 128 rows (a 256 x 256 f32 tile does not fit; 1088-byte pitch), four full 1 KiB rows
+// per wave instruction; with beta = 1 the old values come in the same coalesced way.
+template <int NW, int WTM, int WTN, bool OUT_F32>
+__device__ __forceinline__ void staged_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[WTM / 16][WTN / 16], int wm, int wn,
+                                                int m0, int n0, int tid, int lane) {
+  constexpr int FM = WTM / 16, FN = WTN / 16, BM = 256, BN = 256;
+  const int li = lane & 15, lg = lane >> 4;
+  if constexpr (!OUT_F32) {
+    constexpr int CP = BN * 2 + 32;
+    __syncthreads();   // every wave is done reading the operand tiles (no LDS-DMA in flight after the last k-tile)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int ml = wm * WTM + i * 16 + li;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int nl = wn * WTN + j * 16 + 4 * lg;
+        const int m = m0 + ml, n = n0 + nl;
+        f32x4 v = acc[i][j] * p.alpha;
+        if (m < p.M && n < p.N) {
+          if (p.bias_kind == 1) {
+            bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
+          } else if (p.bias_kind == 2) {
+            v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+          }
+          if (p.gelu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+          }
+          if (p.R) {
+            bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+          }
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        *reinterpret_cast<bf16x4*>(smem + ml * CP + nl * 2) = o;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < BM * BN / 8 / (NW * 64); ++it) {
+      const int id = tid + NW * 64 * it;
+      const int r = id >> 5, c = id & 31;
+      const int m = m0 + r, n = n0 + c * 8;
+      if (m < p.M && n < p.N)   // N % 8 == 0 on this path: a 16-byte piece is inside or outside as a whole
+        *reinterpret_cast<bf16x8*>((bf16*)p.C + (long long)m * p.ldc + n) = *reinterpret_cast<const bf16x8*>(smem + r * CP + c * 16);
+    }
+  } else {
+    constexpr int CP = BN * 4 + 64;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();   // operand tiles dead (first pass) / previous half moved out (second pass)
+      if ((wm * WTM) / 128 == half) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int ml = (wm * WTM) % 128 + i * 16 + li;
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const int nl = wn * WTN + j * 16 + 4 * lg;
+            const int n = n0 + nl;
+            f32x4 v = acc[i][j] * p.alpha;
+            if (n < p.N) {
+              if (p.bias_kind == 1) {
+                bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
+              } else if (p.bias_kind == 2) {
+                v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+              }
+            }
+            *reinterpret_cast<f32x4*>(smem + ml * CP + nl * 4) = v;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 128 * BN / 4 / (NW * 64); ++it) {
+        const int id = tid + NW * 64 * it;
+        const int r = id >> 6, c = id & 63;
+        const int m = m0 + half * 128 + r, n = n0 + c * 4;
+        if (m < p.M && n < p.N) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CP + c * 16);
+          float* dst = (float*)p.C + (long long)m * p.ldc + n;
+          if (p.accum) v += *reinterpret_cast<const f32x4*>(dst);
+          *reinterpret_cast<f32x4*>(dst) = v;
+        }
+      }
+    }
   }
 }
 
@@ -291,107 +394,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
 
   // Epilogue. Lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + 4*(lane>>4).
   const int li = lane & 15, lg = lane >> 4;
-  if constexpr (!OUT_F32 && BM == 256 && BN == 256 && NW == 16) {
-    // bf16 output staged through LDS: straight from the accumulators a lane owns 8-byte pieces of 16 different rows
-    // (32-byte runs per row: 64 narrow stores per wave instruction, store-issue bound, and with one block per CU nothing
-    // overlaps them - ~7 us per tile, 11-18 % of a K <= 2048 tile).  The operand tiles are dead after the k-loop, so the
-    // finished bf16 tile is written to LDS (row pitch 544 B: the 16 rows x 4 column groups of a ds_write_b64 land on
-    // distinct even banks) and leaves as 16-byte stores, two full 512-byte rows per wave instruction.  Same values:
-    // alpha / bias / GELU / residual are applied in registers exactly as in the direct path.
-    if (p.epi_lds) {
-      constexpr int CP = BN * 2 + 32;
-      __syncthreads();   // every wave is done reading the operand tiles (no LDS-DMA in flight after the last k-tile)
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int ml = wm * WTM + i * 16 + li;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const int nl = wn * WTN + j * 16 + 4 * lg;
-          const int m = m0 + ml, n = n0 + nl;
-          f32x4 v = acc[i][j] * p.alpha;
-          if (m < p.M && n < p.N) {
-            if (p.bias_kind == 1) {
-              bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
-            } else if (p.bias_kind == 2) {
-              v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
-            }
-            if (p.gelu) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-            }
-            if (p.R) {
-              bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-            }
-          }
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-          *reinterpret_cast<bf16x4*>(smem + ml * CP + nl * 2) = o;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < BM * BN / 8 / (NW * 64); ++it) {
-        const int id = tid + NW * 64 * it;
-        const int r = id >> 5, c = id & 31;
-        const int m = m0 + r, n = n0 + c * 8;
-        if (m < p.M && n < p.N)   // N % 8 == 0 on this path: a 16-byte piece is inside or outside as a whole
-          *reinterpret_cast<bf16x8*>((bf16*)p.C + (long long)m * p.ldc + n) = *reinterpret_cast<const bf16x8*>(smem + r * CP + c * 16);
-      }
-      return;
-    }
-  }
-  if constexpr (OUT_F32 && BM == 256 && BN == 256 && NW == 16) {
-    // f32 output (weight gradients, logits): the same staging in two halves of 128 rows (a 256 x 256 f32 tile does not fit):
-    // the two wave rows of a half write their accumulators to LDS (1088-byte pitch), then all 16 waves move the half out in
-    // 16-byte pieces, four full 1 KiB rows per wave instruction - with beta = 1 the old values come in the same way.
-    if (p.epi_lds) {
-      constexpr int CP = BN * 4 + 64;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        __syncthreads();   // operand tiles dead (first pass) / previous half moved out (second pass)
-        if ((wm >> 1) == half) {
-#pragma unroll
-          for (int i = 0; i < FM; ++i) {
-            const int ml = (wm & 1) * WTM + i * 16 + li;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-              const int nl = wn * WTN + j * 16 + 4 * lg;
-              const int n = n0 + nl;
-              f32x4 v = acc[i][j] * p.alpha;
-              if (n < p.N) {
-                if (p.bias_kind == 1) {
-                  bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
-                } else if (p.bias_kind == 2) {
-                  v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
-                }
-              }
-              *reinterpret_cast<f32x4*>(smem + ml * CP + nl * 4) = v;
-            }
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 128 * BN / 4 / (NW * 64); ++it) {
-          const int id = tid + NW * 64 * it;
-          const int r = id >> 6, c = id & 63;
-          const int m = m0 + half * 128 + r, n = n0 + c * 4;
-          if (m < p.M && n < p.N) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CP + c * 16);
-            float* dst = (float*)p.C + (long long)m * p.ldc + n;
-            if (p.accum) v += *reinterpret_cast<const f32x4*>(dst);
-            *reinterpret_cast<f32x4*>(dst) = v;
-          }
-        }
-      }
-      return;
-    }
+  if constexpr (BM == 256 && BN == 256 && NW == 16) {
+    if (p.epi_lds) { staged_epilogue<NW, WTM, WTN, OUT_F32>(p, smem, acc, wm, wn, m0, n0, tid, lane); return; }
   }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
@@ -741,6 +745,205 @@ __global__ __launch_bounds__(1024) void gemm_pp16_kernel(GemmParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Software-pipelined 8-wave kernel (tile 10): 256x256x64 tile, 128x64 per wave, TWO fragment register sets.  Per k-tile
+//   A1  issue the raw reads of (kt, k-half 1) into set 1 | first 16 MFMAs on set 0 = (kt, k-half 0)
+//   A2  set 1 landed, my LDS-DMA of tile kt+1 landed, barrier          (every read of tile kt has completed)
+//   A3  last 16 MFMAs on set 0, with the 8 LDS-DMA pieces of tile kt+2 threaded between them (into kt's buffer)
+//   C   issue the raw reads of (kt+1, k-half 0) into set 0 | 32 MFMAs on set 1 = (kt, k-half 1)
+// so that after the barrier every wave already holds 48 MFMAs of work whose operands are in registers: the next reads'
+// latency, the DMA issue cost and the barrier skew hide under them instead of idling the matrix pipe (the lockstep
+// kernel's bubble).  One barrier per k-tile, two LDS buffers, prefetch distance one k-tile.  K % 64 == 0.
+template <int OFF>
+__device__ __forceinline__ bf16x8 ds_read_b128_raw(unsigned addr) {   // valid after lds_wait_*() + lds_tie(), like kc_frag_raw
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+
+template <bool A_KC, bool B_KC, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_sp_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, BK = 64, A_BYTES = BM * BK * 2, STAGE = 2 * A_BYTES, PC = 4;   // 4 pieces / operand / wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  int tm, tn;
+  tile_coords<4>(p, p.tile_base + xcd_remap(blockIdx.x, gridDim.x), tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  auto rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.A, 0, (int)min((long long)(A_KC ? p.M : p.K) * p.lda * 2, 0x7fffffffLL), 0x00020000);
+  auto rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.B, 0, (int)min((long long)(B_KC ? p.N : p.K) * p.ldb * 2, 0x7fffffffLL), 0x00020000);
+  unsigned offA[PC], offB[PC];
+#pragma unroll
+  for (int j = 0; j < PC; ++j) {
+    const int ci = (w * PC + j) * 64 + lane;
+    if (A_KC) {
+      const int row = ci >> 3, c = (ci & 7) ^ ((row >> 1) & 7);
+      offA[j] = (m0 + row < p.M) ? (unsigned)(((long long)(m0 + row) * p.lda + c * 8) * 2) : OOB;
+    } else {
+      const int kr = ci >> 5, c = (ci & 31) ^ (mc_swz(kr) << 1);
+      offA[j] = (m0 + c * 8 < p.M) ? (unsigned)(((long long)kr * p.lda + m0 + c * 8) * 2) : OOB;
+    }
+    if (B_KC) {
+      const int row = ci >> 3, c = (ci & 7) ^ ((row >> 1) & 7);
+      offB[j] = (n0 + row < p.N) ? (unsigned)(((long long)(n0 + row) * p.ldb + c * 8) * 2) : OOB;
+    } else {
+      const int kr = ci >> 5, c = (ci & 31) ^ (mc_swz(kr) << 1);
+      offB[j] = (n0 + c * 8 < p.N) ? (unsigned)(((long long)kr * p.ldb + n0 + c * 8) * 2) : OOB;
+    }
+  }
+  const unsigned stepA = A_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.lda * 2);
+  const unsigned stepB = B_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.ldb * 2);
+  const int nkt_all = p.K / BK;
+  const int kt0 = blockIdx.y * p.ktiles_per_split;
+  const int kt1 = min(nkt_all, kt0 + p.ktiles_per_split);
+  auto piece = [&](int buf, int kt, int j) {   // j < 4: operand A, else B; past the end: zero fill, keeps the counts uniform
+    char* base = smem + buf * STAGE;
+    if (j < PC) {
+      const unsigned v = (offA[j] != OOB && kt < kt1) ? offA[j] + (unsigned)kt * stepA : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(base + (w * PC + j) * 1024), 16, v, 0, 0, 0);
+    } else {
+      const unsigned v = (offB[j - PC] != OOB && kt < kt1) ? offB[j - PC] + (unsigned)kt * stepB : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(base + A_BYTES + (w * PC + j - PC) * 1024), 16, v, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[2][8], fb[2][4];
+  bf16x4 ra[A_KC ? 1 : 2][A_KC ? 1 : 8][2], rb[B_KC ? 1 : 2][B_KC ? 1 : 4][2];
+  // K-contiguous fragments of one operand differ by 16 rows = 2048 bytes and share the swizzle ((row >> 1) & 7 does not
+  // see multiples of 16): one address register + immediate offsets instead of one register per read
+  auto reads = [&](int set, const char* tA, int kk) {
+    const char* tB = tA + A_BYTES;
+    if (B_KC) {
+      const unsigned b0 = lds_addr_of(tB) + kc_tile_off(wn * 64 + (lane & 15), kk * 4 + (lane >> 4));
+      fb[set][0] = ds_read_b128_raw<0>(b0); fb[set][1] = ds_read_b128_raw<2048>(b0);
+      fb[set][2] = ds_read_b128_raw<4096>(b0); fb[set][3] = ds_read_b128_raw<6144>(b0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mc_frag_raw<BN>(tB, wn * 64 + j * 16, kk, lane, rb[B_KC ? 0 : set][B_KC ? 0 : j]);
+    }
+    if (A_KC) {
+      const unsigned a0 = lds_addr_of(tA) + kc_tile_off(wm * 128 + (lane & 15), kk * 4 + (lane >> 4));
+      fa[set][0] = ds_read_b128_raw<0>(a0); fa[set][1] = ds_read_b128_raw<2048>(a0);
+      fa[set][2] = ds_read_b128_raw<4096>(a0); fa[set][3] = ds_read_b128_raw<6144>(a0);
+      fa[set][4] = ds_read_b128_raw<8192>(a0); fa[set][5] = ds_read_b128_raw<10240>(a0);
+      fa[set][6] = ds_read_b128_raw<12288>(a0); fa[set][7] = ds_read_b128_raw<14336>(a0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mc_frag_raw<BM>(tA, wm * 128 + i * 16, kk, lane, ra[A_KC ? 0 : set][A_KC ? 0 : i]);
+    }
+  };
+  auto tie = [&](int set) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (B_KC) lds_tie(fb[set][j]);
+      else { lds_tie(rb[B_KC ? 0 : set][B_KC ? 0 : j][0]); lds_tie(rb[B_KC ? 0 : set][B_KC ? 0 : j][1]);
+             fb[set][j] = join8(rb[B_KC ? 0 : set][B_KC ? 0 : j][0], rb[B_KC ? 0 : set][B_KC ? 0 : j][1]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (A_KC) lds_tie(fa[set][i]);
+      else { lds_tie(ra[A_KC ? 0 : set][A_KC ? 0 : i][0]); lds_tie(ra[A_KC ? 0 : set][A_KC ? 0 : i][1]);
+             fa[set][i] = join8(ra[A_KC ? 0 : set][A_KC ? 0 : i][0], ra[A_KC ? 0 : set][A_KC ? 0 : i][1]); }
+    }
+  };
+#define SP_MMA(SET, I0, I1)                                                        \
+  _Pragma("unroll") for (int i = I0; i < I1; ++i)                                  \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[SET][j], fa[SET][i], acc[i][j]);
+#define SP_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+  // prologue: both buffers requested, tile kt0 awaited, its first k-half read
+#pragma unroll
+  for (int j = 0; j < 2 * PC; ++j) piece(0, kt0, j);
+#pragma unroll
+  for (int j = 0; j < 2 * PC; ++j) piece(1, kt0 + 1, j);
+  wait_vmcnt<2 * PC>();
+  __builtin_amdgcn_s_barrier();
+  SP_FENCE();
+  reads(0, smem, 0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    const char* tA = smem + cur * STAGE;
+    // A1
+    reads(1, tA, 1);
+    SP_FENCE();
+    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");   // the 12 reads of set 0 (older) are back, set 1 still in flight
+    tie(0);
+    SP_MMA(0, 0, 4)
+    SP_FENCE();
+    // A2
+    lds_wait_all();
+    tie(1);
+    wait_vmcnt<0>();
+    SP_FENCE();
+    __builtin_amdgcn_s_barrier();
+    SP_FENCE();
+    // A3: the rest of set 0 with the refill of this tile's buffer (tile kt + 2) threaded through
+#pragma unroll
+    for (int i = 4; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[0][j], fa[0][i], acc[i][j]);
+      SP_FENCE();
+      piece(cur, kt + 2, 2 * (i - 4));
+      piece(cur, kt + 2, 2 * (i - 4) + 1);
+      SP_FENCE();
+    }
+    // C
+    reads(0, smem + (cur ^ 1) * STAGE, 0);   // (kt + 1, k-half 0); past the end: harmless reads of a zero-filled buffer
+    SP_FENCE();
+    SP_MMA(1, 0, 8)
+    SP_FENCE();
+  }
+  wait_vmcnt<0>();
+  lds_wait_all();
+#undef SP_MMA
+#undef SP_FENCE
+
+  if (p.epi_lds) { staged_epilogue<8, 128, 64, OUT_F32>(p, smem, acc, wm, wn, m0, n0, tid, lane); return; }
+  const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * lg;
+      if (n >= p.N) continue;
+      store_tile4<OUT_F32>(p, m, n, acc[i][j]);
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC, bool OUT_F32>
+int launch_sp(GemmParams p, hipStream_t s) {
+  constexpr int LDS = OUT_F32 ? 128 * (256 * 4 + 64) : 256 * (256 * 2 + 32);   // >= the two operand stages (128 KiB)
+  if (p.K & 63) return LAP_ERR_ARG;
+  auto kern = gemm_sp_kernel<A_KC, B_KC, OUT_F32>;
+  p.epi_lds = (!p.part && p.ksplit == 1 && !(OUT_F32 && p.R) && !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) ? 1 : 0;
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  const int nkt = p.K / 64;
+  p.ktiles_per_split = (nkt + p.ksplit - 1) / p.ksplit;
+  const int count = p.tile_count > 0 ? p.tile_count : p.tiles_m * p.tiles_n - p.tile_base;
+  hipLaunchKernelGGL(kern, dim3(count, p.ksplit), dim3(512), LDS, s, p);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
 template <bool A_KC, bool B_KC, bool OUT_F32>
 int launch_pp16(GemmParams p, hipStream_t s) {
   constexpr int LDS = 4 * 2 * 256 * 32 * 2;
@@ -848,6 +1051,7 @@ int launch(GemmParams p, hipStream_t s) {
 template <bool A_KC, bool B_KC, bool OUT_F32>
 int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
   switch (tile) {
+    case 10: return launch_sp<A_KC, B_KC, OUT_F32>(p, s);
     case 9: return launch_pp16<A_KC, B_KC, OUT_F32>(p, s);
     case 8: return launch_pp<A_KC, B_KC, OUT_F32>(p, s);
     case 7: return launch<256, 128, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
@@ -965,7 +1169,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   const bool f32 = flags & LAP_GEMM_OUT_F32;
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
-  if (tile < -1 || tile > 9 || ksplit < 0) return LAP_ERR_ARG;
+  if (tile < -1 || tile > 10 || ksplit < 0) return LAP_ERR_ARG;
   // Few output tiles but a very long contraction (LM-head dgrad: 1504 x 2048 over K = 257152; prefill down
   // projection): the big tile with enough K splits to cover the chip beats the small tile walking all of K.
   if (tile < 0 && ksplit == 0 && scratch != nullptr && K >= 16384 && !(flags & LAP_GEMM_PARTIALS)) {
@@ -1010,6 +1214,9 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
     }
   }
   if (ksplit == 0 && scratch != nullptr && !tail_tiles) ksplit = pick_ksplit(tile, M, N, K, scratch_bytes);
+  // the software-pipelined 8-wave kernel (tile 10) stands in for the 16-wave one wherever K is a multiple of 64
+  const int big = !(K & 63) ? 10 : 5;
+  if (tile == 5) tile = big;
   const bool two_phase = ksplit > 1 && scratch != nullptr;
   if (two_phase && scratch_bytes < (long long)ksplit * M * N * 4) return LAP_ERR_ARG;
   if (ksplit > 1 && !two_phase && (!f32 || !(flags & LAP_GEMM_ACCUM) || bias || residual)) return LAP_ERR_ARG;
@@ -1032,15 +1239,15 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
     // (a) the full rounds, straight to C
     p.ksplit = 1; p.part = nullptr; p.tile_base = 0; p.tile_count = t5 - tail_tiles;
     if (f32) {
-      if (a_kc && b_kc) rc = dispatch_tile<true, true, true>(p, 5, s);
-      else if (a_kc && !b_kc) rc = dispatch_tile<true, false, true>(p, 5, s);
-      else if (!a_kc && !b_kc) rc = dispatch_tile<false, false, true>(p, 5, s);
-      else rc = dispatch_tile<false, true, true>(p, 5, s);
+      if (a_kc && b_kc) rc = dispatch_tile<true, true, true>(p, big, s);
+      else if (a_kc && !b_kc) rc = dispatch_tile<true, false, true>(p, big, s);
+      else if (!a_kc && !b_kc) rc = dispatch_tile<false, false, true>(p, big, s);
+      else rc = dispatch_tile<false, true, true>(p, big, s);
     } else {
-      if (a_kc && b_kc) rc = dispatch_tile<true, true, false>(p, 5, s);
-      else if (a_kc && !b_kc) rc = dispatch_tile<true, false, false>(p, 5, s);
-      else if (!a_kc && !b_kc) rc = dispatch_tile<false, false, false>(p, 5, s);
-      else rc = dispatch_tile<false, true, false>(p, 5, s);
+      if (a_kc && b_kc) rc = dispatch_tile<true, true, false>(p, big, s);
+      else if (a_kc && !b_kc) rc = dispatch_tile<true, false, false>(p, big, s);
+      else if (!a_kc && !b_kc) rc = dispatch_tile<false, false, false>(p, big, s);
+      else rc = dispatch_tile<false, true, false>(p, big, s);
     }
     if (rc) return rc;
     if (tail_sp == 1) {
@@ -1059,10 +1266,10 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
     }
     // (b) the tail tiles, split along K into compact f32 slabs, then reduce + epilogue
     p.ksplit = tail_sp; p.part = (float*)scratch; p.part_compact = 1; p.tile_base = t5 - tail_tiles; p.tile_count = tail_tiles;
-    if (a_kc && b_kc) rc = dispatch_tile<true, true, true>(p, 5, s);
-    else if (a_kc && !b_kc) rc = dispatch_tile<true, false, true>(p, 5, s);
-    else if (!a_kc && !b_kc) rc = dispatch_tile<false, false, true>(p, 5, s);
-    else rc = dispatch_tile<false, true, true>(p, 5, s);
+    if (a_kc && b_kc) rc = dispatch_tile<true, true, true>(p, big, s);
+    else if (a_kc && !b_kc) rc = dispatch_tile<true, false, true>(p, big, s);
+    else if (!a_kc && !b_kc) rc = dispatch_tile<false, false, true>(p, big, s);
+    else rc = dispatch_tile<false, true, true>(p, big, s);
     if (rc) return rc;
     p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
     if (f32) hipLaunchKernelGGL(splitk_tail_reduce_kernel<true>, dim3(tail_tiles * 64), dim3(256), 0, s, p, tail_tiles);
