@@ -9,7 +9,7 @@ LAP-3B (SigLIP So400m/14 + Gemma-2B + Gemma-300M action expert, random-init weig
 samples per GPU: 2 x 224x224 images, 48-token prompt (last 16 = language-action tokens), 50-step action chunk
 (SURVEY.md §8d).  Weak scaling: per-GPU batch fixed, parameters/optimizer FSDP-sharded over RCCL.
 
-Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the bf16 MFMA GEMM, csrc/gemm.hip):
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the bf16 MFMA GEMM family, csrc/gemm.hip: gemm_sp_kernel + gemm_kernel):
 achieved = sum of 2*M*N*K over the GEMM launches of the timed steps / their summed durations, measured with HIP
 events on the launch stream; `cpu_baseline` times the CPU oracle (oracle/lap_oracle.py, kind "port") on the host
 cores on a bounded slice of the same workload.
@@ -199,7 +199,7 @@ def main():
                        if args.config == "lap_bench" else f"NON-HEADLINE flow test: config {args.config}",
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": 610,
                        "parallelism": f"fsdp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA GEMM, csrc/gemm.hip)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm_sp_kernel / gemm_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", "achieved": round(achieved, 1),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "launches_per_step": n_launch // max(args.steps, 1),
                          "avg_launch_us": round(t_gemm / max(n_launch, 1) * 1e6, 2),
