@@ -747,10 +747,11 @@ __global__ __launch_bounds__(1024) void gemm_pp16_kernel(GemmParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Software-pipelined 8-wave kernel (tile 10): 256x256x64 tile, 128x64 per wave, TWO fragment register sets.  Per k-tile
-//   A1  issue the raw reads of (kt, k-half 1) into set 1 | first 16 MFMAs on set 0 = (kt, k-half 0)
+//   A1  set 0 = (kt, k-half 0) is back: 8 MFMAs, issue the raw reads of (kt, k-half 1) into set 1, 8 more MFMAs
 //   A2  set 1 landed, my LDS-DMA of tile kt+1 landed, barrier          (every read of tile kt has completed)
 //   A3  last 16 MFMAs on set 0, with the 8 LDS-DMA pieces of tile kt+2 threaded between them (into kt's buffer)
-//   C   issue the raw reads of (kt+1, k-half 0) into set 0 | 32 MFMAs on set 1 = (kt, k-half 1)
+//   C   8 MFMAs on set 1 = (kt, k-half 1), issue the raw reads of (kt+1, k-half 0) into set 0, the other 24 MFMAs
+// (reads are always issued AFTER a first group of MFMAs has been queued: +1 ms per train step over issuing them first)
 // so that after the barrier every wave already holds 48 MFMAs of work whose operands are in registers: the next reads'
 // latency, the DMA issue cost and the barrier skew hide under them instead of idling the matrix pipe (the lockstep
 // kernel's bubble).  One barrier per k-tile, two LDS buffers, prefetch distance one k-tile.  K % 64 == 0.
@@ -873,11 +874,13 @@ __global__ __launch_bounds__(512) void gemm_sp_kernel(GemmParams p) {
     const int cur = (kt - kt0) & 1;
     const char* tA = smem + cur * STAGE;
     // A1
+    lds_wait_all();                                          // set 0 (read under the previous tile's last MFMAs) is back
+    tie(0);
+    SP_MMA(0, 0, 2)
+    SP_FENCE();
     reads(1, tA, 1);
     SP_FENCE();
-    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");   // the 12 reads of set 0 (older) are back, set 1 still in flight
-    tie(0);
-    SP_MMA(0, 0, 4)
+    SP_MMA(0, 2, 4)
     SP_FENCE();
     // A2
     lds_wait_all();
@@ -897,9 +900,11 @@ __global__ __launch_bounds__(512) void gemm_sp_kernel(GemmParams p) {
       SP_FENCE();
     }
     // C
+    SP_MMA(1, 0, 2)
+    SP_FENCE();
     reads(0, smem + (cur ^ 1) * STAGE, 0);   // (kt + 1, k-half 0); past the end: harmless reads of a zero-filled buffer
     SP_FENCE();
-    SP_MMA(1, 0, 8)
+    SP_MMA(1, 2, 8)
     SP_FENCE();
   }
   wait_vmcnt<0>();
