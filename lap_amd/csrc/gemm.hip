@@ -762,14 +762,16 @@ __device__ __forceinline__ bf16x8 ds_read_b128_raw(unsigned addr) {   // valid a
   return r;
 }
 
-template <bool A_KC, bool B_KC, bool OUT_F32>
-__global__ __launch_bounds__(512) void gemm_sp_kernel(GemmParams p) {
-  constexpr int BM = 256, BN = 256, BK = 64, A_BYTES = BM * BK * 2, STAGE = 2 * A_BYTES, PC = 4;   // 4 pieces / operand / wave
+template <int WGM, int WGN, bool A_KC, bool B_KC, bool OUT_F32>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_sp_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, BK = 64, A_BYTES = BM * BK * 2, STAGE = 2 * A_BYTES;
+  constexpr int NW = WGM * WGN, WTM = BM / WGM, WTN = BN / WGN, FM = WTM / 16, FN = WTN / 16, PC = 32 / NW;   // PC pieces / operand / wave
+  static_assert(FM == 8 && (FN == 4 || FN == 8), "wave tile 128 x 64 or 128 x 128");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 2, wn = w & 3;
+  const int wm = w / WGN, wn = w % WGN;
   int tm, tn;
   tile_coords<4>(p, p.tile_base + xcd_remap(blockIdx.x, gridDim.x), tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -812,45 +814,49 @@ __global__ __launch_bounds__(512) void gemm_sp_kernel(GemmParams p) {
     }
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa[2][8], fb[2][4];
-  bf16x4 ra[A_KC ? 1 : 2][A_KC ? 1 : 8][2], rb[B_KC ? 1 : 2][B_KC ? 1 : 4][2];
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[2][FM], fb[2][FN];
+  bf16x4 ra[A_KC ? 1 : 2][A_KC ? 1 : FM][2], rb[B_KC ? 1 : 2][B_KC ? 1 : FN][2];
   // K-contiguous fragments of one operand differ by 16 rows = 2048 bytes and share the swizzle ((row >> 1) & 7 does not
   // see multiples of 16): one address register + immediate offsets instead of one register per read
   auto reads = [&](int set, const char* tA, int kk) {
     const char* tB = tA + A_BYTES;
     if (B_KC) {
-      const unsigned b0 = lds_addr_of(tB) + kc_tile_off(wn * 64 + (lane & 15), kk * 4 + (lane >> 4));
+      const unsigned b0 = lds_addr_of(tB) + kc_tile_off(wn * WTN + (lane & 15), kk * 4 + (lane >> 4));
       fb[set][0] = ds_read_b128_raw<0>(b0); fb[set][1] = ds_read_b128_raw<2048>(b0);
       fb[set][2] = ds_read_b128_raw<4096>(b0); fb[set][3] = ds_read_b128_raw<6144>(b0);
+      if constexpr (FN == 8) {
+        fb[set][4] = ds_read_b128_raw<8192>(b0); fb[set][5] = ds_read_b128_raw<10240>(b0);
+        fb[set][6] = ds_read_b128_raw<12288>(b0); fb[set][7] = ds_read_b128_raw<14336>(b0);
+      }
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mc_frag_raw<BN>(tB, wn * 64 + j * 16, kk, lane, rb[B_KC ? 0 : set][B_KC ? 0 : j]);
+      for (int j = 0; j < FN; ++j) mc_frag_raw<BN>(tB, wn * WTN + j * 16, kk, lane, rb[B_KC ? 0 : set][B_KC ? 0 : j]);
     }
     if (A_KC) {
-      const unsigned a0 = lds_addr_of(tA) + kc_tile_off(wm * 128 + (lane & 15), kk * 4 + (lane >> 4));
+      const unsigned a0 = lds_addr_of(tA) + kc_tile_off(wm * WTM + (lane & 15), kk * 4 + (lane >> 4));
       fa[set][0] = ds_read_b128_raw<0>(a0); fa[set][1] = ds_read_b128_raw<2048>(a0);
       fa[set][2] = ds_read_b128_raw<4096>(a0); fa[set][3] = ds_read_b128_raw<6144>(a0);
       fa[set][4] = ds_read_b128_raw<8192>(a0); fa[set][5] = ds_read_b128_raw<10240>(a0);
       fa[set][6] = ds_read_b128_raw<12288>(a0); fa[set][7] = ds_read_b128_raw<14336>(a0);
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) mc_frag_raw<BM>(tA, wm * 128 + i * 16, kk, lane, ra[A_KC ? 0 : set][A_KC ? 0 : i]);
+      for (int i = 0; i < FM; ++i) mc_frag_raw<BM>(tA, wm * WTM + i * 16, kk, lane, ra[A_KC ? 0 : set][A_KC ? 0 : i]);
     }
   };
   auto tie = [&](int set) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < FN; ++j) {
       if (B_KC) lds_tie(fb[set][j]);
       else { lds_tie(rb[B_KC ? 0 : set][B_KC ? 0 : j][0]); lds_tie(rb[B_KC ? 0 : set][B_KC ? 0 : j][1]);
              fb[set][j] = join8(rb[B_KC ? 0 : set][B_KC ? 0 : j][0], rb[B_KC ? 0 : set][B_KC ? 0 : j][1]); }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < FM; ++i) {
       if (A_KC) lds_tie(fa[set][i]);
       else { lds_tie(ra[A_KC ? 0 : set][A_KC ? 0 : i][0]); lds_tie(ra[A_KC ? 0 : set][A_KC ? 0 : i][1]);
              fa[set][i] = join8(ra[A_KC ? 0 : set][A_KC ? 0 : i][0], ra[A_KC ? 0 : set][A_KC ? 0 : i][1]); }
@@ -858,7 +864,7 @@ __global__ __launch_bounds__(512) void gemm_sp_kernel(GemmParams p) {
   };
 #define SP_MMA(SET, I0, I1)                                                        \
   _Pragma("unroll") for (int i = I0; i < I1; ++i)                                  \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[SET][j], fa[SET][i], acc[i][j]);
+    _Pragma("unroll") for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[SET][j], fa[SET][i], acc[i][j]);
 #define SP_FENCE() __builtin_amdgcn_sched_barrier(0)
 
   // prologue: both buffers requested, tile kt0 awaited, its first k-half read
@@ -893,10 +899,10 @@ __global__ __launch_bounds__(512) void gemm_sp_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 4; i < 8; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[0][j], fa[0][i], acc[i][j]);
+      for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[0][j], fa[0][i], acc[i][j]);
       SP_FENCE();
-      piece(cur, kt + 2, 2 * (i - 4));
-      piece(cur, kt + 2, 2 * (i - 4) + 1);
+#pragma unroll
+      for (int q = 0; q < PC / 2; ++q) piece(cur, kt + 2, (PC / 2) * (i - 4) + q);
       SP_FENCE();
     }
     // C
@@ -912,26 +918,26 @@ __global__ __launch_bounds__(512) void gemm_sp_kernel(GemmParams p) {
 #undef SP_MMA
 #undef SP_FENCE
 
-  if (p.epi_lds) { staged_epilogue<8, 128, 64, OUT_F32>(p, smem, acc, wm, wn, m0, n0, tid, lane); return; }
+  if (p.epi_lds) { staged_epilogue<NW, WTM, WTN, OUT_F32>(p, smem, acc, wm, wn, m0, n0, tid, lane); return; }
   const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wm * 128 + i * 16 + li;
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + li;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + 4 * lg;
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + 4 * lg;
       if (n >= p.N) continue;
       store_tile4<OUT_F32>(p, m, n, acc[i][j]);
     }
   }
 }
 
-template <bool A_KC, bool B_KC, bool OUT_F32>
+template <int WGM, int WGN, bool A_KC, bool B_KC, bool OUT_F32>
 int launch_sp(GemmParams p, hipStream_t s) {
   constexpr int LDS = OUT_F32 ? 128 * (256 * 4 + 64) : 256 * (256 * 2 + 32);   // >= the two operand stages (128 KiB)
   if (p.K & 63) return LAP_ERR_ARG;
-  auto kern = gemm_sp_kernel<A_KC, B_KC, OUT_F32>;
+  auto kern = gemm_sp_kernel<WGM, WGN, A_KC, B_KC, OUT_F32>;
   p.epi_lds = (!p.part && p.ksplit == 1 && !(OUT_F32 && p.R) && !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) ? 1 : 0;
   static bool done = false;
   if (!done) {
@@ -944,7 +950,7 @@ int launch_sp(GemmParams p, hipStream_t s) {
   const int nkt = p.K / 64;
   p.ktiles_per_split = (nkt + p.ksplit - 1) / p.ksplit;
   const int count = p.tile_count > 0 ? p.tile_count : p.tiles_m * p.tiles_n - p.tile_base;
-  hipLaunchKernelGGL(kern, dim3(count, p.ksplit), dim3(512), LDS, s, p);
+  hipLaunchKernelGGL(kern, dim3(count, p.ksplit), dim3(WGM * WGN * 64), LDS, s, p);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
@@ -1056,7 +1062,7 @@ int launch(GemmParams p, hipStream_t s) {
 template <bool A_KC, bool B_KC, bool OUT_F32>
 int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
   switch (tile) {
-    case 10: return launch_sp<A_KC, B_KC, OUT_F32>(p, s);
+    case 10: return launch_sp<2, 4, A_KC, B_KC, OUT_F32>(p, s);
     case 9: return launch_pp16<A_KC, B_KC, OUT_F32>(p, s);
     case 8: return launch_pp<A_KC, B_KC, OUT_F32>(p, s);
     case 7: return launch<256, 128, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
