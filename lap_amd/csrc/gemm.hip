@@ -130,10 +130,10 @@ __device__ __forceinline__ void store_tile4(const GemmParams& p, int m, int n, f
 // Epilogue of the 256x256 kernels through LDS (set by the host: p.epi_lds).  bf16: straight from the accumulators a lane
 // owns 8-byte pieces of 16 different rows (32-byte runs per row: 64 narrow stores per wave instruction, store-issue bound,
 // and with one block per CU nothing overlaps them - ~7 us per tile, 11-18 % of a K <= 2048 tile).  The operand tiles are
-// dead after the k-loop, so the finished bf16 tile is written to LDS (row pitch 544 B: the 16 rows x 4 column groups of a
-// ds_write_b64 land on distinct even banks) and leaves as 16-byte stores, two full 512-byte rows per wave instruction.
+// dead after the k-loop, so the finished bf16 tile is written to LDS (row pitch 528 B, conflict-free for the
+// ds_write_b64 pattern) and leaves as 16-byte stores, two full 512-byte rows per wave instruction.
 // alpha / bias / GELU / residual are applied in registers exactly as in the direct path: same bits.  f32 (weight gradients,
-// logits): the same in two halves of 128 rows (a 256 x 256 f32 tile does not fit; 1088-byte pitch), four full 1 KiB rows
+// logits): the same in two halves of 128 rows (a 256 x 256 f32 tile does not fit; 1040-byte pitch), four full 1 KiB rows
 // per wave instruction; with beta = 1 the old values come in the same coalesced way.
 template <int NW, int WTM, int WTN, bool OUT_F32>
 __device__ __forceinline__ void staged_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[WTM / 16][WTN / 16], int wm, int wn,
@@ -141,7 +141,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, char* smem,
   constexpr int FM = WTM / 16, FN = WTN / 16, BM = 256, BN = 256;
   const int li = lane & 15, lg = lane >> 4;
   if constexpr (!OUT_F32) {
-    constexpr int CP = BN * 2 + 32;
+    constexpr int CP = BN * 2 + 16;   // 528 B: the 32 lanes of a ds_write_b64 half-wave (16 rows x 2 column groups) hit 64 distinct banks
     __syncthreads();   // every wave is done reading the operand tiles (no LDS-DMA in flight after the last k-tile)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -185,7 +185,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, char* smem,
         *reinterpret_cast<bf16x8*>((bf16*)p.C + (long long)m * p.ldc + n) = *reinterpret_cast<const bf16x8*>(smem + r * CP + c * 16);
     }
   } else {
-    constexpr int CP = BN * 4 + 64;
+    constexpr int CP = BN * 4 + 16;   // 1040 B: the 16 lanes of a ds_write_b128 group (16 rows) hit 64 distinct banks
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       __syncthreads();   // operand tiles dead (first pass) / previous half moved out (second pass)
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_sp_kernel(GemmParams p) {
 
 template <int WGM, int WGN, bool A_KC, bool B_KC, bool OUT_F32>
 int launch_sp(GemmParams p, hipStream_t s) {
-  constexpr int LDS = OUT_F32 ? 128 * (256 * 4 + 64) : 256 * (256 * 2 + 32);   // >= the two operand stages (128 KiB)
+  constexpr int LDS = OUT_F32 ? 128 * (256 * 4 + 16) : 256 * (256 * 2 + 16);   // >= the two operand stages (128 KiB)
   if (p.K & 63) return LAP_ERR_ARG;
   auto kern = gemm_sp_kernel<WGM, WGN, A_KC, B_KC, OUT_F32>;
   p.epi_lds = (!p.part && p.ksplit == 1 && !(OUT_F32 && p.R) && !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) ? 1 : 0;
@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool A_KC, bool B_KC, bool OUT_F32>
 int launch(GemmParams p, hipStream_t s) {
   // staged epilogue of the 256x256 kernel: a bf16 tile (544-byte rows) or half an f32 tile (128 rows of 1088 bytes)
-  constexpr int EPI = (BM == 256 && BN == 256 && WGM * WGN == 16) ? (OUT_F32 ? 128 * (BN * 4 + 64) : BM * (BN * 2 + 32)) : 0;
+  constexpr int EPI = (BM == 256 && BN == 256 && WGM * WGN == 16) ? (OUT_F32 ? 128 * (BN * 4 + 16) : BM * (BN * 2 + 16)) : 0;
   constexpr int LDS = NS * (BM + BN) * BK * 2 > EPI ? NS * (BM + BN) * BK * 2 : EPI;
   auto kern = gemm_kernel<BM, BN, WGM, WGN, BK, NS, A_KC, B_KC, OUT_F32>;
   p.epi_lds = (EPI > 0 && !p.part && p.ksplit == 1 && !(OUT_F32 && p.R) && !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) ? 1 : 0;

@@ -9,7 +9,7 @@ f = glob.glob("$out/**/*counter_collection.csv", recursive=True)
 rows = list(csv.DictReader(open(f[0])))
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for r in rows:
-    if "gemm_kernel" not in r["Kernel_Name"]: continue
+    if "gemm_" not in r["Kernel_Name"] or "splitk" in r["Kernel_Name"]: continue
     agg[r["Kernel_Name"][:60]][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(r["Kernel_Name"][:60], r["Counter_Name"])] += 1
 for k, d in agg.items():
     n = cnt[(k, "SQ_WAVE_CYCLES")]
