@@ -38,8 +38,10 @@ def test_train_resume_matches_uninterrupted_run(hip, tmp_path):
                 w = max(w, float((x - y).norm() / (x.norm() + 1e-12)))
         return w
 
+    # (measured over repeated runs: both distances are usually ~1e-5 and occasionally ~1e-3 - one flipped bf16 rounding early
+    # on; lost moments, a wrong data position or a wrong step count move m / v by >= 1e-1)
     noise = worst(a.model.ps, a2.model.ps)
-    assert worst(a.model.ps, c.model.ps) <= max(5 * noise, 1e-3), (worst(a.model.ps, c.model.ps), noise)
+    assert worst(a.model.ps, c.model.ps) <= max(5 * noise, 1e-2), (worst(a.model.ps, c.model.ps), noise)
     with pytest.raises(FileExistsError):
         main(dataclasses.replace(base, exp_name="split", num_train_steps=8, resume=False), log=lambda s: None)
 
