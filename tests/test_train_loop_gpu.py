@@ -31,15 +31,17 @@ def test_train_resume_matches_uninterrupted_run(hip, tmp_path):
     a2 = main(dataclasses.replace(base, exp_name="full2", num_train_steps=8), log=lambda s: None)
 
     def worst(p, q):
+        """Relative distance per state kind over ALL units together: a per-unit maximum is dominated by units whose norm is
+        ~0 (zero-initialised adaRMS bank, freshly started moments), where one reordered f32 atomic is a large fraction."""
         w = 0.0
-        for u in p.units:
-            for buf in ("master", "m", "v"):
-                x, y = getattr(p, buf)[u.name], getattr(q, buf)[u.name]
-                w = max(w, float((x - y).norm() / (x.norm() + 1e-12)))
+        for buf in ("master", "m", "v"):
+            num = sum(float((getattr(p, buf)[u.name] - getattr(q, buf)[u.name]).double().pow(2).sum()) for u in p.units)
+            den = sum(float(getattr(p, buf)[u.name].double().pow(2).sum()) for u in p.units)
+            w = max(w, (num / (den + 1e-30)) ** 0.5)
         return w
 
-    # (measured over repeated runs: both distances are usually ~1e-5 and occasionally ~1e-3 - one flipped bf16 rounding early
-    # on; lost moments, a wrong data position or a wrong step count move m / v by >= 1e-1)
+    # two uninterrupted runs are usually within ~1e-5 of each other and occasionally ~1e-3 (one flipped bf16 rounding early
+    # on); lost moments, a wrong data position or a wrong step count move m / v by >= 1e-1
     noise = worst(a.model.ps, a2.model.ps)
     assert worst(a.model.ps, c.model.ps) <= max(5 * noise, 1e-2), (worst(a.model.ps, c.model.ps), noise)
     with pytest.raises(FileExistsError):
