@@ -389,8 +389,10 @@ def cli(argv=None) -> TrainConfig:
     import sys
 
     argv = list(sys.argv[1:] if argv is None else argv)
-    if not argv:
-        raise SystemExit(f"usage: <config> [--field value]; configs: {sorted(_CONFIGS_DICT)}")
+    if not argv or argv[0] in ("-h", "--help"):
+        fields = ", ".join("--" + f.name.replace("_", "-") for f in dataclasses.fields(TrainConfig)
+                           if isinstance(f.default, (int, float, str, bool)) or f.default is None)
+        raise SystemExit(f"usage: <config> [--field value ...]\nconfigs: {sorted(_CONFIGS_DICT)}\nscalar fields: {fields}")
     cfg = get_config(argv.pop(0))
     upd = {}
     while argv:
