@@ -1,6 +1,8 @@
-"""bench.py — LAP-3B bf16 train-step throughput on MI355X (BASELINE.json metric, config[1] / config[2]).
+"""bench.py — LAP-3B bf16 train-step throughput on MI355X (BASELINE.json metric, config[1] / config[2]) and, at N = 1,
+the batch-1 action-chunk latency (config[3]) in the same JSON line.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under
+                                                            torch.distributed.run on 127.0.0.1, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -12,7 +14,10 @@ samples per GPU: 2 x 224x224 images, 48-token prompt (last 16 = language-action 
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the bf16 MFMA GEMM family, csrc/gemm.hip: gemm_sp_kernel + gemm_kernel):
 achieved = sum of 2*M*N*K over the GEMM launches of the timed steps / their summed durations, measured with HIP
 events on the launch stream; `cpu_baseline` times the CPU oracle (oracle/lap_oracle.py, kind "port") on the host
-cores on a bounded slice of the same workload.
+cores on a bounded slice of the same workload.  `serve` is the second half of the metric: prefix prefill + 10 denoise
+steps of `sample_actions` at batch 1, hipGraph-replayed, against the 13.4 GB of algorithmic HBM bytes.
+`roofline.traffic` is the HBM-side byte count of ONE launch of the dominant kernel on its largest shape from the
+committed rocprofv3 --pmc passes (profiles/, file named in `traffic_source`); rocprofv3 cannot run inside this process.
 """
 from __future__ import annotations
 
@@ -27,6 +32,13 @@ sys.path.insert(0, ROOT)
 
 import torch
 
+SERVE_BYTES = 4.79e9 + 10 * 0.86e9 + 10 * 10.3e6   # prefix weights once + 10 x (expert weights + KV)
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
+# profiles/r01_gemm_pmc_counters.txt: gate-up forward GEMM M=17920 N=32768 K=2048 (the largest launch of the step),
+# separate --pmc passes: FETCH_SIZE 1,786,773 KB raw x 2 (gfx950 half-count correction for wide coalesced reads,
+# MI355X_MICROARCH.md §HBM) + WRITE_SIZE 1,272,545 KB; algorithmic bytes of that launch: 0.207 GB read + 1.174 GB written
+GEMM_TRAFFIC = {"bytes_per_launch": 2 * 1786772.9e3 + 1272544.9e3, "algorithmic_bytes_per_launch": 73.4e6 + 134.2e6 + 1174.4e6,
+                "shape": "gate-up fwd M=17920 N=32768 K=2048", "source": "profiles/r01_gemm_pmc_counters.txt"}
 TRAIN_FLOP_PER_SAMPLE = 8.375e12  # 3 x forward (2.792 TFLOP), recompute not credited
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA
 
@@ -122,6 +134,57 @@ def cpu_baseline(cores: int):
                       f"path, which cannot be installed offline"}
 
 
+def serve_latency(cfg, dev, reps: int = 20):
+    """BASELINE.json config[3]: LAP-3B batch-1 action chunk = SigLIP + VLM prefix prefill (KV cache kept in HBM) + 10
+    flow-matching denoise steps of the action expert, captured once into a HIP graph and replayed (serve.GraphedSampler).
+    Times `reps` replays bracketed by device synchronisation; also checks the replay against the eager sampler."""
+    from lap_amd.model import LAP
+    from lap_amd.serve import GraphedSampler
+
+    model = LAP(cfg, seed=0, device=dev, with_grads=False)
+    gs = GraphedSampler(model, 1, 10)
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    for k in gs.obs.images:
+        gs.obs.images[k].copy_(torch.rand(1, cfg.image_size, cfg.image_size, 3, generator=gen) * 2 - 1)
+    gs.obs.tokenized_prompt.copy_(torch.randint(0, cfg.vocab_size, gs.obs.tokenized_prompt.shape, generator=gen, dtype=torch.int32))
+    gs.noise.copy_(torch.randn(1, cfg.action_horizon, cfg.action_dim, generator=gen))
+    eager = model.sample_actions(0, gs.obs, num_steps=10, noise=gs.noise).clone()
+    gs.capture()
+    for _ in range(3):
+        gs.graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gs.graph.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    same = bool(torch.equal(eager, gs.out))
+    del gs, model
+    torch.cuda.empty_cache()
+    gbps = SERVE_BYTES / (ms * 1e-3) / 1e9
+    return {"metric": "batch-1 action-chunk ms LAP-3B bf16 (prefix prefill + 10 denoise steps)", "ms_per_chunk": round(ms, 3),
+            "budget_ms": 10.0, "hbm_floor_ms": round(SERVE_BYTES / (HBM_PEAK_GBPS * 1e9) * 1e3, 2),
+            "hbm_floor_ms_at_measured_copy_bw": round(SERVE_BYTES / 6.29e12 * 1e3, 2), "algorithmic_GB": round(SERVE_BYTES / 1e9, 2),
+            "achieved_GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4), "graph": True,
+            "graph_equals_eager": same, "replays": reps, "prompt_len": cfg.max_token_len, "action_horizon": cfg.action_horizon}
+
+
+def _self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start one rank per GPU under
+    torch.distributed.run (rendezvous on 127.0.0.1, a free port) and pass the JSON line through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,9 +193,12 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--config", default="lap_bench")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serve", action="store_true", help="skip the batch-1 action-chunk latency leg (N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for flow tests)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -200,13 +266,20 @@ def main():
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": 610,
                        "parallelism": f"fsdp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "kernel": "gemm_sp_kernel / gemm_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", "achieved": round(achieved, 1),
-                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         "traffic": GEMM_TRAFFIC["bytes_per_launch"], "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE)",
+                         "traffic_shape": GEMM_TRAFFIC["shape"], "traffic_algorithmic_bytes": GEMM_TRAFFIC["algorithmic_bytes_per_launch"],
+                         "traffic_source": GEMM_TRAFFIC["source"],
                          "launches_per_step": n_launch // max(args.steps, 1),
                          "avg_launch_us": round(t_gemm / max(n_launch, 1) * 1e6, 2),
                          "gemm_time_frac_of_step": round(t_gemm / dt, 4),
                          "step_mfu": round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12 / MFMA_PEAK_TFLOPS, 4)},
             "final_loss": round(loss, 5),
         }
+        if world == 1 and not args.no_serve and args.config == "lap_bench":
+            del state, runner, batches
+            torch.cuda.empty_cache()
+            out["serve"] = serve_latency(tc.model, dev)
         if world == 1 and not args.no_cpu_baseline:
             # 16 host threads: torch-CPU matmuls of this size stop scaling well beyond that (256 threads on the
             # GPU box took 166 s for the same slice)

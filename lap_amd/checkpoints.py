@@ -145,17 +145,35 @@ def save_state(checkpoint_manager: CheckpointManager, state, data_loader, step: 
     return checkpoint_manager
 
 
+def _all_ok(ok: bool, device) -> bool:
+    """True iff every rank reports success (MIN all-reduce): ranks agree on retrying or committing together."""
+    d = _dist()
+    if d is None:
+        return ok
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if d.get_backend() == "nccl" else "cpu")
+    d.all_reduce(t, op=d.ReduceOp.MIN)
+    return bool(t.item())
+
+
 def _save_once(mngr: CheckpointManager, state, data_loader, step: int, norm_stats, asset_id):
+    """One save attempt.  Every rank runs the same sequence of collectives whatever happens to its own file I/O: local
+    failures are caught, agreed on with `_all_ok`, and re-raised on ALL ranks, so the caller's retry loop iterates in
+    lock-step (a rank retrying alone would leave barrier / all-gather counts mismatched and hang the job)."""
     ps = state.model.ps
     rank, world = ps.rank, ps.world_size
     final = mngr.step_dir(step)
     tmp = mngr.directory / f".tmp_{step}"
-    if rank == 0:
-        shutil.rmtree(tmp, ignore_errors=True)
-        (tmp / "params").mkdir(parents=True)
-        (tmp / "train_state").mkdir()
-        (tmp / "assets").mkdir()
-    _barrier()
+    err = None
+    try:
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
+            (tmp / "params").mkdir(parents=True)
+            (tmp / "train_state").mkdir()
+            (tmp / "assets").mkdir()
+    except Exception as e:   # noqa: BLE001
+        err = e
+    if not _all_ok(err is None, ps.device):
+        raise err if err is not None else RuntimeError("checkpoint save failed on another rank (directory setup)")
     if hasattr(state.model.comm, "synchronize"):
         state.model.comm.synchronize()   # the optimizer of the last step runs on the side stream
     if torch.cuda.is_available() and ps.device.type == "cuda":
@@ -163,45 +181,56 @@ def _save_once(mngr: CheckpointManager, state, data_loader, step: int, norm_stat
     has_ema = bool(ps.ema)
     # ---- params item: EMA-or-live in the reference's tree (collective when sharded: every rank takes part)
     tree = ps.to_reference_tree("ema" if has_ema else "master")
-    if rank == 0:
-        _save_tensors(tmp / "params" / "params.safetensors", {"params/" + k: v for k, v in tree.items()},
-                      {"format": "lap reference tree, flattened with '/'", "ema": has_ema, "step": step})
-    del tree
-    # ---- train_state item: this rank's slices
-    shard = {}
-    for u in ps.units:
-        if has_ema:
-            shard[f"master/{u.name}"] = ps.master[u.name]
-        if u.name in ps.m:
-            shard[f"m/{u.name}"], shard[f"v/{u.name}"] = ps.m[u.name], ps.v[u.name]
-    _save_tensors(tmp / "train_state" / f"rank{rank}_of{world}.safetensors", shard, {"step": step, "world_size": world})
-    if rank == 0:
-        (tmp / "train_state" / "meta.json").write_text(json.dumps(
-            {"step": step, "world_size": world, "ema_decay": state.ema_decay, "has_ema": has_ema,
-             "units": {u.name: ps.padded(u) for u in ps.units}}))
-        # ---- assets (save_assets callback, :216-285)
-        if norm_stats is not None:
-            d = tmp / "assets" / asset_id
+    try:
+        if rank == 0:
+            _save_tensors(tmp / "params" / "params.safetensors", {"params/" + k: v for k, v in tree.items()},
+                          {"format": "lap reference tree, flattened with '/'", "ema": has_ema, "step": step})
+        del tree
+        # ---- train_state item: this rank's slices
+        shard = {}
+        for u in ps.units:
+            if has_ema:
+                shard[f"master/{u.name}"] = ps.master[u.name]
+            if u.name in ps.m:
+                shard[f"m/{u.name}"], shard[f"v/{u.name}"] = ps.m[u.name], ps.v[u.name]
+        _save_tensors(tmp / "train_state" / f"rank{rank}_of{world}.safetensors", shard, {"step": step, "world_size": world})
+        if rank == 0:
+            (tmp / "train_state" / "meta.json").write_text(json.dumps(
+                {"step": step, "world_size": world, "ema_decay": state.ema_decay, "has_ema": has_ema,
+                 "units": {u.name: ps.padded(u) for u in ps.units}}))
+            # ---- assets (save_assets callback, :216-285)
+            if norm_stats is not None:
+                d = tmp / "assets" / asset_id
+                d.mkdir(parents=True, exist_ok=True)
+                (d / "norm_stats.json").write_text(json.dumps({"norm_stats": norm_stats}))
+        if data_loader is not None and hasattr(data_loader, "get_state"):
+            d = tmp / "assets" / f"dataloader_process_{rank}"
             d.mkdir(parents=True, exist_ok=True)
-            (d / "norm_stats.json").write_text(json.dumps({"norm_stats": norm_stats}))
-    if data_loader is not None and hasattr(data_loader, "get_state"):
-        d = tmp / "assets" / f"dataloader_process_{rank}"
-        d.mkdir(parents=True, exist_ok=True)
-        (d / "dataloader_state.json").write_text(json.dumps(data_loader.get_state()))
-    _barrier()
-    if rank == 0:
-        (tmp / _COMMIT).write_text(str(step))
-        shutil.rmtree(final, ignore_errors=True)
-        tmp.rename(final)
-        mngr.prune()
-    _barrier()
+            (d / "dataloader_state.json").write_text(json.dumps(data_loader.get_state()))
+    except Exception as e:   # noqa: BLE001
+        err = e
+    if not _all_ok(err is None, ps.device):
+        raise err if err is not None else RuntimeError("checkpoint save failed on another rank (write phase)")
+    try:
+        if rank == 0:
+            (tmp / _COMMIT).write_text(str(step))
+            shutil.rmtree(final, ignore_errors=True)
+            tmp.rename(final)
+            mngr.prune()
+    except Exception as e:   # noqa: BLE001
+        err = e
+    if not _all_ok(err is None, ps.device):
+        raise err if err is not None else RuntimeError("checkpoint save failed on rank 0 (commit)")
 
 
 # ----------------------------------------------------------------------------------------------------------- restore
 def restore_params(checkpoint_manager, step: int | None = None) -> dict:
     """checkpoints.py:440-474: the `params` item (reference tree, f32) of `step` (default: latest).  Accepts a manager,
-    a checkpoint directory, a step directory or the safetensors file itself."""
+    a checkpoint directory, a step directory, a `params` item directory or the safetensors file itself (e.g. the output
+    of tools/convert_orbax_checkpoint.py)."""
     p = checkpoint_manager.directory if isinstance(checkpoint_manager, CheckpointManager) else pathlib.Path(checkpoint_manager)
+    if p.is_dir() and (p / "params.safetensors").exists():     # the `params` item itself (weight_loader.params_path, :440-474)
+        p = p / "params.safetensors"
     if p.is_dir() and not (p / "params").exists():
         mngr = CheckpointManager(p)
         step = mngr.latest_step() if step is None else step
@@ -250,6 +279,11 @@ def restore_state(checkpoint_manager: CheckpointManager, state, data_loader=None
         if u.name in ps.m:
             ps.m[u.name].copy_(shard[f"m/{u.name}"])
             ps.v[u.name].copy_(shard[f"v/{u.name}"])
+    if not meta["has_ema"] and ps.ema:
+        # the run tracks an EMA the checkpoint never had: start it from the restored parameters (scripts/train.py:376-396
+        # re-initialises a structurally missing EMA from the live parameters the same way)
+        logging.warning("checkpoint %s has no EMA parameters; initialising the EMA from the restored parameters", d)
+        ps.sync_ema_from_master()
     _refresh_mirrors(state)
     if data_loader is not None and hasattr(data_loader, "set_state"):
         f = d / "assets" / f"dataloader_process_{ps.rank}" / "dataloader_state.json"

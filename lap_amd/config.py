@@ -64,6 +64,30 @@ def get_siglip_config(variant: str) -> SiglipConfig:
     return _SIGLIP[variant]
 
 
+# ------------------------------------------------------------------------------ parameter-path filters
+@dataclasses.dataclass(frozen=True)
+class PathFilter:
+    """Engine counterpart of the nnx filters the reference builds from `nnx_utils.PathRegex` (full-match regexes over
+    the '/'-joined parameter path), `nnx.All`, `nnx.Any` and `nnx.Not`: a path passes when it matches every entry of
+    `all_of`, at least one of `any_of` (if given) and none of `none_of`.  Entries are regex strings or nested filters."""
+    all_of: tuple = ()
+    any_of: tuple = ()
+    none_of: tuple = ()
+
+    @staticmethod
+    def _hit(entry, path: str) -> bool:
+        import re
+
+        return entry(path) if callable(entry) else re.fullmatch(entry, path) is not None
+
+    def __call__(self, path: str) -> bool:
+        if not all(self._hit(e, path) for e in self.all_of):
+            return False
+        if self.any_of and not any(self._hit(e, path) for e in self.any_of):
+            return False
+        return not any(self._hit(e, path) for e in self.none_of)
+
+
 # ------------------------------------------------------------------------------ model config
 @dataclasses.dataclass(frozen=True)
 class LAPConfig:
@@ -126,6 +150,16 @@ class LAPConfig:
     def model_type(self) -> str:
         return "lap_fast" if self.use_fast else "lap"
 
+    def get_freeze_filter(self):
+        """lap_config.py:132-169: only the LoRA variants (out of scope here) freeze anything -> nnx.Nothing."""
+        return None
+
+    def get_vlm_freeze_filter(self):
+        """lap_config.py:171-191: freeze the VLM (every `llm` parameter that is not on the `_1` action-expert branch)
+        and the image encoder; the action expert and the action heads stay trainable.  Returned as a predicate over
+        the reference's '/'-joined parameter paths (the engine's counterpart of an nnx filter)."""
+        return PathFilter(any_of=(PathFilter(all_of=(".*llm.*",), none_of=(".*llm.*_1.*",)), ".*img.*"))
+
     def create(self, rng=0, **kw):
         """lap_config.py:102-111: build a randomly initialised model (rng = integer seed here)."""
         from lap_amd.model import LAP
@@ -186,50 +220,66 @@ def build_cosine_lr(*, warmup_steps=5_000, peak_lr=1e-4, decay_steps=40_000, dec
 # ------------------------------------------------------------------------------ EMA (config.py:372-504)
 @dataclasses.dataclass(frozen=True)
 class EmaStage:
+    """One step interval [start_step, end_step) with a fixed EMA decay; `end_step=None` is open-ended and
+    `decay=None` means "no EMA update inside this interval"."""
     start_step: int
     end_step: int | None = None
     decay: float | None = None
 
-    def validate(self):
+    def covers(self, step: int) -> bool:
+        return step >= self.start_step and (self.end_step is None or step < self.end_step)
+
+    def problems(self) -> list[str]:
+        out = []
         if self.start_step < 0:
-            raise ValueError(f"start_step must be >= 0, got {self.start_step}")
+            out.append(f"negative start_step {self.start_step}")
         if self.end_step is not None and self.end_step <= self.start_step:
-            raise ValueError(f"end_step ({self.end_step}) must be > start_step ({self.start_step})")
-        if self.decay is not None and not 0.0 < self.decay < 1.0:
-            raise ValueError(f"decay must be in (0.0, 1.0), got {self.decay}")
+            out.append(f"empty interval [{self.start_step}, {self.end_step})")
+        if self.decay is not None and not (0.0 < self.decay < 1.0):
+            out.append(f"decay {self.decay} outside (0, 1)")
+        return out
 
 
 @dataclasses.dataclass(frozen=True)
 class EmaSchedule:
+    """Piecewise-constant EMA decay over the step axis: stages in increasing order, non-overlapping (gaps allowed — a
+    step in a gap has no stage), only the last one may be open-ended."""
     stages: tuple[EmaStage, ...]
 
     def __post_init__(self):
-        if not self.stages:
-            raise ValueError("EmaSchedule must have at least one stage")
-        for s in self.stages:
-            s.validate()
-        for i in range(len(self.stages) - 1):
-            cur, nxt = self.stages[i], self.stages[i + 1]
-            if cur.end_step is None:
-                raise ValueError(f"Stage {i} (starting at {cur.start_step}) has end_step=None but is not the last stage")
-            if nxt.start_step < cur.end_step:
-                raise ValueError(f"Stage {i + 1} (starting at {nxt.start_step}) overlaps with stage {i} (ending at {cur.end_step})")
+        errors = [] if self.stages else ["no stages given"]
+        for n, st in enumerate(self.stages):
+            errors += [f"stage {n}: {msg}" for msg in st.problems()]
+        for n, (a, b) in enumerate(zip(self.stages, self.stages[1:])):
+            if a.end_step is None:
+                errors.append(f"stage {n} is open-ended but stage {n + 1} follows it")
+            elif b.start_step < a.end_step:
+                errors.append(f"stage {n + 1} starts at {b.start_step}, inside stage {n} which ends at {a.end_step}")
+        if errors:
+            raise ValueError("invalid EmaSchedule: " + "; ".join(errors))
+
+    def _find(self, step: int) -> EmaStage | None:
+        return next((st for st in self.stages if st.covers(step)), None)
 
     def get_stage_for_step(self, step: int) -> EmaStage:
-        for s in self.stages:
-            if s.start_step <= step and (s.end_step is None or step < s.end_step):
-                return s
-        raise ValueError(f"No EMA stage covers step {step}. Available stages: {[(s.start_step, s.end_step) for s in self.stages]}")
+        st = self._find(step)
+        if st is None:
+            spans = ", ".join(f"[{s.start_step}, {'inf' if s.end_step is None else s.end_step})" for s in self.stages)
+            raise ValueError(f"step {step} lies in no EMA stage (stages: {spans})")
+        return st
 
     def get_decay_for_step(self, step: int) -> tuple[float, bool]:
-        decay, enabled = 0.0, False
-        for s in self.stages:
-            if step >= s.start_step and (s.end_step is None or step < s.end_step):
-                decay, enabled = (0.0 if s.decay is None else s.decay), s.decay is not None
-        return decay, enabled
+        """(decay, enabled) for `step`; a step outside every stage, or in a stage without decay, has EMA off."""
+        st = self._find(step)
+        if st is None or st.decay is None:
+            return 0.0, False
+        return float(st.decay), True
 
     def has_ema(self) -> bool:
-        return any(s.decay is not None for s in self.stages)
+        return any(st.decay is not None for st in self.stages)
+
+    def default_decay(self) -> float | None:
+        return next((st.decay for st in self.stages if st.decay is not None), None)
 
 
 @dataclasses.dataclass(frozen=True)
@@ -295,6 +345,21 @@ class TrainConfig:
     allow_partial_weights: bool = True
     use_validation: bool = False
     val_interval: int = 2000
+    # openpi TrainConfig.freeze_filter (scripts/train.py:225-240,358-363): parameters it selects are kept out of the
+    # gradient / optimizer and stored at bf16 precision.  None = nnx.Nothing; a regex string (full match on the
+    # reference's '/'-joined path), a PathFilter or any predicate over the path.
+    freeze_filter: object | None = None
+
+    def is_frozen(self, path: str) -> bool:
+        f = self.freeze_filter
+        if f is None:
+            return False
+        return PathFilter(all_of=(f,))(path) if isinstance(f, str) else bool(f(path))
+
+    @property
+    def trainable_filter(self):
+        """openpi: nnx.All(nnx.Param, nnx.Not(freeze_filter)) as a predicate over parameter paths."""
+        return lambda path: not self.is_frozen(path)
 
     @property
     def ema_schedule(self) -> EmaSchedule | None:
@@ -391,19 +456,35 @@ def cli(argv=None) -> TrainConfig:
     argv = list(sys.argv[1:] if argv is None else argv)
     if not argv or argv[0] in ("-h", "--help"):
         fields = ", ".join("--" + f.name.replace("_", "-") for f in dataclasses.fields(TrainConfig)
-                           if isinstance(f.default, (int, float, str, bool)) or f.default is None)
+                           if str(f.type).replace(" ", "").replace("|None", "") in ("int", "float", "str", "bool"))
         raise SystemExit(f"usage: <config> [--field value ...]\nconfigs: {sorted(_CONFIGS_DICT)}\nscalar fields: {fields}")
     cfg = get_config(argv.pop(0))
     upd = {}
+    fields = {f.name: f for f in dataclasses.fields(cfg)}
+    casts = {"int": int, "float": float, "str": str}
     while argv:
         key = argv.pop(0)
         if not key.startswith("--") or not argv:
             raise SystemExit(f"bad argument {key}")
         name = key[2:].replace("-", "_")
-        field = {f.name: f for f in dataclasses.fields(cfg)}.get(name)
+        field = fields.get(name)
         if field is None:
             raise SystemExit(f"unknown option {key}")
-        cur = getattr(cfg, name)
         val = argv.pop(0)
-        upd[name] = type(cur)(val) if cur is not None and not isinstance(cur, bool) else (val.lower() in ("1", "true") if isinstance(cur, bool) else val)
+        ann = str(field.type).replace(" ", "")              # "int", "bool", "float|None", "int|None", "str"
+        base = ann.replace("|None", "")
+        if base == "bool":
+            if val.lower() not in ("1", "0", "true", "false"):
+                raise SystemExit(f"{key} expects true / false, got {val!r}")
+            upd[name] = val.lower() in ("1", "true")
+        elif base in casts:
+            if val.lower() == "none" and ann.endswith("|None"):
+                upd[name] = None
+            else:
+                try:
+                    upd[name] = casts[base](val)
+                except ValueError:
+                    raise SystemExit(f"{key} expects {base}, got {val!r}") from None
+        else:   # nested dataclasses (model, data, optimizer, ...) cannot be set from a single string
+            raise SystemExit(f"{key} is a structured field ({ann}); only scalar top-level fields can be overridden here")
     return dataclasses.replace(cfg, **upd)

@@ -410,6 +410,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
   }
 }
 
+#ifdef LAP_GEMM_EXPERIMENTAL   // ping-pong probes (tiles 8 / 9): measured, documented in DESIGN.md §4, not production
+
 // ---------------------------------------------------------------------------------------------------------------
 // Ping-pong 256x256x64 kernel: 8 waves (2 x 4), 128x64 per wave, one block per CU.  Each k-tile is cut into four
 // phases (one 64x32 quadrant of the wave's output x K = 64 = 16 MFMAs); a phase is
@@ -745,6 +747,8 @@ __global__ __launch_bounds__(1024) void gemm_pp16_kernel(GemmParams p) {
   }
 }
 
+#endif  // LAP_GEMM_EXPERIMENTAL
+
 // ---------------------------------------------------------------------------------------------------------------
 // Software-pipelined 8-wave kernel (tile 10): 256x256x64 tile, 128x64 per wave, TWO fragment register sets.  Per k-tile
 //   A1  set 0 = (kt, k-half 0) is back: 8 MFMAs, issue the raw reads of (kt, k-half 1) into set 1, 8 more MFMAs
@@ -955,6 +959,7 @@ int launch_sp(GemmParams p, hipStream_t s) {
   return LAP_OK;
 }
 
+#ifdef LAP_GEMM_EXPERIMENTAL
 template <bool A_KC, bool B_KC, bool OUT_F32>
 int launch_pp16(GemmParams p, hipStream_t s) {
   constexpr int LDS = 4 * 2 * 256 * 32 * 2;
@@ -994,6 +999,7 @@ int launch_pp(GemmParams p, hipStream_t s) {
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
+#endif  // LAP_GEMM_EXPERIMENTAL
 
 // out = epilogue(alpha * sum_s part[s]) for the two-phase split-K path.
 template <bool OUT_F32>
@@ -1062,16 +1068,22 @@ int launch(GemmParams p, hipStream_t s) {
 template <bool A_KC, bool B_KC, bool OUT_F32>
 int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
   switch (tile) {
+    // production: 10 (software-pipelined 8-wave 256x256, K % 64 == 0), 5 (16-wave 256x256), 6 (128x128); 2 is the
+    // direct-epilogue 8-wave kernel the bitwise tests compare against; 0 (default below) the 4-wave 128x128 kernel
     case 10: return launch_sp<2, 4, A_KC, B_KC, OUT_F32>(p, s);
+    case 6: return launch<128, 128, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
+    case 5: return launch<256, 256, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
+    case 2: return launch<256, 256, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
+#ifdef LAP_GEMM_EXPERIMENTAL   // probes kept for the record: build with LAP_GEMM_EXPERIMENTAL=1 python -m lap_amd.build
     case 9: return launch_pp16<A_KC, B_KC, OUT_F32>(p, s);
     case 8: return launch_pp<A_KC, B_KC, OUT_F32>(p, s);
     case 7: return launch<256, 128, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
-    case 6: return launch<128, 128, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
-    case 5: return launch<256, 256, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
     case 4: return launch<128, 128, 2, 2, 32, 4, A_KC, B_KC, OUT_F32>(p, s);
     case 3: return launch<256, 256, 2, 4, 32, 4, A_KC, B_KC, OUT_F32>(p, s);
-    case 2: return launch<256, 256, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
     case 1: return launch<256, 128, 4, 2, 64, 3, A_KC, B_KC, OUT_F32>(p, s);
+#else
+    case 9: case 8: case 7: case 4: case 3: case 1: return LAP_ERR_ARG;   // not in this build
+#endif
     default: return launch<128, 128, 2, 2, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
   }
 }

@@ -79,11 +79,15 @@ class UnitPipeline:
 
     def grads_ready(self, name: str):
         u = self.ps.unit_by_name[name]
+        if not self.ps.unit_trainable(u):
+            return    # fully frozen unit: no reduction, no norm contribution, no update
         with self._on_side():
             self._reduce_grads(u)
             if self.is_cuda:  # (the CPU/gloo tests exercise the collectives only; kernels need a GPU)
                 slot = 0 if (self.ps.sharded(u) or self.world_size == 1) else 1
-                hip.sumsq_f32(self.ps.gshard[name], self.sumsq[slot:slot + 1])
+                g = self.ps.gshard[name]
+                for a, b in self.ps.local_train_ranges(u):     # one range (the whole shard) unless a freeze filter is set
+                    hip.sumsq_f32(g[a:b], self.sumsq[slot:slot + 1])
         self._pending = True
 
     def finish_grads(self):
@@ -105,16 +109,20 @@ class UnitPipeline:
             self._reduce_norm()
             self.scal.copy_(h, non_blocking=True)
             self.scal[0:1] = self.sumsq[0:1] + self.sumsq[1:2]
-            self.gnorm.copy_(self.scal[0].sqrt())
+            gnorm = self.scal[0].sqrt()      # a fresh tensor per step: callers keep the infos of many steps
+            self.gnorm = gnorm
             if self.is_cuda:
                 norm_ready = torch.cuda.Event()
                 norm_ready.record(self.side)
             for u in ps.units:  # build_specs puts the small replicated unit first, then forward order
-                a, b = ps.shard_range(u)
-                p16 = ps.full16[u.name][a:b] if u.big else None
-                hip.adamw_ema(ps.master[u.name], ps.m[u.name], ps.v[u.name], ps.ema.get(u.name), ps.gshard[u.name], p16,
-                              self.scal, opt.b1, opt.b2, opt.eps, opt.weight_decay, opt.clip_gradient_norm)
-                self._after_unit_update(u)
+                lo, _ = ps.shard_range(u)
+                ema = ps.ema.get(u.name)
+                for a, b in ps.local_train_ranges(u):   # shard coordinates; frozen tensors are skipped altogether
+                    p16 = ps.full16[u.name][lo + a:lo + b] if u.big else None
+                    hip.adamw_ema(ps.master[u.name][a:b], ps.m[u.name][a:b], ps.v[u.name][a:b], ema[a:b] if ema is not None else None,
+                                  ps.gshard[u.name][a:b], p16, self.scal, opt.b1, opt.b2, opt.eps, opt.weight_decay, opt.clip_gradient_norm)
+                if ps.unit_trainable(u):
+                    self._after_unit_update(u)
                 if self.is_cuda:
                     ev = torch.cuda.Event()
                     ev.record(self.side)
@@ -124,10 +132,34 @@ class UnitPipeline:
                 self._opt_done.record(self.side)
         if self.is_cuda:
             torch.cuda.current_stream().wait_event(norm_ready)   # so that `gnorm` can be read from the compute stream
-        return self.gnorm
+            gnorm.record_stream(torch.cuda.current_stream())
+        return gnorm
 
     def _reduce_norm(self):
         pass
+
+    def param_sumsq(self, select) -> torch.Tensor:
+        """Sum of squares of the f32 master values of the tensors `select(name, shape)` accepts, over ALL ranks: every
+        rank adds the part of each tensor that lies in its shard, the partial sums are all-reduced (scripts/train.py:401-415
+        reports optax.global_norm of the kernel parameters at every logging step, sharded or not)."""
+        ps = self.ps
+        self.synchronize()
+        acc = torch.zeros(2, dtype=torch.float32, device=ps.device)     # [sharded units, replicated unit]
+        for u in ps.units:
+            lo, hi = ps.shard_range(u)
+            slot = 0 if (ps.sharded(u) or self.world_size == 1) else 1
+            for t in u.tensors:
+                if not select(t.name, t.shape):
+                    continue
+                a, b = max(t.offset, lo), min(t.offset + t.numel, hi)
+                if a < b:
+                    v = ps.master[u.name][a - lo:b - lo]
+                    if self.is_cuda:
+                        hip.sumsq_f32(v, acc[slot:slot + 1])
+                    else:
+                        acc[slot] += (v.double() ** 2).sum().float()
+        acc[1] /= self.world_size       # the replicated unit is counted once
+        return self.all_reduce_sum(acc).sum()
 
     def synchronize(self):
         if self.is_cuda:
@@ -154,6 +186,13 @@ class FsdpComm(UnitPipeline):
             raise ValueError("ParamStore world_size/rank do not match the process group")
         # RCCL ("nccl") has the fused tensor collectives; gloo (CPU tests, single-GPU multi-process tests) does not
         self.fused = dist.get_backend(group) == "nccl"
+        # In-place all-gather (the input is this rank's slice OF the output buffer) is the documented NCCL / RCCL
+        # in-place form and saves a 1/N staging copy per unit; LAP_FSDP_INPLACE_GATHER=0 selects the two-buffer form
+        # (gather from a private copy of the slice) should an RCCL build mishandle the aliasing.  bench.py / train.py
+        # run with the default (in place).
+        import os
+
+        self.inplace_gather = os.environ.get("LAP_FSDP_INPLACE_GATHER", "1") != "0"
 
     # ---- gradients
     def _reduce_grads(self, u):
@@ -189,7 +228,8 @@ class FsdpComm(UnitPipeline):
     # ---- backend shims
     def _all_gather(self, full: torch.Tensor, mine: torch.Tensor):
         if self.fused:
-            self.dist.all_gather_into_tensor(full, mine, group=self.group)  # in place: `mine` is full[rank*n:(rank+1)*n]
+            # in place: `mine` is full[rank*n:(rank+1)*n]; the fallback reads it from a detached copy instead
+            self.dist.all_gather_into_tensor(full, mine if self.inplace_gather else mine.clone(), group=self.group)
         else:
             parts = [torch.empty_like(mine) for _ in range(self.world_size)]
             self.dist.all_gather(parts, mine.clone(), group=self.group)

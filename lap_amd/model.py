@@ -81,6 +81,21 @@ class LAP:
     def G(self, name):
         return self.ps.g(name)
 
+    def _wgrad(self, dy, x, name, **kw):
+        """Weight gradient dWt = dy^T x into the gradient buffer of `name` — skipped for frozen parameters
+        (scripts/train.py:358-361 differentiates w.r.t. the trainable filter only)."""
+        if self.ps.is_trainable(name):
+            hip.linear_wgrad(dy, x, self.G(name), **kw)
+
+    def _prefix_frozen(self) -> bool:
+        """True when no parameter reached by the prefix stream's backward is trainable (e.g. `get_vlm_freeze_filter`):
+        the language-head, VLM and SigLIP backward passes are then skipped altogether."""
+        fr = self.ps.frozen
+        if not fr:
+            return False
+        return all(v for k, v in fr.items() if k.startswith("img/") or k in ("llm/embed", "llm/final_norm")
+                   or (k.startswith("llm/") and (k.endswith("0") or k.endswith("n_attn") or k.endswith("n_ffw"))))
+
     def _lin32(self, x, wname, bname):
         """nnx.Linear in f32: y = x @ W^T + b (W stored [out][in])."""
         w = self.F(wname)
@@ -159,7 +174,7 @@ class LAP:
         x, enc, mean, rstd = ctx["final"]
         N = x.shape[0] // T
         hip.colsum(dtok, self.G("img/head_b"))
-        hip.linear_wgrad(dtok, enc, self.G("img/head_w"))
+        self._wgrad(dtok, enc, "img/head_w")
         denc = hip.linear_dgrad(dtok, self.W("img/head_w"))
         self.comm.grads_ready("img_head")
         dx = hip.layernorm_bwd(x, denc, self.F("img/norm_g"), mean, rstd, self.G("img/norm_g"), self.G("img/norm_b"))
@@ -167,24 +182,24 @@ class LAP:
             p = f"img/{l}/"
             x, y, mean1, rstd1, qkv, o, lse, x1, y2, mean2, rstd2, h, a = ctx["blocks"][l]
             hip.colsum(dx, self.G(p + "b2"))
-            hip.linear_wgrad(dx, a, self.G(p + "w2"))
+            self._wgrad(dx, a, p + "w2")
             da = hip.linear_dgrad(dx, self.W(p + "w2"))
             dh = hip.gelu_bwd(h, da)
             del da
             hip.colsum(dh, self.G(p + "b1"))
-            hip.linear_wgrad(dh, y2, self.G(p + "w1"))
+            self._wgrad(dh, y2, p + "w1")
             dy2 = hip.linear_dgrad(dh, self.W(p + "w1"))
             del dh
             hip.layernorm_bwd(x1, dy2, self.F(p + "ln2_g"), mean2, rstd2, self.G(p + "ln2_g"), self.G(p + "ln2_b"), dx=dx, accum_dx=True)
             hip.colsum(dx, self.G(p + "bo"))
-            hip.linear_wgrad(dx, o, self.G(p + "wo"))
+            self._wgrad(dx, o, p + "wo")
             do = hip.linear_dgrad(dx, self.W(p + "wo"))
             dqkv = torch.empty_like(qkv)
             hip.attention_bwd([qkv[:, :W]], [qkv[:, W:2 * W]], [qkv[:, 2 * W:]], [o], [do], lse, [T], [T], N, s.num_heads, s.num_heads, hd,
                               scale=hd ** -0.5, q_rs=(3 * W, 0), kv_rs=(3 * W, 0),
                               dq_out=[dqkv[:, :W]], dk_out=[dqkv[:, W:2 * W]], dv_out=[dqkv[:, 2 * W:]])
             hip.colsum(dqkv, self.G(p + "bqkv"))
-            hip.linear_wgrad(dqkv, y, self.G(p + "wqkv"))
+            self._wgrad(dqkv, y, p + "wqkv")
             dy = hip.linear_dgrad(dqkv, self.W(p + "wqkv"))
             hip.layernorm_bwd(x, dy, self.F(p + "ln1_g"), mean1, rstd1, self.G(p + "ln1_g"), self.G(p + "ln1_b"), dx=dx, accum_dx=True)
             ctx["blocks"][l] = None
@@ -311,7 +326,7 @@ class LAP:
         xt2, temb, h1, s1, h2, cond16 = sctx
         dmod16 = hip.cast_f32_to_bf16(dmod)
         hip.colsum(dmod, self.G("ada/b"))
-        hip.linear_wgrad(dmod16, cond16, self.G("ada/w"))
+        self._wgrad(dmod16, cond16, "ada/w")
         dcond = hip.cast_bf16_to_f32(hip.linear_dgrad(dmod16, self.W("ada/w")))
         self.comm.grads_ready("ada")
         dh2 = hip.swish_bwd(h2, dcond)
@@ -386,46 +401,53 @@ class LAP:
         NH, HD, KV = v.num_heads, v.head_dim, v.num_kv_heads
         Ttot = pos.shape[1]
         ldm = mod.stride(0)
+        zero_do0 = None
         for l in reversed(range(v.depth)):
             p = f"llm/{l}/"
             c = ctx[l]
             d_o = [None, None]
-            # ---- FFN, prefix stream: xn = xa + act @ wd^T
-            hip.linear_wgrad(dx0, c["act"][0], self.G(p + "wd0"))
-            dact = hip.linear_dgrad(dx0, self.W(p + "wd0"))
-            dgu = hip.geglu_bwd(c["gu"][0], dact)
-            del dact
-            hip.linear_wgrad(dgu, c["hf"][0], self.G(p + "wgu0"))
-            dhf = hip.linear_dgrad(dgu, self.W(p + "wgu0"))
-            del dgu
-            hip.rmsnorm_bwd(c["xa"][0], dhf, c["rstd_f"][0], scale=self.F(p + "n_ffw"), dx=dx0, dscale=self.G(p + "n_ffw"), accum_dx=True)
-            del dhf
-            hip.linear_wgrad(dx0, c["o"][0], self.G(p + "wo0"))
-            d_o[0] = hip.linear_dgrad(dx0, self.W(p + "wo0"))
+            # ---- FFN, prefix stream: xn = xa + act @ wd^T   (dx0 is None: the whole prefix side is frozen)
+            if dx0 is not None:
+                self._wgrad(dx0, c["act"][0], p + "wd0")
+                dact = hip.linear_dgrad(dx0, self.W(p + "wd0"))
+                dgu = hip.geglu_bwd(c["gu"][0], dact)
+                del dact
+                self._wgrad(dgu, c["hf"][0], p + "wgu0")
+                dhf = hip.linear_dgrad(dgu, self.W(p + "wgu0"))
+                del dgu
+                hip.rmsnorm_bwd(c["xa"][0], dhf, c["rstd_f"][0], scale=self.F(p + "n_ffw"), dx=dx0, dscale=self.G(p + "n_ffw"), accum_dx=True)
+                del dhf
+                self._wgrad(dx0, c["o"][0], p + "wo0")
+                d_o[0] = hip.linear_dgrad(dx0, self.W(p + "wo0"))
+            else:   # the attention backward still needs a dO for the prefix queries: zero (their dq / dk / dv are discarded)
+                if zero_do0 is None:
+                    zero_do0 = torch.zeros_like(c["o"][0])
+                d_o[0] = zero_do0
             # ---- FFN, suffix stream: xn = xa + y1f * gate_f
             slot_f, slot_a = 2 * l + 1, 2 * l
             gate_f = self._mod_slot(mod, slot_f)[:, 2 * e.width:]
             dy1f = hip.gated_residual_bwd(dx1, c["y1f"], gate_f, n1, ldm, self._mod_slot(dmod, slot_f)[:, 2 * e.width:], dmod.stride(0))
-            hip.linear_wgrad(dy1f, c["act"][1], self.G(p + "wd1"))
+            self._wgrad(dy1f, c["act"][1], p + "wd1")
             dact = hip.linear_dgrad(dy1f, self.W(p + "wd1"))
             dgu = hip.geglu_bwd(c["gu"][1], dact)
-            hip.linear_wgrad(dgu, c["hf"][1], self.G(p + "wgu1"))
+            self._wgrad(dgu, c["hf"][1], p + "wgu1")
             dhf = hip.linear_dgrad(dgu, self.W(p + "wgu1"))
             hip.rmsnorm_bwd(c["xa"][1], dhf, c["rstd_f"][1], mod=self._mod_slot(mod, slot_f), rows_per_sample=n1, dx=dx1,
                             dmod=self._mod_slot(dmod, slot_f), accum_dx=True)
             gate_a = self._mod_slot(mod, slot_a)[:, 2 * e.width:]
             dy1 = hip.gated_residual_bwd(dx1, c["y1"], gate_a, n1, ldm, self._mod_slot(dmod, slot_a)[:, 2 * e.width:], dmod.stride(0))
-            hip.linear_wgrad(dy1, c["o"][1], self.G(p + "wo1"))
+            self._wgrad(dy1, c["o"][1], p + "wo1")
             d_o[1] = hip.linear_dgrad(dy1, self.W(p + "wo1"))
             # ---- attention
             dq, dk, dv = hip.attention_bwd(c["q"], c["k"], c["v"], c["o"], d_o, c["lse"], [n0, n1], [n0, n1], B, NH, KV, HD, qinfo, kinfo,
                                            stop_q1_to_k0=self.config.stop_action_to_vlm_grad)
-            dqkv = hip.rope_split_bwd(dq[0], dk[0], dv[0], pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5)
-            hip.linear_wgrad(dqkv, c["h"][0], self.G(p + "wqkv0"))
-            dh = hip.linear_dgrad(dqkv, self.W(p + "wqkv0"))
-            hip.rmsnorm_bwd(c["x"][0], dh, c["rstd_a"][0], scale=self.F(p + "n_attn"), dx=dx0, dscale=self.G(p + "n_attn"), accum_dx=True)
+            if dx0 is not None:
+                dqkv = hip.rope_split_bwd(dq[0], dk[0], dv[0], pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5)
+                self._wgrad(dqkv, c["h"][0], p + "wqkv0")
+                dh = hip.linear_dgrad(dqkv, self.W(p + "wqkv0"))
+                hip.rmsnorm_bwd(c["x"][0], dh, c["rstd_a"][0], scale=self.F(p + "n_attn"), dx=dx0, dscale=self.G(p + "n_attn"), accum_dx=True)
             dqkv = hip.rope_split_bwd(dq[1], dk[1], dv[1], pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
-            hip.linear_wgrad(dqkv, c["h"][1], self.G(p + "wqkv1"))
+            self._wgrad(dqkv, c["h"][1], p + "wqkv1")
             dh = hip.linear_dgrad(dqkv, self.W(p + "wqkv1"))
             hip.rmsnorm_bwd(c["x"][1], dh, c["rstd_a"][1], mod=self._mod_slot(mod, slot_a), rows_per_sample=n1, dx=dx1,
                             dmod=self._mod_slot(dmod, slot_a), accum_dx=True)
@@ -554,28 +576,33 @@ class LAP:
         dpre1f = self._lin32_bwd(pre1f, dv.view(B * S, ad), "act/out_w", "act/out_b")
         dx1 = hip.rmsnorm_bwd(xf1, hip.cast_f32_to_bf16(dpre1f), rstd_p1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S,
                               dmod=self._mod_slot(dmod, 2 * self.v.depth))
-        # language head: dlogits = w * (softmax - onehot); w = d loss / d nll
-        w = (cfg.language_loss_weight * lm / cnt[:, None] / n_active).contiguous().view(-1)
-        dpl32 = torch.empty((R, Dv), dtype=torch.float32, device=dev) if len(chunks) > 1 else None
-        gE = self.G("llm/embed")
-        for ci, (v0, vc) in enumerate(chunks):
-            dlogits = torch.empty((R, vc), dtype=torch.bfloat16, device=dev)
-            hip.ce_chunk_grad(logit_chunks[ci], targets, m, lsum, w, dlogits, v0)
-            logit_chunks[ci] = None
-            hip.linear_wgrad(dlogits, pl, gE[v0:v0 + vc])
-            if dpl32 is None:
-                dpl = hip.linear_dgrad(dlogits, table16[v0:v0 + vc])
-            else:
-                hip.linear_dgrad(dlogits, table16[v0:v0 + vc], out=dpl32, accum=ci > 0)
-            del dlogits
-        if dpl32 is not None:
-            dpl = hip.cast_f32_to_bf16(dpl32)
-        drows = hip.rmsnorm_bwd(rows, dpl, rstd_pl, scale=self.F("llm/final_norm"), dscale=self.G("llm/final_norm"))
-        dx0 = torch.zeros((B * Pn, Dv), dtype=torch.bfloat16, device=dev)
-        hip.copy_rows_bf16(drows, dx0, R, Lt - 1, Dv, Lt - 1, 0, Pn, Pn - Lt)
+        skip_prefix = self._prefix_frozen()
+        dx0 = None
+        if not skip_prefix:
+            # language head: dlogits = w * (softmax - onehot); w = d loss / d nll
+            w = (cfg.language_loss_weight * lm / cnt[:, None] / n_active).contiguous().view(-1)
+            dpl32 = torch.empty((R, Dv), dtype=torch.float32, device=dev) if len(chunks) > 1 else None
+            gE = self.G("llm/embed")
+            for ci, (v0, vc) in enumerate(chunks):
+                dlogits = torch.empty((R, vc), dtype=torch.bfloat16, device=dev)
+                hip.ce_chunk_grad(logit_chunks[ci], targets, m, lsum, w, dlogits, v0)
+                logit_chunks[ci] = None
+                if self.ps.is_trainable("llm/embed"):
+                    hip.linear_wgrad(dlogits, pl, gE[v0:v0 + vc])
+                if dpl32 is None:
+                    dpl = hip.linear_dgrad(dlogits, table16[v0:v0 + vc])
+                else:
+                    hip.linear_dgrad(dlogits, table16[v0:v0 + vc], out=dpl32, accum=ci > 0)
+                del dlogits
+            if dpl32 is not None:
+                dpl = hip.cast_f32_to_bf16(dpl32)
+            drows = hip.rmsnorm_bwd(rows, dpl, rstd_pl, scale=self.F("llm/final_norm"), dscale=self.G("llm/final_norm"))
+            dx0 = torch.zeros((B * Pn, Dv), dtype=torch.bfloat16, device=dev)
+            hip.copy_rows_bf16(drows, dx0, R, Lt - 1, Dv, Lt - 1, 0, Pn, Pn - Lt)
         dx0, dx1 = self._llm_bwd(lctx, dx0, dx1, mod, dmod, pos, qinfo, kinfo, B, Pn, S)
         self._embed_suffix_bwd(sctx, dx1, dmod)
-        self._embed_prefix_bwd(pctx, dx0, B, Pn)
+        if not skip_prefix:
+            self._embed_prefix_bwd(pctx, dx0, B, Pn)
         self.comm.grads_ready("small")
         return loss, metrics
 

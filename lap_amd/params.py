@@ -131,6 +131,8 @@ class ParamStore:
         self.ema: dict[str, torch.Tensor] = {}
         self.grad: dict[str, torch.Tensor] = {}     # unit -> f32 full gradient buffer [padded numel]
         self.gshard: dict[str, torch.Tensor] = {}   # unit -> f32 gradient shard (aliases grad when N == 1)
+        self.frozen: dict[str, bool] = {}           # engine tensor -> excluded from gradient / optimizer (set_frozen)
+        self._train_ranges: dict[str, list] = {}    # unit -> [(a, b)] trainable ranges in unit coordinates
         for u in self.units:
             n = self.padded(u)
             sh = self.shard_numel(u)
@@ -164,6 +166,59 @@ class ParamStore:
             return 0, self.padded(u)
         sh = self.shard_numel(u)
         return self.rank * sh, (self.rank + 1) * sh
+
+    # ---- trainable / frozen partition (openpi TrainConfig.freeze_filter, scripts/train.py:225-240,358-363)
+    def set_frozen(self, is_frozen=None):
+        """`is_frozen`: predicate over the REFERENCE's parameter paths (None: everything trainable).  An engine tensor
+        packs one or more reference arrays (`engine_sources`); all of them must fall on the same side.  Frozen tensors
+        are kept out of the optimizer, the gradient norm and the weight-gradient GEMMs, and their values are rounded to
+        bfloat16 as the reference stores them (train.py:225-231)."""
+        self.frozen = {}
+        src = engine_sources(self.cfg)
+        for name in self.tensor_spec:
+            flags = {bool(is_frozen(k)) for k in src[name]} if is_frozen is not None else {False}
+            if len(flags) != 1:
+                raise ValueError(f"freeze filter splits engine tensor {name} (packed from {src[name]})")
+            self.frozen[name] = flags.pop()
+        self._train_ranges = {}
+        for u in self.units:
+            ranges = []
+            for t in u.tensors:
+                if self.frozen[t.name]:
+                    continue
+                a, b = t.offset, t.offset + _align(t.numel)
+                if ranges and ranges[-1][1] == a:
+                    ranges[-1] = (ranges[-1][0], b)
+                else:
+                    ranges.append((a, b))
+            if ranges and ranges[-1][1] == u.numel:        # the unit's tail padding belongs to its last tensor
+                ranges[-1] = (ranges[-1][0], self.padded(u))
+            self._train_ranges[u.name] = ranges
+            lo, hi = self.shard_range(u)
+            for t in u.tensors:                               # frozen values live at bf16 precision
+                if self.frozen[t.name]:
+                    a, b = max(t.offset, lo), min(t.offset + t.numel, hi)
+                    if a < b:
+                        v = self.master[u.name][a - lo:b - lo]
+                        v.copy_(v.to(torch.bfloat16).to(torch.float32))
+        if any(self.frozen.values()):
+            self.sync_ema_from_master()
+
+    def is_trainable(self, name: str) -> bool:
+        return not self.frozen.get(name, False)
+
+    def unit_trainable(self, u: UnitSpec) -> bool:
+        return bool(self._train_ranges.get(u.name, [(0, 1)]))
+
+    def local_train_ranges(self, u: UnitSpec) -> list[tuple[int, int]]:
+        """Trainable ranges of `u` intersected with this rank's shard, in SHARD coordinates."""
+        lo, hi = self.shard_range(u)
+        out = []
+        for a, b in self._train_ranges.get(u.name, [(0, self.padded(u))]):
+            a, b = max(a, lo), min(b, hi)
+            if a < b:
+                out.append((a - lo, b - lo))
+        return out
 
     # ---- views
     def _view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
@@ -275,6 +330,47 @@ class ParamStore:
 
 
 # ================================================================================= reference key map
+def engine_sources(cfg: LAPConfig) -> dict[str, list[str]]:
+    """Engine tensor -> the reference arrays it is packed from (the inverse view of `reference_to_engine`)."""
+    v, e, s = _cfgs(cfg)
+    blk = "PaliGemma/img/Transformer/encoderblock"
+    mha = f"{blk}/MultiHeadDotProductAttention_0"
+    lay = "PaliGemma/llm/layers"
+    out = {"img/stem_w": ["PaliGemma/img/embedding/kernel"], "img/stem_b": ["PaliGemma/img/embedding/bias"],
+           "img/pos": ["PaliGemma/img/pos_embedding"],
+           "img/norm_g": ["PaliGemma/img/Transformer/encoder_norm/scale"], "img/norm_b": ["PaliGemma/img/Transformer/encoder_norm/bias"],
+           "img/head_w": ["PaliGemma/img/head/kernel"], "img/head_b": ["PaliGemma/img/head/bias"],
+           "llm/embed": ["PaliGemma/llm/embedder/input_embedding"], "llm/final_norm": ["PaliGemma/llm/final_norm/scale"]}
+    for l in range(s.depth):
+        out[f"img/{l}/ln1_g"], out[f"img/{l}/ln1_b"] = [f"{blk}/LayerNorm_0/scale"], [f"{blk}/LayerNorm_0/bias"]
+        out[f"img/{l}/ln2_g"], out[f"img/{l}/ln2_b"] = [f"{blk}/LayerNorm_1/scale"], [f"{blk}/LayerNorm_1/bias"]
+        out[f"img/{l}/wqkv"] = [f"{mha}/{n}/kernel" for n in ("query", "key", "value")]
+        out[f"img/{l}/bqkv"] = [f"{mha}/{n}/bias" for n in ("query", "key", "value")]
+        out[f"img/{l}/wo"], out[f"img/{l}/bo"] = [f"{mha}/out/kernel"], [f"{mha}/out/bias"]
+        out[f"img/{l}/w1"], out[f"img/{l}/b1"] = [f"{blk}/MlpBlock_0/Dense_0/kernel"], [f"{blk}/MlpBlock_0/Dense_0/bias"]
+        out[f"img/{l}/w2"], out[f"img/{l}/b2"] = [f"{blk}/MlpBlock_0/Dense_1/kernel"], [f"{blk}/MlpBlock_0/Dense_1/bias"]
+    ada = [f"{lay}/{nm}/Dense_0" for nm in ("pre_attention_norm_1", "pre_ffw_norm_1")] + ["PaliGemma/llm/final_norm_1/Dense_0"]
+    out["ada/w"], out["ada/b"] = [a + "/kernel" for a in ada], [a + "/bias" for a in ada]
+    for l in range(v.depth):
+        for i in range(2):
+            sfx = "" if i == 0 else f"_{i}"
+            out[f"llm/{l}/wqkv{i}"] = [f"{lay}/attn/q_einsum{sfx}/w", f"{lay}/attn/kv_einsum{sfx}/w"]
+            out[f"llm/{l}/wo{i}"] = [f"{lay}/attn/attn_vec_einsum{sfx}/w"]
+            out[f"llm/{l}/wgu{i}"] = [f"{lay}/mlp{sfx}/gating_einsum"]
+            out[f"llm/{l}/wd{i}"] = [f"{lay}/mlp{sfx}/linear"]
+        out[f"llm/{l}/n_attn"], out[f"llm/{l}/n_ffw"] = [f"{lay}/pre_attention_norm/scale"], [f"{lay}/pre_ffw_norm/scale"]
+    for nm, ref in (("in", "action_in_proj"), ("time_in", "time_mlp_in"), ("time_out", "time_mlp_out"), ("out", "action_out_proj")):
+        out[f"act/{nm}_w"], out[f"act/{nm}_b"] = [f"{ref}/kernel"], [f"{ref}/bias"]
+    return out
+
+
+def reference_shapes(cfg: LAPConfig) -> dict[str, tuple]:
+    """Shapes of the reference's parameter tree, derived from the engine specs through the key map
+    (shape-only `meta` tensors: nothing is allocated)."""
+    E = {t.name: torch.empty(t.shape, dtype=torch.float32, device="meta") for u in build_specs(cfg) for t in u.tensors}
+    return {k: tuple(v.shape) for k, v in engine_to_reference(cfg, E).items()}
+
+
 def _cfgs(cfg):
     return get_gemma_config(cfg.paligemma_variant), get_gemma_config(cfg.action_expert_variant), get_siglip_config(cfg.siglip_variant)
 

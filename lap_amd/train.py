@@ -31,10 +31,6 @@ class TrainState:
         return self.model.ps
 
 
-_KERNEL_PARAM_EXCLUDE = ("_b", "ln1_g", "ln2_g", "norm_g", "n_attn", "n_ffw", "final_norm", "img/pos", "llm/embed", "/b1", "/b2", "/bo",
-                         "bqkv", "ada/b")
-
-
 def _is_kernel_param(name: str, shape) -> bool:
     """train.py:401-408: ndim > 1 and not bias / scale / pos_embedding / input_embedding."""
     if len(shape) < 2:
@@ -42,9 +38,59 @@ def _is_kernel_param(name: str, shape) -> bool:
     return not any(name.endswith(s) or s in name for s in ("img/pos", "llm/embed"))
 
 
+def validate_loaded_params(expected: dict, got: dict, *, allow_partial: bool) -> dict:
+    """scripts/train.py:157-187 (_validate_loaded_params) on '/'-flattened trees.  `expected`: path -> shape of the
+    model's parameter tree; `got`: path -> array.  A key the model does not have, or a shape / dtype that differs, is an
+    error; missing keys are an error unless `allow_partial` (they keep their initial values).  Returns `got` (f32)."""
+    import logging
+
+    unexpected = [k for k in got if k not in expected]
+    if unexpected:
+        raise ValueError(f"Loaded params contain unexpected keys (sample): {', '.join(unexpected[:8])}")
+    bad = []
+    for k, v in got.items():
+        if tuple(v.shape) != tuple(expected[k]):
+            bad.append(f"{k} (shape {tuple(v.shape)} != {tuple(expected[k])})")
+        elif not torch.as_tensor(v).dtype.is_floating_point:
+            bad.append(f"{k} (dtype {torch.as_tensor(v).dtype} is not a float type)")
+    if bad:
+        raise ValueError(f"Loaded params do not match expected shapes/dtypes (sample): {', '.join(bad[:8])}")
+    missing = sorted(set(expected) - set(got))
+    if missing:
+        if not allow_partial:
+            raise ValueError(f"Loaded params missing required keys: {', '.join(missing)}")
+        logging.info("Weight loader missing %d params; using random init for them: %s", len(missing), ", ".join(missing))
+    return got
+
+
+def load_weights(config: TrainConfig, store: ParamStore):
+    """The `weight_loader` of the config executed against a freshly initialised store (scripts/train.py:191-199,248-310;
+    weight_loaders.py:55-105,691-719): load the checkpoint's `params` item in the reference's tree layout, keep the
+    keys the model knows (CheckpointWeightLoader drops the rest and casts dtypes), validate, and merge over the init."""
+    from lap_amd import checkpoints as ck
+    from lap_amd.params import reference_shapes
+
+    wl = config.weight_loader
+    if wl.kind == "none":
+        return False
+    if wl.kind != "checkpoint":
+        raise NotImplementedError(f"weight loader kind {wl.kind!r} (paligemma / gemma3 .npz loaders are out of scope: SURVEY.md §2)")
+    expected = reference_shapes(config.model)
+    loaded = ck.restore_params(wl.params_path)           # '/value' suffixes and the 'params/' prefix are stripped there
+    subset = {k: torch.as_tensor(v) for k, v in loaded.items() if k in expected}     # _merge_params: subset of the model's keys
+    subset = validate_loaded_params(expected, subset, allow_partial=config.allow_partial_weights)
+    if len(subset) < len(expected):                      # partial: the model's own (random-init) arrays fill the gaps
+        base = store.to_reference_tree("master")
+        base.update(subset)
+        subset = base
+    store.load_reference_tree(subset)
+    return True
+
+
 def init_train_state(config: TrainConfig, seed: int | None = None, *, device="cuda", params: dict | None = None, comm=None,
-                     world_size: int = 1, rank: int = 0, use_fsdp: bool = False) -> TrainState:
-    """scripts/train.py:202-326 (init_train_state): model init (+ optional weight merge), optimizer and EMA state.
+                     world_size: int = 1, rank: int = 0, use_fsdp: bool = False, resume: bool = False) -> TrainState:
+    """scripts/train.py:202-326 (init_train_state): model init, the config's weight loader merged over it (skipped when
+    resuming: the checkpoint overwrites everything), frozen parameters per `freeze_filter`, optimizer and EMA state.
     With use_fsdp the store is sharded over the default process group (every rank draws the same full random
     init from the same seed and keeps its slice)."""
     ema_decay, ema_enabled = config.get_ema_init()
@@ -53,6 +99,9 @@ def init_train_state(config: TrainConfig, seed: int | None = None, *, device="cu
         store.load_reference_tree(params)
     else:
         store.init_random(config.seed if seed is None else seed)
+        if not resume:
+            load_weights(config, store)
+    store.set_frozen(config.is_frozen if config.freeze_filter is not None else None)
     if comm is None:
         from lap_amd.fsdp import FsdpComm, UnitPipeline
 
@@ -92,14 +141,9 @@ class TrainingStepRunner:
         return dataclasses.replace(state, step=state.step + 1), info
 
     def param_norm(self, state: TrainState) -> torch.Tensor:
-        """optax.global_norm over kernel parameters (train.py:401-415); computed on demand (logging interval)."""
-        ps = state.model.ps
-        state.model.comm.synchronize() if hasattr(state.model.comm, "synchronize") else None
-        acc = torch.zeros(1, dtype=torch.float32, device=state.model.device)
-        for name, spec in ps.tensor_spec.items():
-            if _is_kernel_param(name, spec.shape) and not ps.sharded(ps.tensor_unit[name]):
-                hip.sumsq_f32(ps.f32(name).reshape(-1), acc)
-        return acc.sqrt().view(())
+        """optax.global_norm over kernel parameters (train.py:401-415); computed on demand (logging interval).
+        Collective under FSDP: per-shard partial sums, all-reduced."""
+        return state.model.comm.param_sumsq(_is_kernel_param).sqrt().view(())
 
 
 # ====================================================================================== training entry point
@@ -147,6 +191,7 @@ def main(config: TrainConfig, *, data_loader=None, device: str | None = None, lo
     and checkpointing.  One process per GPU; under `torch.distributed.run` the parameters / optimizer / EMA are ZeRO-3
     sharded over all ranks and `batch_size` is the GLOBAL batch (config.py:783)."""
     import os
+    import pathlib
     import time as _time
 
     import torch.distributed as dist
@@ -165,11 +210,25 @@ def main(config: TrainConfig, *, data_loader=None, device: str | None = None, lo
         dist.init_process_group("nccl" if torch.device(device).type == "cuda" else "gloo", rank=rank, world_size=world)
     if config.batch_size % world:
         raise ValueError(f"batch_size {config.batch_size} must be divisible by the number of ranks {world}")
-    mngr, resuming = ck.initialize_checkpoint_dir(config.checkpoint_dir, keep_period=config.keep_period,
-                                                  overwrite=config.overwrite and rank == 0, resume=config.resume)
+    # rank 0 alone looks at / wipes / creates the directory and decides whether this is a resume; everyone else waits
+    # and takes its verdict (each rank deciding for itself races: a late rank would see the directory rank 0 just made)
+    if rank == 0:
+        try:
+            mngr, resuming = ck.initialize_checkpoint_dir(config.checkpoint_dir, keep_period=config.keep_period,
+                                                          overwrite=config.overwrite, resume=config.resume)
+            verdict = [resuming, None]
+        except Exception as e:   # noqa: BLE001 - re-raised on every rank below
+            verdict = [False, f"{type(e).__name__}: {e}"]
+    else:
+        verdict = [False, None]
     if world > 1:
-        dist.barrier()
-    state = init_train_state(config, device=device, world_size=world, rank=rank, use_fsdp=world > 1)
+        dist.broadcast_object_list(verdict, src=0)
+    if verdict[1] is not None:
+        raise RuntimeError(f"checkpoint directory initialisation failed on rank 0: {verdict[1]}")
+    resuming = bool(verdict[0])
+    if rank != 0:
+        mngr = ck.CheckpointManager(pathlib.Path(config.checkpoint_dir), keep_period=config.keep_period)
+    state = init_train_state(config, device=device, world_size=world, rank=rank, use_fsdp=world > 1, resume=resuming)
     if data_loader is None:
         data_loader = SyntheticDataLoader(config.model, config.batch_size // world, device, seed=config.seed, rank=rank, world_size=world)
     if resuming:
@@ -189,7 +248,7 @@ def main(config: TrainConfig, *, data_loader=None, device: str | None = None, lo
                 t = torch.tensor([mean[k] for k in keys], device=device)
                 dist.all_reduce(t)
                 mean = {k: float(v) / world for k, v in zip(keys, t)}
-            mean["param_norm"] = float(runner.param_norm(state)) if world == 1 else float("nan")
+            mean["param_norm"] = float(runner.param_norm(state))
             dt = _time.perf_counter() - t_last
             if rank == 0:
                 log(f"step {step + 1}: " + ", ".join(f"{k}={v:.4f}" for k, v in mean.items()) +

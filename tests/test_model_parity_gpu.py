@@ -29,7 +29,7 @@ def test_loss_activations_and_grads(hip, B, ragged, stop):
     _check_loss_activations_and_grads(debug_model_cfg(stop_action_to_vlm_grad=stop), B, ragged)
 
 
-def _full_width_cfg(monkeypatch):
+def _full_width_cfg(monkeypatch, **kw):
     """LAP-3B WIDTHS (Gemma-2B 2048 / 16384, expert 1024 / 4096, SigLIP So400m 1152 / 4304, head sizes 256 and 72, 224 x 224
     images, 48-token prompt, 50-step chunk, action_dim 32) with 2 layers per tower and a 16k-word vocabulary, so that the
     oracle finishes in seconds."""
@@ -42,9 +42,10 @@ def _full_width_cfg(monkeypatch):
     monkeypatch.setitem(O.GEMMA, "gemma_2b_x2", O.GemmaCfg(2048, 2, 16384, 8, 1, 256))
     monkeypatch.setitem(O.GEMMA, "gemma_300m_x2", O.GemmaCfg(1024, 2, 4096, 8, 1, 256))
     monkeypatch.setitem(O.SIGLIP, "So400m/14_x2", O.SiglipCfg(1152, 2, 4304, 16))
-    return LAPConfig(paligemma_variant="gemma_2b_x2", action_expert_variant="gemma_300m_x2", siglip_variant="So400m/14_x2",
-                     image_size=224, vocab_size=16384, action_dim=32, action_horizon=50, max_token_len=48,
-                     language_loss_weight=0.4, enable_image_augmentation=False, enable_action_training=True)
+    base = dict(paligemma_variant="gemma_2b_x2", action_expert_variant="gemma_300m_x2", siglip_variant="So400m/14_x2",
+                image_size=224, vocab_size=16384, action_dim=32, action_horizon=50, max_token_len=48,
+                language_loss_weight=0.4, enable_image_augmentation=False, enable_action_training=True)
+    return LAPConfig(**(base | kw))
 
 
 def test_full_width_two_layer_slice_matches_oracle(hip, monkeypatch):
@@ -52,6 +53,21 @@ def test_full_width_two_layer_slice_matches_oracle(hip, monkeypatch):
     never reaches (256x256 tiles with staged epilogue and tail split, LDS-DMA attention for both head sizes, the hi/lo f32
     stem, vocabulary-chunked cross entropy at width 2048)."""
     _check_loss_activations_and_grads(_full_width_cfg(monkeypatch), B=2, ragged=True)
+
+
+@pytest.mark.parametrize("name,kw", [
+    # training/config.py:752-785 lap_libero: P = 180, S = 10, action_dim 7, language weight 0.4, no stop-grad
+    ("lap_libero", dict(max_token_len=180, action_horizon=10, action_dim=7, language_loss_weight=0.4, stop_action_to_vlm_grad=False)),
+    # training/config.py:608-619 lap: P = 180, S = 16, action_dim 7, language weight 1.0, stop_action_to_vlm_grad=True
+    ("lap", dict(max_token_len=180, action_horizon=16, action_dim=7, language_loss_weight=1.0, stop_action_to_vlm_grad=True)),
+    # BASELINE.json synthetic shapes with the benchmark's action_dim 7 (bench.py / lap_bench)
+    ("lap_bench", dict(max_token_len=48, action_horizon=50, action_dim=7, language_loss_weight=0.4)),
+])
+def test_full_width_reference_config_shapes_match_oracle(hip, monkeypatch, name, kw):
+    """The shapes of the reference's own TrainConfigs (parity at both prompt budgets) at the LAP-3B widths:
+    692-token joint sequences (2 x 256 image tokens + 180 prompt + S), the stop-gradient split of the `lap` config at
+    full width, action_dim 7 (ragged K = 7 f32 action projections)."""
+    _check_loss_activations_and_grads(_full_width_cfg(monkeypatch, **kw), B=2, ragged=True)
 
 
 def test_full_width_sample_actions_matches_oracle(hip, monkeypatch):
@@ -107,6 +123,7 @@ def _check_loss_activations_and_grads(cfg, B, ragged):
     err1, base1 = rel(x1, col32[f"llm/layer{last:02d}/x1"]), rel(col16[f"llm/layer{last:02d}/x1"], col32[f"llm/layer{last:02d}/x1"])
     assert err1 < max(3 * base1, 1e-2), (err1, base1)
     assert rel(col["v_t"], m32["v_t"]) < 2e-2
+    _per_layer_sweep(cfg, oc, col, col32, col16, B, pm)
     # ---- every parameter gradient, mapped back to the reference's tree layout
     from lap_amd.params import engine_to_reference
 
@@ -121,6 +138,128 @@ def _check_loss_activations_and_grads(cfg, B, ragged):
         # bf16 backward: 5e-2 relative L2 per tensor; tiny-norm tensors compared absolutely
         assert r < 5e-2 or (gref[k] - g32).abs().max() < 1e-4, (k, r)
     assert len(worst) == len(P)
+
+
+# Per-layer bounds (relative L2 over valid positions), stated once:
+#   * against the f32 oracle: within 3x of the bf16-emulating oracle's own distance to it (absolute floor 1e-2);
+#   * against the bf16-emulating oracle (same rounding points as the reference's dtype flow, different f32 summation
+#     order): LAYER_BOUND_BF16.  One bf16 rounding is 2^-9 = 2e-3 relative per element; two implementations that round
+#     the same real number agree except where f32 summation noise straddles a rounding boundary, and every such flip is
+#     carried (and amplified by the residual stream) through the layers above it.
+LAYER_BOUND_BF16 = 6e-3
+
+
+def _per_layer_sweep(cfg, oc, col, col32, col16, B, pm, bound16=LAYER_BOUND_BF16, report=None):
+    """EVERY collected activation (SigLIP stem / blocks / output of the first image key, both streams of every joint
+    Gemma layer) against both oracle modes."""
+    T = (cfg.image_size // oc.img.patch) ** 2
+    S = cfg.action_horizon
+    Pn = pm.shape[1]
+    im = pm[:, :T]          # first image key's validity per sample (oracle collects SigLIP for that key only)
+    keys = ["img/stem"] + [f"img/block{l:02d}" for l in range(oc.img.depth)] + ["img/out"]
+    keys += [f"llm/layer{l:02d}/x{i}" for l in range(oc.vlm.depth) for i in (0, 1)]
+    worst16 = worst32 = 0.0
+    for k in keys:
+        e = col[k].float().cpu()
+        if k.startswith("img/"):
+            e = e.view(-1, T, e.shape[-1])[:B]      # engine runs all image keys as one batch, key-major
+            a32, a16, e = col32[k], col16[k], e
+            # SigLIP has no mask: every image is encoded (an invalid image only loses its keys in the joint attention)
+        elif k.endswith("x0"):
+            e = e.view(B, Pn, -1)[pm]
+            a32, a16 = col32[k][pm], col16[k][pm]
+        else:
+            e = e.view(B, S, -1)
+            a32, a16 = col32[k], col16[k]
+        err32, base, err16 = rel(e, a32), rel(a16, a32), rel(e, a16)
+        if report is not None:
+            report.append((k, err32, base, err16))
+        assert err32 < max(3 * base, 1e-2), (k, err32, base)
+        assert err16 < bound16, (k, err16, base)
+        worst16, worst32 = max(worst16, err16), max(worst32, err32)
+    return worst16, worst32
+
+
+def test_full_depth_lap3b_forward_and_sampler_match_oracle(hip):
+    """The real LAP-3B: SigLIP So400m/14 (27 blocks) + Gemma-2B / Gemma-300M (18 joint layers), 257,152-word vocabulary,
+    action_dim 7, BASELINE.json shapes (2 x 224 x 224 images, 48-token prompt, 50-step chunk), batch 1, random-init
+    weights in the reference's tree layout.  Forward loss with EVERY layer's activations and the batch-1 sampler
+    (prefill + 10 denoise steps) against both oracle modes.  CPU oracle time: a few minutes."""
+    import time as _t
+
+    from lap_amd.config import get_config
+
+    cfg = get_config("lap_bench").model
+    oc = oracle_cfg(cfg)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(32, nthr))    # torch-CPU matmuls stop scaling (and get slower) far beyond that
+    try:
+        t0 = _t.perf_counter()
+        P = O.init_params(oc, seed=21)
+        obs, actions, noise, time = make_inputs(cfg, B=1, ragged=True)
+        col32, col16 = {}, {}
+        with torch.no_grad():
+            loss32, m32 = O.compute_loss(P, oc, obs, actions, noise, time, collect=col32)
+            oc16 = dataclasses.replace(oc, emulate_bf16=True)
+            loss16, _ = O.compute_loss(P, oc16, obs, actions, noise, time, collect=col16)
+            so = {k: v for k, v in obs.items() if k != "tokenized_langact_mask"}
+            ref = O.sample_actions(P, oc, so, noise, num_steps=10)
+            ref16 = O.sample_actions(P, oc16, so, noise, num_steps=10)
+        t_oracle = _t.perf_counter() - t0
+    finally:
+        torch.set_num_threads(nthr)
+    from lap_amd.model import LAP
+
+    model = LAP(cfg, params=P, device=DEV, with_grads=False)
+    del P
+    col = {}
+    loss, _ = model.compute_loss(0, to_observation(obs, DEV), actions.to(DEV), noise=noise.to(DEV), time=time.to(DEV), collect=col)
+    torch.cuda.synchronize()
+    ref_noise = abs(loss16.item() - loss32.item()) / abs(loss32.item())
+    assert abs(loss.item() - loss32.item()) / abs(loss32.item()) < max(3 * ref_noise, 5e-3), (loss.item(), loss32.item(), loss16.item())
+    pm = torch.cat([obs["image_masks"][k][:, None].expand(1, model.n_img_tok) for k in cfg.image_keys] + [obs["tokenized_prompt_mask"]], 1)
+    report = []
+    w16, w32 = _per_layer_sweep(cfg, oc, col, col32, col16, 1, pm, bound16=FULL_DEPTH_BOUND_BF16, report=report)
+    assert rel(col["per_sample_lang"], m32["per_sample_lang"]) < 2e-2 and rel(col["per_sample_action"], m32["per_sample_action"]) < 2e-2
+    o = to_observation(so | {"tokenized_langact_mask": None}, DEV)
+    out = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV))
+    assert torch.equal(out, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused=False))
+    err, base = rel(out, ref), rel(ref16, ref)
+    print(f"full depth: oracle {t_oracle:.0f} s; loss {loss.item():.5f} / f32 {loss32.item():.5f} / bf16 {loss16.item():.5f}; "
+          f"worst layer vs bf16 oracle {w16:.2e}, vs f32 {w32:.2e}; sampler {err:.2e} (bf16 oracle {base:.2e})")
+    for k, e32, b, e16 in report[::6]:
+        print(f"  {k:22s} engine-f32 {e32:.2e}  bf16oracle-f32 {b:.2e}  engine-bf16oracle {e16:.2e}")
+    assert out.shape == (1, 50, 7) and err < max(3 * base, 1e-2), (err, base)
+
+
+FULL_DEPTH_BOUND_BF16 = 1.2e-2   # 18 / 27 layers of carried rounding flips (see LAYER_BOUND_BF16)
+
+
+def test_graphed_sampler_replay_equals_eager_and_oracle(hip):
+    """BASELINE config 4: the hipGraph-captured batch-1 sampler (serve.GraphedSampler).  Capture once, replay for two
+    DIFFERENT requests: every replay must equal the eager sampler bit for bit (same kernels, same order) and agree
+    with the oracle; a second replay of the first request must reproduce the first result (no state leaks between replays)."""
+    from lap_amd.serve import GraphedSampler
+
+    cfg = debug_model_cfg()
+    oc = oracle_cfg(cfg)
+    P = O.init_params(oc, seed=17)
+    model = _engine(cfg, P)
+    sampler = GraphedSampler(model, 1, 10).capture()
+    outs = []
+    for seed in (1, 2, 1):
+        obs, _, noise, _ = make_inputs(cfg, B=1, ragged=False, seed=seed)
+        so = {k: v for k, v in obs.items() if k != "tokenized_langact_mask"}
+        o = to_observation(so | {"tokenized_langact_mask": None}, DEV)
+        got = sampler(o, noise.to(DEV)).clone()
+        eager = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV))
+        assert torch.equal(got, eager), seed
+        ref = O.sample_actions(P, oc, so, noise, num_steps=10)
+        ref16 = O.sample_actions(P, dataclasses.replace(oc, emulate_bf16=True), so, noise, num_steps=10)
+        err, base = rel(got, ref), rel(ref16, ref)
+        assert err < max(3 * base, 1e-2), (seed, err, base)
+        outs.append(got)
+    assert torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
 
 
 def test_sample_actions_matches_oracle(hip):

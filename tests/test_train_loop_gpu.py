@@ -102,3 +102,48 @@ def test_train_step_with_image_augmentation(hip):
     l3, _ = model.loss_and_grad(8, o, actions.cuda(), noise=noise.cuda(), time=time.cuda(), train=True)
     l0, _ = model.compute_loss(7, o, actions.cuda(), noise=noise.cuda(), time=time.cuda(), train=False)
     assert torch.isfinite(l1) and float(l1) == float(l2) and float(l1) != float(l3) and float(l1) != float(l0)
+
+
+def test_frozen_vlm_trains_only_the_action_expert(hip):
+    """openpi freeze_filter semantics (scripts/train.py:225-240,358-363) with LAPConfig.get_vlm_freeze_filter: frozen
+    parameters keep their (bf16-rounded) values and stay out of the gradient norm; trainable ones move exactly as in an
+    unfrozen run fed the same gradients; the prefix stream's backward is skipped."""
+    import dataclasses
+
+    from lap_amd.config import get_config
+    from lap_amd.train import TrainingStepRunner, init_train_state
+    from oracle import lap_oracle as O
+    from tests.common import make_inputs, oracle_cfg, rel, to_observation
+
+    tc = get_config("debug")
+    cfg = tc.model
+    oc = oracle_cfg(cfg)
+    P = O.init_params(oc, seed=5)
+    frz = cfg.get_vlm_freeze_filter()
+    P = {k: (v.to(torch.bfloat16).float() if frz(k) else v) for k, v in P.items()}     # what the frozen store holds
+    obs, actions, noise, time = make_inputs(cfg, B=2, ragged=True)
+    tcf = dataclasses.replace(tc, freeze_filter=frz)
+    state = init_train_state(tcf, params=P, device="cuda")
+    assert state.model._prefix_frozen()
+    runner = TrainingStepRunner(tcf)
+    state, info = runner(0, state, (to_observation(obs, "cuda"), actions.cuda()), 0, noise=noise.cuda(), time=time.cuda())
+    torch.cuda.synchronize()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss32, _ = O.compute_loss(Pg, oc, obs, actions, noise, time)
+    loss32.backward()
+    gn = torch.sqrt(sum((v.grad ** 2).sum() for k, v in Pg.items() if not frz(k)))      # optax.global_norm over the trainable grads
+    assert abs(info["grad_norm"].item() - gn.item()) / gn.item() < 3e-2, (info["grad_norm"].item(), gn.item())
+    assert abs(info["loss"].item() - loss32.item()) / abs(loss32.item()) < 1e-2
+    new = state.model.ps.to_reference_tree("master")
+    moved = 0
+    for k, v in P.items():
+        if frz(k):
+            assert torch.equal(new[k], v), k
+        else:
+            moved += int(not torch.equal(new[k], v))
+    assert moved >= 20
+    cs = O.clip_scale(gn.item(), tc.optimizer.clip_gradient_norm)
+    for k in ("PaliGemma/llm/layers/mlp_1/linear", "action_out_proj/kernel", "PaliGemma/llm/layers/pre_ffw_norm_1/Dense_0/kernel"):
+        p1, _, _ = O.adamw_step(P[k], Pg[k].grad, torch.zeros_like(P[k]), torch.zeros_like(P[k]), 1, tc.lr_schedule(0), tc.optimizer.b1,
+                                tc.optimizer.b2, tc.optimizer.eps, tc.optimizer.weight_decay, cs)
+        assert rel(new[k] - P[k], p1 - P[k]) < 0.15, k
