@@ -210,6 +210,38 @@ int lap_attention_bwd(const lap_attn_bwd_args* a, void* stream);
    rounding of the probabilities. */
 int lap_attention_set_variant(int variant);
 
+/* ---------------------------------------- skinny-M fused projections (batch-1 denoise step) -- */
+/* One launch per projection of a denoise-step layer (lap.py:634-667 -> gemma.py:336-387, action-expert stream only,
+ * M = B x action_horizon rows, 64 per block tile): the 8 waves of a block split K and reduce through LDS in wave order
+ * (no cross-block partial slabs, deterministic), weights are streamed once, and the neighbouring ops run in the
+ * prologue / epilogue.  Shapes: D = 1024 (Gemma-300M width), HD = 256, K in {1024, 2048, 4096}; other shapes are
+ * rejected with LAP_ERR_ARG and the caller uses lap_gemm_bf16_ex(LAP_GEMM_PARTIALS) + lap_fused_reduce_* instead.
+ *
+ * lap_serve_qkv_rope: h = adaRMS(x; mod) (gemma.py:113-131; mod = scale|shift|gate bf16 [.., 3D], row stride mod_ld,
+ *   0 = one row for all samples) -> qkv = h @ wqkv^T (wqkv [(NH+2)*HD][D], gemma.py:188-202) -> RoPE with the hoisted
+ *   sin / cos table + q scale + head split (gemma.py:215-218,548-564) -> q [M][NH*HD], k [M][HD], v [M][HD]. */
+int lap_serve_qkv_rope(const void* x, const void* mod, int mod_ld, int rows_per_sample, const void* wqkv,
+                       const float* rope_table, void* q, void* k, void* v, int M, int D, int NH, int HD, float q_scale,
+                       float eps, void* stream);
+/* lap_serve_gate_up: h = adaRMS(x; mod) -> [gate | up] = h @ wgu^T (wgu [2H][D]) -> act = bf16(gelu(gate)) * up
+ *   (gemma.py:303-312) -> act [M][H]. */
+int lap_serve_gate_up(const void* x, const void* mod, int mod_ld, int rows_per_sample, const void* wgu, void* act, int M,
+                      int D, int H, float eps, void* stream);
+/* lap_serve_proj_residual: out = x + bf16((a @ w^T) * gate[sample]) (attention out-projection / FFN down-projection with
+ *   the gated residual of gemma.py:577-583; gate NULL: plain add).  a [M][K], w [N][K], x / out [M][N]. */
+int lap_serve_proj_residual(const void* a, const void* w, const void* x, const void* gate, int gate_ld, int rows_per_sample,
+                            void* out, int M, int N, int K, void* stream);
+/* Head and tail of one Euler step (lap.py:655-672): tokens = bf16(x_t @ w_in^T + b_in) (action_in_proj, f32 nnx.Linear,
+ *   lap.py:52; w_in [D][action_dim]);  and  v_t = adaRMS_final(x; mod) @ w_out^T + b_out (f32, w_out [action_dim][D]),
+ *   x_t += dt * v_t, v_t optionally stored. */
+/* Tuning knob (process-wide, not thread safe): feature tiles per block of lap_serve_proj_residual (1 default, 2). */
+int lap_serve_set_variant(int feature_tiles);
+int lap_serve_embed_actions(const float* x_t, const float* w_in, const float* b_in, void* tokens, int rows, int action_dim,
+                            int D, void* stream);
+int lap_serve_final_euler(const void* x, const void* mod, int mod_ld, int rows_per_sample, const float* w_out,
+                          const float* b_out, float* x_t, float* v_t, int rows, int D, int action_dim, float dt, float eps,
+                          void* stream);
+
 /* ---------------------------------------- fused consumers of GEMM partials (serving) -- */
 /* partials: f32 [ksplit][rows][cols] from lap_gemm_bf16_ex(LAP_GEMM_PARTIALS).  Each kernel sums the slabs, rounds to
  * bf16 like the GEMM would have, and applies the ops that follow the projection in gemma.py:336-387. */

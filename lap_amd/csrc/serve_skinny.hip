@@ -1,0 +1,372 @@
+// Skinny-M fused projections for the batch-1 denoise step (lap.py:634-667 -> gemma.py:336-387 with only the
+// action-expert stream active): one action chunk is 50 tokens = four 16-token MFMA column tiles, every projection is a
+// pure weight stream.  Round 1 ran each projection as a split-K GEMM leaving f32 partial slabs plus a consumer kernel
+// (10 launches of 4-12 us per layer); here ONE launch does the whole projection and its neighbours:
+//
+//   prologue (qkv, gate|up)  adaptive RMSNorm of the block input, recomputed by every block from the full rows it
+//                            needs anyway as its operand (gemma.py:113-131): var over the row in f32, x * rsqrt(var+eps)
+//                            * bf16(1 + scale) + shift, rounded to bf16;
+//   main                     out^T[16 FT features, 16 tokens] = W[16 FT, K] . x^T[K, 16]: the 8 waves of a block split K
+//                            (no cross-block reduction, so no partial slabs, no fences, deterministic), operands straight
+//                            from global memory to MFMA fragments (weights are read exactly once per launch; x is
+//                            L2-resident), partial tiles reduced across the waves through LDS in wave order;
+//   epilogue                 qkv: RoPE + q-scale + head split (gemma.py:188-218,548-564) — a block owns 8 frequencies of one
+//                            head and BOTH halves (d, d + HD/2) of each rotation pair;
+//                            gate|up: GeGLU (gemma.py:303-312) — a block owns 8 gate columns and the same 8 up columns;
+//                            out / down: gated residual x + bf16(y * gate) (gemma.py:577-583).
+//
+// Rounding points are the reference's (bf16 GEMM outputs, bf16 norm outputs, f32 statistics); the K summation order differs
+// from the generic GEMM path (8 in-block slices instead of split-K slabs), so the two serving paths agree to bf16
+// rounding noise, not bit for bit (tests/test_model_parity_gpu.py states the bound).
+#include "common.hpp"
+#include "../../include/lap_hip.h"
+
+namespace {
+
+constexpr int SK_WAVES = 8;
+constexpr int SK_TOK = 16;      // tokens per block (one MFMA column tile)
+
+enum { EPI_ROPE = 1, EPI_GEGLU = 2, EPI_RESID = 3 };
+
+struct SkinnyP {
+  const bf16* x;        // [M][ldx] block input (K columns used)
+  const bf16* W;        // [N][K] weights, K contiguous
+  int M, N, K, ldx;
+  // prologue
+  const bf16* mod;      // scale | shift | gate, [.., 3K] per sample (row stride mod_ld; 0 = one row for all samples)
+  int mod_ld, rps;      // rows per sample
+  float eps;
+  // epilogues
+  bf16 *o0, *o1, *o2;   // ROPE: q [M][NH*HD], k [M][HD], v [M][HD];  GEGLU: act [M][H];  RESID: out [M][N]
+  const bf16* resid;    // RESID: x [M][N]
+  const bf16* gate;     // RESID: gate [.., N] per sample (row stride gate_ld; NULL = plain add)
+  int gate_ld;
+  const float* rope;    // ROPE: sin / cos f32 [M][HD/2][2] (lap_rope_table)
+  int NH, HD;
+  float q_scale;
+};
+
+__device__ __forceinline__ float sum4groups(float v) {   // over lanes {i, i+16, i+32, i+48}
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+__device__ __forceinline__ bf16x8 ldg8(const __amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// Block = (FT x 16 output features, TT x 16 tokens): grid.x = feature groups, grid.y = token groups.  Measured on MI355X
+// (tools/bench_skinny.py): a block's time is ~2.4 us + (bytes it loads) / ~35 GB/s — the per-CU vector-memory path, not HBM
+// latency (L2-warm weights are only 0.6 us faster) — so the shape of a block is chosen to minimise (TT + FT) * 16 * K * 2
+// bytes per block at one round of <= 256 blocks: qkv 32 x 32, gate|up 32 tokens x 64 features, out / down 16 x 16.  The
+// token groups of a chunk re-read the same weight rows; with grid.x a multiple of 8 they share an XCD (block id % 8), so
+// the repeats are L2 hits and HBM sees every weight byte once.
+template <int EPI, bool NORM, int KS, int FT, int TT>   // KS: 32-deep k-steps per wave (K = KS * 32 * SK_WAVES)
+__global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyP p) {
+  __shared__ __attribute__((aligned(16))) float part[SK_WAVES][FT * TT][64][4];   // per-wave partial output tiles
+  __shared__ float red[SK_WAVES][TT][SK_TOK];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int k0 = w * (KS * 32) + g * 8;
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((long long)p.N * p.K * 2), 0x00020000);
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)(((long long)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
+  // ---- the weight stream: which weight row feeds operand row i of feature tile f (sub-block sb = blockIdx.x * FT + f)
+  bf16x8 wf[FT][KS];
+#pragma unroll
+  for (int f = 0; f < FT; ++f) {
+    const int sb = blockIdx.x * FT + f;
+    int wrow;
+    if (EPI == EPI_ROPE) {
+      const int bph = p.HD / 16, h = sb / bph, j = sb % bph;
+      wrow = h * p.HD + (i < 8 ? j * 8 + i : p.HD / 2 + j * 8 + (i - 8));
+    } else if (EPI == EPI_GEGLU) {
+      wrow = i < 8 ? sb * 8 + i : p.N / 2 + sb * 8 + (i - 8);
+    } else {
+      wrow = sb * 16 + i;
+    }
+    const unsigned woff = (unsigned)(((long long)wrow * p.K + k0) * 2);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wf[f][s] = ldg8(rsW, woff + s * 64);
+  }
+  bf16x8 xf[TT][KS];
+  bf16x8 sc[NORM ? TT : 1][NORM ? KS : 1], sh[NORM ? TT : 1][NORM ? KS : 1];
+#pragma unroll
+  for (int t = 0; t < TT; ++t) {
+    const int r = (blockIdx.y * TT + t) * SK_TOK + i;     // this lane's token row of tile t (MFMA column i)
+    const unsigned xoff = r < p.M ? (unsigned)(((long long)r * p.ldx + k0) * 2) : 0x80000000u;   // rows past M read as zeros
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[t][s] = ldg8(rsX, xoff + s * 64);
+    if (NORM) {
+      const bf16* mrow = p.mod + (long long)((r < p.M ? r : 0) / p.rps) * p.mod_ld + k0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        sc[t][s] = *reinterpret_cast<const bf16x8*>(mrow + s * 32);
+        sh[t][s] = *reinterpret_cast<const bf16x8*>(mrow + p.K + s * 32);
+      }
+    }
+  }
+  // every load of the block is in flight before anything waits: left alone, hipcc sinks each load next to its use and
+  // turns the weight stream into a chain of dependent round trips
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc[FT][TT];
+#pragma unroll
+  for (int f = 0; f < FT; ++f)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (NORM) {
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      float ss = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float v = (float)xf[t][s][e]; ss += v * v; }
+      ss = sum4groups(ss);
+      if (g == 0) red[w][t][i] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      float tot = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < SK_WAVES; ++ww) tot += red[ww][t][i];
+      const float rstd = 1.0f / sqrtf(tot / (float)p.K + p.eps);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        bf16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = f2bf((float)xf[t][s][e] * rstd * round_bf16(1.0f + (float)sc[t][s][e]) + (float)sh[t][s][e]);
+        xf[t][s] = h;
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+      for (int t = 0; t < TT; ++t) acc[f][t] = mfma16(wf[f][s], xf[t][s], acc[f][t]);
+  // ---- cross-wave reduction (wave order): lane (i, g) of tile (f, t) holds features 4g .. 4g+3 of token i
+#pragma unroll
+  for (int f = 0; f < FT; ++f)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) *reinterpret_cast<f32x4*>(&part[w][f * TT + t][lane][0]) = acc[f][t];
+  __syncthreads();
+  if (w >= FT * TT) return;          // wave (f, t) finishes output tile (f, t)
+  const int f = w / TT, t = w % TT, sb = blockIdx.x * FT + f;
+  const int r = (blockIdx.y * TT + t) * SK_TOK + i;
+  f32x4 y = *reinterpret_cast<const f32x4*>(&part[0][w][lane][0]);
+#pragma unroll
+  for (int ww = 1; ww < SK_WAVES; ++ww) y += *reinterpret_cast<const f32x4*>(&part[ww][w][lane][0]);
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = round_bf16(y[e]);      // the projection's bf16 output
+  // partner lane (g ^ 2) holds the other half of each pair (rotation partner d + HD/2, or the up column of a gate column)
+  float pv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) pv[e] = __shfl_xor(v[e], 32, 64);
+  if (r >= p.M) return;
+  if (EPI == EPI_RESID) {
+    const int c = sb * 16 + 4 * g;
+    const bf16x4 xr = *reinterpret_cast<const bf16x4*>(p.resid + (long long)r * p.N + c);
+    bf16x4 o;
+    if (p.gate) {
+      const bf16x4 gt = *reinterpret_cast<const bf16x4*>(p.gate + (long long)(r / p.rps) * p.gate_ld + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf((float)xr[e] + round_bf16(v[e] * (float)gt[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf((float)xr[e] + v[e]);
+    }
+    *reinterpret_cast<bf16x4*>(p.o0 + (long long)r * p.N + c) = o;
+  } else if (EPI == EPI_GEGLU) {
+    if (g >= 2) return;        // lanes g = 0, 1 hold gate columns 4g .. 4g+3; their partners the matching up columns
+    const int H = p.N / 2, c = sb * 8 + 4 * g;
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(round_bf16(gelu_tanh_f(v[e])) * pv[e]);
+    *reinterpret_cast<bf16x4*>(p.o0 + (long long)r * H + c) = o;
+  } else {   // EPI_ROPE
+    const int HD = p.HD, half = HD / 2, bph = HD / 16, h = sb / bph, j = sb % bph;
+    const int f0 = j * 8 + 4 * (g & 1);             // first of this lane's 4 frequencies
+    bf16x4 o;
+    if (h <= p.NH) {                                 // q heads and the k head rotate
+      const float* tb = p.rope + ((long long)r * half + f0) * 2;
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(tb), t1 = *reinterpret_cast<const f32x4*>(tb + 4);
+      const float sn[4] = {t0[0], t0[2], t1[0], t1[2]}, cs[4] = {t0[1], t0[3], t1[1], t1[3]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x1 = g < 2 ? v[e] : pv[e], x2 = g < 2 ? pv[e] : v[e];
+        float r1, r2;
+        rope_rotate(x1, x2, sn[e], cs[e], r1, r2);
+        float rr = round_bf16(g < 2 ? r1 : r2);
+        if (h < p.NH) rr *= p.q_scale;
+        o[e] = f2bf(rr);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+    }
+    const int d = (g < 2 ? 0 : half) + f0;
+    bf16* dst = h < p.NH ? p.o0 + (long long)r * p.NH * HD + h * HD : (h == p.NH ? p.o1 + (long long)r * HD : p.o2 + (long long)r * HD);
+    *reinterpret_cast<bf16x4*>(dst + d) = o;
+  }
+}
+
+template <int EPI, bool NORM, int FT, int TT>
+int launch_skinny(const SkinnyP& p, int n_sub, hipStream_t s) {
+  if (n_sub % FT) return LAP_ERR_ARG;
+  const dim3 grid(n_sub / FT, (p.M + SK_TOK * TT - 1) / (SK_TOK * TT)), block(SK_WAVES * 64);
+  if constexpr (NORM) {   // the prologue keeps the whole K slice of a wave in registers: K = 1024 only
+    if (p.K != 32 * SK_WAVES * 4) return LAP_ERR_ARG;
+    hipLaunchKernelGGL((skinny_kernel<EPI, true, 4, FT, TT>), grid, block, 0, s, p);
+  } else {
+    switch (p.K / (32 * SK_WAVES)) {
+      case 4: hipLaunchKernelGGL((skinny_kernel<EPI, false, 4, FT, TT>), grid, block, 0, s, p); break;
+      case 8: hipLaunchKernelGGL((skinny_kernel<EPI, false, 8, FT, TT>), grid, block, 0, s, p); break;
+      case 16: hipLaunchKernelGGL((skinny_kernel<EPI, false, 16, FT, TT>), grid, block, 0, s, p); break;
+      default: return LAP_ERR_ARG;
+    }
+  }
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+bool k_ok(int K) { return K == 1024 || K == 2048 || K == 4096; }
+
+// ---------------------------------------------------------------- per-step head / tail of the denoise loop
+// tokens = bf16(x_t @ W_in^T + b_in)   (action_in_proj, nnx.Linear f32, lap.py:52; cast to bf16 at gemma.py:494)
+__global__ __launch_bounds__(256) void embed_actions_kernel(const float* __restrict__ xt, const float* __restrict__ w, const float* __restrict__ b,
+                                                            bf16* __restrict__ out, int rows, int ad, int D) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)rows * D) return;
+  const int row = (int)(gid / D), c = (int)(gid % D);
+  float a = 0.f;
+  for (int k = 0; k < ad; ++k) a += xt[row * ad + k] * w[c * ad + k];
+  out[gid] = f2bf(a + b[c]);
+}
+
+// final adaptive RMSNorm (final_norm_1, gemma.py:525-527) -> action_out_proj in f32 (lap.py:298-299, 661-667) -> Euler
+// update x_t += dt * v_t (lap.py:669-672).  One wave per row; W_out f32 [ad][D].
+template <int NCH>
+__global__ __launch_bounds__(256) void final_norm_out_euler_kernel(const bf16* __restrict__ x, const bf16* __restrict__ mod, int mod_ld, int rps,
+                                                                   const float* __restrict__ w, const float* __restrict__ b,
+                                                                   float* __restrict__ xt, float* __restrict__ vout, int rows, int D, int ad,
+                                                                   float dt, float eps) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= rows) return;
+  float v[NCH][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int c = (lane + 64 * q) * 8;
+    if (c < D) {
+      const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + (long long)row * D + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[q][e] = (float)t[e]; ss += v[q][e] * v[q][e]; }
+    }
+  }
+  ss = wave_sum(ss);
+  const float r = 1.0f / sqrtf(ss / (float)D + eps);
+  const bf16* mrow = mod + (long long)(row / rps) * mod_ld;
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int c = (lane + 64 * q) * 8;
+    if (c < D) {
+      const bf16x8 sc = *reinterpret_cast<const bf16x8*>(mrow + c), sh = *reinterpret_cast<const bf16x8*>(mrow + D + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[q][e] = round_bf16(v[q][e] * r * round_bf16(1.0f + (float)sc[e]) + (float)sh[e]);
+    }
+  }
+  for (int a = 0; a < ad; ++a) {
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int c = (lane + 64 * q) * 8;
+      if (c < D) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + (long long)a * D + c), w1 = *reinterpret_cast<const f32x4*>(w + (long long)a * D + c + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += v[q][e] * w0[e] + v[q][4 + e] * w1[e];
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float vt = acc + b[a];
+      if (vout) vout[row * ad + a] = vt;
+      xt[row * ad + a] += dt * vt;
+    }
+  }
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+
+extern "C" int lap_serve_qkv_rope(const void* x, const void* mod, int mod_ld, int rows_per_sample, const void* wqkv,
+                                  const float* rope_table, void* q, void* k, void* v, int M, int D, int NH, int HD,
+                                  float q_scale, float eps, void* stream) {
+  if (!x || !mod || !wqkv || !rope_table || !q || !k || !v || M <= 0 || rows_per_sample <= 0 || D != 1024 || HD != 256 || NH <= 0 ||
+      (mod_ld & 7))
+    return LAP_ERR_ARG;
+  SkinnyP p = {};
+  p.x = (const bf16*)x; p.W = (const bf16*)wqkv; p.M = M; p.N = (NH + 2) * HD; p.K = D; p.ldx = D;
+  p.mod = (const bf16*)mod; p.mod_ld = mod_ld; p.rps = rows_per_sample; p.eps = eps;
+  p.o0 = (bf16*)q; p.o1 = (bf16*)k; p.o2 = (bf16*)v; p.rope = rope_table; p.NH = NH; p.HD = HD; p.q_scale = q_scale;
+  return launch_skinny<EPI_ROPE, true, 2, 2>(p, p.N / 16, S_);
+}
+
+extern "C" int lap_serve_gate_up(const void* x, const void* mod, int mod_ld, int rows_per_sample, const void* wgu, void* act,
+                                 int M, int D, int H, float eps, void* stream) {
+  if (!x || !mod || !wgu || !act || M <= 0 || rows_per_sample <= 0 || D != 1024 || H <= 0 || (H & 31) || (mod_ld & 7)) return LAP_ERR_ARG;
+  SkinnyP p = {};
+  p.x = (const bf16*)x; p.W = (const bf16*)wgu; p.M = M; p.N = 2 * H; p.K = D; p.ldx = D;
+  p.mod = (const bf16*)mod; p.mod_ld = mod_ld; p.rps = rows_per_sample; p.eps = eps;
+  p.o0 = (bf16*)act;
+  return launch_skinny<EPI_GEGLU, true, 4, 2>(p, H / 8, S_);
+}
+
+static int g_resid_ft = 1;
+extern "C" int lap_serve_set_variant(int ft) { g_resid_ft = ft; return LAP_OK; }   // tuning knob (tools/bench_skinny.py)
+
+extern "C" int lap_serve_proj_residual(const void* a, const void* w, const void* x, const void* gate, int gate_ld,
+                                       int rows_per_sample, void* out, int M, int N, int K, void* stream) {
+  if (!a || !w || !x || !out || M <= 0 || rows_per_sample <= 0 || N <= 0 || (N & 15) || !k_ok(K) || (gate_ld & 3)) return LAP_ERR_ARG;
+  SkinnyP p = {};
+  p.x = (const bf16*)a; p.W = (const bf16*)w; p.M = M; p.N = N; p.K = K; p.ldx = K;
+  p.rps = rows_per_sample; p.o0 = (bf16*)out; p.resid = (const bf16*)x; p.gate = (const bf16*)gate; p.gate_ld = gate_ld;
+  if (g_resid_ft == 2) return launch_skinny<EPI_RESID, false, 2, 1>(p, N / 16, S_);
+  return launch_skinny<EPI_RESID, false, 1, 1>(p, N / 16, S_);
+}
+
+extern "C" int lap_serve_embed_actions(const float* x_t, const float* w_in, const float* b_in, void* tokens, int rows, int action_dim,
+                                       int D, void* stream) {
+  if (!x_t || !w_in || !b_in || !tokens || rows <= 0 || action_dim <= 0 || D <= 0) return LAP_ERR_ARG;
+  const long long n = (long long)rows * D;
+  hipLaunchKernelGGL(embed_actions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_, x_t, w_in, b_in, (bf16*)tokens, rows, action_dim, D);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_serve_final_euler(const void* x, const void* mod, int mod_ld, int rows_per_sample, const float* w_out,
+                                     const float* b_out, float* x_t, float* v_t, int rows, int D, int action_dim, float dt,
+                                     float eps, void* stream) {
+  if (!x || !mod || !w_out || !b_out || !x_t || rows <= 0 || rows_per_sample <= 0 || D <= 0 || (D & 7) || action_dim <= 0 || (mod_ld & 7))
+    return LAP_ERR_ARG;
+  const int nch = (D / 8 + 63) / 64;
+  const dim3 grid((rows + 3) / 4);
+#define GO(N) hipLaunchKernelGGL(final_norm_out_euler_kernel<N>, grid, dim3(256), 0, S_, (const bf16*)x, (const bf16*)mod, mod_ld, \
+                                 rows_per_sample, w_out, b_out, x_t, v_t, rows, D, action_dim, dt, eps)
+  switch (nch) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 3: GO(3); break;
+    case 4: GO(4); break;
+    default: return LAP_ERR_ARG;
+  }
+#undef GO
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}

@@ -103,6 +103,12 @@ SIGNATURES: dict[str, list] = {
     "lap_fused_reduce_rope_split": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "lap_fused_reduce_geglu": [_vp, _i, _vp, _i, _i, _vp],
     "lap_fused_reduce_residual_norm": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp],
+    "lap_serve_qkv_rope": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp],
+    "lap_serve_gate_up": [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp],
+    "lap_serve_proj_residual": [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "lap_serve_set_variant": [_i],
+    "lap_serve_embed_actions": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "lap_serve_final_euler": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
     "lap_ce_chunk_update": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_ce_chunk_grad": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lap_sumsq_f32": [_vp, _ll, _vp, _vp],
@@ -616,3 +622,52 @@ def fused_reduce_residual_norm(part, ksplit, x, gate, ldg, mod, mod_ld, rows_per
     call("lap_fused_reduce_residual_norm", _p(part), ksplit, _p(x), _p(gate), ldg, _p(mod), mod_ld, _p(xn), _p(h), rows, D,
          rows_per_sample, float(eps))
     return xn, h
+
+
+# ------------------------------------------------ skinny-M fused projections (batch-1 denoise step, csrc/serve_skinny.hip)
+def serve_supported(D, HD, mlp_dim, NH):
+    """Shapes the skinny kernels are built for (the LAP-3B action expert); anything else takes the partials + consumers path."""
+    return D == 1024 and HD == 256 and NH * HD in (1024, 2048, 4096) and mlp_dim in (1024, 2048, 4096)
+
+
+def serve_qkv_rope(x, mod, mod_ld, rps, wqkv, table, NH, HD, q_scale, eps=1e-6):
+    M, D = x.shape
+    q = torch.empty((M, NH * HD), dtype=torch.bfloat16, device=x.device)
+    k = torch.empty((M, HD), dtype=torch.bfloat16, device=x.device)
+    v = torch.empty((M, HD), dtype=torch.bfloat16, device=x.device)
+    call("lap_serve_qkv_rope", _p(x), _p(mod), mod_ld, rps, _p(wqkv), _p(table), _p(q), _p(k), _p(v), M, D, NH, HD, float(q_scale), float(eps))
+    return q, k, v
+
+
+def serve_gate_up(x, mod, mod_ld, rps, wgu, eps=1e-6):
+    M, D = x.shape
+    H = wgu.shape[0] // 2
+    act = torch.empty((M, H), dtype=torch.bfloat16, device=x.device)
+    call("lap_serve_gate_up", _p(x), _p(mod), mod_ld, rps, _p(wgu), _p(act), M, D, H, float(eps))
+    return act
+
+
+def serve_proj_residual(a, w, x, gate, gate_ld, rps):
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    call("lap_serve_proj_residual", _p(a), _p(w), _p(x), _p(gate), gate_ld, rps, _p(out), M, N, K)
+    return out
+
+
+def serve_embed_actions(x_t, w_in, b_in):
+    rows, ad = x_t.shape
+    D = w_in.shape[0]
+    tok = torch.empty((rows, D), dtype=torch.bfloat16, device=x_t.device)
+    call("lap_serve_embed_actions", _p(x_t), _p(w_in), _p(b_in), _p(tok), rows, ad, D)
+    return tok
+
+
+def serve_final_euler(x, mod, mod_ld, rps, w_out, b_out, x_t, dt, v_out=None, eps=1e-6):
+    rows, D = x.shape
+    call("lap_serve_final_euler", _p(x), _p(mod), mod_ld, rps, _p(w_out), _p(b_out), _p(x_t), _p(v_out), rows, D, w_out.shape[0], float(dt), float(eps))
+
+
+def serve_set_variant(feature_tiles: int):
+    """Tuning knob of lap_serve_proj_residual (tools/bench_skinny.py)."""
+    _chk(_fn["lap_serve_set_variant"](int(feature_tiles)), "lap_serve_set_variant")

@@ -116,14 +116,21 @@ class LAP:
                             a_kc=True, b_kc=False)
 
     # ================================================================== SigLIP
-    def _siglip_fwd(self, images: torch.Tensor, save: bool, collect=None):
+    def _siglip_fwd(self, images: torch.Tensor, save: bool, collect=None, x_in=None, blocks=None):
         """images f32 [N,H,W,3] -> tokens bf16 [N*T, Dv].  openpi siglip (missing) restated in
-        siglip_gemma3.py:382-545 minus :432, plus head bias."""
+        siglip_gemma3.py:382-545 minus :432, plus head bias.
+        Test hook (teacher-forced per-block parity): with `x_in` (bf16 [N*T, W]) the stem is skipped, only `blocks` run
+        and the block output is returned instead of the projected tokens."""
         s, T = self.s, self.n_img_tok
-        N = images.shape[0]
         W = s.width
         hd = W // s.num_heads
         ctx = {"blocks": []} if save else None
+        if x_in is not None:
+            x, N = x_in, x_in.shape[0] // T
+            for l in blocks:
+                x = self._siglip_block(l, x, N, T, W, hd, None, False)
+            return x, None
+        N = images.shape[0]
         patches = hip.im2col_patch(images.contiguous(), s.patch)
         # f32 stem (siglip_gemma3.py:398-408) on the MFMA path: x = hi + lo (2 x bf16, 16 mantissa bits), products exact
         # in the f32 accumulator, the lo.lo term (2^-18 relative) dropped
@@ -142,20 +149,7 @@ class LAP:
         if save:
             ctx["patches"] = (p_hi, p_lo)
         for l in range(s.depth):
-            self.comm.wait_unit(f"img{l}")
-            p = f"img/{l}/"
-            y, mean1, rstd1 = hip.layernorm_fwd(x, self.F(p + "ln1_g"), self.F(p + "ln1_b"))
-            qkv = hip.linear_fwd(y, self.W(p + "wqkv"), bias=self.F(p + "bqkv"))
-            (o, _), lse = hip.attention_fwd([qkv[:, :W]], [qkv[:, W:2 * W]], [qkv[:, 2 * W:]], [T], [T], N, s.num_heads, s.num_heads, hd,
-                                            scale=hd ** -0.5, q_rs=(3 * W, 0), kv_rs=(3 * W, 0), need_lse=save)
-            x1 = hip.linear_fwd(o, self.W(p + "wo"), bias=self.F(p + "bo"), residual=x)
-            y2, mean2, rstd2 = hip.layernorm_fwd(x1, self.F(p + "ln2_g"), self.F(p + "ln2_b"))
-            h = hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"))
-            a = hip.gelu_fwd(h)
-            x2 = hip.linear_fwd(a, self.W(p + "w2"), bias=self.F(p + "b2"), residual=x1)
-            if save:
-                ctx["blocks"].append((x, y, mean1, rstd1, qkv, o, lse, x1, y2, mean2, rstd2, h, a))
-            x = x2
+            x = self._siglip_block(l, x, N, T, W, hd, ctx, save)
             if collect is not None:
                 collect[f"img/block{l:02d}"] = x
         self.comm.wait_unit("img_head")
@@ -166,6 +160,24 @@ class LAP:
         if collect is not None:
             collect["img/out"] = tok
         return tok, ctx
+
+    def _siglip_block(self, l, x, N, T, W, hd, ctx, save):
+        """One pre-LN encoder block (siglip_gemma3.py:59-167): x + MHA(LN(x)), then + MLP(LN(.))."""
+        s = self.s
+        self.comm.wait_unit(f"img{l}")
+        p = f"img/{l}/"
+        y, mean1, rstd1 = hip.layernorm_fwd(x, self.F(p + "ln1_g"), self.F(p + "ln1_b"))
+        qkv = hip.linear_fwd(y, self.W(p + "wqkv"), bias=self.F(p + "bqkv"))
+        (o, _), lse = hip.attention_fwd([qkv[:, :W]], [qkv[:, W:2 * W]], [qkv[:, 2 * W:]], [T], [T], N, s.num_heads, s.num_heads, hd,
+                                        scale=hd ** -0.5, q_rs=(3 * W, 0), kv_rs=(3 * W, 0), need_lse=save)
+        x1 = hip.linear_fwd(o, self.W(p + "wo"), bias=self.F(p + "bo"), residual=x)
+        y2, mean2, rstd2 = hip.layernorm_fwd(x1, self.F(p + "ln2_g"), self.F(p + "ln2_b"))
+        h = hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"))
+        a = hip.gelu_fwd(h)
+        x2 = hip.linear_fwd(a, self.W(p + "w2"), bias=self.F(p + "b2"), residual=x1)
+        if save:
+            ctx["blocks"].append((x, y, mean1, rstd1, qkv, o, lse, x1, y2, mean2, rstd2, h, a))
+        return x2
 
     def _siglip_bwd(self, ctx, dtok: torch.Tensor):
         s, T = self.s, self.n_img_tok
@@ -341,7 +353,7 @@ class LAP:
         return mod[:, slot * W3:(slot + 1) * W3]
 
     def _llm_fwd(self, x0, x1, mod, pos, qinfo, kinfo, B, n0, n1, save: bool, kv_cache=None, cache_out=None, collect=None,
-                 mod_shared: bool = False):
+                 mod_shared: bool = False, layers=None):
         """gemma.Module.__call__ layers (gemma.py:336-387,167-290).  x0 [B*n0, Dv] or None, x1 [B*n1, De] or None.
         kv_cache: per-layer (k, v) of the prefix used as key segment 0 when x0 is None (serving).
         Returns final pre-norm activations and the saved context."""
@@ -350,7 +362,7 @@ class LAP:
         Ttot = pos.shape[1]
         ctx = [] if save else None
         mld = 0 if mod_shared else (mod.stride(0) if mod is not None else 0)  # 0: one modulation row for every sample
-        for l in range(v.depth):
+        for l in (range(v.depth) if layers is None else layers):    # `layers`: test hook (teacher-forced per-layer parity)
             self.comm.wait_unit(f"llm{l}")
             p = f"llm/{l}/"
             q = [None, None]; k = [None, None]; vv = [None, None]; h = [None, None]; rstd_a = [None, None]
@@ -482,6 +494,27 @@ class LAP:
             part, ks = hip.linear_partials(act, self.W(p + "wd1"), scratch)
             x, h = hip.fused_reduce_residual_norm(part, ks, xa, slot(2 * l + 1)[:, 2 * We:], 0, slot(2 * l + 2), 0, S)
         return h   # slot 2L is final_norm_1: h == final adaRMS norm of the last layer's output
+
+    def _expert_denoise_skinny(self, x1, mod, qinfo, kinfo, B, Pn, S, cache, rope_tab):
+        """The same 18 layers on the skinny-M fused projections (csrc/serve_skinny.hip): five launches per layer —
+        [adaRMS + qkv + RoPE/split] -> attention -> [out-proj + gated residual] -> [adaRMS + gate|up + GeGLU] ->
+        [down-proj + gated residual] — with no f32 partial slabs in between.  Returns the last layer's residual stream
+        (the final adaRMS norm is part of lap_serve_final_euler)."""
+        v, e = self.v, self.e
+        NH, HD, KV = v.num_heads, v.head_dim, v.num_kv_heads
+        We = e.width
+        slot = lambda j: self._mod_slot(mod, j)
+        x = x1
+        for l in range(v.depth):
+            self.comm.wait_unit(f"llm{l}")
+            p = f"llm/{l}/"
+            q, k, vv = hip.serve_qkv_rope(x, slot(2 * l), 0, S, self.W(p + "wqkv1"), rope_tab, NH, HD, HD ** -0.5)
+            ck, cv = cache[l]
+            o, _ = hip.attention_fwd([None, q], [ck, k], [cv, vv], [0, S], [Pn, S], B, NH, KV, HD, qinfo, kinfo, need_lse=False)
+            xa = hip.serve_proj_residual(o[1], self.W(p + "wo1"), x, slot(2 * l)[:, 2 * We:], 0, S)
+            act = hip.serve_gate_up(xa, slot(2 * l + 1), 0, S, self.W(p + "wgu1"))
+            x = hip.serve_proj_residual(act, self.W(p + "wd1"), xa, slot(2 * l + 1)[:, 2 * We:], 0, S)
+        return x
 
     # ================================================================== training forward (+ backward)
     def _loss_impl(self, rng, observation: CoTObservation, actions: torch.Tensor, *, train: bool, noise=None, time=None,
@@ -617,15 +650,21 @@ class LAP:
 
     # ================================================================== serving
     @torch.no_grad()
-    def sample_actions(self, rng, observation, *, num_steps: int = 10, noise=None, collect=None, fused: bool = True):
+    def sample_actions(self, rng, observation, *, num_steps: int = 10, noise=None, collect=None, fused=True):
         """lap.py:605-675: prefix prefill once -> per-layer K/V kept in HBM -> `num_steps` Euler steps of the action
-        expert attending to [cached prefix | fresh suffix] as two key segments (the reference concatenates, gemma.py:228-230)."""
+        expert attending to [cached prefix | fresh suffix] as two key segments (the reference concatenates, gemma.py:228-230).
+        `fused`: True = the fastest denoise-step kernels the shapes allow ("skinny" fused projections for the LAP-3B action
+        expert, else "partials" = split-K partial slabs + fused consumers); False = the generic layer path (A/B tests)."""
         cfg = self.config
         dev = self.device
         self.comm.wait_unit("small")
         obs = preprocess_observation(observation, train=False, image_keys=cfg.image_keys, image_resolution=cfg.image_resolution)
         B = obs.tokenized_prompt.shape[0]
         S, ad = self.action_horizon, self.action_dim
+        if fused is True:
+            fused = "skinny" if hip.serve_supported(self.e.width, self.v.head_dim, self.e.mlp_dim, self.v.num_heads) else "partials"
+        if fused not in (False, "skinny", "partials"):
+            raise ValueError(f"fused={fused!r}")
         if noise is None:
             noise = torch.randn((B, S, ad), generator=_gen(rng, dev), device=dev, dtype=torch.float32)
         x_t = noise.to(dev, torch.float32).contiguous().clone()
@@ -644,14 +683,23 @@ class LAP:
         mods, _ = self._time_mod(tvec, False)
         # ... and so are the action tokens' positions: one sin / cos table serves the 10 x 18 fused RoPE kernels
         rope_tab = hip.rope_table(pos_all, B, S, pos_all.shape[1], pos_all.shape[1] - S, self.v.head_dim) if fused else None
+        nslot = 2 * self.v.depth
         for step in range(len(times)):
             mod = mods[step:step + 1]
+            if fused == "skinny":
+                x1 = hip.serve_embed_actions(x_t.view(B * S, ad), self.F("act/in_w"), self.F("act/in_b"))
+                xf1 = self._expert_denoise_skinny(x1, mod, qinfo_s, kinfo_all, B, Pn, S, cache, rope_tab)
+                v_t = torch.empty((B * S, ad), dtype=torch.float32, device=dev) if collect is not None else None
+                hip.serve_final_euler(xf1, self._mod_slot(mod, nslot), 0, S, self.F("act/out_w"), self.F("act/out_b"), x_t.view(B * S, ad), dt, v_t)
+                if collect is not None:
+                    collect[f"v_t/{step}"] = v_t.view(B, S, ad)
+                continue
             x1, _ = self._embed_actions(x_t)
-            if fused:
+            if fused == "partials":
                 pre1 = self._expert_denoise_fwd(x1, mod, pos_all, qinfo_s, kinfo_all, B, Pn, S, cache, rope_tab)
             else:  # generic path (same numerics; kept for A/B tests)
                 _, xf1, _ = self._llm_fwd(None, x1, mod, pos_all, qinfo_s, kinfo_all, B, Pn, S, False, kv_cache=cache, mod_shared=True)
-                pre1, _ = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=False, mod_ld=0)
+                pre1, _ = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, nslot), rows_per_sample=S, save_rstd=False, mod_ld=0)
             v_t = self._lin32(hip.cast_bf16_to_f32(pre1), "act/out_w", "act/out_b")
             if collect is not None:
                 collect[f"v_t/{step}"] = v_t.view(B, S, ad).clone()

@@ -216,15 +216,15 @@ def main(config: TrainConfig, *, data_loader=None, device: str | None = None, lo
         try:
             mngr, resuming = ck.initialize_checkpoint_dir(config.checkpoint_dir, keep_period=config.keep_period,
                                                           overwrite=config.overwrite, resume=config.resume)
-            verdict = [resuming, None]
+            verdict = [resuming, None, None]
         except Exception as e:   # noqa: BLE001 - re-raised on every rank below
-            verdict = [False, f"{type(e).__name__}: {e}"]
+            verdict = [False, type(e).__name__, str(e)]
     else:
-        verdict = [False, None]
+        verdict = [False, None, None]
     if world > 1:
         dist.broadcast_object_list(verdict, src=0)
-    if verdict[1] is not None:
-        raise RuntimeError(f"checkpoint directory initialisation failed on rank 0: {verdict[1]}")
+    if verdict[1] is not None:   # the same exception on every rank (FileExistsError keeps its type: callers catch it)
+        raise (FileExistsError if verdict[1] == "FileExistsError" else RuntimeError)(verdict[2])
     resuming = bool(verdict[0])
     if rank != 0:
         mngr = ck.CheckpointManager(pathlib.Path(config.checkpoint_dir), keep_period=config.keep_period)

@@ -292,6 +292,10 @@ def gemma_forward(P, cfg: OracleCfg, embedded, positions, mask, adarms_cond=None
     if adarms_cond is None:
         adarms_cond = [None, None]
     xs = [r(e) if e is not None else None for e in embedded]  # astype(embed_dtype) (:494)
+    if collect is not None:
+        for i, x in enumerate(xs):
+            if x is not None:
+                collect[f"llm/in{i}"] = x
     L = cfg.vlm.depth
     new_cache = []
     nkv = cfg.vlm.num_kv_heads

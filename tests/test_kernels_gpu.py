@@ -670,3 +670,68 @@ def test_augment_images_matches_oracle_and_identity(hip):
     pr[:, 4], pr[:, 5] = float(torch.cos(torch.tensor(0.0873))), float(torch.sin(torch.tensor(0.0873)))
     rot = hip.augment_images(white, pr)
     assert torch.allclose(rot[0, 24:40, 24:40], torch.ones(16, 16, 3, device=DEV), atol=1e-6) and rot[0, 0, 0, 0] < 0.0
+
+
+# ------------------------------------------------------------------ skinny-M fused projections (batch-1 denoise step)
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("M,rps,shared", [(50, 50, True), (50, 50, False), (130, 50, False), (64, 16, True)])
+def test_serve_skinny_projections_match_unfused_ops(hip, M, rps, shared):
+    """lap_serve_qkv_rope / lap_serve_gate_up / lap_serve_proj_residual / lap_serve_embed_actions / lap_serve_final_euler
+    against a torch f32 restatement with the reference's rounding points (bf16 GEMM outputs, bf16 norm output, bf16
+    products), at the LAP-3B action-expert shapes; M = 130 spans three row tiles and three samples with per-sample
+    modulation rows.  Tolerance: a few flipped bf16 roundings (2^-9 each) from the different f32 summation order."""
+    D, NH, HD, H = 1024, 8, 256, 4096
+    nB = (M + rps - 1) // rps
+    x = rnd(M, D, seed=1)
+    mod = rnd(1 if shared else nB, 3 * D, scale=0.3, seed=2)
+    mld = 0 if shared else mod.stride(0)
+    samp = torch.zeros(M, dtype=torch.long, device=DEV) if shared else (torch.arange(M, device=DEV) // rps)
+    sc, sh, gt = (mod[samp, j * D:(j + 1) * D].float() for j in range(3))
+    xf = x.float()
+    h = _bf(xf * torch.rsqrt((xf ** 2).mean(-1, keepdim=True) + 1e-6) * _bf(1 + sc) + sh)
+    # ---- qkv + RoPE + split
+    wqkv = rnd((NH + 2) * HD, D, scale=D ** -0.5, seed=3)
+    pos = (torch.arange(M, device=DEV, dtype=torch.int32) % rps + 37).view(1, M).contiguous()
+    tab = hip.rope_table(pos, 1, M, M, 0, HD)
+    q, k, v = hip.serve_qkv_rope(x, mod, mld, rps, wqkv, tab, NH, HD, HD ** -0.5)
+    qkv = _bf(h @ wqkv.float().t()).view(M, NH + 2, HD)
+    fe = 10000.0 ** ((2.0 / HD) * torch.arange(HD // 2, device=DEV, dtype=torch.float32))
+    rad = pos.view(M, 1, 1).float() / fe
+    sn, cs = torch.sin(rad), torch.cos(rad)
+    x1, x2 = qkv[..., :HD // 2], qkv[..., HD // 2:]
+    rot = _bf(torch.cat([x1 * cs - x2 * sn, x2 * cs + x1 * sn], -1))
+    assert rel_err(q, _bf(rot[:, :NH] * HD ** -0.5).reshape(M, -1)) < 4e-3
+    assert rel_err(k, rot[:, NH]) < 4e-3 and rel_err(v, qkv[:, NH + 1]) < 4e-3
+    # ---- gate|up + GeGLU
+    wgu = rnd(2 * H, D, scale=D ** -0.5, seed=4)
+    act = hip.serve_gate_up(x, mod, mld, rps, wgu)
+    gu = _bf(h @ wgu.float().t())
+    ref_act = _bf(_bf(torch.nn.functional.gelu(gu[:, :H], approximate="tanh")) * gu[:, H:])
+    assert rel_err(act, ref_act) < 5e-3
+    # ---- out / down projections + gated residual, K = 1024 / 2048 / 4096
+    for K in (1024, 2048, 4096):
+        a = rnd(M, K, seed=5 + K)
+        w = rnd(D, K, scale=K ** -0.5, seed=6 + K)
+        gate_view = mod[:, 2 * D:]
+        out = hip.serve_proj_residual(a, w, x, gate_view, mld, rps)
+        ref = _bf(xf + _bf(_bf(a.float() @ w.float().t()) * gt))
+        assert rel_err(out, ref) < 4e-3, K
+        out0 = hip.serve_proj_residual(a, w, x, None, 0, rps)
+        assert rel_err(out0, _bf(xf + _bf(a.float() @ w.float().t()))) < 4e-3, K
+    # ---- head / tail of an Euler step
+    ad = 7
+    xt = rnd(M, ad, dtype=torch.float32, seed=7)
+    w_in, b_in = rnd(D, ad, dtype=torch.float32, scale=ad ** -0.5, seed=8), rnd(D, dtype=torch.float32, scale=0.02, seed=9)
+    tok = hip.serve_embed_actions(xt, w_in, b_in)
+    assert rel_err(tok, _bf(xt @ w_in.t() + b_in)) < 3e-3
+    w_out, b_out = rnd(ad, D, dtype=torch.float32, scale=D ** -0.5, seed=10), rnd(ad, dtype=torch.float32, scale=0.02, seed=11)
+    xt2, vt = xt.clone(), torch.empty(M, ad, device=DEV)
+    hip.serve_final_euler(x, mod, mld, rps, w_out, b_out, xt2, -0.1, vt)
+    ref_v = h @ w_out.t() + b_out
+    assert rel_err(vt, ref_v) < 2e-3 and rel_err(xt2, xt - 0.1 * ref_v) < 1e-3
+    # unsupported shapes are rejected, not mis-computed
+    with pytest.raises(hip.LapHipError):
+        hip.serve_proj_residual(rnd(M, 1536), rnd(D, 1536), x, None, 0, rps)

@@ -7,6 +7,7 @@ distance to the f32 oracle to be within a small factor of the bf16 oracle's own 
 rounding noise is the reference's rounding noise), plus absolute caps stated inline.
 """
 import dataclasses
+import os
 
 import pytest
 import torch
@@ -82,10 +83,13 @@ def test_full_width_sample_actions_matches_oracle(hip, monkeypatch):
     ref16 = O.sample_actions(P, dataclasses.replace(oc, emulate_bf16=True), so, noise, num_steps=10)
     model = _engine(cfg, P)
     o = to_observation(so | {"tokenized_langact_mask": None}, DEV)
-    out = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV))
-    assert torch.equal(out, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused=False))
+    out = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV))                     # skinny fused projections
+    generic = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused=False)
+    assert torch.equal(generic, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused="partials"))
     err, base = rel(out, ref), rel(ref16, ref)
-    assert out.shape == (1, 50, 32) and err < max(3 * base, 1e-2), (err, base)
+    assert out.shape == (1, 50, 32) and err < max(FREE_RUN_RATIO * base, 5e-3), (err, base)
+    assert rel(generic, ref) < max(FREE_RUN_RATIO * base, 5e-3)
+    assert rel(out, generic) < max(FREE_RUN_RATIO * base, 5e-3)    # same rounding points, different K summation order
 
 
 def _check_loss_activations_and_grads(cfg, B, ragged):
@@ -124,6 +128,7 @@ def _check_loss_activations_and_grads(cfg, B, ragged):
     assert err1 < max(3 * base1, 1e-2), (err1, base1)
     assert rel(col["v_t"], m32["v_t"]) < 2e-2
     _per_layer_sweep(cfg, oc, col, col32, col16, B, pm)
+    _teacher_forced_sweep(model, cfg, oc, obs, col, col16, B, pm)
     # ---- every parameter gradient, mapped back to the reference's tree layout
     from lap_amd.params import engine_to_reference
 
@@ -140,31 +145,39 @@ def _check_loss_activations_and_grads(cfg, B, ragged):
     assert len(worst) == len(P)
 
 
-# Per-layer bounds (relative L2 over valid positions), stated once:
-#   * against the f32 oracle: within 3x of the bf16-emulating oracle's own distance to it (absolute floor 1e-2);
-#   * against the bf16-emulating oracle (same rounding points as the reference's dtype flow, different f32 summation
-#     order): LAYER_BOUND_BF16.  One bf16 rounding is 2^-9 = 2e-3 relative per element; two implementations that round
-#     the same real number agree except where f32 summation noise straddles a rounding boundary, and every such flip is
-#     carried (and amplified by the residual stream) through the layers above it.
-LAYER_BOUND_BF16 = 6e-3
+# Per-layer bounds (relative L2 over valid positions), stated once.  Measured on MI355X (round 2, LAP-3B
+# full depth, gpurun_out/r2_par1.log): the bf16-emulating oracle itself sits 1.7e-3 (stem) ... 1.3e-2 (SigLIP block 26)
+# ... 1.8e-2 (Gemma layer 17) from the f32 oracle, the engine 0.85-1.0x of that, and the two bf16 implementations are as
+# far from each other as each is from f32: one bf16 rounding is 2^-9 relative, a flipped rounding is carried and amplified
+# by every layer above it, so two FREE-RUNNING bf16 implementations decorrelate within a few layers.
+#   * free-running, every layer, against the f32 oracle: the engine must not be further from it than 1.5x the bf16 oracle
+#     is (floor 3e-3);  against the bf16 oracle: not further than 1.5x the bf16 oracle's own distance to f32 (same floor);
+#   * TEACHER-FORCED, every layer (the tight per-layer statement): the engine's layer l is fed the bf16 oracle's
+#     layer l-1 output and its result is compared with the bf16 oracle's layer l — only the rounding flips of ONE layer
+#     remain.  Measured: joint Gemma layers 2.8-4.0e-3 (prefix stream) / 0.5-1.2e-3 (action stream), SigLIP blocks
+#     4.3-5.6e-3 (the reference rounds the SigLIP attention logits and probabilities to bf16 [FLAX-RECALL]; the engine keeps
+#     them in f32, i.e. it is closer to the f32 oracle there than the bf16 oracle is).  Bounds: TEACHER_FORCED_BOUND.
+FREE_RUN_RATIO, FREE_RUN_FLOOR = 1.5, 3e-3
+TEACHER_FORCED_BOUND = {"img": 7e-3, "llm": 5e-3}
 
 
-def _per_layer_sweep(cfg, oc, col, col32, col16, B, pm, bound16=LAYER_BOUND_BF16, report=None):
+def _sweep_keys(oc):
+    keys = ["img/stem"] + [f"img/block{l:02d}" for l in range(oc.img.depth)] + ["img/out"]
+    return keys + [f"llm/layer{l:02d}/x{i}" for l in range(oc.vlm.depth) for i in (0, 1)]
+
+
+def _per_layer_sweep(cfg, oc, col, col32, col16, B, pm, report=None):
     """EVERY collected activation (SigLIP stem / blocks / output of the first image key, both streams of every joint
-    Gemma layer) against both oracle modes."""
+    Gemma layer) of the free-running engine against both oracle modes."""
     T = (cfg.image_size // oc.img.patch) ** 2
     S = cfg.action_horizon
     Pn = pm.shape[1]
-    im = pm[:, :T]          # first image key's validity per sample (oracle collects SigLIP for that key only)
-    keys = ["img/stem"] + [f"img/block{l:02d}" for l in range(oc.img.depth)] + ["img/out"]
-    keys += [f"llm/layer{l:02d}/x{i}" for l in range(oc.vlm.depth) for i in (0, 1)]
     worst16 = worst32 = 0.0
-    for k in keys:
+    for k in _sweep_keys(oc):
         e = col[k].float().cpu()
         if k.startswith("img/"):
             e = e.view(-1, T, e.shape[-1])[:B]      # engine runs all image keys as one batch, key-major
-            a32, a16, e = col32[k], col16[k], e
-            # SigLIP has no mask: every image is encoded (an invalid image only loses its keys in the joint attention)
+            a32, a16 = col32[k], col16[k]           # SigLIP has no mask: every image is encoded
         elif k.endswith("x0"):
             e = e.view(B, Pn, -1)[pm]
             a32, a16 = col32[k][pm], col16[k][pm]
@@ -174,10 +187,53 @@ def _per_layer_sweep(cfg, oc, col, col32, col16, B, pm, bound16=LAYER_BOUND_BF16
         err32, base, err16 = rel(e, a32), rel(a16, a32), rel(e, a16)
         if report is not None:
             report.append((k, err32, base, err16))
-        assert err32 < max(3 * base, 1e-2), (k, err32, base)
-        assert err16 < bound16, (k, err16, base)
+        if os.environ.get("LAP_PARITY_REPORT"):       # measurement mode (tools / DESIGN.md tables): print, do not judge
+            print(f"  {k:22s} engine-f32 {err32:.2e}  bf16oracle-f32 {base:.2e}  engine-bf16oracle {err16:.2e}")
+            continue
+        lim = max(FREE_RUN_RATIO * base, FREE_RUN_FLOOR)
+        assert err32 < lim, (k, err32, base)
+        assert err16 < lim, (k, err16, base)
         worst16, worst32 = max(worst16, err16), max(worst32, err32)
     return worst16, worst32
+
+
+def _teacher_forced_sweep(model, cfg, oc, obs, col, col16, B, pm, report=None):
+    """Layer by layer: engine(layer l)(bf16 oracle's input of layer l) vs the bf16 oracle's output of layer l, for every
+    SigLIP block (first image key) and every joint Gemma layer (both streams), at valid positions."""
+    T = (cfg.image_size // oc.img.patch) ** 2
+    S = cfg.action_horizon
+    Pn = pm.shape[1]
+    dev = model.device
+    bf = lambda t: t.to(torch.bfloat16).to(dev).contiguous()
+    worst = 0.0
+
+    def check(k, got, want):
+        nonlocal worst
+        err = rel(got, want)
+        if report is not None:
+            report.append((k, err))
+        if os.environ.get("LAP_PARITY_REPORT"):
+            print(f"  teacher-forced {k:22s} engine-bf16oracle {err:.2e}")
+        else:
+            assert err < TEACHER_FORCED_BOUND[k[:3]], (k, err)
+        worst = max(worst, err)
+
+    prev = col16["img/stem"]
+    for l in range(oc.img.depth):
+        out, _ = model._siglip_fwd(None, False, x_in=bf(prev).view(B * T, -1), blocks=[l])
+        want = col16[f"img/block{l:02d}"]
+        check(f"img/block{l:02d}", out.float().cpu().view(B, T, -1), want)
+        prev = want
+    qinfo, kinfo, pos = model._train_infos(to_observation(obs, dev), S)
+    mod = col["mod"]
+    x0p, x1p = col16["llm/in0"], col16["llm/in1"]
+    for l in range(oc.vlm.depth):
+        x0, x1, _ = model._llm_fwd(bf(x0p).view(B * Pn, -1), bf(x1p).view(B * S, -1), mod, pos, qinfo, kinfo, B, Pn, S, False, layers=[l])
+        w0, w1 = col16[f"llm/layer{l:02d}/x0"], col16[f"llm/layer{l:02d}/x1"]
+        check(f"llm/layer{l:02d}/x0", x0.float().cpu().view(B, Pn, -1)[pm], w0[pm])
+        check(f"llm/layer{l:02d}/x1", x1.float().cpu().view(B, S, -1), w1)
+        x0p, x1p = w0, w1
+    return worst
 
 
 def test_full_depth_lap3b_forward_and_sampler_match_oracle(hip):
@@ -219,20 +275,21 @@ def test_full_depth_lap3b_forward_and_sampler_match_oracle(hip):
     assert abs(loss.item() - loss32.item()) / abs(loss32.item()) < max(3 * ref_noise, 5e-3), (loss.item(), loss32.item(), loss16.item())
     pm = torch.cat([obs["image_masks"][k][:, None].expand(1, model.n_img_tok) for k in cfg.image_keys] + [obs["tokenized_prompt_mask"]], 1)
     report = []
-    w16, w32 = _per_layer_sweep(cfg, oc, col, col32, col16, 1, pm, bound16=FULL_DEPTH_BOUND_BF16, report=report)
+    w16, w32 = _per_layer_sweep(cfg, oc, col, col32, col16, 1, pm, report=report)
+    wtf = _teacher_forced_sweep(model, cfg, oc, obs, col, col16, 1, pm)
     assert rel(col["per_sample_lang"], m32["per_sample_lang"]) < 2e-2 and rel(col["per_sample_action"], m32["per_sample_action"]) < 2e-2
     o = to_observation(so | {"tokenized_langact_mask": None}, DEV)
     out = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV))
-    assert torch.equal(out, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused=False))
+    generic = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused=False)
+    assert torch.equal(generic, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused="partials"))
     err, base = rel(out, ref), rel(ref16, ref)
+    assert rel(generic, ref) < max(FREE_RUN_RATIO * base, 5e-3) and rel(out, generic) < max(FREE_RUN_RATIO * base, 5e-3)
     print(f"full depth: oracle {t_oracle:.0f} s; loss {loss.item():.5f} / f32 {loss32.item():.5f} / bf16 {loss16.item():.5f}; "
-          f"worst layer vs bf16 oracle {w16:.2e}, vs f32 {w32:.2e}; sampler {err:.2e} (bf16 oracle {base:.2e})")
+          f"free-running worst layer vs bf16 oracle {w16:.2e}, vs f32 {w32:.2e}; teacher-forced worst layer {wtf:.2e}; "
+          f"sampler {err:.2e} (bf16 oracle {base:.2e})")
     for k, e32, b, e16 in report[::6]:
         print(f"  {k:22s} engine-f32 {e32:.2e}  bf16oracle-f32 {b:.2e}  engine-bf16oracle {e16:.2e}")
-    assert out.shape == (1, 50, 7) and err < max(3 * base, 1e-2), (err, base)
-
-
-FULL_DEPTH_BOUND_BF16 = 1.2e-2   # 18 / 27 layers of carried rounding flips (see LAYER_BOUND_BF16)
+    assert out.shape == (1, 50, 7) and err < max(FREE_RUN_RATIO * base, 5e-3), (err, base)
 
 
 def test_graphed_sampler_replay_equals_eager_and_oracle(hip):

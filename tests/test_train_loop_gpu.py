@@ -141,7 +141,7 @@ def test_frozen_vlm_trains_only_the_action_expert(hip):
             assert torch.equal(new[k], v), k
         else:
             moved += int(not torch.equal(new[k], v))
-    assert moved >= 20
+    assert moved == sum(not frz(k) for k in P) == 19      # every action-expert / action-head array moved
     cs = O.clip_scale(gn.item(), tc.optimizer.clip_gradient_norm)
     for k in ("PaliGemma/llm/layers/mlp_1/linear", "action_out_proj/kernel", "PaliGemma/llm/layers/pre_ffw_norm_1/Dense_0/kernel"):
         p1, _, _ = O.adamw_step(P[k], Pg[k].grad, torch.zeros_like(P[k]), torch.zeros_like(P[k]), 1, tc.lr_schedule(0), tc.optimizer.b1,
