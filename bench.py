@@ -194,6 +194,9 @@ def main():
     ap.add_argument("--config", default="lap_bench")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serve", action="store_true", help="skip the batch-1 action-chunk latency leg (N = 1 only)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="bf16 = the headline metric; fp8 = BASELINE.json config 5 (fp8 forward / data-gradient GEMMs of the VLM "
+                         "expert, everything else bf16) — reported with dtype 'fp8', a NON-headline line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for flow tests)")
     args = ap.parse_args()
 
@@ -223,7 +226,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
-    tc = dataclasses.replace(get_config(args.config), batch_size=args.batch * world, fsdp_devices=world)
+    tc = dataclasses.replace(get_config(args.config), batch_size=args.batch * world, fsdp_devices=world, gemm_dtype=args.dtype)
     state = init_train_state(tc, device=dev, world_size=world, rank=rank, use_fsdp=world > 1)
     runner = TrainingStepRunner(tc)
     batches = [synthetic_batch(tc.model, args.batch, dev, seed=1000 * rank + i) for i in range(2)]
@@ -259,10 +262,13 @@ def main():
         out = {
             "metric": "train-step samples/sec LAP-3B bf16", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("LAP-3B (SigLIP So400m/14 + Gemma-2B + Gemma-300M expert) full train step fwd+bwd+AdamW+EMA, "
                                     "2x224x224 images + 48-token prompt + 50-step action chunk, random-init weights")
-                       if args.config == "lap_bench" else f"NON-HEADLINE flow test: config {args.config}",
+                       if args.config == "lap_bench" and args.dtype == "bf16" else
+                       ("NON-HEADLINE: BASELINE.json config 5 on one GPU — the same train step with fp8 (e4m3, per-tensor scaling) forward / "
+                        "data-gradient GEMMs in the VLM expert, bf16 weight gradients and everything else" if args.config == "lap_bench"
+                        else f"NON-HEADLINE flow test: config {args.config}"),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": 610,
                        "parallelism": f"fsdp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "kernel": "gemm_sp_kernel / gemm_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", "achieved": round(achieved, 1),
@@ -276,7 +282,7 @@ def main():
                          "step_mfu": round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12 / MFMA_PEAK_TFLOPS, 4)},
             "final_loss": round(loss, 5),
         }
-        if world == 1 and not args.no_serve and args.config == "lap_bench":
+        if world == 1 and not args.no_serve and args.config == "lap_bench" and args.dtype == "bf16":
             del state, runner, batches
             torch.cuda.empty_cache()
             out["serve"] = serve_latency(tc.model, dev)

@@ -47,6 +47,10 @@ int lap_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const
                   int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
                   int a_kc, int b_kc, int flags, void* stream);
 
+/* Ablation knob for kernel studies (tools/gemm_ablate.py); rejected (LAP_ERR_ARG) unless the library was built with
+ * LAP_GEMM_EXPERIMENTAL=1.  bits: 1 = tile 10 issues no LDS-DMA inside its k-loop, 2 = no MFMA (results are garbage). */
+int lap_gemm_set_debug(int bits);
+
 /* Same with explicit scheduling knobs: tile = -1 (heuristic: 5 or 6) | 0 (128x128x64, 4 waves) | 1 (256x128x64, 3 stages)
  * | 2 (256x256x64, 8 waves) | 3 (256x256x32, 4 stages) | 4 (128x128x32, 4 stages) | 5 (256x256x64, 16 waves: production,
  * with the tail split of a poorly filled last round and the LDS-staged bf16 epilogue) | 6 (128x128x64, 8 waves, 2 blocks
@@ -209,6 +213,26 @@ int lap_attention_bwd(const lap_attn_bwd_args* a, void* stream);
    0 = generic padded-LDS kernels also for HD = 256; 1 = the HD = 256 LDS-DMA kernels.  Both agree to bf16
    rounding of the probabilities. */
 int lap_attention_set_variant(int variant);
+
+/* ---------------------------------------------------------------- fp8 GEMM ---- */
+/* BASELINE.json config 5 (north_star: "fp8 weights/activations, CDNA4 fp8 MFMA"; the reference itself has bf16 only,
+ * lap_config.py:24).  OCP e4m3, per-tensor scaling: q = e4m3(clamp(x * s, +-448)), s = 448 / amax(x).
+ * lap_gemm_fp8: C[M,N] = alpha / (s_a * s_b) * A8[M,K] . B8[N,K]^T (+ residual) — both operands K-contiguous fp8 bytes,
+ *   f32 accumulation on v_mfma_scale_f32_16x16x128_f8f6f4 (block scales 2^0); K % 128 == 0; flags: LAP_GEMM_OUT_F32,
+ *   LAP_GEMM_ACCUM.  scale_a / scale_b: DEVICE scalars (as written by lap_quantize_fp8*), so no host round trip.
+ *   Stands in for lap_gemm_bf16 on the forward (x8 . W8^T) and data-gradient (dy8 . W8t^T) products of the Gemma
+ *   projections (gemma.py:188-202,279-285,303-319); weight gradients stay bf16. */
+int lap_gemm_fp8(const void* A8, const void* B8, void* C, const void* residual, const float* scale_a, const float* scale_b,
+                 int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha, int flags, void* stream);
+/* amax[0] = max(amax[0], max |x|) over a bf16 [rows][cols] view (row stride ld); the caller zeroes amax first. */
+int lap_amax_bf16(const void* x, long long rows, int cols, long long ld, float* amax, void* stream);
+/* out8[r][c] = e4m3(x[r][c] * 448 / amax[0]); the scale used is written to scale[0]. */
+int lap_quantize_fp8(const void* x, long long rows, int cols, long long ld, const float* amax, void* out8, long long ldo,
+                     float* scale, void* stream);
+/* Weights Wt[rows = out][cols = in] (contiguous): the fp8 copy out8 [rows][cols] for the forward AND its transpose
+ * out8_t [cols][rows] for the data gradient (so that both products are the K-contiguous NT form). */
+int lap_quantize_fp8_weight(const void* w, int rows, int cols, const float* amax, void* out8, void* out8_t, float* scale,
+                            void* stream);
 
 /* ---------------------------------------- skinny-M fused projections (batch-1 denoise step) -- */
 /* One launch per projection of a denoise-step layer (lap.py:634-667 -> gemma.py:336-387, action-expert stream only,

@@ -14,7 +14,7 @@ import sys
 ROOT = pathlib.Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 LIB = ROOT / "liblap_hip.so"
-SOURCES = ["gemm.hip", "norm.hip", "elementwise.hip", "attention.hip", "loss_optim.hip", "serve_fused.hip", "serve_skinny.hip"]
+SOURCES = ["gemm.hip", "gemm_fp8.hip", "norm.hip", "elementwise.hip", "attention.hip", "loss_optim.hip", "serve_fused.hip", "serve_skinny.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]  # no fast-math: parity with the f32 reference ops
 if os.environ.get("LAP_GEMM_EXPERIMENTAL") == "1":   # also compile the non-production GEMM tile probes (1, 3, 4, 7, 8, 9)
     FLAGS.append("-DLAP_GEMM_EXPERIMENTAL")

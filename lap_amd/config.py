@@ -349,6 +349,10 @@ class TrainConfig:
     # gradient / optimizer and stored at bf16 precision.  None = nnx.Nothing; a regex string (full match on the
     # reference's '/'-joined path), a PathFilter or any predicate over the path.
     freeze_filter: object | None = None
+    # Engine option (BASELINE.json config 5, not a reference field): "fp8" runs the forward and data-gradient GEMMs of
+    # the VLM expert's projections on e4m3 operands with per-tensor scaling (csrc/gemm_fp8.hip); weight gradients,
+    # the action expert, SigLIP and every non-GEMM op stay bf16.
+    gemm_dtype: str = "bf16"
 
     def is_frozen(self, path: str) -> bool:
         f = self.freeze_filter

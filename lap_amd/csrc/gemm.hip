@@ -35,200 +35,10 @@
 // Split-K (f32 output, atomic accumulate) covers weight gradients whose output
 // has too few tiles to fill 256 CUs.
 #include "common.hpp"
-#include "../../include/lap_hip.h"
+#include "gemm_common.hpp"
 
 namespace {
 
-constexpr unsigned OOB = 0x80000000u;
-
-struct GemmParams {
-  const bf16* A; const bf16* B;
-  void* C;
-  const void* bias;      // [N] or null
-  const bf16* R;         // residual [M][ldr] bf16 or null
-  int M, N, K;
-  int lda, ldb, ldc, ldr;
-  float alpha;
-  int tiles_m, tiles_n;
-  int bias_kind;         // 0 none, 1 bf16, 2 f32
-  int gelu, accum;
-  int ksplit, ktiles_per_split;
-  float* part;           // split-K scratch: f32 [ksplit][M][N] partial products (null: atomic accumulate into C)
-  int tile_base;         // this launch covers the logical tiles [tile_base, tile_base + gridDim.x)
-  int tile_count;        // host side only: tiles of this launch (0 = all from tile_base)
-  int part_compact;      // partial slabs are [ksplit][gridDim.x][256][256] (tail split of the 256x256 kernel)
-  int sub256;            // 128x128 launch that covers tiles [tile_base, ..) of the 256x256 grid, 4 blocks (quadrants) per tile
-  int epi_lds;           // bf16 output of the 256x256 kernel goes out through LDS in full 512-byte rows (set by the host)
-};
-
-// logical tile -> (m-tile, n-tile): groups of GM m-tiles sweep n so that neighbouring tiles share operand panels
-template <int GM>
-__device__ __forceinline__ void tile_coords(const GemmParams& p, int t, int& tm, int& tn) {
-  const int group_sz = GM * p.tiles_n;
-  const int first_m = (t / group_sz) * GM;
-  const int gm = min(p.tiles_m - first_m, GM);
-  tm = first_m + (t % group_sz) % gm;
-  tn = (t % group_sz) / gm;
-}
-
-// 64-byte-row K-contiguous tile (BK = 32): 16-byte chunk c of row r is stored at chunk c ^ ((-(r >> 2)) & 3), which
-// makes every 16-lane service group of ds_read_b128 cover all 64 banks once.
-__device__ __forceinline__ unsigned kc32_tile_off(int row, int chunk16) {
-  return (unsigned)(row * 64 + ((chunk16 ^ ((-(row >> 2)) & 3)) << 4));
-}
-__device__ __forceinline__ bf16x8 kc32_frag(const char* tile, int row0, int lane) {
-  const int i = lane & 15, g = lane >> 4;
-  return *reinterpret_cast<const bf16x8*>(tile + kc32_tile_off(row0 + i, g));
-}
-
-// Epilogue for 4 consecutive outputs C[m][n..n+3] held by one lane (shared by every kernel shape).
-template <bool OUT_F32>
-__device__ __forceinline__ void store_tile4(const GemmParams& p, int m, int n, f32x4 a) {
-  if (p.part) {  // split-K partial: raw product, epilogue happens in splitk_reduce_kernel
-    if (p.part_compact) {
-      const int slot = xcd_remap(blockIdx.x, gridDim.x);
-      *reinterpret_cast<f32x4*>(p.part + (((long long)blockIdx.y * gridDim.x + slot) << 16) + ((m & 255) << 8) + (n & 255)) = a;
-    } else {
-      *reinterpret_cast<f32x4*>(p.part + ((long long)blockIdx.y * p.M + m) * p.N + n) = a;
-    }
-    return;
-  }
-  f32x4 v = a * p.alpha;
-  if (p.bias_kind == 1) {
-    bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
-  } else if (p.bias_kind == 2) {
-    v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
-  }
-  if (p.gelu) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-  }
-  if (p.R) {
-    bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-  }
-  if (OUT_F32) {
-    float* c = (float*)p.C + (long long)m * p.ldc + n;
-    if (p.ksplit > 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
-    } else {
-      if (p.accum) v += *reinterpret_cast<const f32x4*>(c);
-      *reinterpret_cast<f32x4*>(c) = v;
-    }
-  } else {
-    bf16x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-    *reinterpret_cast<bf16x4*>((bf16*)p.C + (long long)m * p.ldc + n) = o;
-  }
-}
-
-// Epilogue of the 256x256 kernels through LDS (set by the host: p.epi_lds).  bf16: straight from the accumulators a lane
-// owns 8-byte pieces of 16 different rows (32-byte runs per row: 64 narrow stores per wave instruction, store-issue bound,
-// and with one block per CU nothing overlaps them - ~7 us per tile, 11-18 % of a K <= 2048 tile).  The operand tiles are
-// dead after the k-loop, so the finished bf16 tile is written to LDS (row pitch 528 B, conflict-free for the
-// ds_write_b64 pattern) and leaves as 16-byte stores, two full 512-byte rows per wave instruction.
-// alpha / bias / GELU / residual are applied in registers exactly as in the direct path: same bits.  f32 (weight gradients,
-// logits): the same in two halves of 128 rows (a 256 x 256 f32 tile does not fit; 1040-byte pitch), four full 1 KiB rows
-// per wave instruction; with beta = 1 the old values come in the same coalesced way.
-template <int NW, int WTM, int WTN, bool OUT_F32>
-__device__ __forceinline__ void staged_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[WTM / 16][WTN / 16], int wm, int wn,
-                                                int m0, int n0, int tid, int lane) {
-  constexpr int FM = WTM / 16, FN = WTN / 16, BM = 256, BN = 256;
-  const int li = lane & 15, lg = lane >> 4;
-  if constexpr (!OUT_F32) {
-    constexpr int CP = BN * 2 + 16;   // 528 B: the 32 lanes of a ds_write_b64 half-wave (16 rows x 2 column groups) hit 64 distinct banks
-    __syncthreads();   // every wave is done reading the operand tiles (no LDS-DMA in flight after the last k-tile)
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int ml = wm * WTM + i * 16 + li;
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int nl = wn * WTN + j * 16 + 4 * lg;
-        const int m = m0 + ml, n = n0 + nl;
-        f32x4 v = acc[i][j] * p.alpha;
-        if (m < p.M && n < p.N) {
-          if (p.bias_kind == 1) {
-            bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
-          } else if (p.bias_kind == 2) {
-            v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
-          }
-          if (p.gelu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-          }
-          if (p.R) {
-            bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-          }
-        }
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-        *reinterpret_cast<bf16x4*>(smem + ml * CP + nl * 2) = o;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < BM * BN / 8 / (NW * 64); ++it) {
-      const int id = tid + NW * 64 * it;
-      const int r = id >> 5, c = id & 31;
-      const int m = m0 + r, n = n0 + c * 8;
-      if (m < p.M && n < p.N)   // N % 8 == 0 on this path: a 16-byte piece is inside or outside as a whole
-        *reinterpret_cast<bf16x8*>((bf16*)p.C + (long long)m * p.ldc + n) = *reinterpret_cast<const bf16x8*>(smem + r * CP + c * 16);
-    }
-  } else {
-    constexpr int CP = BN * 4 + 16;   // 1040 B: the 16 lanes of a ds_write_b128 group (16 rows) hit 64 distinct banks
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();   // operand tiles dead (first pass) / previous half moved out (second pass)
-      if ((wm * WTM) / 128 == half) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          const int ml = (wm * WTM) % 128 + i * 16 + li;
-#pragma unroll
-          for (int j = 0; j < FN; ++j) {
-            const int nl = wn * WTN + j * 16 + 4 * lg;
-            const int n = n0 + nl;
-            f32x4 v = acc[i][j] * p.alpha;
-            if (n < p.N) {
-              if (p.bias_kind == 1) {
-                bf16x4 b = *reinterpret_cast<const bf16x4*>((const bf16*)p.bias + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
-              } else if (p.bias_kind == 2) {
-                v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
-              }
-            }
-            *reinterpret_cast<f32x4*>(smem + ml * CP + nl * 4) = v;
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < 128 * BN / 4 / (NW * 64); ++it) {
-        const int id = tid + NW * 64 * it;
-        const int r = id >> 6, c = id & 63;
-        const int m = m0 + half * 128 + r, n = n0 + c * 4;
-        if (m < p.M && n < p.N) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CP + c * 16);
-          float* dst = (float*)p.C + (long long)m * p.ldc + n;
-          if (p.accum) v += *reinterpret_cast<const f32x4*>(dst);
-          *reinterpret_cast<f32x4*>(dst) = v;
-        }
-      }
-    }
-  }
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // BK: k-depth of one LDS stage (32 or 64); NS: LDS stages.  Loads of tile t+NS-1 are issued while tile t is
 // multiplied; the wait before the (single, raw) barrier is a COUNTED vmcnt that leaves NS-2 tiles in flight.
@@ -766,7 +576,7 @@ __device__ __forceinline__ bf16x8 ds_read_b128_raw(unsigned addr) {   // valid a
   return r;
 }
 
-template <int WGM, int WGN, bool A_KC, bool B_KC, bool OUT_F32>
+template <int WGM, int WGN, bool A_KC, bool B_KC, bool OUT_F32, bool TWOB = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_sp_kernel(GemmParams p) {
   constexpr int BM = 256, BN = 256, BK = 64, A_BYTES = BM * BK * 2, STAGE = 2 * A_BYTES;
   constexpr int NW = WGM * WGN, WTM = BM / WGM, WTN = BN / WGN, FM = WTM / 16, FN = WTN / 16, PC = 32 / NW;   // PC pieces / operand / wave
@@ -866,9 +676,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_sp_kernel(GemmParams p) {
              fa[set][i] = join8(ra[A_KC ? 0 : set][A_KC ? 0 : i][0], ra[A_KC ? 0 : set][A_KC ? 0 : i][1]); }
     }
   };
+#ifdef LAP_GEMM_EXPERIMENTAL
+  const bool no_dma = p.dbg & 1, no_mma = p.dbg & 2;
 #define SP_MMA(SET, I0, I1)                                                        \
-  _Pragma("unroll") for (int i = I0; i < I1; ++i)                                  \
-    _Pragma("unroll") for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[SET][j], fa[SET][i], acc[i][j]);
+  if (!no_mma) { _Pragma("unroll") for (int i_ = I0; i_ < I1; ++i_)                \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j) acc[i_][j] = mfma16(fb[SET][j], fa[SET][i_], acc[i_][j]); }
+#else
+  constexpr bool no_dma = false, no_mma = false;
+#define SP_MMA(SET, I0, I1)                                                        \
+  _Pragma("unroll") for (int i_ = I0; i_ < I1; ++i_)                               \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j) acc[i_][j] = mfma16(fb[SET][j], fa[SET][i_], acc[i_][j]);
+#endif
 #define SP_FENCE() __builtin_amdgcn_sched_barrier(0)
 
   // prologue: both buffers requested, tile kt0 awaited, its first k-half read
@@ -895,23 +713,30 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_sp_kernel(GemmParams p) {
     // A2
     lds_wait_all();
     tie(1);
-    wait_vmcnt<0>();
+    if constexpr (!TWOB) wait_vmcnt<0>();   // TWOB: this barrier only says "tile kt is read"; the landing of kt+1 is awaited in C
     SP_FENCE();
     __builtin_amdgcn_s_barrier();
     SP_FENCE();
     // A3: the rest of set 0 with the refill of this tile's buffer (tile kt + 2) threaded through
 #pragma unroll
     for (int i = 4; i < 8; ++i) {
-#pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[0][j], fa[0][i], acc[i][j]);
+      SP_MMA(0, i, i + 1)
       SP_FENCE();
+      if (!no_dma) {
 #pragma unroll
-      for (int q = 0; q < PC / 2; ++q) piece(cur, kt + 2, (PC / 2) * (i - 4) + q);
+        for (int q = 0; q < PC / 2; ++q) piece(cur, kt + 2, (PC / 2) * (i - 4) + q);
+      }
       SP_FENCE();
     }
     // C
     SP_MMA(1, 0, 2)
     SP_FENCE();
+    if constexpr (TWOB) {   // two tiles of LDS-DMA in flight: only the older one (kt + 1) has to have landed here
+      wait_vmcnt<2 * PC>();
+      SP_FENCE();
+      __builtin_amdgcn_s_barrier();
+      SP_FENCE();
+    }
     reads(0, smem + (cur ^ 1) * STAGE, 0);   // (kt + 1, k-half 0); past the end: harmless reads of a zero-filled buffer
     SP_FENCE();
     SP_MMA(1, 2, 8)
@@ -937,11 +762,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_sp_kernel(GemmParams p) {
   }
 }
 
-template <int WGM, int WGN, bool A_KC, bool B_KC, bool OUT_F32>
+template <int WGM, int WGN, bool A_KC, bool B_KC, bool OUT_F32, bool TWOB = false>
 int launch_sp(GemmParams p, hipStream_t s) {
   constexpr int LDS = OUT_F32 ? 128 * (256 * 4 + 16) : 256 * (256 * 2 + 16);   // >= the two operand stages (128 KiB)
   if (p.K & 63) return LAP_ERR_ARG;
-  auto kern = gemm_sp_kernel<WGM, WGN, A_KC, B_KC, OUT_F32>;
+  auto kern = gemm_sp_kernel<WGM, WGN, A_KC, B_KC, OUT_F32, TWOB>;
   p.epi_lds = (!p.part && p.ksplit == 1 && !(OUT_F32 && p.R) && !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) ? 1 : 0;
   static bool done = false;
   if (!done) {
@@ -1075,6 +900,7 @@ int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
     case 5: return launch<256, 256, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
     case 2: return launch<256, 256, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
 #ifdef LAP_GEMM_EXPERIMENTAL   // probes kept for the record: build with LAP_GEMM_EXPERIMENTAL=1 python -m lap_amd.build
+    case 11: return launch_sp<2, 4, A_KC, B_KC, OUT_F32, true>(p, s);   // tile 10 with two barriers per k-tile (probe)
     case 9: return launch_pp16<A_KC, B_KC, OUT_F32>(p, s);
     case 8: return launch_pp<A_KC, B_KC, OUT_F32>(p, s);
     case 7: return launch<256, 128, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
@@ -1082,7 +908,7 @@ int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
     case 3: return launch<256, 256, 2, 4, 32, 4, A_KC, B_KC, OUT_F32>(p, s);
     case 1: return launch<256, 128, 4, 2, 64, 3, A_KC, B_KC, OUT_F32>(p, s);
 #else
-    case 9: case 8: case 7: case 4: case 3: case 1: return LAP_ERR_ARG;   // not in this build
+    case 11: case 9: case 8: case 7: case 4: case 3: case 1: return LAP_ERR_ARG;   // not in this build
 #endif
     default: return launch<128, 128, 2, 2, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
   }
@@ -1175,6 +1001,16 @@ int pick_ksplit(int tile, int M, int N, int K, long long scratch_bytes) {
 
 }  // namespace
 
+static int g_gemm_dbg = 0;
+extern "C" int lap_gemm_set_debug(int bits) {   // ablation knob; has an effect in LAP_GEMM_EXPERIMENTAL builds only
+#ifdef LAP_GEMM_EXPERIMENTAL
+  g_gemm_dbg = bits;
+  return LAP_OK;
+#else
+  return bits ? LAP_ERR_ARG : LAP_OK;
+#endif
+}
+
 extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const void* bias, const void* residual,
                                 int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
                                 int a_kc, int b_kc, int flags, int tile, int ksplit, void* scratch,
@@ -1192,7 +1028,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   const bool f32 = flags & LAP_GEMM_OUT_F32;
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
-  if (tile < -1 || tile > 10 || ksplit < 0) return LAP_ERR_ARG;
+  if (tile < -1 || tile > 11 || ksplit < 0) return LAP_ERR_ARG;
   // Few output tiles but a very long contraction (LM-head dgrad: 1504 x 2048 over K = 257152; prefill down
   // projection): the big tile with enough K splits to cover the chip beats the small tile walking all of K.
   if (tile < 0 && ksplit == 0 && scratch != nullptr && K >= 16384 && !(flags & LAP_GEMM_PARTIALS)) {
@@ -1250,6 +1086,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   p.gelu = (flags & LAP_GEMM_GELU) ? 1 : 0;
   p.accum = (flags & LAP_GEMM_ACCUM) ? 1 : 0;
   p.ksplit = ksplit > 1 ? ksplit : 1;
+  p.dbg = g_gemm_dbg;
   p.part = two_phase ? (float*)scratch : nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (flags & LAP_GEMM_PARTIALS) {

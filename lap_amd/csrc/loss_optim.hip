@@ -105,19 +105,31 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 }
 
 // -------------------------------------------------------------------- optimizer
+// Four independent 16-byte loads in flight per thread and iteration (the first version had one and streamed at 1.5 TB/s
+// beside the backward GEMMs it shares the chip with; profiles/r01_bench_n1_kernel_stats.md).
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
   __shared__ float red[4];
-  float acc = 0.f;
-  const long long stride = (long long)gridDim.x * 256 * 4;
-  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const long long lane4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long long span = (long long)gridDim.x * 256 * 4;        // elements covered by one sweep of the grid
+  long long i = lane4;
+  for (; i + 3 * span + 4 <= n; i += 4 * span) {
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(x + i), t1 = *reinterpret_cast<const f32x4*>(x + i + span);
+    const f32x4 t2 = *reinterpret_cast<const f32x4*>(x + i + 2 * span), t3 = *reinterpret_cast<const f32x4*>(x + i + 3 * span);
+    a0 += t0[0] * t0[0] + t0[1] * t0[1] + t0[2] * t0[2] + t0[3] * t0[3];
+    a1 += t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2] + t1[3] * t1[3];
+    a2 += t2[0] * t2[0] + t2[1] * t2[1] + t2[2] * t2[2] + t2[3] * t2[3];
+    a3 += t3[0] * t3[0] + t3[1] * t3[1] + t3[2] * t3[2] + t3[3] * t3[3];
+  }
+  for (; i < n; i += span) {
     if (i + 4 <= n) {
-      f32x4 t = *reinterpret_cast<const f32x4*>(x + i);
-      acc += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+      const f32x4 t = *reinterpret_cast<const f32x4*>(x + i);
+      a0 += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
     } else {
-      for (long long j = i; j < n; ++j) acc += x[j] * x[j];
+      for (long long j = i; j < n; ++j) a0 += x[j] * x[j];
     }
   }
-  acc = block_sum<4>(acc, red);
+  const float acc = block_sum<4>((a0 + a1) + (a2 + a3), red);
   if (threadIdx.x == 0) atomicAdd(out, acc);
 }
 

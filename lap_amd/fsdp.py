@@ -102,6 +102,7 @@ class UnitPipeline:
     def run_optimizer(self, lr, bc1, bc2, ema_decay, ema_on, opt):
         """Side stream: global norm -> per-unit fused update (+ all-gather) in forward order, one event per unit."""
         ps = self.ps
+        ps.version += 1     # derived copies of the weights (fp8 mirrors) are stale from here on
         h = torch.tensor([0.0, lr, bc1, bc2, ema_decay, 1.0 if ema_on else 0.0, 0.0, 0.0], dtype=torch.float32)
         if self.is_cuda:
             h = h.pin_memory()

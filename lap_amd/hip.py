@@ -69,6 +69,11 @@ SIGNATURES: dict[str, list] = {
     "lap_abi_version": [],
     "lap_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
     "lap_gemm_bf16_ex": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _ll, _vp],
+    "lap_gemm_set_debug": [_i],
+    "lap_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "lap_amax_bf16": [_vp, _ll, _i, _ll, _vp, _vp],
+    "lap_quantize_fp8": [_vp, _ll, _i, _ll, _vp, _vp, _ll, _vp, _vp],
+    "lap_quantize_fp8_weight": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "lap_gemm_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp],
     "lap_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "lap_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -158,6 +163,7 @@ def _req(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
 
 # ------------------------------------------------------------------------------ GEMM
 _SCRATCH: dict = {}
+_NSPLIT_ENV = __import__("os").environ.get("LAP_ATTN_NSPLIT")
 
 
 def _gemm_scratch(device, floats: int = 160 * 1024 * 1024):
@@ -452,6 +458,8 @@ def attention_fwd(q, k, v, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None,
     ntk = (a.k_len[0] + 63) // 64 + (a.k_len[1] + 63) // 64
     blocks = B * NH * ntq
     nsplit = 1
+    if nsplit_hint is None and _NSPLIT_ENV and blocks < 128 and ntk > 1:
+        nsplit_hint = min(int(_NSPLIT_ENV), ntk)     # tuning knob (tools/bench_serve_split.py)
     if nsplit_hint is not None:
         nsplit = nsplit_hint
     elif blocks < 128 and ntk > 1:
@@ -671,3 +679,43 @@ def serve_final_euler(x, mod, mod_ld, rps, w_out, b_out, x_t, dt, v_out=None, ep
 def serve_set_variant(feature_tiles: int):
     """Tuning knob of lap_serve_proj_residual (tools/bench_skinny.py)."""
     _chk(_fn["lap_serve_set_variant"](int(feature_tiles)), "lap_serve_set_variant")
+
+
+# ------------------------------------------------------------------------- fp8 GEMM path (csrc/gemm_fp8.hip, config 5)
+def quantize_fp8(x):
+    """bf16 [rows, cols] (row stride x.stride(0)) -> (uint8 [rows, cols] e4m3 bytes, f32 scale [1]); per-tensor current scaling."""
+    _req(x, torch.bfloat16, "x")
+    rows, cols = x.shape
+    amax = torch.zeros(1, dtype=torch.float32, device=x.device)
+    call("lap_amax_bf16", _p(x), rows, cols, x.stride(0), _p(amax))
+    out = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    call("lap_quantize_fp8", _p(x), rows, cols, x.stride(0), _p(amax), _p(out), cols, _p(scale))
+    return out, scale
+
+
+def quantize_fp8_weight(wt):
+    """bf16 Wt [out, in] contiguous -> (W8 [out, in], W8t [in, out], scale [1])."""
+    _req(wt, torch.bfloat16, "wt")
+    if not wt.is_contiguous():
+        raise ValueError("quantize_fp8_weight needs a contiguous weight")
+    rows, cols = wt.shape
+    amax = torch.zeros(1, dtype=torch.float32, device=wt.device)
+    call("lap_amax_bf16", _p(wt), rows, cols, cols, _p(amax))
+    w8 = torch.empty((rows, cols), dtype=torch.uint8, device=wt.device)
+    w8t = torch.empty((cols, rows), dtype=torch.uint8, device=wt.device)
+    scale = torch.empty(1, dtype=torch.float32, device=wt.device)
+    call("lap_quantize_fp8_weight", _p(wt), rows, cols, _p(amax), _p(w8), _p(w8t), _p(scale))
+    return w8, w8t, scale
+
+
+def gemm_fp8(a8, sa, b8, sb, out=None, *, residual=None, out_dtype=torch.bfloat16, accum=False, alpha=1.0):
+    """out[M, N] = alpha / (sa * sb) * a8[M, K] @ b8[N, K]^T (+ residual): fp8 e4m3 operands, f32 accumulate."""
+    M, K = a8.shape
+    N = b8.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
+    flags = (GEMM_OUT_F32 if out.dtype == torch.float32 else 0) | (GEMM_ACCUM if accum else 0)
+    call("lap_gemm_fp8", _p(a8), _p(b8), _p(out), _p(residual), _p(sa), _p(sb), M, N, K, a8.stride(0), b8.stride(0), out.stride(0),
+         residual.stride(0) if residual is not None else 0, float(alpha), flags)
+    return out

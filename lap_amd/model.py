@@ -53,8 +53,12 @@ class LAP:
     EOS_TOKEN = 1
 
     def __init__(self, config: LAPConfig, seed: int = 0, params: dict | None = None, device="cuda", store: ParamStore | None = None,
-                 comm=None, with_optimizer: bool = False, with_ema: bool = False, with_grads: bool = True):
+                 comm=None, with_optimizer: bool = False, with_ema: bool = False, with_grads: bool = True, gemm_dtype: str = "bf16"):
         self.config = config
+        if gemm_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"gemm_dtype {gemm_dtype!r}: 'bf16' or 'fp8'")
+        self.gemm_dtype = gemm_dtype
+        self._w8: dict = {}     # fp8 mirrors of the VLM projections: name -> (store version, W8, W8t, scale)
         self.device = torch.device(device)
         self.v = get_gemma_config(config.paligemma_variant)
         self.e = get_gemma_config(config.action_expert_variant)
@@ -70,6 +74,10 @@ class LAP:
         self.ps = store
         self.n_img_tok = (config.image_size // self.s.patch) ** 2
         self.deterministic = True
+        if gemm_dtype == "fp8":
+            dims = (self.v.width, self.v.num_heads * self.v.head_dim, self.v.mlp_dim, (self.v.num_heads + 2 * self.v.num_kv_heads) * self.v.head_dim)
+            if any(d % 128 for d in dims):
+                raise ValueError(f"gemm_dtype='fp8' needs projection dimensions that are multiples of 128, got {dims}")
 
     # ------------------------------------------------------------------ small helpers
     def W(self, name):
@@ -86,6 +94,31 @@ class LAP:
         (scripts/train.py:358-361 differentiates w.r.t. the trainable filter only)."""
         if self.ps.is_trainable(name):
             hip.linear_wgrad(dy, x, self.G(name), **kw)
+
+    # ---- fp8 routing of the VLM expert's projections (BASELINE.json config 5; csrc/gemm_fp8.hip)
+    def _w8_of(self, name):
+        """(W8 [out][in], W8t [in][out], scale) of a VLM projection, re-quantised when the parameters changed."""
+        ent = self._w8.get(name)
+        if ent is None or ent[0] != self.ps.version:
+            ent = (self.ps.version, *hip.quantize_fp8_weight(self.W(name)))
+            self._w8[name] = ent
+        return ent[1:]
+
+    def _lin0(self, x, name, residual=None):
+        """y = x @ Wt^T (+ residual) for a prefix-stream projection: bf16 MFMA GEMM, or e4m3 x e4m3 when gemm_dtype == 'fp8'."""
+        if self.gemm_dtype == "fp8":
+            x8, sx = hip.quantize_fp8(x)
+            w8, _, sw = self._w8_of(name)
+            return hip.gemm_fp8(x8, sx, w8, sw, residual=residual)
+        return hip.linear_fwd(x, self.W(name), residual=residual)
+
+    def _dgrad0(self, dy, name):
+        """dx = dy @ Wt for a prefix-stream projection (the fp8 route multiplies by the transposed fp8 copy)."""
+        if self.gemm_dtype == "fp8":
+            d8, sd = hip.quantize_fp8(dy)
+            _, w8t, sw = self._w8_of(name)
+            return hip.gemm_fp8(d8, sd, w8t, sw)
+        return hip.linear_dgrad(dy, self.W(name))
 
     def _prefix_frozen(self) -> bool:
         """True when no parameter reached by the prefix stream's backward is trainable (e.g. `get_vlm_freeze_filter`):
@@ -368,7 +401,7 @@ class LAP:
             q = [None, None]; k = [None, None]; vv = [None, None]; h = [None, None]; rstd_a = [None, None]
             if x0 is not None:
                 h[0], rstd_a[0] = hip.rmsnorm_fwd(x0, scale=self.F(p + "n_attn"), save_rstd=save)
-                qkv = hip.linear_fwd(h[0], self.W(p + "wqkv0"))
+                qkv = self._lin0(h[0], p + "wqkv0")
                 q[0], k[0], vv[0] = hip.rope_split_fwd(qkv, pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5)
                 del qkv
             elif kv_cache is not None:
@@ -386,11 +419,11 @@ class LAP:
             xa = [None, None]; y1 = None; hf = [None, None]; rstd_f = [None, None]; gu = [None, None]; act = [None, None]; y1f = None
             xn = [None, None]
             if x0 is not None:
-                xa[0] = hip.linear_fwd(o[0], self.W(p + "wo0"), residual=x0)
+                xa[0] = self._lin0(o[0], p + "wo0", residual=x0)
                 hf[0], rstd_f[0] = hip.rmsnorm_fwd(xa[0], scale=self.F(p + "n_ffw"), save_rstd=save)
-                gu[0] = hip.linear_fwd(hf[0], self.W(p + "wgu0"))
+                gu[0] = self._lin0(hf[0], p + "wgu0")
                 act[0] = hip.geglu_fwd(gu[0])
-                xn[0] = hip.linear_fwd(act[0], self.W(p + "wd0"), residual=xa[0])
+                xn[0] = self._lin0(act[0], p + "wd0", residual=xa[0])
             if x1 is not None:
                 We3 = 3 * e.width
                 y1 = hip.linear_fwd(o[1], self.W(p + "wo1"))
@@ -421,16 +454,16 @@ class LAP:
             # ---- FFN, prefix stream: xn = xa + act @ wd^T   (dx0 is None: the whole prefix side is frozen)
             if dx0 is not None:
                 self._wgrad(dx0, c["act"][0], p + "wd0")
-                dact = hip.linear_dgrad(dx0, self.W(p + "wd0"))
+                dact = self._dgrad0(dx0, p + "wd0")
                 dgu = hip.geglu_bwd(c["gu"][0], dact)
                 del dact
                 self._wgrad(dgu, c["hf"][0], p + "wgu0")
-                dhf = hip.linear_dgrad(dgu, self.W(p + "wgu0"))
+                dhf = self._dgrad0(dgu, p + "wgu0")
                 del dgu
                 hip.rmsnorm_bwd(c["xa"][0], dhf, c["rstd_f"][0], scale=self.F(p + "n_ffw"), dx=dx0, dscale=self.G(p + "n_ffw"), accum_dx=True)
                 del dhf
                 self._wgrad(dx0, c["o"][0], p + "wo0")
-                d_o[0] = hip.linear_dgrad(dx0, self.W(p + "wo0"))
+                d_o[0] = self._dgrad0(dx0, p + "wo0")
             else:   # the attention backward still needs a dO for the prefix queries: zero (their dq / dk / dv are discarded)
                 if zero_do0 is None:
                     zero_do0 = torch.zeros_like(c["o"][0])
@@ -456,7 +489,7 @@ class LAP:
             if dx0 is not None:
                 dqkv = hip.rope_split_bwd(dq[0], dk[0], dv[0], pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5)
                 self._wgrad(dqkv, c["h"][0], p + "wqkv0")
-                dh = hip.linear_dgrad(dqkv, self.W(p + "wqkv0"))
+                dh = self._dgrad0(dqkv, p + "wqkv0")
                 hip.rmsnorm_bwd(c["x"][0], dh, c["rstd_a"][0], scale=self.F(p + "n_attn"), dx=dx0, dscale=self.G(p + "n_attn"), accum_dx=True)
             dqkv = hip.rope_split_bwd(dq[1], dk[1], dv[1], pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
             self._wgrad(dqkv, c["h"][1], p + "wqkv1")

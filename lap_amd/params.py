@@ -131,6 +131,7 @@ class ParamStore:
         self.ema: dict[str, torch.Tensor] = {}
         self.grad: dict[str, torch.Tensor] = {}     # unit -> f32 full gradient buffer [padded numel]
         self.gshard: dict[str, torch.Tensor] = {}   # unit -> f32 gradient shard (aliases grad when N == 1)
+        self.version = 0                            # bumped whenever parameter values change (derived copies re-quantise)
         self.frozen: dict[str, bool] = {}           # engine tensor -> excluded from gradient / optimizer (set_frozen)
         self._train_ranges: dict[str, list] = {}    # unit -> [(a, b)] trainable ranges in unit coordinates
         for u in self.units:
@@ -257,6 +258,7 @@ class ParamStore:
     def _write_full(self, u: UnitSpec, full: torch.Tensor):
         """full: f32 [padded] on device -> master shard (+ bf16 mirror)."""
         a, b = self.shard_range(u)
+        self.version += 1
         self.master[u.name].copy_(full[a:b])
         if u.big:
             self.full16[u.name].copy_(full)  # dtype cast

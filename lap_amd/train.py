@@ -106,7 +106,7 @@ def init_train_state(config: TrainConfig, seed: int | None = None, *, device="cu
         from lap_amd.fsdp import FsdpComm, UnitPipeline
 
         comm = FsdpComm(store) if use_fsdp else UnitPipeline(store)
-    model = LAP(config.model, device=device, store=store, comm=comm)
+    model = LAP(config.model, device=device, store=store, comm=comm, gemm_dtype=config.gemm_dtype)
     return TrainState(step=0, model=model, ema_decay=ema_decay)
 
 

@@ -79,6 +79,9 @@ class OracleCfg:
     action_loss_weight: float = 1.0
     stop_action_to_vlm_grad: bool = False
     emulate_bf16: bool = False
+    # BASELINE.json config 5 (not a reference mode: lap_config.py:24 knows bfloat16 only): the VLM expert's projections
+    # multiply e4m3-quantised operands (per-tensor scale 448 / amax, f32 accumulation), everything else as emulate_bf16
+    emulate_fp8: bool = False
 
     @property
     def vlm(self) -> GemmaCfg:
@@ -108,8 +111,27 @@ class _RoundSTE(torch.autograd.Function):
 
 
 def _mk_round(cfg: OracleCfg):
-    if cfg.emulate_bf16:
+    if cfg.emulate_bf16 or cfg.emulate_fp8:
         return _RoundSTE.apply
+    return lambda x: x
+
+
+class _Fp8STE(torch.autograd.Function):
+    """Quantise-dequantise to OCP e4m3 with the per-tensor scale 448 / amax (straight-through in the backward)."""
+    @staticmethod
+    def forward(ctx, x):
+        s = 448.0 / x.detach().abs().max().clamp_min(1e-12)
+        return (x * s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) / s
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _mk_q8(cfg: OracleCfg, expert: int):
+    """Operand quantiser of expert `expert`'s projections: fp8 for the VLM (expert 0) in emulate_fp8 mode, identity otherwise."""
+    if cfg.emulate_fp8 and expert == 0:
+        return _Fp8STE.apply
     return lambda x: x
 
 
@@ -318,8 +340,14 @@ def gemma_forward(P, cfg: OracleCfg, embedded, positions, mask, adarms_cond=None
             if x is None:
                 continue
             sfx = "" if i == 0 else f"_{i}"
-            qs.append(r(torch.einsum("btd,ndh->btnh", x, r(P[f"{lay}/attn/q_einsum{sfx}/w"][l]))))
-            kv = r(torch.einsum("bsd,xkdh->xbskh", x, r(P[f"{lay}/attn/kv_einsum{sfx}/w"][l])))
+            q8 = _mk_q8(cfg, i)
+            wq, wkv = r(P[f"{lay}/attn/q_einsum{sfx}/w"][l]), r(P[f"{lay}/attn/kv_einsum{sfx}/w"][l])
+            if cfg.emulate_fp8 and i == 0:   # the engine quantises the packed q|k|v weight with ONE scale
+                flat = q8(torch.cat([wq.reshape(-1), wkv.reshape(-1)]))
+                wq, wkv = flat[:wq.numel()].view_as(wq), flat[wq.numel():].view_as(wkv)
+            xq = q8(x)
+            qs.append(r(torch.einsum("btd,ndh->btnh", xq, wq)))
+            kv = r(torch.einsum("bsd,xkdh->xbskh", xq, wkv))
             ks.append(kv[0]); vs.append(kv[1])
         q = torch.cat(qs, dim=1); k = torch.cat(ks, dim=1); v = torch.cat(vs, dim=1)
         q = r(apply_rope(q, positions))
@@ -357,7 +385,8 @@ def gemma_forward(P, cfg: OracleCfg, embedded, positions, mask, adarms_cond=None
                 outs.append(None); continue
             sfx = "" if i == 0 else f"_{i}"
             end = start + x.shape[1]
-            outs.append(r(torch.einsum("btnh,nhd->btd", enc[:, start:end], r(P[f"{lay}/attn/attn_vec_einsum{sfx}/w"][l]))))
+            q8 = _mk_q8(cfg, i)
+            outs.append(r(torch.einsum("btnh,nhd->btd", q8(enc[:, start:end]), q8(r(P[f"{lay}/attn/attn_vec_einsum{sfx}/w"][l])))))
             start = end
         xs = [_gated_residual(x, y, g, r) for x, y, g in zip(xs, outs, gates)]
         outs, gates = [], []
@@ -370,11 +399,13 @@ def gemma_forward(P, cfg: OracleCfg, embedded, positions, mask, adarms_cond=None
             else:
                 y, gate = rmsnorm(x, cond=adarms_cond[i], dense_k=P[f"{lay}/pre_ffw_norm{sfx}/Dense_0/kernel"][l],
                                   dense_b=P[f"{lay}/pre_ffw_norm{sfx}/Dense_0/bias"][l], r=r)
-            wg = r(P[f"{lay}/mlp{sfx}/gating_einsum"][l])
-            ff_gate = r(y @ wg[0])
-            ff1 = r(y @ wg[1])
+            q8 = _mk_q8(cfg, i)
+            wg = q8(r(P[f"{lay}/mlp{sfx}/gating_einsum"][l]))      # gate | up share one scale (packed weight)
+            yq = q8(y)
+            ff_gate = r(yq @ wg[0])
+            ff1 = r(yq @ wg[1])
             act = r(r(gelu_tanh(ff_gate)) * ff1)
-            outs.append(r(act @ r(P[f"{lay}/mlp{sfx}/linear"][l])))
+            outs.append(r(q8(act) @ q8(r(P[f"{lay}/mlp{sfx}/linear"][l]))))
             gates.append(gate)
         xs = [_gated_residual(x, y, g, r) for x, y, g in zip(xs, outs, gates)]
         if collect is not None:

@@ -735,3 +735,42 @@ def test_serve_skinny_projections_match_unfused_ops(hip, M, rps, shared):
     # unsupported shapes are rejected, not mis-computed
     with pytest.raises(hip.LapHipError):
         hip.serve_proj_residual(rnd(M, 1536), rnd(D, 1536), x, None, 0, rps)
+
+
+# ------------------------------------------------------------------ fp8 GEMM path (BASELINE config 5)
+def _e4m3(x, s):
+    """torch restatement of the quantiser: e4m3fn(clamp(x * s, +-448)) as f32 (still scaled by s)."""
+    return (x.float() * s).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 384), (1600, 2560, 2048), (17920, 2048, 2560)])
+def test_gemm_fp8_matches_quantised_reference(hip, M, N, K):
+    """Quantiser and fp8 GEMM against torch: the e4m3 bytes must be exactly torch's float8_e4m3fn rounding of x * 448 / amax,
+    and the product must equal the f32 product of the de-quantised operands up to f32 summation order + the bf16 output
+    rounding; against the unquantised product the error is the stated fp8 tolerance (two e4m3 operands: ~2^-4 per element,
+    ~3e-2 relative L2 for Gaussian data)."""
+    a = rnd(M, K); w = rnd(N, K, seed=1, scale=0.05)
+    a8, sa = hip.quantize_fp8(a)
+    w8, w8t, sw = hip.quantize_fp8_weight(w)
+    assert abs(sa.item() - 448.0 / a.float().abs().max().item()) < 1e-3 * sa.item()
+    qa, qw = _e4m3(a, sa.item()), _e4m3(w, sw.item())
+    assert torch.equal(a8.view(torch.float8_e4m3fn).float(), qa)
+    assert torch.equal(w8.view(torch.float8_e4m3fn).float(), qw)
+    assert torch.equal(w8t, w8.t().contiguous())
+    ref_q = (qa @ qw.t()) / (sa.item() * sw.item())
+    out = hip.gemm_fp8(a8, sa, w8, sw)
+    assert rel_err(out, ref_q) < 4e-3                                 # bf16 output rounding only
+    assert rel_err(out, a.float() @ w.float().t()) < 6e-2             # fp8 quantisation noise
+    res = rnd(M, N, seed=3)
+    assert rel_err(hip.gemm_fp8(a8, sa, w8, sw, residual=res), ref_q + res.float()) < 4e-3
+    o32 = torch.full((M, N), 1.0, device=DEV)
+    hip.gemm_fp8(a8, sa, w8, sw, out=o32, accum=True)
+    assert rel_err(o32, ref_q + 1.0) < 5e-5                           # f32 output: summation order only
+    # data gradient through the transposed copy: dx[M, K] = dy[M, N] @ W[N, K]
+    dy = rnd(M, N, seed=4)
+    if N % 128 == 0:
+        dy8, sd = hip.quantize_fp8(dy)
+        dx = hip.gemm_fp8(dy8, sd, w8t, sw)
+        assert rel_err(dx, (_e4m3(dy, sd.item()) @ qw) / (sd.item() * sw.item())) < 4e-3
+    with pytest.raises(hip.LapHipError):
+        hip.gemm_fp8(a8[:, :K - 64].contiguous(), sa, w8[:, :K - 64].contiguous(), sw)      # K % 128 != 0

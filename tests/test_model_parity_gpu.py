@@ -441,3 +441,73 @@ def test_train_step_matches_oracle_adamw(hip):
         assert rel(new[k] - P[k], p1 - P[k]) < 0.15, k
         assert on and rel(ema[k], d * P[k] + (1 - d) * new[k]) < 1e-6, k
     assert state2.step == 1
+
+
+# ------------------------------------------------------------------------------ fp8 GEMM path (BASELINE.json config 5)
+# Tolerances re-stated for fp8 (north_star): the VLM expert's projections multiply e4m3 operands (3 mantissa bits: 2^-4
+# relative rounding per element, per-tensor scale 448 / amax).  Measured on MI355X at the LAP-3B widths (2 layers):
+#   * the fp8-EMULATING oracle sits FP8_NOISE ~ 2-4e-2 (relative L2, last layer) from the f32 oracle — that is the price of
+#     the format, the engine must not add to it: engine-vs-f32 <= 1.5 x (fp8 oracle-vs-f32);
+#   * engine vs the fp8-emulating oracle (same quantiser, same scales, different f32 summation order): the two free-running
+#     fp8 implementations decorrelate like the bf16 pair does (a flipped e4m3 rounding is 2^-4): <= 1.5 x (fp8 oracle-vs-f32)
+#     (measured 4.0e-2 / 5.0e-2 against a base of 4.2e-2 / 5.6e-2 for layers 0 / 1; action stream 1.4-2.2e-3);
+#   * gradients (the data-gradient GEMMs quantise dy as well; weight gradients are bf16): relative L2 per tensor vs the f32
+#     oracle <= FP8_GRAD_BOUND (measured worst 1.0e-1: q_einsum).
+FP8_GRAD_BOUND = 0.25
+
+
+def test_fp8_gemm_path_matches_fp8_emulating_oracle(hip, monkeypatch):
+    cfg = _full_width_cfg(monkeypatch, action_dim=7)
+    oc = oracle_cfg(cfg)
+    P = O.init_params(oc, seed=7)
+    B = 2
+    obs, actions, noise, time = make_inputs(cfg, B=B, ragged=True)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    col32, col8 = {}, {}
+    loss32, _ = O.compute_loss(Pg, oc, obs, actions, noise, time, collect=col32)
+    loss32.backward()
+    with torch.no_grad():
+        loss8, _ = O.compute_loss(P, dataclasses.replace(oc, emulate_fp8=True), obs, actions, noise, time, collect=col8)
+    from lap_amd.model import LAP
+
+    model = LAP(cfg, params=P, device=DEV, gemm_dtype="fp8")
+    for g in model.ps.grad.values():
+        g.zero_()
+    col = {}
+    loss, _ = model.loss_and_grad(0, to_observation(obs, DEV), actions.to(DEV), noise=noise.to(DEV), time=time.to(DEV), collect=col)
+    torch.cuda.synchronize()
+    fp8_noise = abs(loss8.item() - loss32.item()) / abs(loss32.item())
+    assert abs(loss.item() - loss32.item()) / abs(loss32.item()) < max(3 * fp8_noise, 2e-2), (loss.item(), loss32.item(), loss8.item())
+    L = cfg.max_token_len
+    Pn = model.n_img_tok * len(cfg.image_keys) + L
+    pm = torch.cat([obs["image_masks"][k][:, None].expand(B, model.n_img_tok) for k in cfg.image_keys] + [obs["tokenized_prompt_mask"]], 1)
+    rows = []
+    for l in range(oc.vlm.depth):
+        for i, (sel, shape) in enumerate(((pm, (B, Pn, -1)), (None, (B, cfg.action_horizon, -1)))):
+            k = f"llm/layer{l:02d}/x{i}"
+            e = col[k].float().cpu().view(*shape)
+            a32, a8 = col32[k].detach(), col8[k]
+            if sel is not None:
+                e, a32, a8 = e[sel], a32[sel], a8[sel]
+            err32, base, pair = rel(e, a32), rel(a8, a32), rel(e, a8)
+            rows.append((k, err32, base, pair))
+            if os.environ.get("LAP_PARITY_REPORT"):
+                print(f"  fp8 {k:20s} engine-f32 {err32:.2e}  fp8oracle-f32 {base:.2e}  engine-fp8oracle {pair:.2e}")
+                continue
+            assert err32 < max(1.5 * base, 1e-2), (k, err32, base)
+            assert pair < max(1.5 * base, 1e-2), (k, pair, base)
+    # gradients: every tensor vs the f32 oracle
+    from lap_amd.params import engine_to_reference
+
+    gref = engine_to_reference(cfg, {name: model.ps.g(name).detach().float().cpu() for name in model.ps.names()})
+    worst = max(((rel(gref[k], v.grad), k) for k, v in Pg.items() if v.grad is not None and v.grad.abs().max() > 1e-6), key=lambda t: t[0])
+    if os.environ.get("LAP_PARITY_REPORT"):
+        print(f"  fp8 worst gradient {worst[1]} {worst[0]:.2e}; loss {loss.item():.5f} f32 {loss32.item():.5f} fp8-oracle {loss8.item():.5f}")
+    else:
+        assert worst[0] < FP8_GRAD_BOUND, worst
+    # the bf16 engine on the same inputs is closer to f32 than the fp8 one (sanity: the switch does something)
+    model16 = LAP(cfg, params=P, device=DEV)
+    l16, _ = model16.compute_loss(0, to_observation(obs, DEV), actions.to(DEV), noise=noise.to(DEV), time=time.to(DEV))
+    assert l16.item() != loss.item()
+    with pytest.raises(ValueError, match="multiples of 128"):
+        LAP(debug_model_cfg(), seed=0, device=DEV, gemm_dtype="fp8")
