@@ -989,8 +989,11 @@ int pick_ksplit(int tile, int M, int N, int K, long long scratch_bytes) {
   }
   if (tile == 6 || tile == 0) {
     const long long t6 = (long long)((M + 127) / 128) * ((N + 127) / 128);
-    if (t6 > 96 || K < 1024) return 1;
-    long long sp = 256 / t6;
+    if (t6 > (M <= 1024 ? 256 : 96) || K < 1024) return 1;   // (the wider window is tuned on the serving shapes only)
+    // Few tiles (serving prefill at M ~ 512, small weights): a 128x128 block that walks all of K loads 512 * K bytes through
+    // ONE CU's vector-memory path (~45 GB/s, tools/bench_skinny.py) — 22 us at K = 2048 whatever the MFMA rate.  Splitting K
+    // until the chip holds two blocks per CU shortens that chain; the reduce pass costs ~5 us + the slab traffic.
+    long long sp = (t6 > 96 ? 512 : 256) / t6;
     if (sp > K / 256) sp = K / 256;
     if (sp > 16) sp = 16;
     if (sp > cap) sp = cap;

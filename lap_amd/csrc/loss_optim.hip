@@ -105,29 +105,27 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 }
 
 // -------------------------------------------------------------------- optimizer
-// Four independent 16-byte loads in flight per thread and iteration (the first version had one and streamed at 1.5 TB/s
-// beside the backward GEMMs it shares the chip with; profiles/r01_bench_n1_kernel_stats.md).
+// Four independent 16-byte loads in flight per thread: a block sweeps contiguous 16 KiB chunks (4 x 4 KiB, thread t takes
+// bytes [16 t, 16 t + 16) of each KiB-quad), so the stream stays page-local; the first version had one load in flight and
+// ran at 1.5 TB/s beside the backward GEMMs it shares the chip with (profiles/r01_bench_n1_kernel_stats.md).
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
   __shared__ float red[4];
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  const long long lane4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-  const long long span = (long long)gridDim.x * 256 * 4;        // elements covered by one sweep of the grid
-  long long i = lane4;
-  for (; i + 3 * span + 4 <= n; i += 4 * span) {
-    const f32x4 t0 = *reinterpret_cast<const f32x4*>(x + i), t1 = *reinterpret_cast<const f32x4*>(x + i + span);
-    const f32x4 t2 = *reinterpret_cast<const f32x4*>(x + i + 2 * span), t3 = *reinterpret_cast<const f32x4*>(x + i + 3 * span);
+  const long long chunk = 4096;                                  // elements per block and iteration
+  long long base = (long long)blockIdx.x * chunk;
+  const long long step = (long long)gridDim.x * chunk;
+  const int t4 = threadIdx.x * 4;
+  for (; base + chunk <= n; base += step) {
+    const float* p = x + base + t4;
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(p), t1 = *reinterpret_cast<const f32x4*>(p + 1024);
+    const f32x4 t2 = *reinterpret_cast<const f32x4*>(p + 2048), t3 = *reinterpret_cast<const f32x4*>(p + 3072);
     a0 += t0[0] * t0[0] + t0[1] * t0[1] + t0[2] * t0[2] + t0[3] * t0[3];
     a1 += t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2] + t1[3] * t1[3];
     a2 += t2[0] * t2[0] + t2[1] * t2[1] + t2[2] * t2[2] + t2[3] * t2[3];
     a3 += t3[0] * t3[0] + t3[1] * t3[1] + t3[2] * t3[2] + t3[3] * t3[3];
   }
-  for (; i < n; i += span) {
-    if (i + 4 <= n) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(x + i);
-      a0 += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
-    } else {
-      for (long long j = i; j < n; ++j) a0 += x[j] * x[j];
-    }
+  if (base < n) {                                                // ragged tail of the last sweep (at most one block has one)
+    for (long long j = base + threadIdx.x; j < n && j < base + chunk; j += 256) a0 += x[j] * x[j];
   }
   const float acc = block_sum<4>((a0 + a1) + (a2 + a3), red);
   if (threadIdx.x == 0) atomicAdd(out, acc);
@@ -294,7 +292,7 @@ extern "C" int lap_argmax_rows_f32(const float* x, int rows, int n, int ld, int*
 }
 extern "C" int lap_sumsq_f32(const float* x, long long n, float* sumsq, void* stream) {
   if (n <= 0) return LAP_ERR_ARG;
-  const long long blocks = (n + 1023) / 1024;
+  const long long blocks = (n + 4095) / 4096;
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, S_, x, n, sumsq);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
