@@ -11,7 +11,7 @@ LAP-3B (SigLIP So400m/14 + Gemma-2B + Gemma-300M action expert, random-init weig
 samples per GPU: 2 x 224x224 images, 48-token prompt (last 16 = language-action tokens), 50-step action chunk
 (SURVEY.md §8d).  Weak scaling: per-GPU batch fixed, parameters/optimizer FSDP-sharded over RCCL.
 
-Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the bf16 MFMA GEMM family, csrc/gemm.hip: gemm_sp_kernel + gemm_kernel):
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the bf16 MFMA GEMM family, csrc/gemm.hip: gemm_sp_kernel + gemm_pq_kernel + gemm_kernel):
 achieved = sum of 2*M*N*K over the GEMM launches of the timed steps / their summed durations, measured with HIP
 events on the launch stream; `cpu_baseline` times the CPU oracle (oracle/lap_oracle.py, kind "port") on the host
 cores on a bounded slice of the same workload.  `serve` is the second half of the metric: prefix prefill + 10 denoise
@@ -271,7 +271,7 @@ def main():
                         else f"NON-HEADLINE flow test: config {args.config}"),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": 610,
                        "parallelism": f"fsdp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_sp_kernel / gemm_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm_sp_kernel / gemm_pq_kernel / gemm_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", "achieved": round(achieved, 1),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "traffic": GEMM_TRAFFIC["bytes_per_launch"], "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE)",
                          "traffic_shape": GEMM_TRAFFIC["shape"], "traffic_algorithmic_bytes": GEMM_TRAFFIC["algorithmic_bytes_per_launch"],

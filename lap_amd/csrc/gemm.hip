@@ -35,6 +35,7 @@
 // Split-K (f32 output, atomic accumulate) covers weight gradients whose output
 // has too few tiles to fill 256 CUs.
 #include "common.hpp"
+#include <stdlib.h>
 #include "gemm_common.hpp"
 
 namespace {
@@ -762,6 +763,205 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_sp_kernel(GemmParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong kernel (tile 12), designed from the round-2 ablation of tile 10: a wave's instruction stream is
+// serial (32 MFMAs, then 12 fragment reads + 4 LDS-DMA pieces, per 32-deep k-half), and in tile 10 the two waves of a
+// SIMD do the same thing at the same time, so the matrix pipe idles whenever they load.  Here the block's waves form two
+// groups (waves 0-3 / 4-7: one wave of each per SIMD) that run every interval in OPPOSITE order:
+//     group 0:  barrier | L(j): read k-half j into set j&1, issue the DMA of k-half j+3, wait  | M(j):   32 MFMAs
+//     group 1:  barrier | M(j-1): 32 MFMAs on the set read in the previous interval            | L(j)
+// so that one wave of each SIMD multiplies while the other loads; ONE barrier per k-half, nothing else synchronises.
+// LDS: a ring of FOUR 32 KiB slots, one per k-half (k-half j in slot j & 3; [A 256 x 32 | B 256 x 32], 64-byte rows with
+// the kc32 swizzle, or 32 k-rows x 512 B for M-contiguous operands).  Hand-offs: a wave waits for its OWN pieces of k-half
+// j (counted vmcnt: the 8 pieces of k-halves j+1, j+2 stay in flight) before barrier j, so after it the k-half is complete;
+// both groups have finished reading k-half j-1 before barrier j (group 1's L(j-1) ends interval j-1), so its slot is
+// refilled with k-half j+3 during interval j — three intervals (~2 us) ahead of its use instead of tile 10's < 1 k-tile.
+template <bool A_KC, bool B_KC, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_pq_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, KH = 32, HALF = BM * KH * 2, SLOT = 2 * HALF, NSLOT = 4;
+  constexpr int WGN = 4, NW = 8, WTM = 128, WTN = 64, FM = 8, FN = 4, PC = 2;   // PC: 1 KiB pieces per operand, wave and k-half
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w / WGN, wn = w % WGN;
+  const bool g1 = w >= 4;
+  int tm, tn;
+  tile_coords<4>(p, p.tile_base + xcd_remap(blockIdx.x, gridDim.x), tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  auto rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.A, 0, (int)min((long long)(A_KC ? p.M : p.K) * p.lda * 2, 0x7fffffffLL), 0x00020000);
+  auto rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.B, 0, (int)min((long long)(B_KC ? p.N : p.K) * p.ldb * 2, 0x7fffffffLL), 0x00020000);
+  unsigned offA[PC], offB[PC];
+#pragma unroll
+  for (int j = 0; j < PC; ++j) {
+    const int ci = (w * PC + j) * 64 + lane;     // 16-byte chunk of one operand's k-half image (1024 chunks)
+    if (A_KC) {
+      const int row = ci >> 2, c = (ci & 3) ^ ((-(row >> 2)) & 3);
+      offA[j] = (m0 + row < p.M) ? (unsigned)(((long long)(m0 + row) * p.lda + c * 8) * 2) : OOB;
+    } else {
+      const int kr = ci >> 5, c = (ci & 31) ^ (mc_swz(kr) << 1);
+      offA[j] = (m0 + c * 8 < p.M) ? (unsigned)(((long long)kr * p.lda + m0 + c * 8) * 2) : OOB;
+    }
+    if (B_KC) {
+      const int row = ci >> 2, c = (ci & 3) ^ ((-(row >> 2)) & 3);
+      offB[j] = (n0 + row < p.N) ? (unsigned)(((long long)(n0 + row) * p.ldb + c * 8) * 2) : OOB;
+    } else {
+      const int kr = ci >> 5, c = (ci & 31) ^ (mc_swz(kr) << 1);
+      offB[j] = (n0 + c * 8 < p.N) ? (unsigned)(((long long)kr * p.ldb + n0 + c * 8) * 2) : OOB;
+    }
+  }
+  const unsigned stepA = A_KC ? (unsigned)(KH * 2) : (unsigned)((long long)KH * p.lda * 2);
+  const unsigned stepB = B_KC ? (unsigned)(KH * 2) : (unsigned)((long long)KH * p.ldb * 2);
+  const int h0 = 2 * blockIdx.y * p.ktiles_per_split;
+  const int h1 = min(p.K / KH, h0 + 2 * p.ktiles_per_split);       // k-halves [h0, h1): an even count (K % 64 == 0)
+  auto pieces = [&](int jh) {   // all 4 pieces of this wave for k-half jh -> slot (jh - h0) & 3; past the end: zero fill
+    char* base = smem + ((jh - h0) & (NSLOT - 1)) * SLOT;
+#pragma unroll
+    for (int j = 0; j < PC; ++j) {
+      const unsigned v = (offA[j] != OOB && jh < h1) ? offA[j] + (unsigned)jh * stepA : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(base + (w * PC + j) * 1024), 16, v, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PC; ++j) {
+      const unsigned v = (offB[j] != OOB && jh < h1) ? offB[j] + (unsigned)jh * stepB : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(base + HALF + (w * PC + j) * 1024), 16, v, 0, 0, 0);
+    }
+  };
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ONE fragment register set: a wave never multiplies and reads at the same time (that is the other wave's job), and a
+  // group-1 wave re-reads the registers its MFMAs of k-half j-1 were just issued from (an MFMA takes its A / B operands in
+  // its first cycles; the LDS data returns tens of cycles later)
+  bf16x8 fa[1][FM], fb[1][FN];
+  bf16x4 ra[1][A_KC ? 1 : FM][2], rb[1][B_KC ? 1 : FN][2];
+  const int li = lane & 15, lg = lane >> 4;
+  auto reads = [&](int set, const char* tA) {
+    const char* tB = tA + HALF;
+    if (B_KC) {   // fragments are 16 rows = 1024 bytes apart and share the swizzle
+      const unsigned b0 = lds_addr_of(tB) + kc32_tile_off(wn * WTN + li, lg);
+      fb[set][0] = ds_read_b128_raw<0>(b0); fb[set][1] = ds_read_b128_raw<1024>(b0);
+      fb[set][2] = ds_read_b128_raw<2048>(b0); fb[set][3] = ds_read_b128_raw<3072>(b0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mc_frag_raw<BN>(tB, wn * WTN + j * 16, 0, lane, rb[0][B_KC ? 0 : j]);
+    }
+    if (A_KC) {
+      const unsigned a0 = lds_addr_of(tA) + kc32_tile_off(wm * WTM + li, lg);
+      fa[set][0] = ds_read_b128_raw<0>(a0); fa[set][1] = ds_read_b128_raw<1024>(a0);
+      fa[set][2] = ds_read_b128_raw<2048>(a0); fa[set][3] = ds_read_b128_raw<3072>(a0);
+      fa[set][4] = ds_read_b128_raw<4096>(a0); fa[set][5] = ds_read_b128_raw<5120>(a0);
+      fa[set][6] = ds_read_b128_raw<6144>(a0); fa[set][7] = ds_read_b128_raw<7168>(a0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) mc_frag_raw<BM>(tA, wm * WTM + i * 16, 0, lane, ra[0][A_KC ? 0 : i]);
+    }
+  };
+  auto tie = [&](int set) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      if (B_KC) lds_tie(fb[set][j]);
+      else { lds_tie(rb[0][B_KC ? 0 : j][0]); lds_tie(rb[0][B_KC ? 0 : j][1]);
+             fb[set][j] = join8(rb[0][B_KC ? 0 : j][0], rb[0][B_KC ? 0 : j][1]); }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      if (A_KC) lds_tie(fa[set][i]);
+      else { lds_tie(ra[0][A_KC ? 0 : i][0]); lds_tie(ra[0][A_KC ? 0 : i][1]);
+             fa[set][i] = join8(ra[0][A_KC ? 0 : i][0], ra[0][A_KC ? 0 : i][1]); }
+    }
+  };
+#ifdef LAP_GEMM_EXPERIMENTAL   // ablation / variant bits (lap_gemm_set_debug): 1 no in-loop DMA, 2 no MFMA, 4 no s_setprio
+  const bool no_dma = p.dbg & 1, no_mma = p.dbg & 2, no_prio = p.dbg & 4;
+#else
+  constexpr bool no_dma = false, no_mma = false, no_prio = false;
+#endif
+#define PQ_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define PQ_L(SET, JH)                                                         \
+  reads(SET, smem + (((JH) - h0) & (NSLOT - 1)) * SLOT);                      \
+  PQ_FENCE();                                                                 \
+  if (!no_dma) pieces((JH) + 3);                                              \
+  PQ_FENCE();                                                                 \
+  lds_wait_all();                                                             \
+  tie(SET);                                                                   \
+  PQ_FENCE();
+#define PQ_M(SET)                                                             \
+  if (!no_prio) __builtin_amdgcn_s_setprio(1);                                \
+  if (!no_mma) {                                                              \
+  _Pragma("unroll") for (int i_ = 0; i_ < FM; ++i_)                           \
+    _Pragma("unroll") for (int j_ = 0; j_ < FN; ++j_) acc[i_][j_] = mfma16(fb[SET][j_], fa[SET][i_], acc[i_][j_]); } \
+  if (!no_prio) __builtin_amdgcn_s_setprio(0);                                \
+  PQ_FENCE();
+#define PQ_SYNC()                                                             \
+  wait_vmcnt<8>();   /* my 4 pieces of this k-half landed; the next two k-halves may fly */ \
+  PQ_FENCE();                                                                 \
+  __builtin_amdgcn_s_barrier();                                               \
+  PQ_FENCE();
+
+  pieces(h0); pieces(h0 + 1); pieces(h0 + 2);
+  if (!g1) {      // two separate loops (same barrier count): one loop with a group branch inside made hipcc spill 450 bytes
+    for (int jh = h0; jh < h1; ++jh) {
+      PQ_SYNC()
+      PQ_L(0, jh)
+      PQ_M(0)
+    }
+  } else {
+    PQ_SYNC()
+    PQ_L(0, h0)
+    for (int jh = h0 + 1; jh < h1; ++jh) {
+      PQ_SYNC()
+      PQ_M(0)
+      PQ_L(0, jh)
+    }
+    PQ_M(0)
+  }
+  wait_vmcnt<0>();
+  lds_wait_all();
+#undef PQ_SYNC
+#undef PQ_M
+#undef PQ_L
+#undef PQ_FENCE
+
+  if (p.epi_lds) { staged_epilogue<NW, WTM, WTN, OUT_F32>(p, smem, acc, wm, wn, m0, n0, tid, lane); return; }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + 4 * lg;
+      if (n >= p.N) continue;
+      store_tile4<OUT_F32>(p, m, n, acc[i][j]);
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC, bool OUT_F32>
+int launch_pq(GemmParams p, hipStream_t s) {
+  constexpr int LDS = OUT_F32 ? 128 * (256 * 4 + 16) : 256 * (256 * 2 + 16);   // >= the four 32 KiB slots
+  if (p.K & 63) return LAP_ERR_ARG;
+  auto kern = gemm_pq_kernel<A_KC, B_KC, OUT_F32>;
+  p.epi_lds = (!p.part && p.ksplit == 1 && !(OUT_F32 && p.R) && !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) ? 1 : 0;
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  const int nkt = p.K / 64;
+  p.ktiles_per_split = (nkt + p.ksplit - 1) / p.ksplit;
+  const int count = p.tile_count > 0 ? p.tile_count : p.tiles_m * p.tiles_n - p.tile_base;
+  hipLaunchKernelGGL(kern, dim3(count, p.ksplit), dim3(512), LDS, s, p);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
 template <int WGM, int WGN, bool A_KC, bool B_KC, bool OUT_F32, bool TWOB = false>
 int launch_sp(GemmParams p, hipStream_t s) {
   constexpr int LDS = OUT_F32 ? 128 * (256 * 4 + 16) : 256 * (256 * 2 + 16);   // >= the two operand stages (128 KiB)
@@ -895,6 +1095,7 @@ int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
   switch (tile) {
     // production: 10 (software-pipelined 8-wave 256x256, K % 64 == 0), 5 (16-wave 256x256), 6 (128x128); 2 is the
     // direct-epilogue 8-wave kernel the bitwise tests compare against; 0 (default below) the 4-wave 128x128 kernel
+    case 12: return launch_pq<A_KC, B_KC, OUT_F32>(p, s);
     case 10: return launch_sp<2, 4, A_KC, B_KC, OUT_F32>(p, s);
     case 6: return launch<128, 128, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
     case 5: return launch<256, 256, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
@@ -1031,7 +1232,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   const bool f32 = flags & LAP_GEMM_OUT_F32;
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
-  if (tile < -1 || tile > 11 || ksplit < 0) return LAP_ERR_ARG;
+  if (tile < -1 || tile > 12 || ksplit < 0) return LAP_ERR_ARG;
   // Few output tiles but a very long contraction (LM-head dgrad: 1504 x 2048 over K = 257152; prefill down
   // projection): the big tile with enough K splits to cover the chip beats the small tile walking all of K.
   if (tile < 0 && ksplit == 0 && scratch != nullptr && K >= 16384 && !(flags & LAP_GEMM_PARTIALS)) {
@@ -1076,8 +1277,11 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
     }
   }
   if (ksplit == 0 && scratch != nullptr && !tail_tiles) ksplit = pick_ksplit(tile, M, N, K, scratch_bytes);
-  // the software-pipelined 8-wave kernel (tile 10) stands in for the 16-wave one wherever K is a multiple of 64
-  const int big = !(K & 63) ? 10 : 5;
+  // K % 64 == 0: the software-pipelined 8-wave kernel (tile 10) for the forward layout, the ping-pong kernel (tile 12) as
+  // soon as an operand is M-contiguous (data / weight gradients: +5-11 % measured, tools/bench_kernels.py; on the forward
+  // layout its 64-byte k-half rows cost more in LDS-DMA requests than the ping-pong gains); else the 16-wave kernel
+  static const bool no_pq = getenv("LAP_GEMM_NO_PINGPONG") != nullptr;   // A/B switch for benchmarks
+  const int big = !(K & 63) ? ((a_kc && b_kc) || no_pq ? 10 : 12) : 5;
   if (tile == 5) tile = big;
   const bool two_phase = ksplit > 1 && scratch != nullptr;
   if (two_phase && scratch_bytes < (long long)ksplit * M * N * 4) return LAP_ERR_ARG;

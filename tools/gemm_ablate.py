@@ -29,7 +29,7 @@ for name, kind, m, n, k in (("gateup fwd", "fwd", 17920, 32768, 2048), ("square 
         dy = rnd(m, n); x = rnd(m, k); out = torch.empty(n, k, dtype=torch.float32, device=dev); fn = lambda: hip.linear_wgrad(dy, x, out, tile=TILE, ksplit=1)
     res = []
     TILE = int(os.environ.get("TILE", "10"))
-    for bits, label in ((0, "normal"), (1, "no DMA"), (2, "no MFMA"), (3, "neither")):
+    for bits, label in ((0, "normal"), (1, "no DMA"), (2, "no MFMA"), (3, "neither"), (4, "no setprio")):
         hip.call_noexcept = None
         hip._fn["lap_gemm_set_debug"](bits)
         t = timeit(fn)
