@@ -57,7 +57,7 @@ int lap_gemm_set_debug(int bits);
  * per CU: production for small shapes) | 7 (256x128x64, 16 waves) | 8, 9 (8- / 16-wave ping-pong probes) | 10 (256x256x64,
  * 8 waves, software-pipelined with two fragment register sets; K % 64 == 0; stands in for 5 in production on the forward layout)
  * | 11 (probe: 10 with two barriers per k-tile) | 12 (256x256, 8 waves as two ping-pong groups over a ring of four 32-deep k-half
- * slots; K % 64 == 0; production for the data- / weight-gradient layouts).  All tiles give
+ * slots; K % 64 == 0; production for the data- / weight-gradient layouts) | 13 (probe: ping-pong for the forward layout).  All tiles give
  * the same bits for the same ksplit (k is accumulated in the same order).  ksplit > 1 splits K over grid.y:
  *  - with `scratch` (>= ksplit*M*N*4 bytes): f32 partials + a reduce/epilogue kernel, any output / epilogue
  *    (deterministic; used for GEMMs with too few output tiles to fill 256 CUs: skinny-M serving, small weights);

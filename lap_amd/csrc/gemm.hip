@@ -940,6 +940,214 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmParams p) {
   }
 }
 
+#ifdef LAP_GEMM_EXPERIMENTAL   // probe: correct (bitwise), not faster than tile 10 on the forward layout
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong kernel for the forward layout (tile 13: both operands K-contiguous).  Tile 12's 32-deep k-half slots would
+// cut every 128-byte operand row into two 64-byte LDS-DMA requests; here the two intervals of a 64-deep k-tile split the
+// wave's A FRAGMENTS instead of K, so every piece still moves full lines:
+//     interval 2t   : A_lo(t) x B(t)   (A fragments 0-3, both k-steps, 32 MFMAs)      reads: 8 B + 8 A_lo fragments
+//     interval 2t+1 : A_hi(t) x B(t)   (A fragments 4-7; B stays in registers)        reads: 8 A_hi fragments
+// with the two wave groups in opposite order inside every interval (group 0: read, multiply; group 1: multiply what it read
+// in the previous interval, read) and one barrier per interval, as in tile 12.  LDS: rings of two for each of
+// A_lo (16 KiB: tile rows 0-63 and 128-191), A_hi (16 KiB: rows 64-127, 192-255) and B (32 KiB) = 128 KiB.  A_hi(t+1) is
+// requested in interval 2t (its slot held A_hi(t-1), read in interval 2t-1), A_lo / B(t+2) in interval 2t+1 — three
+// intervals ahead of their first use; a wave's own pieces are awaited with vmcnt(8) in both kinds of interval.
+template <bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_pn_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, BK = 64, HALF_A = 128 * BK * 2, B_BYTES = BN * BK * 2;   // 16 KiB, 32 KiB
+  constexpr int OFF_ALO = 0, OFF_AHI = 2 * HALF_A, OFF_B = 4 * HALF_A;                         // rings of two
+  constexpr int WGN = 4, NW = 8, WTM = 128, WTN = 64, FM = 8, FN = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w / WGN, wn = w % WGN;
+  const bool g1 = w >= 4;
+  int tm, tn;
+  tile_coords<4>(p, p.tile_base + xcd_remap(blockIdx.x, gridDim.x), tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)min((long long)p.M * p.lda * 2, 0x7fffffffLL), 0x00020000);
+  auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)min((long long)p.N * p.ldb * 2, 0x7fffffffLL), 0x00020000);
+  // per-lane source offsets: A halves 2 pieces per wave each, B 4 pieces; image row r of an A half <-> tile row
+  // (r & 63) + 128 (r >> 6) (+ 64 for the hi half); 8 chunks of 16 bytes per 128-byte row, XOR-swizzled on the source side
+  unsigned offAlo[2], offAhi[2], offB[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ci = (w * 2 + j) * 64 + lane;
+    const int r = ci >> 3, c = (ci & 7) ^ ((r >> 1) & 7);
+    const int trow = (r & 63) + 128 * (r >> 6);
+    offAlo[j] = (m0 + trow < p.M) ? (unsigned)(((long long)(m0 + trow) * p.lda + c * 8) * 2) : OOB;
+    offAhi[j] = (m0 + trow + 64 < p.M) ? (unsigned)(((long long)(m0 + trow + 64) * p.lda + c * 8) * 2) : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ci = (w * 4 + j) * 64 + lane;
+    const int r = ci >> 3, c = (ci & 7) ^ ((r >> 1) & 7);
+    offB[j] = (n0 + r < p.N) ? (unsigned)(((long long)(n0 + r) * p.ldb + c * 8) * 2) : OOB;
+  }
+  const int kt0 = blockIdx.y * p.ktiles_per_split;
+  const int kt1 = min(p.K / BK, kt0 + p.ktiles_per_split);
+  auto dma_alo_b = [&](int kt) {     // A_lo(kt) + B(kt): 6 pieces
+    const int sl = (kt - kt0) & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned v = (offAlo[j] != OOB && kt < kt1) ? offAlo[j] + (unsigned)kt * (BK * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(smem + OFF_ALO + sl * HALF_A + (w * 2 + j) * 1024), 16, v, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned v = (offB[j] != OOB && kt < kt1) ? offB[j] + (unsigned)kt * (BK * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(smem + OFF_B + sl * B_BYTES + (w * 4 + j) * 1024), 16, v, 0, 0, 0);
+    }
+  };
+  auto dma_ahi = [&](int kt) {       // A_hi(kt): 2 pieces
+    const int sl = (kt - kt0) & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned v = (offAhi[j] != OOB && kt < kt1) ? offAhi[j] + (unsigned)kt * (BK * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(smem + OFF_AHI + sl * HALF_A + (w * 2 + j) * 1024), 16, v, 0, 0, 0);
+    }
+  };
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[2][4], fb[2][FN];    // [k-step][fragment]: ONE set (see tile 12)
+  const int li = lane & 15, lg = lane >> 4;
+  auto read_b = [&](int sl) {
+    const char* tB = smem + OFF_B + sl * B_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const unsigned b0 = lds_addr_of(tB) + kc_tile_off(wn * WTN + li, kk * 4 + lg);
+      fb[kk][0] = ds_read_b128_raw<0>(b0); fb[kk][1] = ds_read_b128_raw<2048>(b0);
+      fb[kk][2] = ds_read_b128_raw<4096>(b0); fb[kk][3] = ds_read_b128_raw<6144>(b0);
+    }
+  };
+  auto read_a = [&](const char* tA) {   // the wave's four fragments of an A half: image rows wm * 64 + 16 f + li
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const unsigned a0 = lds_addr_of(tA) + kc_tile_off(wm * 64 + li, kk * 4 + lg);
+      fa[kk][0] = ds_read_b128_raw<0>(a0); fa[kk][1] = ds_read_b128_raw<2048>(a0);
+      fa[kk][2] = ds_read_b128_raw<4096>(a0); fa[kk][3] = ds_read_b128_raw<6144>(a0);
+    }
+  };
+  auto tie_a = [&]() {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lds_tie(fa[kk][i]);
+  };
+  auto tie_b = [&]() {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) lds_tie(fb[kk][j]);
+  };
+#define PN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define PN_SYNC()                                                             \
+  wait_vmcnt<8>();                                                            \
+  PN_FENCE();                                                                 \
+  __builtin_amdgcn_s_barrier();                                               \
+  PN_FENCE();
+#define PN_L_EVEN(KT)   /* B(KT) and A_lo(KT) into registers; request A_hi(KT + 1) */ \
+  read_b(((KT) - kt0) & 1);                                                   \
+  read_a(smem + OFF_ALO + (((KT) - kt0) & 1) * HALF_A);                       \
+  PN_FENCE();                                                                 \
+  dma_ahi((KT) + 1);                                                          \
+  PN_FENCE();                                                                 \
+  lds_wait_all();                                                             \
+  tie_b(); tie_a();                                                           \
+  PN_FENCE();
+#define PN_L_ODD(KT)    /* A_hi(KT) into registers; request A_lo / B(KT + 2) */ \
+  read_a(smem + OFF_AHI + (((KT) - kt0) & 1) * HALF_A);                       \
+  PN_FENCE();                                                                 \
+  dma_alo_b((KT) + 2);                                                        \
+  PN_FENCE();                                                                 \
+  lds_wait_all();                                                             \
+  tie_a();                                                                    \
+  PN_FENCE();
+#define PN_M(I0)                                                              \
+  __builtin_amdgcn_s_setprio(1);                                              \
+  _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                          \
+      _Pragma("unroll") for (int j_ = 0; j_ < FN; ++j_)                       \
+        acc[(I0) + i_][j_] = mfma16(fb[kk_][j_], fa[kk_][i_], acc[(I0) + i_][j_]); \
+  __builtin_amdgcn_s_setprio(0);                                              \
+  PN_FENCE();
+
+  // prologue: the steady-state request order from its start — A_lo/B(0), A_hi(0), A_lo/B(1); interval 0 then asks for A_hi(1)
+  dma_alo_b(kt0); dma_ahi(kt0); dma_alo_b(kt0 + 1);
+  if (!g1) {
+    for (int kt = kt0; kt < kt1; ++kt) {
+      PN_SYNC()
+      PN_L_EVEN(kt)
+      PN_M(0)
+      PN_SYNC()
+      PN_L_ODD(kt)
+      PN_M(4)
+    }
+  } else {
+    PN_SYNC()
+    PN_L_EVEN(kt0)
+    for (int kt = kt0; kt < kt1; ++kt) {
+      PN_SYNC()
+      PN_M(0)
+      PN_L_ODD(kt)
+      if (kt + 1 < kt1) {
+        PN_SYNC()
+        PN_M(4)
+        PN_L_EVEN(kt + 1)
+      }
+    }
+    PN_M(4)
+  }
+  wait_vmcnt<0>();
+  lds_wait_all();
+#undef PN_M
+#undef PN_L_ODD
+#undef PN_L_EVEN
+#undef PN_SYNC
+#undef PN_FENCE
+
+  if (p.epi_lds) { staged_epilogue<NW, WTM, WTN, OUT_F32>(p, smem, acc, wm, wn, m0, n0, tid, lane); return; }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + 4 * lg;
+      if (n >= p.N) continue;
+      store_tile4<OUT_F32>(p, m, n, acc[i][j]);
+    }
+  }
+}
+
+template <bool OUT_F32>
+int launch_pn(GemmParams p, hipStream_t s) {
+  constexpr int LDS = OUT_F32 ? 128 * (256 * 4 + 16) : 256 * (256 * 2 + 16);
+  if (p.K & 63) return LAP_ERR_ARG;
+  auto kern = gemm_pn_kernel<OUT_F32>;
+  p.epi_lds = (!p.part && p.ksplit == 1 && !(OUT_F32 && p.R) && !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) ? 1 : 0;
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  const int nkt = p.K / 64;
+  p.ktiles_per_split = (nkt + p.ksplit - 1) / p.ksplit;
+  const int count = p.tile_count > 0 ? p.tile_count : p.tiles_m * p.tiles_n - p.tile_base;
+  hipLaunchKernelGGL(kern, dim3(count, p.ksplit), dim3(512), LDS, s, p);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+#endif  // LAP_GEMM_EXPERIMENTAL
+
 template <bool A_KC, bool B_KC, bool OUT_F32>
 int launch_pq(GemmParams p, hipStream_t s) {
   constexpr int LDS = OUT_F32 ? 128 * (256 * 4 + 16) : 256 * (256 * 2 + 16);   // >= the four 32 KiB slots
@@ -1101,6 +1309,7 @@ int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
     case 5: return launch<256, 256, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
     case 2: return launch<256, 256, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
 #ifdef LAP_GEMM_EXPERIMENTAL   // probes kept for the record: build with LAP_GEMM_EXPERIMENTAL=1 python -m lap_amd.build
+    case 13: if constexpr (A_KC && B_KC) return launch_pn<OUT_F32>(p, s); else return LAP_ERR_ARG;
     case 11: return launch_sp<2, 4, A_KC, B_KC, OUT_F32, true>(p, s);   // tile 10 with two barriers per k-tile (probe)
     case 9: return launch_pp16<A_KC, B_KC, OUT_F32>(p, s);
     case 8: return launch_pp<A_KC, B_KC, OUT_F32>(p, s);
@@ -1109,7 +1318,7 @@ int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
     case 3: return launch<256, 256, 2, 4, 32, 4, A_KC, B_KC, OUT_F32>(p, s);
     case 1: return launch<256, 128, 4, 2, 64, 3, A_KC, B_KC, OUT_F32>(p, s);
 #else
-    case 11: case 9: case 8: case 7: case 4: case 3: case 1: return LAP_ERR_ARG;   // not in this build
+    case 13: case 11: case 9: case 8: case 7: case 4: case 3: case 1: return LAP_ERR_ARG;   // not in this build
 #endif
     default: return launch<128, 128, 2, 2, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
   }
@@ -1232,7 +1441,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   const bool f32 = flags & LAP_GEMM_OUT_F32;
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
-  if (tile < -1 || tile > 12 || ksplit < 0) return LAP_ERR_ARG;
+  if (tile < -1 || tile > 13 || ksplit < 0) return LAP_ERR_ARG;
   // Few output tiles but a very long contraction (LM-head dgrad: 1504 x 2048 over K = 257152; prefill down
   // projection): the big tile with enough K splits to cover the chip beats the small tile walking all of K.
   if (tile < 0 && ksplit == 0 && scratch != nullptr && K >= 16384 && !(flags & LAP_GEMM_PARTIALS)) {

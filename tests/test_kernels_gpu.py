@@ -123,6 +123,11 @@ def test_gemm_pingpong_matches_single_phase_bitwise(hip):
             hip.linear_wgrad(dy, x, g2, tile=2, ksplit=1)
             for pp in extra + ((10, 12) if k % 64 == 0 else ()):
                 assert torch.equal(hip.linear_fwd(a, w, tile=pp, ksplit=1), hip.linear_fwd(a, w, tile=2, ksplit=1)), (pp, m, n, k)
+                if pp == 12 and extra:   # experimental builds: the forward-layout ping-pong probe (tile 13), bf16 and f32 outputs
+                    assert torch.equal(hip.linear_fwd(a, w, tile=13, ksplit=1), hip.linear_fwd(a, w, tile=2, ksplit=1)), (13, m, n, k)
+                    o13 = torch.zeros(m, n, device=DEV); o2 = torch.zeros(m, n, device=DEV)
+                    hip.linear_fwd(a, w, out=o13, tile=13, ksplit=1); hip.linear_fwd(a, w, out=o2, tile=2, ksplit=1)
+                    assert torch.equal(o13, o2), (13, "f32", m, n, k)
                 assert torch.equal(hip.linear_dgrad(a, w2, tile=pp, ksplit=1), hip.linear_dgrad(a, w2, tile=2, ksplit=1)), (pp, m, n, k)
                 gp = torch.empty(m, n, device=DEV)
                 hip.linear_wgrad(dy, x, gp, tile=pp, ksplit=1)

@@ -46,7 +46,7 @@ def bench_gemms():
             dy = rnd(m, n); x = rnd(m, k); out = torch.empty(n, k, dtype=torch.float32, device=dev)
             fn = lambda: hip.linear_wgrad(dy, x, out)
         res = []
-        for tile in (10, 12):
+        for tile in ((10, 13) if kind == 'fwd' else (10, 12)):
             if kind == "fwd":
                 fn = lambda: hip.linear_fwd(a, w, out, tile=tile)
             elif kind == "dgrad":
