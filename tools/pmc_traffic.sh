@@ -7,7 +7,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python - <<PY
 import csv, glob
 f = glob.glob("$out/**/*counter_collection.csv", recursive=True)
-rows = [r for r in csv.DictReader(open(f[0])) if "gemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "$c"]
+rows = [r for r in csv.DictReader(open(f[0])) if "gemm_" in r["Kernel_Name"] and "splitk" not in r["Kernel_Name"] and r["Counter_Name"] == "$c"]
 v = [float(r["Counter_Value"]) for r in rows]
 print("$c per launch (raw counter units, KB):", sum(v) / len(v), "launches", len(v))
 PY
