@@ -20,6 +20,11 @@ from typing import Literal
 
 PALIGEMMA_VOCAB_SIZE = 257_152
 IMAGE_RESOLUTION = (224, 224)
+# VQA dataset ids as the reference's registry assigns them (datasets/registry.py:243-304: 1, 2, ... in registration order =
+# import order of datasets/vqa/__init__.py:10-18; 0 = not a VQA sample).  `LAPConfig.vqa_loss_weights` is keyed by these names
+# (lap.py:107-115) and `CoTObservation.vqa_dataset_id` carries the ids.  Extend the dict for additional VQA sets.
+VQA_DATASET_ID_MAP: dict[str, int] = {"coco_captions": 1, "lvis": 2, "paco_lvis": 3, "paco_ego4d": 4, "pixmo_cap": 5,
+                                      "pixmo_point": 6, "vqa": 7}
 
 
 # ------------------------------------------------------------------------------ backbones

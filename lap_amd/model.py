@@ -555,8 +555,6 @@ class LAP:
         cfg = self.config
         if not (cfg.enable_action_training and cfg.enable_langact_training):
             raise NotImplementedError("lap_amd implements the LAP-3B training path: action + langact losses enabled")
-        if cfg.enable_vqa_training or cfg.enable_prediction_training:
-            raise NotImplementedError("VQA / prediction loss mixing is not on the benchmarked path")
         dev = self.device
         self.comm.wait_unit("small")
         g = _gen(rng, dev)
@@ -617,18 +615,55 @@ class LAP:
         pre1, rstd_p1 = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=backward)
         pre1f = hip.cast_bf16_to_f32(pre1)
         v_t = self._lin32(pre1f, "act/out_w", "act/out_b")  # [B*S, ad]
-        # ---- combination (lap.py:542-596; VQA / prediction masks absent)
-        nB = self.comm.all_reduce_sum(torch.tensor([float(B)], device=dev))
-        if obs.sample_mask is not None:
-            n_active = torch.clamp(self.comm.all_reduce_sum(obs.sample_mask.to(torch.float32).sum().view(1)), min=1.0)
+        # ---- combination (lap.py:472-596).  Per-sample weights: language loss x {language, VQA (optionally per dataset),
+        # prediction} weight by sample kind; action loss only on samples that are neither VQA nor prediction samples.
+        fb = lambda t: t.to(torch.float32)
+        sm = obs.sample_mask if obs.sample_mask is not None else torch.ones(B, dtype=torch.bool, device=dev)
+        mixing = cfg.enable_vqa_training or cfg.enable_prediction_training
+        vqa = obs.is_vqa_sample.to(dev, torch.bool) if (cfg.enable_vqa_training and obs.is_vqa_sample is not None) else None
+        pred = obs.is_prediction_sample.to(dev, torch.bool) if (cfg.enable_prediction_training and obs.is_prediction_sample is not None) else None
+        extra_metrics = {}
+        if mixing:
+            vqa_m = (vqa if vqa is not None else torch.zeros(B, dtype=torch.bool, device=dev)) & sm      # lap.py:480-486
+            pred_m = (pred if pred is not None else torch.zeros(B, dtype=torch.bool, device=dev)) & sm
+            lang_m = ~((vqa if vqa is not None else vqa_m) | (pred if pred is not None else pred_m)) & sm
+            vqa_w = torch.full((B,), cfg.vqa_loss_weight, dtype=torch.float32, device=dev)               # lap.py:526-543
+            if cfg.enable_vqa_training and cfg.vqa_loss_weights and obs.vqa_dataset_id is not None:
+                from lap_amd.config import VQA_DATASET_ID_MAP
+
+                ids = obs.vqa_dataset_id.to(dev)
+                for name, wgt in cfg.vqa_loss_weights.items():
+                    if name in VQA_DATASET_ID_MAP:
+                        vqa_w = torch.where(ids == VQA_DATASET_ID_MAP[name], torch.full_like(vqa_w, float(wgt)), vqa_w)
+            wl = vqa_w * fb(vqa_m) + cfg.prediction_loss_weight * fb(pred_m) + cfg.language_loss_weight * fb(lang_m)
+            act_mask = ~vqa_m & ~pred_m          # the masks were AND-ed with the sample mask before this point (lap.py:484-485,562-566)
+            n_act_loc = fb(sm).sum()
+            for pfx, msk in (("vqa_", vqa_m), ("pred_", pred_m), ("langact_", lang_m)):   # metrics.py:49-56 (per-rank values)
+                if (pfx == "vqa_" and not cfg.enable_vqa_training) or (pfx == "pred_" and not cfg.enable_prediction_training):
+                    continue
+                extra_metrics[pfx + "loss"] = (lang_loss * fb(msk)).sum() / torch.clamp(fb(msk).sum(), min=1.0)
+                extra_metrics[pfx + "num_samples"] = fb(msk).sum()
+                extra_metrics[pfx + "sample_portion"] = fb(msk).sum() / torch.clamp(n_act_loc, min=1.0)
+            extra_metrics["active_num_samples"] = n_act_loc
+            extra_metrics["active_sample_portion"] = n_act_loc / max(B, 1)
         else:
-            n_active = nB
-        coef = torch.full((B,), cfg.action_loss_weight, dtype=torch.float32, device=dev) / nB
+            wl = torch.full((B,), cfg.language_loss_weight, dtype=torch.float32, device=dev)
+            act_mask = torch.ones(B, dtype=torch.bool, device=dev)
+            if vqa is not None:
+                act_mask = act_mask & ~vqa
+            if pred is not None:
+                act_mask = act_mask & ~pred
+        n_active = torch.clamp(self.comm.all_reduce_sum(fb(sm).sum().view(1)), min=1.0) if obs.sample_mask is not None else \
+            self.comm.all_reduce_sum(torch.tensor([float(B)], device=dev))
+        n_action = torch.clamp(self.comm.all_reduce_sum(fb(act_mask).sum().view(1)), min=1.0)
+        coef = cfg.action_loss_weight * fb(act_mask) / n_action
         act_loss, dv = hip.mse_fwd_bwd(v_t.view(B, S * ad), u_t.view(B, S * ad), coef, need_grad=backward)
-        lang_term = (cfg.language_loss_weight * lang_loss).sum() / n_active
-        action_term = (cfg.action_loss_weight * act_loss).sum() / nB
+        lang_term = (wl * lang_loss).sum() / n_active
+        action_term = (cfg.action_loss_weight * act_loss * fb(act_mask)).sum() / n_action
         loss = self.comm.all_reduce_sum((lang_term + action_term).view(1)).view(())
-        metrics = {"lang_loss": lang_loss.mean(), "action_loss": act_loss.mean(), "langact_loss": lang_loss.mean()}
+        metrics = {"lang_loss": lang_loss.mean(), "action_loss": (act_loss * fb(act_mask)).sum() / torch.clamp(fb(act_mask).sum(), min=1.0),
+                   "langact_loss": (lang_loss * fb(sm)).sum() / torch.clamp(fb(sm).sum(), min=1.0) if not mixing else extra_metrics["langact_loss"],
+                   **{k: v for k, v in extra_metrics.items() if k != "langact_loss"}}
         if collect is not None:
             collect.update(pl=pl, pre1=pre1, v_t=v_t.view(B, S, ad), u_t=u_t, per_sample_lang=lang_loss, per_sample_action=act_loss)
         if not backward:
@@ -646,7 +681,7 @@ class LAP:
         dx0 = None
         if not skip_prefix:
             # language head: dlogits = w * (softmax - onehot); w = d loss / d nll
-            w = (cfg.language_loss_weight * lm / cnt[:, None] / n_active).contiguous().view(-1)
+            w = (wl[:, None] * lm / cnt[:, None] / n_active).contiguous().view(-1)
             dpl32 = torch.empty((R, Dv), dtype=torch.float32, device=dev) if len(chunks) > 1 else None
             gE = self.G("llm/embed")
             for ci, (v0, vc) in enumerate(chunks):

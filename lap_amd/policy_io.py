@@ -263,7 +263,10 @@ class CoTInputs:
     (text_utils.py:37-63, incl. the r1_lite `@` rule), frame description, actions padded to action_dim.  With raw
     `language_actions` in the sample (training) the label text is produced by `lang_actions.ActionProcessor`, the frame
     description follows the frame actually used, and idle labels clear `sample_mask` (sample_handlers.py:372-431).
-    VQA / prediction samples (question synthesis) are dataset-time work of the data path and are refused."""
+    VQA samples (`is_vqa_sample`: caption = label text, no wrist dropout / random un-masking, always active) and prediction
+    samples (`is_prediction_sample`: both frames taken as they are; default prompt, or — with `enable_diverse_questions` — a
+    question / answer pair drawn by `questions.PredictionSampleHandler`) follow input_transforms.py:214-249 and
+    image_handler.py:45-107."""
     action_dim: int
     language_action_format: Any = "verbose_eef_with_rotation"
     wrist_image_dropout_prob: float = 0.0
@@ -271,6 +274,8 @@ class CoTInputs:
     use_rough_scale: bool = False
     random_base_prob: float = 0.0
     random_mask_prob: float = 0.0
+    enable_diverse_questions: bool = False
+    question_config: Any = None
     image_keys: tuple[str, ...] = IMAGE_KEYS
 
     def __post_init__(self):
@@ -278,32 +283,40 @@ class CoTInputs:
         f = self.language_action_format
         if f is not None and not isinstance(f, la.LanguageActionFormat):
             object.__setattr__(self, "language_action_format", la.get_language_action_format(f))
+        if self.enable_diverse_questions and self.question_config is None:
+            from lap_amd.questions import QuestionConfig
+            object.__setattr__(self, "question_config", QuestionConfig())
 
     def _mask(self, image, random_mask_prob: float = 0.0):
         if np.all(image == 0.0):
             return np.True_ if (random_mask_prob > 0.0 and np.random.rand() < random_mask_prob) else np.False_
         return np.True_
 
-    def _wrist(self, obs: dict, key: str, base):
+    def _wrist(self, obs: dict, key: str, base, is_vqa: bool = False):
         if key not in obs:
             return np.zeros_like(base)
         image = parse_image(obs[key])
-        if self.wrist_image_dropout_prob > 0.0 and np.random.rand() < float(self.wrist_image_dropout_prob):
+        if not is_vqa and self.wrist_image_dropout_prob > 0.0 and np.random.rand() < float(self.wrist_image_dropout_prob):
             return np.zeros_like(base)
         return image
 
     def __call__(self, data: dict) -> dict:
         from lap_amd import lang_actions as la
         assert "observation" in data
-        if data.get("is_vqa_sample", False) or data.get("is_prediction_sample", False):
-            raise NotImplementedError("VQA / prediction sample handlers are part of the data path (SURVEY.md 8f rank 4)")
+        is_vqa, is_pred = bool(data.get("is_vqa_sample", False)), bool(data.get("is_prediction_sample", False))
         obs = data["observation"]
         raw = obs.get(self.image_keys[0])
         base = None if (isinstance(raw, (str, bytes)) and len(raw) == 0) else parse_image(raw)
         if base is None:
             base = np.zeros((224, 224, 3), dtype=np.uint8)   # masked out below: an all-zero image
-        images = [base] + [self._wrist(obs, k, base) for k in self.image_keys[1:]]
-        masks = [self._mask(base)] + [self._mask(im, self.random_mask_prob) for im in images[1:]]
+        if not is_pred:
+            images = [base] + [self._wrist(obs, k, base, is_vqa) for k in self.image_keys[1:]]
+            masks = [self._mask(base)] + [self._mask(im, 0.0 if is_vqa else self.random_mask_prob) for im in images[1:]]
+        else:   # prediction samples: the two frames as they are (image_handler.py:88-105), no dropout, no random un-masking
+            first = base if data.get("pred_use_primary", False) else (parse_image(obs[self.image_keys[0]]) if self.image_keys[0] in obs
+                                                                      else np.zeros_like(base))
+            images = [first] + [parse_image(obs[k]) if k in obs else np.zeros_like(base) for k in self.image_keys[1:]]
+            masks = [self._mask(im) for im in images]
         dataset_name = _text(data.get("dataset_name"))
         prompt = data.get("prompt")
         assert prompt is not None, "Prompt missing from data"
@@ -315,7 +328,7 @@ class CoTInputs:
             "image": dict(zip(self.image_keys, images)),
             "image_mask": dict(zip(self.image_keys, masks)),
             "prompt": prompt,
-            "is_prediction_sample": False,
+            "is_prediction_sample": is_pred,
         }
         if dataset_name:
             out["dataset_name"] = dataset_name
@@ -323,9 +336,18 @@ class CoTInputs:
             out["frame_description"] = _text(data["frame_description"], default="robot base frame")
         if "actions" in data:
             out["actions"] = np.array(pad_to_dim(data["actions"], self.action_dim))
-        out["is_vqa_sample"] = False
+        out["is_vqa_sample"] = is_vqa
         out["time_horizon_seconds"] = data.get("time_horizon_seconds")
         out["vqa_dataset_id"] = data.get("vqa_dataset_id", 0)
+        if is_vqa:
+            from lap_amd.questions import VQASampleHandler
+            return VQASampleHandler(enable_diverse_questions=self.enable_diverse_questions).process(data, out)
+        if is_pred:
+            out["prompt"] = "predict the robot's action between two images in the prediction"
+            if self.enable_diverse_questions and self.question_config is not None:
+                from lap_amd.questions import PredictionSampleHandler
+                proc = la.ActionProcessor(language_action_format=self.language_action_format, random_base_prob=self.random_base_prob)
+                return PredictionSampleHandler(self.question_config, proc).process(data, out, dataset_name, data.get("rotation_applied", False))
         fmt = self.language_action_format
         if "language_actions" in data and self.enable_langact_training:
             proc = la.ActionProcessor(language_action_format=fmt, random_base_prob=self.random_base_prob)

@@ -78,6 +78,11 @@ class OracleCfg:
     language_loss_weight: float = 1.0
     action_loss_weight: float = 1.0
     stop_action_to_vlm_grad: bool = False
+    enable_vqa_training: bool = False          # lap_config.py:40-47 / lap.py:101-115
+    enable_prediction_training: bool = False
+    vqa_loss_weight: float = 0.1
+    prediction_loss_weight: float = 1.0
+    vqa_loss_weights_by_id: tuple = ()         # ((dataset id, weight), ...): lap.py:107-115 after the registry lookup
     emulate_bf16: bool = False
     # BASELINE.json config 5 (not a reference mode: lap_config.py:24 knows bfloat16 only): the VLM expert's projections
     # multiply e4m3-quantised operands (per-tensor scale 448 / amax, f32 accumulation), everything else as emulate_bf16
@@ -525,12 +530,34 @@ def compute_loss(P, cfg: OracleCfg, obs, actions, noise, time, collect=None):
     # action loss (lap.py:291-301)
     v_t = pre1[:, -cfg.action_horizon:] @ P["action_out_proj/kernel"] + P["action_out_proj/bias"]
     act_loss = torch.mean(torch.square(v_t - u_t), dim=(-1, -2))
-    # combination (lap.py:542-596), vqa/pred masks absent
-    action_term = (cfg.action_loss_weight * act_loss).sum() / B
-    if sm is not None:
-        lang_term = (cfg.language_loss_weight * lang_loss).sum() / torch.clamp(sm.to(torch.float32).sum(), min=1.0)
+    # combination (lap.py:472-596)
+    vqa = obs.get("is_vqa_sample") if cfg.enable_vqa_training else None
+    pred = obs.get("is_prediction_sample") if cfg.enable_prediction_training else None
+    smb = sm if sm is not None else torch.ones(B, dtype=torch.bool)
+    if cfg.enable_vqa_training or cfg.enable_prediction_training:
+        vqa_raw = vqa if vqa is not None else torch.zeros(B, dtype=torch.bool)
+        pred_raw = pred if pred is not None else torch.zeros(B, dtype=torch.bool)
+        lang_mask = ~(vqa_raw | pred_raw) & smb
+        vqa_mask, pred_mask = vqa_raw & smb, pred_raw & smb
+        vqa_w = torch.full((B,), cfg.vqa_loss_weight)
+        if cfg.enable_vqa_training and cfg.vqa_loss_weights_by_id and obs.get("vqa_dataset_id") is not None:
+            for did, wgt in cfg.vqa_loss_weights_by_id:
+                vqa_w = torch.where(obs["vqa_dataset_id"] == did, torch.tensor(float(wgt)), vqa_w)
+        lang_ps = vqa_w * lang_loss * vqa_mask + cfg.prediction_loss_weight * lang_loss * pred_mask + cfg.language_loss_weight * lang_loss * lang_mask
+        act_mask = ~vqa_mask & ~pred_mask
     else:
-        lang_term = (cfg.language_loss_weight * lang_loss).mean()
+        lang_ps = cfg.language_loss_weight * lang_loss
+        act_mask = torch.ones(B, dtype=torch.bool)
+        if vqa is not None:
+            act_mask = act_mask & ~vqa
+        if pred is not None:
+            act_mask = act_mask & ~pred
+    amf = act_mask.to(torch.float32)
+    action_term = (cfg.action_loss_weight * act_loss * amf).sum() / torch.clamp(amf.sum(), min=1.0)
+    if sm is not None:
+        lang_term = lang_ps.sum() / torch.clamp(sm.to(torch.float32).sum(), min=1.0)
+    else:
+        lang_term = lang_ps.mean()
     loss = lang_term + action_term
     metrics = {"lang_loss": lang_loss.mean(), "action_loss": act_loss.mean(), "per_sample_lang": lang_loss,
                "per_sample_action": act_loss, "v_t": v_t, "u_t": u_t}

@@ -3,7 +3,7 @@ import dataclasses
 
 import torch
 
-from lap_amd.config import get_config
+from lap_amd.config import VQA_DATASET_ID_MAP, get_config
 from oracle import lap_oracle as O
 
 
@@ -13,7 +13,11 @@ def oracle_cfg(model_cfg, **kw) -> O.OracleCfg:
                        action_horizon=model_cfg.action_horizon, max_token_len=model_cfg.max_token_len,
                        image_size=model_cfg.image_size, image_keys=model_cfg.image_keys, vocab_size=model_cfg.vocab_size,
                        language_loss_weight=model_cfg.language_loss_weight, action_loss_weight=model_cfg.action_loss_weight,
-                       stop_action_to_vlm_grad=model_cfg.stop_action_to_vlm_grad, **kw)
+                       stop_action_to_vlm_grad=model_cfg.stop_action_to_vlm_grad,
+                       enable_vqa_training=model_cfg.enable_vqa_training, enable_prediction_training=model_cfg.enable_prediction_training,
+                       vqa_loss_weight=model_cfg.vqa_loss_weight, prediction_loss_weight=model_cfg.prediction_loss_weight,
+                       vqa_loss_weights_by_id=tuple((VQA_DATASET_ID_MAP[k], v) for k, v in (model_cfg.vqa_loss_weights or {}).items()
+                                                    if k in VQA_DATASET_ID_MAP), **kw)
 
 
 def debug_model_cfg(**kw):
@@ -56,7 +60,10 @@ def to_observation(obs, device):
                           state=obs["state"].to(device), tokenized_prompt=obs["tokenized_prompt"].to(torch.int32).to(device),
                           tokenized_prompt_mask=obs["tokenized_prompt_mask"].to(device),
                           tokenized_langact_mask=obs["tokenized_langact_mask"].to(device) if obs.get("tokenized_langact_mask") is not None else None,
-                          token_loss_mask=obs["token_loss_mask"].to(device), sample_mask=obs["sample_mask"].to(device))
+                          token_loss_mask=obs["token_loss_mask"].to(device), sample_mask=obs["sample_mask"].to(device),
+                          is_vqa_sample=obs["is_vqa_sample"].to(device) if obs.get("is_vqa_sample") is not None else None,
+                          is_prediction_sample=obs["is_prediction_sample"].to(device) if obs.get("is_prediction_sample") is not None else None,
+                          vqa_dataset_id=obs["vqa_dataset_id"].to(device) if obs.get("vqa_dataset_id") is not None else None)
 
 
 def rel(a, b):

@@ -511,3 +511,46 @@ def test_fp8_gemm_path_matches_fp8_emulating_oracle(hip, monkeypatch):
     assert l16.item() != loss.item()
     with pytest.raises(ValueError, match="multiples of 128"):
         LAP(debug_model_cfg(), seed=0, device=DEV, gemm_dtype="fp8")
+
+
+def test_vqa_and_prediction_loss_mixing_matches_oracle(hip):
+    """lap.py:401-413,472-596: VQA / prediction samples carry their own language-loss weights (per-dataset VQA weights through
+    the registry ids) and are excluded from the action loss, whose normaliser becomes the number of action samples; idle
+    samples (`sample_mask` False) drop out of every language term.  Loss, per-kind metrics and every gradient vs the oracle."""
+    cfg = debug_model_cfg(enable_vqa_training=True, enable_prediction_training=True, vqa_loss_weight=0.1, prediction_loss_weight=0.7,
+                          vqa_loss_weights={"lvis": 0.3, "not_registered": 9.0})
+    oc = oracle_cfg(cfg)
+    P = O.init_params(oc, seed=23)
+    B = 6
+    obs, actions, noise, time = make_inputs(cfg, B=B, ragged=True)
+    obs["is_vqa_sample"] = torch.tensor([True, False, False, True, False, True])
+    obs["is_prediction_sample"] = torch.tensor([False, False, True, False, False, False])
+    obs["vqa_dataset_id"] = torch.tensor([2, 0, 0, 7, 0, 2])                # lvis, -, -, vqa, -, lvis
+    obs["sample_mask"] = torch.tensor([True, False, True, True, True, False])   # an idle robot sample and an idle VQA sample
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss32, m32 = O.compute_loss(Pg, oc, obs, actions, noise, time)
+    loss32.backward()
+    loss16, _ = O.compute_loss(P, dataclasses.replace(oc, emulate_bf16=True), obs, actions, noise, time)
+    model = _engine(cfg, P)
+    for g in model.ps.grad.values():
+        g.zero_()
+    loss, metrics = model.loss_and_grad(0, to_observation(obs, DEV), actions.to(DEV), noise=noise.to(DEV), time=time.to(DEV))
+    torch.cuda.synchronize()
+    ref_noise = abs(loss16.item() - loss32.item()) / abs(loss32.item())
+    assert abs(loss.item() - loss32.item()) / abs(loss32.item()) < max(3 * ref_noise, 5e-3), (loss.item(), loss32.item(), loss16.item())
+    # the same inputs without the sample kinds give a different loss (the switch does something)
+    plain = debug_model_cfg()
+    l0, _ = _engine(plain, P).compute_loss(0, to_observation(obs, DEV), actions.to(DEV), noise=noise.to(DEV), time=time.to(DEV))
+    assert abs(l0.item() - loss.item()) > 1e-2
+    # per-kind bookkeeping (metrics.py:49-56): 2 active VQA samples, 1 prediction sample, 1 language-action sample of 4 active
+    assert metrics["vqa_num_samples"].item() == 2 and metrics["pred_num_samples"].item() == 1 and metrics["langact_num_samples"].item() == 1
+    assert metrics["active_num_samples"].item() == 4 and abs(metrics["vqa_sample_portion"].item() - 0.5) < 1e-6
+    pl = m32["per_sample_lang"]
+    assert abs(metrics["vqa_loss"].item() - (pl[0] + pl[3]).item() / 2) < 2e-2 * abs((pl[0] + pl[3]).item() / 2) + 1e-3
+    from lap_amd.params import engine_to_reference
+
+    gref = engine_to_reference(cfg, {name: model.ps.g(name).detach().float().cpu() for name in model.ps.names()})
+    for k, v in Pg.items():
+        if v.grad is None:
+            continue
+        assert rel(gref[k], v.grad) < 5e-2 or (gref[k] - v.grad).abs().max() < 1e-4, (k, rel(gref[k], v.grad))

@@ -141,8 +141,8 @@ def test_input_and_output_stacks(tiny_tokenizer):
                                                          "state": np.zeros(8)}, "prompt": "a@b@fold the towel", "dataset_name": b"r1_lite_x",
                                        "actions": np.ones((4, 7))})
     assert o3["prompt"] == "fold the towel" and o3["image_mask"]["left_wrist_0_rgb"] and o3["actions"].shape == (4, 32)
-    with pytest.raises(NotImplementedError):
-        pio.CoTInputs(action_dim=32)({"observation": {"state": np.zeros(8)}, "prompt": "x", "is_vqa_sample": True})
+    v = pio.CoTInputs(action_dim=32)({"observation": {"state": np.zeros(8)}, "prompt": "x", "is_vqa_sample": True})   # VQA sample without caption
+    assert v["language_actions"] == "" and v["sample_mask"] is True and v["is_vqa_sample"]
     # outputs: model-space action chunk [50, 32] -> client units on the 7 recorded dimensions, rest untouched
     acts = rs.uniform(-1, 1, (50, 32))
     res = pio.compose([pio.Unnormalize(stats, "bounds_q99"), pio.CoTOutputs()])({"state": out["state"], "actions": acts})
