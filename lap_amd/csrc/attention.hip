@@ -307,27 +307,39 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(AttnP p) {
 }
 
 // ====================================================================== delta = rowsum(dO * O)
+// 16 lanes per (b, t, h) row (a wave covers 4 rows: head size 72 keeps 9 of 16 lanes busy instead of 9 of 64; head size
+// 256 has two 16-byte loads per tensor and lane in flight); the rows of one token are contiguous, so a wave reads
+// 4 * HD * 2 contiguous bytes per tensor.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int l16 = lane & 15;
   const int Tq = p.qlen[0] + p.qlen[1];
-  const long long item = (long long)blockIdx.x * 4 + w;     // (b, t, h)
-  if (item >= (long long)p.B * Tq * p.NH) return;
-  const int h = (int)(item % p.NH);
-  const int t = (int)((item / p.NH) % Tq);
-  const int b = (int)(item / ((long long)p.NH * Tq));
+  const long long item = ((long long)blockIdx.x * 4 + w) * 4 + (lane >> 4);     // (b, t, h)
+  const bool live = item < (long long)p.B * Tq * p.NH;
+  const long long it = live ? item : 0;
+  const int h = (int)(it % p.NH);
+  const int t = (int)((it / p.NH) % Tq);
+  const int b = (int)(it / ((long long)p.NH * Tq));
   const int seg = t >= p.qlen[0];
   const int tt = seg ? t - p.qlen[0] : t;
   const long long off = (b * (long long)p.qlen[seg] + tt) * p.o_rs[seg] + h * HD;
   float acc = 0.f;
-  for (int c = lane * 8; c < HD; c += 512) {
-    bf16x8 a = *reinterpret_cast<const bf16x8*>(p.o[seg] + off + c);
-    bf16x8 d = *reinterpret_cast<const bf16x8*>(p.d_o[seg] + off + c);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)d[e];
+  for (int c0 = 0; c0 < HD; c0 += 128) {
+    const int c = c0 + l16 * 8;
+    if (c < HD) {
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(p.o[seg] + off + c);
+      bf16x8 d = *reinterpret_cast<const bf16x8*>(p.d_o[seg] + off + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)d[e];
+    }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) p.delta[((long long)b * p.NH + h) * Tq + t] = acc;
+  acc += __shfl_xor(acc, 8, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 1, 64);
+  if (l16 == 0 && live) p.delta[((long long)b * p.NH + h) * Tq + t] = acc;
 }
 
 // ======================================================================== backward: dK, dV
@@ -652,7 +664,7 @@ int launch_bwd(const AttnP& p, hipStream_t s) {
   const int Tq = p.qlen[0] + p.qlen[1];
   const int lds = 2 * Cfg<HD>::TILE + 1024;   // + staged info words / lse / delta
   const long long items = (long long)p.B * Tq * p.NH;
-  hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, s, p);
   LAP_CHECK_LAUNCH();
   const int ntk = (p.klen[0] + 63) / 64 + (p.klen[1] + 63) / 64;
   bool kv_dma = false;

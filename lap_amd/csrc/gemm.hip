@@ -1381,7 +1381,7 @@ int pick_tile(int M, int N, int K) {
 
 // Automatic two-phase split-K (only when the caller lends scratch): fills the last round of a poorly filled
 // 256x256 grid, or spreads a GEMM with a handful of output tiles (skinny-M serving, small weights) over the chip.
-int pick_ksplit(int tile, int M, int N, int K, long long scratch_bytes) {
+int pick_ksplit(int tile, int M, int N, int K, long long scratch_bytes, bool fwd_layout) {
   const long long cap = scratch_bytes / ((long long)M * N * 4);
   if (cap < 2) return 1;
   if (tile == 5 || tile == 8) {
@@ -1399,12 +1399,16 @@ int pick_ksplit(int tile, int M, int N, int K, long long scratch_bytes) {
   }
   if (tile == 6 || tile == 0) {
     const long long t6 = (long long)((M + 127) / 128) * ((N + 127) / 128);
-    if (t6 > (M <= 1024 ? 256 : 96) || K < 1024) return 1;   // (the wider window is tuned on the serving shapes only)
+    // windows tuned per regime (tools/gemm_sweep.py): the serving prefill (forward layout, M <= 1024) splits up to 256
+    // tiles; the train step's action-expert GEMMs (M = 1600: 104 tiles walking K = 2048 .. 8192) up to 128
+    const bool serving = fwd_layout && M <= 1024;
+    if (t6 > (serving ? 256 : 128) || K < 1024) return 1;
     // Few tiles (serving prefill at M ~ 512, small weights): a 128x128 block that walks all of K loads 512 * K bytes through
     // ONE CU's vector-memory path (~45 GB/s, tools/bench_skinny.py) — 22 us at K = 2048 whatever the MFMA rate.  Splitting K
     // until the chip holds two blocks per CU shortens that chain; the reduce pass costs ~5 us + the slab traffic.
     long long sp = (t6 > 96 ? 512 : 256) / t6;
     if (sp > K / 256) sp = K / 256;
+    if (!serving && t6 > 96 && sp > K / 1024) sp = K / 1024;
     if (sp > 16) sp = 16;
     if (sp > cap) sp = cap;
     return sp < 2 ? 1 : (int)sp;
@@ -1485,7 +1489,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
       else if (sp >= 2) { tail_tiles = tail; tail_sp = sp; }
     }
   }
-  if (ksplit == 0 && scratch != nullptr && !tail_tiles) ksplit = pick_ksplit(tile, M, N, K, scratch_bytes);
+  if (ksplit == 0 && scratch != nullptr && !tail_tiles) ksplit = pick_ksplit(tile, M, N, K, scratch_bytes, a_kc && b_kc);
   // K % 64 == 0: the software-pipelined 8-wave kernel (tile 10) for the forward layout, the ping-pong kernel (tile 12) as
   // soon as an operand is M-contiguous (data / weight gradients: +5-11 % measured, tools/bench_kernels.py; on the forward
   // layout its 64-byte k-half rows cost more in LDS-DMA requests than the ping-pong gains); else the 16-wave kernel
