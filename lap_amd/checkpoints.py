@@ -250,6 +250,7 @@ def restore_state(checkpoint_manager: CheckpointManager, state, data_loader=None
     step = mngr.latest_step() if step is None else int(step)
     if step is None:
         raise FileNotFoundError(f"no committed checkpoint under {mngr.directory}")
+    state.model.ps.quiesce()     # nothing of an earlier optimizer pass may land on top of the restored values
     d = mngr.step_dir(step)
     meta = json.loads((d / "train_state" / "meta.json").read_text())
     ps = state.model.ps

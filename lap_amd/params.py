@@ -134,6 +134,7 @@ class ParamStore:
         self.version = 0                            # bumped whenever parameter values change (derived copies re-quantise)
         self.frozen: dict[str, bool] = {}           # engine tensor -> excluded from gradient / optimizer (set_frozen)
         self._train_ranges: dict[str, list] = {}    # unit -> [(a, b)] trainable ranges in unit coordinates
+        self._quiesce = None                        # set by the step pipeline (UnitPipeline.synchronize), see quiesce()
         for u in self.units:
             n = self.padded(u)
             sh = self.shard_numel(u)
@@ -279,7 +280,15 @@ class ParamStore:
             del full
         self.sync_ema_from_master()
 
+    def quiesce(self):
+        """Host-side readers / writers of the state first let the step pipeline finish: its optimizer pass is released
+        unit by unit while the next forward runs (lap_amd/fsdp.py), so after a train step part of it may not even be
+        enqueued yet.  Collective under FSDP (every rank calls the readers below together)."""
+        if self._quiesce is not None:
+            self._quiesce()
+
     def sync_ema_from_master(self):
+        self.quiesce()
         for k, e in self.ema.items():
             e.copy_(self.master[k])
 
@@ -292,6 +301,7 @@ class ParamStore:
     def load_reference_tree(self, P: dict):
         """Fill from a parameter tree in the reference's names / layouts (see module docstring and
         `reference_key_map`).  P values: torch tensors or numpy arrays."""
+        self.quiesce()
         eng = reference_to_engine(self.cfg, P)
         missing = set(self.tensor_spec) - set(eng)
         if missing:
@@ -310,6 +320,7 @@ class ParamStore:
         """Engine-layout f32 tensors (CPU) from master or EMA; all-gathers shards when world_size > 1."""
         import torch.distributed as dist
 
+        self.quiesce()
         src = self.master if which == "master" else self.ema
         out = {}
         for u in self.units:

@@ -77,7 +77,7 @@ def _worker(rank, world, port, ret):
 def test_fsdp_world2_gloo():
     world = 2
     port = 29500 + os.getpid() % 500
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()   # (a forked manager next to an initialised HIP runtime is not safe)
     ret = mgr.dict()
     procs = [mp.get_context("spawn").Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
@@ -178,7 +178,7 @@ def test_checkpoint_round_trip_single(tmp_path):
 def test_checkpoint_round_trip_world2_gloo(tmp_path):
     world = 2
     port = 30100 + os.getpid() % 500
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()   # (a forked manager next to an initialised HIP runtime is not safe)
     ret = mgr.dict()
     procs = [mp.get_context("spawn").Process(target=_ckpt_worker, args=(r, world, port, ret, str(tmp_path / "ck"))) for r in range(world)]
     for p in procs:

@@ -65,7 +65,7 @@ def test_two_rank_step_equals_single_rank(hip):
 
     world = 2
     port = 29600 + os.getpid() % 300
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()   # (a forked manager next to an initialised HIP runtime is not safe)
     ret = mgr.dict()
     procs = [mp.get_context("spawn").Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
@@ -158,7 +158,7 @@ def test_rccl_backend_executes_with_world_size_one(hip):
     all_gather_into_tensor in place and through the two-buffer fallback, all_reduce) runs here at least in its
     degenerate world_size-1 form on the real "nccl" backend, plus a train step over that process group."""
     port = 29950 + os.getpid() % 40
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()   # (a forked manager next to an initialised HIP runtime is not safe)
     ret = mgr.dict()
     p = mp.get_context("spawn").Process(target=_rccl_worker, args=(port, ret))
     p.start()

@@ -209,7 +209,7 @@ def _w2(rank, world, port, ret, tmp, mode):
 def _run2(tmp, mode):
     world = 2
     port = 30700 + os.getpid() % 400
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()   # (a forked manager next to an initialised HIP runtime is not safe)
     ret = mgr.dict()
     procs = [mp.get_context("spawn").Process(target=_w2, args=(r, world, port, ret, str(tmp), mode)) for r in range(world)]
     for p in procs:
