@@ -2,6 +2,7 @@
 // (lap.py:221-260 materialises them), the fused clip + AdamW + EMA + bf16
 // refresh step (scripts/train.py:363-396 with optax.chain(clip_by_global_norm,
 // adamw)), and the global-norm reduction (optax.global_norm).  All HBM-bound.
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/lap_hip.h"
 
@@ -301,7 +302,7 @@ extern "C" int lap_adamw_ema(float* p, float* m, float* v, float* ema, const flo
                              const float* scalars, float b1, float b2, float eps, float wd, float max_norm,
                              void* stream) {
   if (n <= 0 || (n & 1) || !scalars) return LAP_ERR_ARG;
-  const long long cap = 4096;
+  static const long long cap = getenv("LAP_ADAMW_BLOCKS") ? atoll(getenv("LAP_ADAMW_BLOCKS")) : 4096;   // tuning knob (tools/ab_bench.sh)
   const long long CH = 1LL << 29;
   for (long long o = 0; o < n; o += CH) {
     const long long cnt = n - o < CH ? n - o : CH;
