@@ -1419,6 +1419,7 @@ int pick_ksplit(int tile, int M, int N, int K, long long scratch_bytes, bool fwd
 }  // namespace
 
 static int g_gemm_dbg = 0;
+
 extern "C" int lap_gemm_set_debug(int bits) {   // ablation knob; has an effect in LAP_GEMM_EXPERIMENTAL builds only
 #ifdef LAP_GEMM_EXPERIMENTAL
   g_gemm_dbg = bits;
@@ -1445,7 +1446,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   const bool f32 = flags & LAP_GEMM_OUT_F32;
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
-  if (tile < -1 || tile > 13 || ksplit < 0) return LAP_ERR_ARG;
+  if (tile < -1 || tile > 14 || ksplit < 0) return LAP_ERR_ARG;
   // Few output tiles but a very long contraction (LM-head dgrad: 1504 x 2048 over K = 257152; prefill down
   // projection): the big tile with enough K splits to cover the chip beats the small tile walking all of K.
   if (tile < 0 && ksplit == 0 && scratch != nullptr && K >= 16384 && !(flags & LAP_GEMM_PARTIALS)) {
@@ -1457,6 +1458,25 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
       if (sp > (K + 63) / 64 / 16) sp = (K + 63) / 64 / 16;
       if (sp > cap) sp = cap;
       if (sp >= 2) { tile = 5; ksplit = (int)sp; }
+    }
+  }
+  // Plain products over whole 256-tiles (no bias / residual / GELU / accumulate / split): the hand-scheduled assembly main
+  // loop (csrc/gemm_asm_kernels.s: forward bf16, data-gradient bf16, weight-gradient f32 layouts; same accumulation order,
+  // bitwise equal) whenever its persistent rounds are well filled, or the contraction is too short for the tail split
+  // below to pay.  tile 14 forces it (tests); LAP_GEMM_NO_ASM=1 disables it (A/B runs).
+  {
+    static const bool no_asm = getenv("LAP_GEMM_NO_ASM") != nullptr;
+    const bool plain = !bias && !residual && !(flags & (LAP_GEMM_GELU | LAP_GEMM_ACCUM | LAP_GEMM_PARTIALS)) && alpha == 1.0f && ksplit <= 1 &&
+                       lap_gemm_asm_ok(a_kc, b_kc, f32, M, N, K, lda, ldb, ldc);
+    if (tile == 14) return plain ? lap_gemm_asm(A, B, C, M, N, K, lda, ldb, ldc, a_kc, b_kc, f32, stream) : LAP_ERR_ARG;
+    if (tile < 0 && plain && !no_asm) {
+      const long long t5 = (long long)(M / 256) * (N / 256);
+      const double fill = (double)t5 / (256.0 * ((t5 + 255) / 256));
+      // measured against the HIP tiles (tools/bench_asm_gemm.py bench): forward +10-17 % whenever the rounds are filled or the
+      // contraction is short; weight gradient +10 % on wide outputs (down projection: 2048 x 16384), -6 % on tall ones
+      // (gate|up: 32768 x 2048: stays on the ping-pong tile); data gradient: parity (stays on the ping-pong tile)
+      const bool win = (a_kc && b_kc) ? (fill >= 0.8 || K <= 4096) : (!a_kc && !b_kc) ? (fill >= 0.8 && N >= M) : false;
+      if (t5 >= 128 && win) return lap_gemm_asm(A, B, C, M, N, K, lda, ldb, ldc, a_kc, b_kc, f32, stream);
     }
   }
   if (tile < 0) tile = pick_tile(M, N, K);

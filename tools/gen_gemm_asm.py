@@ -1,56 +1,72 @@
-"""Generator of lap_amd/csrc/gemm_nt_asm.s: the forward-layout (A [M,K], B [N,K], both K-contiguous) bf16 GEMM main loop as
-hand-scheduled gfx950 assembly.  The HIP kernels of csrc/gemm.hip stop at 1.15-1.35 PF on this layout because hipcc
-cannot be made to keep ONE wave per SIMD fed; here the instruction stream is fixed by this script:
+"""Generator of lap_amd/csrc/gemm_asm_kernels.s: the bf16 GEMM main loop as hand-scheduled gfx950 assembly, one kernel per
+operand layout.  The HIP kernels of csrc/gemm.hip stop at 1.15-1.35 PF because hipcc cannot be made to keep ONE wave per SIMD
+fed; here the instruction stream is fixed by this script:
 
   256 x 256 x 64 tile, 4 waves (2 x 2), one per SIMD, each 128 x 128 = 8 x 8 MFMA 16x16x32 tiles in 256 AGPRs;
-  LDS: 2 stages x [A 256 rows x 128 B | B 256 rows x 128 B], 16-byte chunks XOR-swizzled with (row >> 1) & 7
-  (the same image as csrc/common.hpp kc_tile_off: ds_read_b128 conflict free), filled by LDS-DMA
-  (`buffer_load_dwordx4 ... lds`, 16 one-KiB pieces per wave and k-tile, swizzle applied to the SOURCE address);
-  two fragment register sets (k-step 0 / 1 of a k-tile): every ds_read and every DMA piece is threaded between the MFMAs
-  of the other set; one barrier per k-tile.
+  PERSISTENT blocks (one per CU): block b walks tiles t0, t0 + grid, ...; the operand stream (LDS-DMA) runs two k-tiles ahead
+  of the MFMAs and straight across tile seams, so a tile's epilogue overlaps the next tile's first fetches;
+  LDS: 2 stages x [A tile 32 KiB | B tile 32 KiB].  A K-contiguous operand tile is [256 rows][128 B], 16-byte chunks
+  XOR-swizzled with (row >> 1) & 7 and read with ds_read_b128; an M- / N-contiguous operand tile is [64 k-rows][512 B],
+  chunks XOR-swizzled with mc_swz(k) << 1 and read with ds_read_b64_tr_b16 (the images of csrc/common.hpp kc_tile_off /
+  mc_tile_off: conflict free); both are filled by `buffer_load_dwordx4 ... lds` (16 one-KiB pieces per wave and k-tile), the
+  swizzle applied to the SOURCE address;
+  two fragment register sets (k-step 0 / 1 of a k-tile): every LDS read and every DMA piece is threaded between the MFMAs of
+  the other set; one barrier per k-tile.
 
 Per k-tile kt (stage s = kt & 1):
-  P0   64 MFMA on set 0                 | 16 ds_read (kt, k-step 1) -> set 1
+  P0   64 MFMA on set 0                 | fragment reads (kt, k-step 1) -> set 1
   MID  s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier      (tile kt+1 has landed everywhere; stage s is no longer read)
-  P1   64 MFMA on set 1                 | 16 ds_read (kt+1, k-step 0) -> set 0, 16 DMA pieces of tile kt+2 -> stage s
+  P1   64 MFMA on set 1                 | fragment reads (kt+1, k-step 0) -> set 0, 16 DMA pieces of k-tile kt+2 -> stage s
 The accumulation order per output element (k-tiles ascending, k-step 0 then 1) is that of every other tile of the library,
-so results are bitwise equal.  Output: D' = B A^T per MFMA, i.e. a lane owns 4 consecutive n of one m -> 8-byte bf16 stores.
+so results are bitwise equal.  Output: D' = B A^T per MFMA, i.e. a lane owns 4 consecutive n of one m -> 8-byte (bf16) or
+16-byte (f32) stores.
 
-Constraints checked by the launcher (csrc/gemm_asm.hip): M % 256 == 0, N % 256 == 0, K % 128 == 0, lda / ldb / ldc % 8 == 0,
-bf16 output, no bias / residual / GELU / accumulate.
+Kernels: lap_gemm_asm_nt (A [M,K], B [N,K]; bf16 out: forward), lap_gemm_asm_nn (A [M,K], B [K,N]; bf16 out: data
+gradient), lap_gemm_asm_tn (A [K,M], B [K,N]; f32 out: weight gradient).  Constraints checked by the launcher
+(csrc/gemm_asm.hip): M % 256 == 0, N % 256 == 0, K % 128 == 0, K >= 256, strides % 8 == 0, no epilogue extras.
 
-Usage: python tools/gen_gemm_asm.py > lap_amd/csrc/gemm_nt_asm.s
+Usage: python tools/gen_gemm_asm.py > lap_amd/csrc/gemm_asm_kernels.s
 """
+import os
 import sys
 
 out = []
 E = out.append
 
-# ---- register map -------------------------------------------------------------------------------------------------
+
+def L(x):
+    E(("" if x.startswith(".L") else "\t") + x)
+
+
+# ---- register map (shared by the kernels) ---------------------------------------------------------------------------
 S_KARG = "s[0:1]"; S_WG = "s2"
 S_A = 4; S_B = 6            # pointers (pairs) after the kernarg load
 S_M, S_N, S_K, S_LDA, S_LDB, S_LDC, S_TN, S_MAGIC = range(12, 20)
-S_TM, S_GML, S_MAGL, S_NT, S_ONE, S_GSH, S_G = 42, 43, 44, 45, 46, 47, 48   # tiles_m, last group size + magic, tiles, ..., log2 group, grid
-S_TCUR, S_TDMA, S_DLEFT, S_NKT, S_BUMP = 50, 51, 52, 53, 54
-RCN = 92                    # C descriptor of the tile the DMA stream is already fetching   # tiles_m, size of the last (partial) group of m-tiles, magic of that size
-S_T = 20                    # s20..s35 scratch
+S_T = 20                    # s20..s35 scratch (s35: wave id)
 S_W8K = 40                  # wave * 8192: LDS byte base of this wave's DMA pieces
 S_LOOP = 41
-S_NBLK = 58
+S_TM, S_GML, S_MAGL, S_NT, S_ONE, S_GSH, S_G = 42, 43, 44, 45, 46, 47, 48
+S_TCUR, S_TDMA, S_DLEFT, S_NKT = 50, 51, 52, 53
+S_BUMPA, S_BUMPB = 54, 55   # bytes per k-tile along each operand
 S_C = 56                    # C pointer pair
 RA, RB, RC = 60, 64, 68     # buffer descriptors
 S_OFFA, S_OFFB = 72, 80     # soffset of the 8 pieces per operand
-S_CROW = 88                 # epilogue: fm * 16 * ldc * 2
+S_CROW = 88                 # epilogue: fm * 16 rows of C in bytes
+S_STEPA, S_STEPB = 89, 90   # the live values of S_BUMPA / S_BUMPB (0 once the stream is parked)
+RCN = 92                    # C descriptor of the tile the DMA stream is already fetching
+S_C16 = 96                  # 16 rows of C in bytes
 V_TID, V_LANE = 0, 1
-V_DA0, V_DA1, V_DB0, V_DB1 = 2, 3, 4, 5          # DMA lane offsets (even / odd piece)
-V_RA = {(0, 0): 6, (1, 0): 7, (0, 1): 8, (1, 1): 9}      # (k-step, stage) -> LDS read base A
-V_RB = {(0, 0): 10, (1, 0): 11, (0, 1): 12, (1, 1): 13}
-V_T = 14                    # v14, v15 scratch
-FA = {0: 16, 1: 80}         # fragment sets: A frags at FA[set] + 4 f, B frags at FB[set] + 4 f
-FB = {0: 48, 1: 112}
-V_E = 144                   # epilogue scratch v144..v151
+V_DA, V_DB = 2, 6           # DMA lane offsets: up to 4 classes of pieces per operand
+V_T = 10                    # v10, v11 scratch; v12: epilogue lane offset
+V_CO = 12
+V_RA, V_RB = 16, 32         # fragment read addresses: up to 16 per operand
+FA = {0: 48, 1: 112}        # fragment sets: A frags at FA[set] + 4 f, B frags at FB[set] + 4 f
+FB = {0: 80, 1: 144}
+V_E = 176                   # scratch v176..v191
+NVGPR = 192
 STAGE = 65536
 BOFF = 32768
+_uid = [0]
 
 
 def acc(fm, fn):
@@ -62,87 +78,6 @@ def mfma(fm, fn, st):
     return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a+3}], v[{FB[st]+4*fn}:{FB[st]+4*fn+3}], v[{FA[st]+4*fm}:{FA[st]+4*fm+3}], a[{a}:{a+3}]"
 
 
-def reads(kk, stage, st):
-    """16 ds_read_b128: fragments of k-step kk from `stage` into register set st."""
-    r = []
-    for f in range(8):
-        r.append(f"ds_read_b128 v[{FA[st]+4*f}:{FA[st]+4*f+3}], v{V_RA[(kk, stage)]} offset:{f*2048}")
-        r.append(f"ds_read_b128 v[{FB[st]+4*f}:{FB[st]+4*f+3}], v{V_RB[(kk, stage)]} offset:{f*2048}")
-    return r
-
-
-def dma(stage):
-    """16 LDS-DMA pieces of the next tile (A pieces then B pieces interleaved) into `stage`; each = [m0 write, load]."""
-    r = []
-    for j in range(8):
-        for op, (rs, soff, ve, vo, boff) in enumerate(((RA, S_OFFA, V_DA0, V_DA1, 0), (RB, S_OFFB, V_DB0, V_DB1, BOFF))):
-            lds = stage * STAGE + boff + j * 1024
-            r.append((f"s_add_u32 m0, s{S_W8K}, {lds}",
-                      f"buffer_load_dwordx4 v{vo if j & 1 else ve}, s[{rs}:{rs+3}], s{soff+j} offen lds"))
-    return r
-
-
-def bump():
-    """advance both descriptors by one k-tile (S_BUMP = 128 bytes; 0 once the stream has run out of tiles)"""
-    r = []
-    for rs in (RA, RB):
-        r += [f"s_add_u32 s{rs}, s{rs}, s{S_BUMP}", f"s_addc_u32 s{rs+1}, s{rs+1}, 0", f"s_sub_u32 s{rs+2}, s{rs+2}, s{S_BUMP}"]
-    return r
-
-
-_uid = [0]
-
-
-def setup(treg):
-    """SALU: logical tile id in s{treg} -> (tm, tn) (groups of 2^gsh m-tiles sweep n: csrc/gemm_common.hpp tile_coords), then the
-    DMA descriptors RA / RB of its operand panels and the C descriptor RCN.  Scratch s20..s34."""
-    t = S_T
-    r = [f"s_mul_hi_u32 s{t+10}, s{treg}, s{S_MAGIC}",        # group = tile / (GM tiles_n)
-         f"s_lshl_b32 s{t+11}, s{S_TN}, s{S_GSH}",
-         f"s_mul_i32 s{t+12}, s{t+10}, s{t+11}",
-         f"s_sub_u32 s{t+12}, s{treg}, s{t+12}",              # rem
-         f"s_lshl_b32 s{t+10}, s{t+10}, s{S_GSH}",            # first_m
-         f"s_lshl_b32 s{t+14}, 1, s{S_GSH}",
-         f"s_add_u32 s{t+11}, s{t+10}, s{t+14}",
-         f"s_sub_u32 s{t+14}, s{t+14}, 1",
-         f"s_lshr_b32 s{t+9}, s{t+12}, s{S_GSH}",             # full group: tn = rem >> gsh, tm = first_m + (rem & (GM - 1))
-         f"s_and_b32 s{t+8}, s{t+12}, s{t+14}",
-         f"s_mul_hi_u32 s{t+13}, s{t+12}, s{S_MAGL}",         # partial group: tn = rem / gm_last
-         f"s_mul_i32 s{t+14}, s{t+12}, s{S_ONE}",
-         f"s_add_u32 s{t+13}, s{t+13}, s{t+14}",
-         f"s_mul_i32 s{t+14}, s{t+13}, s{S_GML}",
-         f"s_sub_u32 s{t+14}, s{t+12}, s{t+14}",
-         f"s_cmp_le_u32 s{t+11}, s{S_TM}",
-         f"s_cselect_b32 s{t+9}, s{t+9}, s{t+13}",
-         f"s_cselect_b32 s{t+8}, s{t+8}, s{t+14}",
-         f"s_add_u32 s{t+8}, s{t+8}, s{t+10}",                # tm
-         f"s_lshl_b32 s{t+8}, s{t+8}, 8",                     # m0
-         f"s_lshl_b32 s{t+9}, s{t+9}, 8"]                     # n0
-    for rs, ptr, row0, ld in ((RA, S_A, t + 8, S_LDA), (RB, S_B, t + 9, S_LDB)):
-        r += [f"s_mul_i32 s{t+10}, s{row0}, s{ld}", f"s_mul_hi_u32 s{t+11}, s{row0}, s{ld}",
-              f"s_add_u32 s{rs}, s{ptr}, s{t+10}", f"s_addc_u32 s{rs+1}, s{ptr+1}, s{t+11}", f"s_and_b32 s{rs+1}, s{rs+1}, 0xffff",
-              f"s_mul_i32 s{rs+2}, s{ld}, 255", f"s_add_u32 s{rs+2}, s{rs+2}, s{S_K}"]
-    r += [f"s_mul_i32 s{t+10}, s{t+8}, s{S_LDC}", f"s_mul_hi_u32 s{t+11}, s{t+8}, s{S_LDC}", f"s_lshl_b32 s{t+12}, s{t+9}, 1",
-          f"s_add_u32 s{t+10}, s{t+10}, s{t+12}", f"s_addc_u32 s{t+11}, s{t+11}, 0",
-          f"s_add_u32 s{RCN}, s{S_C}, s{t+10}", f"s_addc_u32 s{RCN+1}, s{S_C+1}, s{t+11}", f"s_and_b32 s{RCN+1}, s{RCN+1}, 0xffff"]
-    return r
-
-
-def stream_step():
-    """after a k-tile's DMA pieces: advance the descriptors; when the tile's last k-tile is requested, move the stream on to
-    this block's next tile (or park it: every further request then falls outside the range and fetches zeros)"""
-    _uid[0] += 1
-    u = _uid[0]
-    r = bump()
-    r += [f"s_sub_u32 s{S_DLEFT}, s{S_DLEFT}, 1", f"s_cmp_lg_u32 s{S_DLEFT}, 0", f"s_cbranch_scc1 .Lstream_done{u}",
-          f"s_add_u32 s{S_TDMA}, s{S_TDMA}, s{S_G}", f"s_cmp_lt_u32 s{S_TDMA}, s{S_NT}", f"s_cbranch_scc0 .Lstream_park{u}"]
-    r += setup(S_TDMA)
-    r += [f"s_mov_b32 s{S_DLEFT}, s{S_NKT}", f"s_branch .Lstream_done{u}", f".Lstream_park{u}:",
-          f"s_mov_b32 s{RA+2}, 0", f"s_mov_b32 s{RB+2}, 0", f"s_mov_b32 s{S_BUMP}, 0", f"s_mov_b32 s{S_DLEFT}, 0x7fffffff",
-          f".Lstream_done{u}:"]
-    return r
-
-
 def order():
     """MFMA order of a k-step: serpentine over (fm, fn) so consecutive instructions share one operand."""
     o = []
@@ -152,217 +87,359 @@ def order():
     return o
 
 
-def phase(st, side):
-    """64 MFMAs of register set st with the side instructions threaded in: side = list of (slot, text)."""
-    byslot = {}
-    for slot, txt in side:
-        byslot.setdefault(slot, []).append(txt)
-    for n, (fm, fn) in enumerate(order()):
-        E("\t" + mfma(fm, fn, st))
-        for txt in byslot.get(n, []):
-            E(("" if txt.startswith(".L") else "\t") + txt)
+class Kernel:
+    def __init__(self, name, a_kc, b_kc, out_f32):
+        self.name, self.kc, self.f32 = name, (a_kc, b_kc), out_f32
 
+    # ---- fragment reads of k-step kk from `stage` into register set st
+    def reads(self, kk, stage, st):
+        per = []
+        for op, (F, VR) in enumerate(((FA, V_RA), (FB, V_RB))):
+            ops = []
+            for f in range(8):
+                d = F[st] + 4 * f
+                if self.kc[op]:     # address registers: VR + 2 * stage + kk; fragment f: + 2048 f
+                    ops.append([f"ds_read_b128 v[{d}:{d+3}], v{VR + 2*stage + kk} offset:{f*2048}"])
+                else:               # address registers: VR + 8 * stage + f; k-step: + 16384 kk; second half: k-row + 4
+                    ops.append([f"ds_read_b64_tr_b16 v[{d}:{d+1}], v{VR + 8*stage + f} offset:{kk*16384}",
+                                f"ds_read_b64_tr_b16 v[{d+2}:{d+3}], v{VR + 8*stage + f} offset:{kk*16384 + 2048}"])
+            per.append(ops)
+        r = []
+        for f in range(8):
+            r += per[0][f] + per[1][f]
+        return r
 
-def ktile(stage):
-    # P0: reads of k-step 1 under the first half of the MFMAs
-    side = [(2 * n, t) for n, t in enumerate(reads(1, stage, 1))]
-    phase(0, side)
-    E("\ts_waitcnt vmcnt(0) lgkmcnt(0)")
-    E("\ts_barrier")
-    # P1: reads of the next tile's k-step 0 early, the 16 DMA pieces spread over the phase, descriptor bump at the end
-    side = [(2 * n, t) for n, t in enumerate(reads(0, stage ^ 1, 0))]
-    for n, (m0w, ld) in enumerate(dma(stage)):
-        side.append((4 * n + 1, m0w))
-        side.append((4 * n + 2, ld))
-    for n, t in enumerate(stream_step()):
-        side.append((63, t))
-    phase(1, side)
-    E("\ts_waitcnt lgkmcnt(0)")
+    def dma(self, stage):
+        """16 LDS-DMA pieces of the stream's next k-tile into `stage`; each = (m0 write, load)."""
+        r = []
+        for j in range(8):
+            for op, (rs, soff, vd, boff) in enumerate(((RA, S_OFFA, V_DA, 0), (RB, S_OFFB, V_DB, BOFF))):
+                cls = (j & 1) if self.kc[op] else ((j & 1) + 2 * ((j >> 2) & 1))
+                lds = stage * STAGE + boff + j * 1024
+                r.append((f"s_add_u32 m0, s{S_W8K}, {lds}", f"buffer_load_dwordx4 v{vd + cls}, s[{rs}:{rs+3}], s{soff+j} offen lds"))
+        return r
 
+    def bump(self):
+        r = []
+        for rs, step in ((RA, S_STEPA), (RB, S_STEPB)):
+            r += [f"s_add_u32 s{rs}, s{rs}, s{step}", f"s_addc_u32 s{rs+1}, s{rs+1}, 0", f"s_sub_u32 s{rs+2}, s{rs+2}, s{step}",
+                  f"s_max_i32 s{rs+2}, s{rs+2}, 0"]
+        return r
 
+    def setup(self, treg):
+        """SALU: logical tile id in s{treg} -> (tm, tn) (groups of 2^gsh m-tiles sweep n: csrc/gemm_common.hpp tile_coords),
+        then the DMA descriptors RA / RB of its operand panels and the C descriptor RCN.  Scratch s20..s34."""
+        t = S_T
+        r = [f"s_mul_hi_u32 s{t+10}, s{treg}, s{S_MAGIC}",        # group = tile / (GM tiles_n)
+             f"s_lshl_b32 s{t+11}, s{S_TN}, s{S_GSH}",
+             f"s_mul_i32 s{t+12}, s{t+10}, s{t+11}",
+             f"s_sub_u32 s{t+12}, s{treg}, s{t+12}",              # rem
+             f"s_lshl_b32 s{t+10}, s{t+10}, s{S_GSH}",            # first_m
+             f"s_lshl_b32 s{t+14}, 1, s{S_GSH}",
+             f"s_add_u32 s{t+11}, s{t+10}, s{t+14}",
+             f"s_sub_u32 s{t+14}, s{t+14}, 1",
+             f"s_lshr_b32 s{t+9}, s{t+12}, s{S_GSH}",             # full group: tn = rem >> gsh, tm = first_m + (rem & (GM - 1))
+             f"s_and_b32 s{t+8}, s{t+12}, s{t+14}",
+             f"s_mul_hi_u32 s{t+13}, s{t+12}, s{S_MAGL}",         # partial group: tn = rem / gm_last
+             f"s_mul_i32 s{t+14}, s{t+12}, s{S_ONE}",
+             f"s_add_u32 s{t+13}, s{t+13}, s{t+14}",
+             f"s_mul_i32 s{t+14}, s{t+13}, s{S_GML}",
+             f"s_sub_u32 s{t+14}, s{t+12}, s{t+14}",
+             f"s_cmp_le_u32 s{t+11}, s{S_TM}",
+             f"s_cselect_b32 s{t+9}, s{t+9}, s{t+13}",
+             f"s_cselect_b32 s{t+8}, s{t+8}, s{t+14}",
+             f"s_add_u32 s{t+8}, s{t+8}, s{t+10}",                # tm
+             f"s_lshl_b32 s{t+8}, s{t+8}, 8",                     # m0
+             f"s_lshl_b32 s{t+9}, s{t+9}, 8"]                     # n0
+        for op, (rs, ptr, row0, ld) in enumerate(((RA, S_A, t + 8, S_LDA), (RB, S_B, t + 9, S_LDB))):
+            if self.kc[op]:     # panel rows row0 .. row0 + 255, all of K: base + row0 * ld; range 255 ld + K bytes
+                r += [f"s_mul_i32 s{t+10}, s{row0}, s{ld}", f"s_mul_hi_u32 s{t+11}, s{row0}, s{ld}",
+                      f"s_add_u32 s{rs}, s{ptr}, s{t+10}", f"s_addc_u32 s{rs+1}, s{ptr+1}, s{t+11}", f"s_and_b32 s{rs+1}, s{rs+1}, 0xffff",
+                      f"s_mul_i32 s{rs+2}, s{ld}, 255", f"s_add_u32 s{rs+2}, s{rs+2}, s{S_K}"]
+            else:               # panel columns row0 .. row0 + 255 of all K rows: base + row0 * 2; range (K - 1) ld + 512 bytes
+                r += [f"s_lshl_b32 s{t+10}, s{row0}, 1",
+                      f"s_add_u32 s{rs}, s{ptr}, s{t+10}", f"s_addc_u32 s{rs+1}, s{ptr+1}, 0", f"s_and_b32 s{rs+1}, s{rs+1}, 0xffff",
+                      f"s_lshr_b32 s{t+10}, s{S_K}, 1", f"s_sub_u32 s{t+10}, s{t+10}, 1",
+                      f"s_mul_i32 s{rs+2}, s{t+10}, s{ld}", f"s_add_u32 s{rs+2}, s{rs+2}, 512"]
+        sh = 2 if self.f32 else 1
+        r += [f"s_mul_i32 s{t+10}, s{t+8}, s{S_LDC}", f"s_mul_hi_u32 s{t+11}, s{t+8}, s{S_LDC}", f"s_lshl_b32 s{t+12}, s{t+9}, {sh}",
+              f"s_add_u32 s{t+10}, s{t+10}, s{t+12}", f"s_addc_u32 s{t+11}, s{t+11}, 0",
+              f"s_add_u32 s{RCN}, s{S_C}, s{t+10}", f"s_addc_u32 s{RCN+1}, s{S_C+1}, s{t+11}", f"s_and_b32 s{RCN+1}, s{RCN+1}, 0xffff"]
+        return r
 
-def L(x):
-    E(("" if x.startswith(".L") else "\t") + x)
+    def stream_step(self):
+        """after a k-tile's DMA pieces: advance the descriptors; when the tile's last k-tile has been requested, move the
+        stream on to this block's next tile (or park it: every further request then falls outside the range: zero fill)"""
+        _uid[0] += 1
+        u = _uid[0]
+        r = self.bump()
+        r += [f"s_sub_u32 s{S_DLEFT}, s{S_DLEFT}, 1", f"s_cmp_lg_u32 s{S_DLEFT}, 0", f"s_cbranch_scc1 .Lstream_done{u}",
+              f"s_add_u32 s{S_TDMA}, s{S_TDMA}, s{S_G}", f"s_cmp_lt_u32 s{S_TDMA}, s{S_NT}", f"s_cbranch_scc0 .Lstream_park{u}"]
+        r += self.setup(S_TDMA)
+        r += [f"s_mov_b32 s{S_DLEFT}, s{S_NKT}", f"s_branch .Lstream_done{u}", f".Lstream_park{u}:",
+              f"s_mov_b32 s{RA+2}, 0", f"s_mov_b32 s{RB+2}, 0", f"s_mov_b32 s{S_STEPA}, 0", f"s_mov_b32 s{S_STEPB}, 0",
+              f"s_mov_b32 s{S_DLEFT}, 0x7fffffff", f".Lstream_done{u}:"]
+        return r
 
+    def phase(self, st, side):
+        """64 MFMAs of register set st with the side instructions threaded in: side = list of (slot, text)."""
+        byslot = {}
+        for slot, txt in side:
+            byslot.setdefault(slot, []).append(txt)
+        for n, (fm, fn) in enumerate(order()):
+            E("\t" + mfma(fm, fn, st))
+            for txt in byslot.get(n, []):
+                L(txt)
 
-E('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
-E("\t.amdhsa_code_object_version 6")
-E("\t.text")
-E("\t.protected\tlap_gemm_nt_asm_kernel")
-E("\t.globl\tlap_gemm_nt_asm_kernel")
-E("\t.p2align\t8")
-E("\t.type\tlap_gemm_nt_asm_kernel,@function")
-E("lap_gemm_nt_asm_kernel:")
-# ---- arguments (csrc/gemm_asm.hip AsmArgs): A B C | M N K lda ldb ldc tiles_n magic_group | tiles_m gm_last magic_last ntiles |
-#      last_is_one gm_shift grid pad
-E(f"\ts_load_dwordx4 s[{S_A}:{S_A+3}], {S_KARG}, 0x0")
-E(f"\ts_load_dwordx2 s[{S_C}:{S_C+1}], {S_KARG}, 0x10")
-E(f"\ts_load_dwordx8 s[{S_M}:{S_M+7}], {S_KARG}, 0x18")
-E(f"\ts_load_dwordx2 s[{S_TM}:{S_TM+1}], {S_KARG}, 0x38")
-E(f"\ts_load_dwordx2 s[{S_MAGL}:{S_MAGL+1}], {S_KARG}, 0x40")
-E(f"\ts_load_dwordx2 s[{S_ONE}:{S_ONE+1}], {S_KARG}, 0x48")
-E(f"\ts_load_dword s{S_G}, {S_KARG}, 0x50")
-E(f"\tv_and_b32 v{V_LANE}, 63, v{V_TID}")
-E(f"\tv_lshrrev_b32 v{V_T}, 6, v{V_TID}")
-E("\ts_nop 1")                                           # VALU write -> v_readfirstlane of the same VGPR needs a wait state
-E(f"\tv_readfirstlane_b32 s{S_T+15}, v{V_T}")            # wave id
-E("\ts_nop 4")
-E("\ts_waitcnt lgkmcnt(0)")
-t = S_T
-W = t + 15
-# ---- this block's first tile: block b runs on XCD b % 8; the 32 blocks of an XCD take consecutive tiles of every round
-E(f"\ts_and_b32 s{t}, {S_WG}, 7")
-E(f"\ts_lshr_b32 s{t+1}, s{S_G}, 3")
-E(f"\ts_mul_i32 s{t}, s{t}, s{t+1}")
-E(f"\ts_lshr_b32 s{t+1}, {S_WG}, 3")
-E(f"\ts_add_u32 s{S_TCUR}, s{t}, s{t+1}")
-E(f"\ts_cmp_lt_u32 s{S_TCUR}, s{S_NT}")
-E("\ts_cbranch_scc1 .Lhave_work")
-E("\ts_endpgm")
-E(".Lhave_work:")
-E(f"\ts_mov_b32 s{S_TDMA}, s{S_TCUR}")
-E(f"\ts_lshl_b32 s{S_LDA}, s{S_LDA}, 1")         # leading dimensions and K in bytes from here on
-E(f"\ts_lshl_b32 s{S_LDB}, s{S_LDB}, 1")
-E(f"\ts_lshl_b32 s{S_LDC}, s{S_LDC}, 1")
-E(f"\ts_lshl_b32 s{S_K}, s{S_K}, 1")
-E(f"\ts_lshr_b32 s{S_NKT}, s{S_K}, 7")
-E(f"\ts_mov_b32 s{S_DLEFT}, s{S_NKT}")
-E(f"\ts_mov_b32 s{S_BUMP}, 128")
-for rs in (RA, RB, RC, RCN):
-    E(f"\ts_mov_b32 s{rs+3}, 0x00020000")
-E(f"\ts_mul_i32 s{RC+2}, s{S_LDC}, 255")
-E(f"\ts_add_u32 s{RC+2}, s{RC+2}, 512")
-E(f"\ts_mov_b32 s{RCN+2}, s{RC+2}")
-for x in setup(S_TDMA):
-    L(x)
-# ---- DMA: piece j of wave w covers tile rows (8w + j) * 8 .. + 7; lane l: row l >> 3, physical chunk l & 7
-E(f"\ts_lshl_b32 s{S_W8K}, s{W}, 13")
-E(f"\ts_lshl_b32 s{t+12}, s{W}, 6")              # first tile row of the wave's pieces
-for soff, ld in ((S_OFFA, S_LDA), (S_OFFB, S_LDB)):
-    for j in range(8):
-        E(f"\ts_add_u32 s{t+13}, s{t+12}, {8*j}")
-        E(f"\ts_mul_i32 s{soff+j}, s{t+13}, s{ld}")
-E(f"\tv_lshrrev_b32 v{V_T}, 3, v{V_LANE}")                   # l >> 3
-E(f"\tv_lshrrev_b32 v{V_T+1}, 4, v{V_LANE}")                 # h = l >> 4  (swizzle of an even piece; odd: h ^ 4)
-E(f"\tv_and_b32 v{V_E}, 7, v{V_LANE}")                       # physical chunk
-E(f"\tv_xor_b32 v{V_E}, v{V_E}, v{V_T+1}")                   # logical chunk (even piece)
-E(f"\tv_xor_b32 v{V_E+1}, 4, v{V_E}")                        # logical chunk (odd piece)
-E(f"\tv_lshlrev_b32 v{V_E}, 4, v{V_E}")
-E(f"\tv_lshlrev_b32 v{V_E+1}, 4, v{V_E+1}")
-for ve, vo, ld in ((V_DA0, V_DA1, S_LDA), (V_DB0, V_DB1, S_LDB)):
-    E(f"\tv_mul_lo_u32 v{V_E+2}, v{V_T}, s{ld}")
-    E(f"\tv_add_u32 v{ve}, v{V_E+2}, v{V_E}")
-    E(f"\tv_add_u32 v{vo}, v{V_E+2}, v{V_E+1}")
-# ---- fragment read bases: lane (i = l & 15, g = l >> 4); A rows wm*128 + 16 f + i, B rows wn*128 + 16 f + i
-E(f"\tv_and_b32 v{V_E}, 15, v{V_LANE}")                      # i
-E(f"\tv_lshrrev_b32 v{V_E+1}, 4, v{V_LANE}")                 # g
-E(f"\tv_bfe_u32 v{V_E+2}, v{V_LANE}, 1, 3")                  # (i >> 1) & 7
-E(f"\tv_xor_b32 v{V_E+3}, v{V_E+1}, v{V_E+2}")               # chunk of k-step 0: g ^ swz
-E(f"\tv_xor_b32 v{V_E+4}, 4, v{V_E+3}")                      # chunk of k-step 1
-E(f"\tv_lshlrev_b32 v{V_E+3}, 4, v{V_E+3}")
-E(f"\tv_lshlrev_b32 v{V_E+4}, 4, v{V_E+4}")
-E(f"\tv_lshlrev_b32 v{V_E}, 7, v{V_E}")                      # i * 128
-E(f"\ts_lshr_b32 s{t+12}, s{W}, 1")                          # wm
-E(f"\ts_and_b32 s{t+13}, s{W}, 1")                           # wn
-E(f"\ts_lshl_b32 s{t+12}, s{t+12}, 14")                      # wm * 128 rows * 128 B
-E(f"\ts_lshl_b32 s{t+13}, s{t+13}, 14")
-E(f"\ts_add_u32 s{t+13}, s{t+13}, {BOFF}")
-for V, base in ((V_RA, t + 12), (V_RB, t + 13)):
-    for kk in (0, 1):
-        E(f"\tv_add_u32 v{V[(kk, 0)]}, v{V_E}, v{V_E+3+kk}")
-        E(f"\tv_add_u32 v{V[(kk, 0)]}, s{base}, v{V[(kk, 0)]}")
-        E(f"\tv_add_u32 v{V[(kk, 1)]}, {STAGE}, v{V[(kk, 0)]}")
-# ---- epilogue lane offset: m = wm*128 + fm*16 + (l & 15), n = wn*128 + fn*16 + 4 (l >> 4)   (kept in v15)
-V_CO = V_T + 1
-E(f"\tv_and_b32 v{V_E}, 15, v{V_LANE}")
-E(f"\tv_lshrrev_b32 v{V_E+1}, 4, v{V_LANE}")
-E(f"\ts_lshr_b32 s{t+12}, s{W}, 1")
-E(f"\ts_and_b32 s{t+13}, s{W}, 1")
-E(f"\ts_lshl_b32 s{t+12}, s{t+12}, 7")
-E(f"\tv_add_u32 v{V_E}, s{t+12}, v{V_E}")
-E(f"\tv_mul_lo_u32 v{V_E}, v{V_E}, s{S_LDC}")
-E(f"\tv_lshlrev_b32 v{V_E+1}, 3, v{V_E+1}")                  # 4 g * 2 bytes
-E(f"\ts_lshl_b32 s{t+13}, s{t+13}, 8")                       # wn * 128 * 2 bytes
-E(f"\tv_add_u32 v{V_E}, v{V_E}, v{V_E+1}")
-E(f"\tv_add_u32 v{V_CO}, s{t+13}, v{V_E}")
-E(f"\ts_lshl_b32 s{96}, s{S_LDC}, 4")                        # 16 rows of C in bytes
-# ---- prologue: k-tiles 0 and 1 of the first tile in flight, accumulators cleared
-for stage in (0, 1):
-    for m0w, ld in dma(stage):
-        E("\t" + m0w)
-        E("\ts_nop 0")
-        E("\t" + ld)
-    for x in stream_step():
-        L(x)
-for a in range(256):
-    E(f"\tv_accvgpr_write_b32 a{a}, 0")
-for r in range(3):
-    E(f"\ts_mov_b32 s{RC+r}, s{RCN+r}")
-E("\ts_waitcnt vmcnt(16)")
-E("\ts_barrier")
-for x in reads(0, 0, 0):
-    E("\t" + x)
-E("\ts_waitcnt lgkmcnt(0)")
-E(".Ltile:")
-E(f"\ts_lshr_b32 s{S_LOOP}, s{S_NKT}, 1")
-E(".Lloop:")
-ktile(0)
-ktile(1)
-E(f"\ts_sub_u32 s{S_LOOP}, s{S_LOOP}, 1")
-E(f"\ts_cmp_lg_u32 s{S_LOOP}, 0")
-E("\ts_cbranch_scc1 .Lloop")
-# ---- epilogue.  The stream is two k-tiles into this block's next tile (k-tile 0 landed at the last barrier, k-tile 1 is in
-# flight and is waited for, together with these stores, by the vmcnt(0) of the next tile's first barrier)
-E("\ts_nop 15")
-E("\ts_nop 15")
-E(f"\ts_mov_b32 s{S_CROW}, 0")
-tiles = [(fm, fn) for fm in range(8) for fn in range(8)]
-def rd(n, base):
-    a = acc(*tiles[n])
-    for r in range(4):
-        E(f"\tv_accvgpr_read_b32 v{base+r}, a{a+r}")
-    for r in range(4):
-        E(f"\tv_accvgpr_write_b32 a{a+r}, 0")
-rd(0, V_E)
-for n, (fm, fn) in enumerate(tiles):
-    cur = V_E + (n & 1) * 8
-    nxt = V_E + ((n + 1) & 1) * 8
-    if n + 1 < 64:
-        rd(n + 1, nxt)
-    E(f"\tv_cvt_pk_bf16_f32 v{cur+4}, v{cur}, v{cur+1}")
-    E(f"\tv_cvt_pk_bf16_f32 v{cur+5}, v{cur+2}, v{cur+3}")
-    E(f"\tbuffer_store_dwordx2 v[{cur+4}:{cur+5}], v{V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*32}")
-    if fn == 7:
-        E(f"\ts_add_u32 s{S_CROW}, s{S_CROW}, s96")
-E(f"\ts_add_u32 s{S_TCUR}, s{S_TCUR}, s{S_G}")
-E(f"\ts_cmp_lt_u32 s{S_TCUR}, s{S_NT}")
-E("\ts_cbranch_scc1 .Lnext")
-E("\ts_endpgm")
-E(".Lnext:")       # (register set 0 already holds the next tile's first fragments: the last P1 of the loop read them)
-for r in range(3):
-    E(f"\ts_mov_b32 s{RC+r}, s{RCN+r}")
-E("\ts_branch .Ltile")
-E("\t.section\t.rodata,\"a\",@progbits")
-E("\t.p2align\t6, 0x0")
-E("\t.amdhsa_kernel lap_gemm_nt_asm_kernel")
-for k, v in (("group_segment_fixed_size", 131072), ("private_segment_fixed_size", 0), ("kernarg_size", 96),
-             ("user_sgpr_count", 2), ("user_sgpr_dispatch_ptr", 0), ("user_sgpr_queue_ptr", 0), ("user_sgpr_kernarg_segment_ptr", 1),
-             ("user_sgpr_dispatch_id", 0), ("user_sgpr_kernarg_preload_length", 0), ("user_sgpr_kernarg_preload_offset", 0),
-             ("user_sgpr_private_segment_size", 0), ("uses_dynamic_stack", 0), ("enable_private_segment", 0),
-             ("system_sgpr_workgroup_id_x", 1), ("system_sgpr_workgroup_id_y", 0), ("system_sgpr_workgroup_id_z", 0),
-             ("system_sgpr_workgroup_info", 0), ("system_vgpr_workitem_id", 0), ("next_free_vgpr", 512), ("next_free_sgpr", 100),
-             ("accum_offset", 256), ("reserve_vcc", 1), ("float_round_mode_32", 0), ("float_round_mode_16_64", 0),
-             ("float_denorm_mode_32", 3), ("float_denorm_mode_16_64", 3), ("dx10_clamp", 1), ("ieee_mode", 1), ("fp16_overflow", 0),
-             ("tg_split", 0), ("exception_fp_ieee_invalid_op", 0), ("exception_fp_denorm_src", 0), ("exception_fp_ieee_div_zero", 0),
-             ("exception_fp_ieee_overflow", 0), ("exception_fp_ieee_underflow", 0), ("exception_fp_ieee_inexact", 0),
-             ("exception_int_div_zero", 0)):
-    E(f"\t\t.amdhsa_{k} {v}")
-E("\t.end_amdhsa_kernel")
-E("\t.text")
-E("""\t.amdgpu_metadata
----
-amdhsa.kernels:
-  - .agpr_count:     256
+    def ktile(self, stage):
+        RS = float(os.environ.get("ASM_RD_STRIDE", "2"))        # MFMAs between two fragment reads (K-contiguous count)
+        DS = int(os.environ.get("ASM_DMA_STRIDE", "4"))         # MFMAs between two DMA pieces
+        rd = self.reads(1, stage, 1)
+        rs = RS * 16 / len(rd)
+        self.phase(0, [(min(int(rs * n), 63), t) for n, t in enumerate(rd)])
+        E("\ts_waitcnt vmcnt(0) lgkmcnt(0)")
+        E("\ts_barrier")
+        rd = self.reads(0, stage ^ 1, 0)
+        side = [(min(int(rs * n), 63), t) for n, t in enumerate(rd)]
+        for n, (m0w, ld) in enumerate(self.dma(stage)):
+            slot = min(1 + n * DS, 62)
+            side += [(slot, m0w), (slot, "s_nop 0"), (slot, ld)]
+        side += [(63, t) for t in self.stream_step()]
+        self.phase(1, side)
+        E("\ts_waitcnt lgkmcnt(0)")
+
+    def emit(self):
+        nm = self.name
+        t = S_T
+        W = t + 15
+        E("\t.text")
+        E(f"\t.protected\t{nm}")
+        E(f"\t.globl\t{nm}")
+        E("\t.p2align\t8")
+        E(f"\t.type\t{nm},@function")
+        E(f"{nm}:")
+        # ---- arguments (csrc/gemm_asm.hip AsmArgs): A B C | M N K lda ldb ldc tiles_n magic_group | tiles_m gm_last magic_last
+        #      ntiles | last_is_one gm_shift grid pad
+        E(f"\ts_load_dwordx4 s[{S_A}:{S_A+3}], {S_KARG}, 0x0")
+        E(f"\ts_load_dwordx2 s[{S_C}:{S_C+1}], {S_KARG}, 0x10")
+        E(f"\ts_load_dwordx8 s[{S_M}:{S_M+7}], {S_KARG}, 0x18")
+        E(f"\ts_load_dwordx2 s[{S_TM}:{S_TM+1}], {S_KARG}, 0x38")
+        E(f"\ts_load_dwordx2 s[{S_MAGL}:{S_MAGL+1}], {S_KARG}, 0x40")
+        E(f"\ts_load_dwordx2 s[{S_ONE}:{S_ONE+1}], {S_KARG}, 0x48")
+        E(f"\ts_load_dword s{S_G}, {S_KARG}, 0x50")
+        E(f"\tv_and_b32 v{V_LANE}, 63, v{V_TID}")
+        E(f"\tv_lshrrev_b32 v{V_T}, 6, v{V_TID}")
+        E("\ts_nop 1")                                           # VALU write -> v_readfirstlane of the same VGPR: wait state
+        E(f"\tv_readfirstlane_b32 s{W}, v{V_T}")                 # wave id
+        E("\ts_nop 4")
+        E("\ts_waitcnt lgkmcnt(0)")
+        # ---- this block's first tile: block b runs on XCD b % 8; the blocks of an XCD take consecutive tiles of every round
+        E(f"\ts_and_b32 s{t}, {S_WG}, 7")
+        E(f"\ts_lshr_b32 s{t+1}, s{S_G}, 3")
+        E(f"\ts_mul_i32 s{t}, s{t}, s{t+1}")
+        E(f"\ts_lshr_b32 s{t+1}, {S_WG}, 3")
+        E(f"\ts_add_u32 s{S_TCUR}, s{t}, s{t+1}")
+        E(f"\ts_cmp_lt_u32 s{S_TCUR}, s{S_NT}")
+        E(f"\ts_cbranch_scc1 .Lhave_work_{nm}")
+        E("\ts_endpgm")
+        E(f".Lhave_work_{nm}:")
+        E(f"\ts_mov_b32 s{S_TDMA}, s{S_TCUR}")
+        E(f"\ts_lshl_b32 s{S_LDA}, s{S_LDA}, 1")         # leading dimensions and K in bytes from here on
+        E(f"\ts_lshl_b32 s{S_LDB}, s{S_LDB}, 1")
+        E(f"\ts_lshl_b32 s{S_LDC}, s{S_LDC}, {2 if self.f32 else 1}")
+        E(f"\ts_lshl_b32 s{S_K}, s{S_K}, 1")
+        E(f"\ts_lshr_b32 s{S_NKT}, s{S_K}, 7")
+        E(f"\ts_mov_b32 s{S_DLEFT}, s{S_NKT}")
+        for op, (bump, ld) in enumerate(((S_BUMPA, S_LDA), (S_BUMPB, S_LDB))):
+            if self.kc[op]:
+                E(f"\ts_mov_b32 s{bump}, 128")
+            else:
+                E(f"\ts_lshl_b32 s{bump}, s{ld}, 6")
+        E(f"\ts_mov_b32 s{S_STEPA}, s{S_BUMPA}")
+        E(f"\ts_mov_b32 s{S_STEPB}, s{S_BUMPB}")
+        for rs in (RA, RB, RC, RCN):
+            E(f"\ts_mov_b32 s{rs+3}, 0x00020000")
+        E(f"\ts_mul_i32 s{RC+2}, s{S_LDC}, 255")
+        E(f"\ts_add_u32 s{RC+2}, s{RC+2}, {1024 if self.f32 else 512}")
+        E(f"\ts_mov_b32 s{RCN+2}, s{RC+2}")
+        for x in self.setup(S_TDMA):
+            L(x)
+        # ---- DMA lane offsets and piece offsets
+        E(f"\ts_lshl_b32 s{S_W8K}, s{W}, 13")
+        for op, (soff, ld, vd) in enumerate(((S_OFFA, S_LDA, V_DA), (S_OFFB, S_LDB, V_DB))):
+            if self.kc[op]:
+                # piece j of wave w covers tile rows (8w + j) * 8 .. + 7; lane l: row l >> 3, physical chunk l & 7,
+                # logical chunk = physical ^ swz, swz = (row >> 1) & 7 = (l >> 4) [even piece] or (l >> 4) ^ 4 [odd piece]
+                E(f"\ts_lshl_b32 s{t+12}, s{W}, 6")
+                for j in range(8):
+                    E(f"\ts_add_u32 s{t+13}, s{t+12}, {8*j}")
+                    E(f"\ts_mul_i32 s{soff+j}, s{t+13}, s{ld}")
+                E(f"\tv_lshrrev_b32 v{V_T}, 3, v{V_LANE}")
+                E(f"\tv_lshrrev_b32 v{V_T+1}, 4, v{V_LANE}")
+                E(f"\tv_and_b32 v{V_E}, 7, v{V_LANE}")
+                E(f"\tv_xor_b32 v{V_E}, v{V_E}, v{V_T+1}")
+                E(f"\tv_xor_b32 v{V_E+1}, 4, v{V_E}")
+                E(f"\tv_lshlrev_b32 v{V_E}, 4, v{V_E}")
+                E(f"\tv_lshlrev_b32 v{V_E+1}, 4, v{V_E+1}")
+                E(f"\tv_mul_lo_u32 v{V_E+2}, v{V_T}, s{ld}")
+                E(f"\tv_add_u32 v{vd}, v{V_E+2}, v{V_E}")
+                E(f"\tv_add_u32 v{vd+1}, v{V_E+2}, v{V_E+1}")
+            else:
+                # piece j of wave w covers k-rows (8w + j) * 2 .. + 1; lane l: row hi = l >> 5, physical chunk l & 31,
+                # logical chunk = physical ^ (mc_swz(k) << 1), mc_swz(k) = (k & 3) | (((k >> 3) & 1) << 2) with
+                # k & 3 = 2 (j & 1) + hi and (k >> 3) & 1 = (j >> 2) & 1: four classes of pieces c = (j & 1) + 2 ((j >> 2) & 1)
+                E(f"\ts_lshl_b32 s{t+12}, s{W}, 4")
+                for j in range(8):
+                    E(f"\ts_add_u32 s{t+13}, s{t+12}, {2*j}")
+                    E(f"\ts_mul_i32 s{soff+j}, s{t+13}, s{ld}")
+                E(f"\tv_lshrrev_b32 v{V_T}, 5, v{V_LANE}")              # hi
+                E(f"\tv_and_b32 v{V_T+1}, 31, v{V_LANE}")               # physical chunk
+                E(f"\tv_mul_lo_u32 v{V_E+2}, v{V_T}, s{ld}")
+                for c in range(4):
+                    swz0 = 2 * (c & 1) + 4 * (c >> 1)                   # + hi
+                    E(f"\tv_add_u32 v{V_E}, {swz0}, v{V_T}")
+                    E(f"\tv_lshlrev_b32 v{V_E}, 1, v{V_E}")
+                    E(f"\tv_xor_b32 v{V_E}, v{V_E}, v{V_T+1}")
+                    E(f"\tv_lshlrev_b32 v{V_E}, 4, v{V_E}")
+                    E(f"\tv_add_u32 v{vd+c}, v{V_E+2}, v{V_E}")
+        # ---- fragment read addresses; lane (i = l & 15, g = l >> 4)
+        E(f"\ts_lshr_b32 s{t+12}, s{W}, 1")                          # wm
+        E(f"\ts_and_b32 s{t+13}, s{W}, 1")                           # wn
+        for op, (VR, wreg, boff) in enumerate(((V_RA, t + 12, 0), (V_RB, t + 13, BOFF))):
+            if self.kc[op]:
+                # rows w?*128 + 16 f + i, chunk (4 kk + g) ^ ((i >> 1) & 7): registers VR + 2 stage + kk
+                E(f"\tv_and_b32 v{V_E}, 15, v{V_LANE}")
+                E(f"\tv_lshrrev_b32 v{V_E+1}, 4, v{V_LANE}")
+                E(f"\tv_bfe_u32 v{V_E+2}, v{V_LANE}, 1, 3")
+                E(f"\tv_xor_b32 v{V_E+3}, v{V_E+1}, v{V_E+2}")
+                E(f"\tv_xor_b32 v{V_E+4}, 4, v{V_E+3}")
+                E(f"\tv_lshlrev_b32 v{V_E+3}, 4, v{V_E+3}")
+                E(f"\tv_lshlrev_b32 v{V_E+4}, 4, v{V_E+4}")
+                E(f"\tv_lshlrev_b32 v{V_E}, 7, v{V_E}")
+                E(f"\ts_lshl_b32 s{t+14}, s{wreg}, 14")
+                if boff:
+                    E(f"\ts_add_u32 s{t+14}, s{t+14}, {boff}")
+                for kk in (0, 1):
+                    E(f"\tv_add_u32 v{VR+kk}, v{V_E}, v{V_E+3+kk}")
+                    E(f"\tv_add_u32 v{VR+kk}, s{t+14}, v{VR+kk}")
+                    E(f"\tv_add_u32 v{VR+2+kk}, {STAGE}, v{VR+kk}")
+            else:
+                # k-row 8 g + (i >> 2) (+ 32 kk, + 4 for the second half), columns w?*128 + 16 f + 4 (i & 3):
+                # chunk = (16 w? + 2 f + ((i & 3) >> 1)) ^ (mc_swz << 1), mc_swz = (i >> 2) | ((g & 1) << 2); + 8 bytes if i & 1.
+                # registers VR + 8 stage + f  (f enters by XOR of f << 5)
+                E(f"\tv_and_b32 v{V_E}, 15, v{V_LANE}")                  # i
+                E(f"\tv_lshrrev_b32 v{V_E+1}, 4, v{V_LANE}")             # g
+                E(f"\tv_lshrrev_b32 v{V_E+2}, 2, v{V_E}")                # i >> 2
+                E(f"\tv_lshlrev_b32 v{V_E+3}, 3, v{V_E+1}")              # 8 g
+                E(f"\tv_add_u32 v{V_E+3}, v{V_E+3}, v{V_E+2}")           # k-row
+                E(f"\tv_lshlrev_b32 v{V_E+3}, 9, v{V_E+3}")              # * 512
+                E(f"\tv_and_b32 v{V_E+4}, 1, v{V_E+1}")                  # g & 1
+                E(f"\tv_lshlrev_b32 v{V_E+4}, 2, v{V_E+4}")
+                E(f"\tv_or_b32 v{V_E+4}, v{V_E+4}, v{V_E+2}")            # mc_swz
+                E(f"\tv_lshlrev_b32 v{V_E+4}, 1, v{V_E+4}")              # << 1
+                E(f"\tv_bfe_u32 v{V_E+5}, v{V_LANE}, 1, 1")              # (i & 3) >> 1
+                E(f"\ts_lshl_b32 s{t+14}, s{wreg}, 4")                   # 16 w?
+                E(f"\tv_or_b32 v{V_E+5}, s{t+14}, v{V_E+5}")
+                E(f"\tv_xor_b32 v{V_E+5}, v{V_E+5}, v{V_E+4}")           # chunk of f = 0
+                E(f"\tv_lshlrev_b32 v{V_E+5}, 4, v{V_E+5}")
+                E(f"\tv_and_b32 v{V_E+6}, 1, v{V_LANE}")                 # i & 1
+                E(f"\tv_lshlrev_b32 v{V_E+6}, 3, v{V_E+6}")
+                E(f"\tv_add_u32 v{V_E+5}, v{V_E+5}, v{V_E+6}")
+                E(f"\tv_add_u32 v{V_E+5}, v{V_E+5}, v{V_E+3}")
+                if boff:
+                    E(f"\tv_add_u32 v{V_E+5}, {boff}, v{V_E+5}")
+                for f in range(8):
+                    E(f"\tv_xor_b32 v{VR+f}, {f << 5}, v{V_E+5}")
+                    E(f"\tv_add_u32 v{VR+8+f}, {STAGE}, v{VR+f}")
+        # ---- epilogue lane offset: m = wm*128 + fm*16 + (l & 15), n = wn*128 + fn*16 + 4 (l >> 4)
+        E(f"\tv_and_b32 v{V_E}, 15, v{V_LANE}")
+        E(f"\tv_lshrrev_b32 v{V_E+1}, 4, v{V_LANE}")
+        E(f"\ts_lshl_b32 s{t+14}, s{t+12}, 7")
+        E(f"\tv_add_u32 v{V_E}, s{t+14}, v{V_E}")
+        E(f"\tv_mul_lo_u32 v{V_E}, v{V_E}, s{S_LDC}")
+        E(f"\tv_lshlrev_b32 v{V_E+1}, {4 if self.f32 else 3}, v{V_E+1}")      # 4 g elements in bytes
+        E(f"\ts_lshl_b32 s{t+14}, s{t+13}, {9 if self.f32 else 8}")           # wn * 128 elements in bytes
+        E(f"\tv_add_u32 v{V_E}, v{V_E}, v{V_E+1}")
+        E(f"\tv_add_u32 v{V_CO}, s{t+14}, v{V_E}")
+        E(f"\ts_lshl_b32 s{S_C16}, s{S_LDC}, 4")
+        # ---- prologue: k-tiles 0 and 1 of the first tile in flight, accumulators cleared
+        for stage in (0, 1):
+            for m0w, ld in self.dma(stage):
+                E("\t" + m0w)
+                E("\ts_nop 0")
+                E("\t" + ld)
+            for x in self.stream_step():
+                L(x)
+        for a in range(256):
+            E(f"\tv_accvgpr_write_b32 a{a}, 0")
+        for r in range(3):
+            E(f"\ts_mov_b32 s{RC+r}, s{RCN+r}")
+        E("\ts_waitcnt vmcnt(16)")
+        E("\ts_barrier")
+        for x in self.reads(0, 0, 0):
+            E("\t" + x)
+        E("\ts_waitcnt lgkmcnt(0)")
+        E(f".Ltile_{nm}:")
+        E(f"\ts_lshr_b32 s{S_LOOP}, s{S_NKT}, 1")
+        E(f".Lloop_{nm}:")
+        self.ktile(0)
+        self.ktile(1)
+        E(f"\ts_sub_u32 s{S_LOOP}, s{S_LOOP}, 1")
+        E(f"\ts_cmp_lg_u32 s{S_LOOP}, 0")
+        E(f"\ts_cbranch_scc1 .Lloop_{nm}")
+        # ---- epilogue.  The stream is two k-tiles into this block's next tile (k-tile 0 landed at the last barrier, k-tile 1
+        # is in flight and is waited for, together with these stores, by the vmcnt(0) of the next tile's first barrier)
+        E("\ts_nop 15")
+        E("\ts_nop 15")
+        E(f"\ts_mov_b32 s{S_CROW}, 0")
+        tiles = [(fm, fn) for fm in range(8) for fn in range(8)]
+
+        def rd(n, base):
+            a = acc(*tiles[n])
+            for r in range(4):
+                E(f"\tv_accvgpr_read_b32 v{base+r}, a{a+r}")
+            for r in range(4):
+                E(f"\tv_accvgpr_write_b32 a{a+r}, 0")
+        rd(0, V_E)
+        for n, (fm, fn) in enumerate(tiles):
+            cur = V_E + (n & 1) * 8
+            if n + 1 < 64:
+                rd(n + 1, V_E + ((n + 1) & 1) * 8)
+            if self.f32:
+                E(f"\tbuffer_store_dwordx4 v[{cur}:{cur+3}], v{V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*64}")
+            else:
+                E(f"\tv_cvt_pk_bf16_f32 v{cur+4}, v{cur}, v{cur+1}")
+                E(f"\tv_cvt_pk_bf16_f32 v{cur+5}, v{cur+2}, v{cur+3}")
+                E(f"\tbuffer_store_dwordx2 v[{cur+4}:{cur+5}], v{V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*32}")
+            if fn == 7:
+                E(f"\ts_add_u32 s{S_CROW}, s{S_CROW}, s{S_C16}")
+        E(f"\ts_add_u32 s{S_TCUR}, s{S_TCUR}, s{S_G}")
+        E(f"\ts_cmp_lt_u32 s{S_TCUR}, s{S_NT}")
+        E(f"\ts_cbranch_scc1 .Lnext_{nm}")
+        E("\ts_endpgm")
+        E(f".Lnext_{nm}:")     # (register set 0 already holds the next tile's first fragments: the last P1 read them)
+        for r in range(3):
+            E(f"\ts_mov_b32 s{RC+r}, s{RCN+r}")
+        E(f"\ts_branch .Ltile_{nm}")
+        E("\t.section\t.rodata,\"a\",@progbits")
+        E("\t.p2align\t6, 0x0")
+        E(f"\t.amdhsa_kernel {nm}")
+        for k, v in (("group_segment_fixed_size", 131072), ("private_segment_fixed_size", 0), ("kernarg_size", 96),
+                     ("user_sgpr_count", 2), ("user_sgpr_dispatch_ptr", 0), ("user_sgpr_queue_ptr", 0), ("user_sgpr_kernarg_segment_ptr", 1),
+                     ("user_sgpr_dispatch_id", 0), ("user_sgpr_kernarg_preload_length", 0), ("user_sgpr_kernarg_preload_offset", 0),
+                     ("user_sgpr_private_segment_size", 0), ("uses_dynamic_stack", 0), ("enable_private_segment", 0),
+                     ("system_sgpr_workgroup_id_x", 1), ("system_sgpr_workgroup_id_y", 0), ("system_sgpr_workgroup_id_z", 0),
+                     ("system_sgpr_workgroup_info", 0), ("system_vgpr_workitem_id", 0), ("next_free_vgpr", NVGPR + 256), ("next_free_sgpr", 100),
+                     ("accum_offset", NVGPR), ("reserve_vcc", 1), ("float_round_mode_32", 0), ("float_round_mode_16_64", 0),
+                     ("float_denorm_mode_32", 3), ("float_denorm_mode_16_64", 3), ("dx10_clamp", 1), ("ieee_mode", 1), ("fp16_overflow", 0),
+                     ("tg_split", 0), ("exception_fp_ieee_invalid_op", 0), ("exception_fp_denorm_src", 0), ("exception_fp_ieee_div_zero", 0),
+                     ("exception_fp_ieee_overflow", 0), ("exception_fp_ieee_underflow", 0), ("exception_fp_ieee_inexact", 0),
+                     ("exception_int_div_zero", 0)):
+            E(f"\t\t.amdhsa_{k} {v}")
+        E("\t.end_amdhsa_kernel")
+
+    def meta(self):
+        return f"""  - .agpr_count:     256
     .args:
       - .offset:         0
         .size:           96
@@ -371,21 +448,27 @@ amdhsa.kernels:
     .kernarg_segment_align: 8
     .kernarg_segment_size: 96
     .max_flat_workgroup_size: 256
-    .name:           lap_gemm_nt_asm_kernel
+    .name:           {self.name}
     .private_segment_fixed_size: 0
     .sgpr_count:     104
     .sgpr_spill_count: 0
-    .symbol:         lap_gemm_nt_asm_kernel.kd
+    .symbol:         {self.name}.kd
     .uniform_work_group_size: 1
     .uses_dynamic_stack: false
-    .vgpr_count:     512
+    .vgpr_count:     {NVGPR + 256}
     .vgpr_spill_count: 0
-    .wavefront_size: 64
-amdhsa.target:   amdgcn-amd-amdhsa--gfx950
-amdhsa.version:
-  - 1
-  - 2
-...
+    .wavefront_size: 64"""
 
-\t.end_amdgpu_metadata""")
+
+KERNELS = [Kernel("lap_gemm_asm_nt", True, True, False), Kernel("lap_gemm_asm_nn", True, False, False),
+           Kernel("lap_gemm_asm_tn", False, False, True)]
+E('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+E("\t.amdhsa_code_object_version 6")
+for k in KERNELS:
+    k.emit()
+E("\t.text")
+E("\t.amdgpu_metadata\n---\namdhsa.kernels:")
+for k in KERNELS:
+    E(k.meta())
+E("amdhsa.target:   amdgcn-amd-amdhsa--gfx950\namdhsa.version:\n  - 1\n  - 2\n...\n\n\t.end_amdgpu_metadata")
 sys.stdout.write("\n".join(out) + "\n")
