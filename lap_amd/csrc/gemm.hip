@@ -1468,6 +1468,16 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
     static const bool no_asm = getenv("LAP_GEMM_NO_ASM") != nullptr;
     const bool plain = !bias && !residual && !(flags & (LAP_GEMM_GELU | LAP_GEMM_ACCUM | LAP_GEMM_PARTIALS)) && alpha == 1.0f && ksplit <= 1 &&
                        lap_gemm_asm_ok(a_kc, b_kc, f32, M, N, K, lda, ldb, ldc);
+    // forward + f32 bias per column (Flax Dense of SigLIP: qkv, fc1), N any multiple of 16
+    const bool biased = a_kc && b_kc && !f32 && bias && (flags & LAP_GEMM_BIAS_F32) && !residual &&
+                        !(flags & (LAP_GEMM_GELU | LAP_GEMM_ACCUM | LAP_GEMM_PARTIALS)) && alpha == 1.0f && ksplit <= 1 &&
+                        lap_gemm_asm_bias_ok(M, N, K, lda, ldb, ldc) && !((uintptr_t)bias & 15);
+    if (tile == 14 && biased) return lap_gemm_asm_bias(A, B, C, (const float*)bias, M, N, K, lda, ldb, ldc, stream);
+    if (tile < 0 && biased && !no_asm) {
+      const long long t5 = (long long)(M / 256) * ((N + 255) / 256);
+      const double fill = (double)t5 / (256.0 * ((t5 + 255) / 256));
+      if (t5 >= 128 && fill >= 0.8) return lap_gemm_asm_bias(A, B, C, (const float*)bias, M, N, K, lda, ldb, ldc, stream);
+    }
     if (tile == 14) return plain ? lap_gemm_asm(A, B, C, M, N, K, lda, ldb, ldc, a_kc, b_kc, f32, stream) : LAP_ERR_ARG;
     if (tile < 0 && plain && !no_asm) {
       const long long t5 = (long long)(M / 256) * (N / 256);

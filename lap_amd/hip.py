@@ -72,6 +72,8 @@ SIGNATURES: dict[str, list] = {
     "lap_gemm_set_debug": [_i],
     "lap_gemm_asm": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_asm_ok": [_i, _i, _i, _i, _i, _i, _i, _i, _i],
+    "lap_gemm_asm_bias": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "lap_gemm_asm_bias_ok": [_i, _i, _i, _i, _i, _i],
     "lap_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "lap_amax_bf16": [_vp, _ll, _i, _ll, _vp, _vp],
     "lap_quantize_fp8": [_vp, _ll, _i, _ll, _vp, _vp, _ll, _vp, _vp],

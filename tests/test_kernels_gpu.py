@@ -164,7 +164,24 @@ def test_gemm_assembly_kernels_match_hip_tiles_bitwise(hip, lay):
     # epilogue extras are not this kernel's: asking for it explicitly is rejected, the automatic choice falls back
     with pytest.raises(hip.LapHipError):
         hip.gemm(rnd(256, 256), rnd(512, 256), torch.empty(256, 512, device=DEV, dtype=torch.bfloat16), M=256, N=512, K=256, lda=256, ldb=256,
-                 ldc=512, bias=torch.zeros(512, device=DEV), tile=14)
+                 ldc=512, residual=rnd(256, 512), ldr=512, tile=14)
+
+
+def test_gemm_assembly_bias_kernel_ragged_n_matches_hip_tiles_bitwise(hip):
+    """lap_gemm_asm_nt_bias: forward + f32 bias per column, N any multiple of 16 (SigLIP qkv N = 3456, fc1 N = 4304): the last
+    n-tile's missing rows of B read as zeros and its missing output columns are never stored."""
+    for M, N, K, pad in [(512, 528, 256, 0), (1024, 1152, 1152, 48), (2304, 4304, 384, 0), (768, 3456, 1152, 16)]:
+        a = rnd(M, K + pad, seed=1)[:, :K]
+        b = rnd(N, K, seed=2)
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(DEV)
+        outs = []
+        for tile in (10, 14):
+            out = torch.full((M, N + pad), 3.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm(a, b, out, M=M, N=N, K=K, lda=a.stride(0), ldb=K, ldc=N + pad, bias=bias, tile=tile, ksplit=1)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), (M, N, K)
+        assert (outs[1][:, N:] == 3.0).all()
+        assert rel_err(outs[1][:, :N], a.float() @ b.float().t() + bias) < 5e-3
 
 
 def test_gemm_tail_split(hip):

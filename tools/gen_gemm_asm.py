@@ -22,8 +22,10 @@ so results are bitwise equal.  Output: D' = B A^T per MFMA, i.e. a lane owns 4 c
 16-byte (f32) stores.
 
 Kernels: lap_gemm_asm_nt (A [M,K], B [N,K]; bf16 out: forward), lap_gemm_asm_nn (A [M,K], B [K,N]; bf16 out: data
-gradient), lap_gemm_asm_tn (A [K,M], B [K,N]; f32 out: weight gradient).  Constraints checked by the launcher
-(csrc/gemm_asm.hip): M % 256 == 0, N % 256 == 0, K % 128 == 0, K >= 256, strides % 8 == 0, no epilogue extras.
+gradient), lap_gemm_asm_tn (A [K,M], B [K,N]; f32 out: weight gradient), lap_gemm_asm_nt_bias (forward + f32 bias per
+column, N any multiple of 16: the last n-tile's missing rows of B read as zeros, its missing columns of C are masked out of
+the stores).  Constraints checked by the launcher (csrc/gemm_asm.hip): M % 256 == 0, N % 256 == 0 (plain kernels), K % 128
+== 0, K >= 256, strides % 8 == 0.
 
 Usage: python tools/gen_gemm_asm.py > lap_amd/csrc/gemm_asm_kernels.s
 """
@@ -55,6 +57,11 @@ S_CROW = 88                 # epilogue: fm * 16 rows of C in bytes
 S_STEPA, S_STEPB = 89, 90   # the live values of S_BUMPA / S_BUMPB (0 once the stream is parked)
 RCN = 92                    # C descriptor of the tile the DMA stream is already fetching
 S_C16 = 96                  # 16 rows of C in bytes
+S_NREM, S_NREMN = 97, 98    # epilogue variant: N - n0 of the current tile / of the tile the stream is fetching
+RBI = 36                    # s[36:39]: bias descriptor (epilogue variant; the pointer pair is loaded into its first two words)
+V_MOFF = 112                # v112..v119 (fragment set 1, idle during the epilogue): store offsets per fn with the ragged-N mask
+V_NCOL = 13                 # epilogue variant: wn*128 + 4 g (column of the lane's first output inside the tile)
+V_BIAS = 192                # v192..v223: the lane's 8 x 4 bias values of the tile
 V_TID, V_LANE = 0, 1
 V_DA, V_DB = 2, 6           # DMA lane offsets: up to 4 classes of pieces per operand
 V_T = 10                    # v10, v11 scratch; v12: epilogue lane offset
@@ -63,7 +70,7 @@ V_RA, V_RB = 16, 32         # fragment read addresses: up to 16 per operand
 FA = {0: 48, 1: 112}        # fragment sets: A frags at FA[set] + 4 f, B frags at FB[set] + 4 f
 FB = {0: 80, 1: 144}
 V_E = 176                   # scratch v176..v191
-NVGPR = 192
+NVGPR = 224
 STAGE = 65536
 BOFF = 32768
 _uid = [0]
@@ -88,8 +95,9 @@ def order():
 
 
 class Kernel:
-    def __init__(self, name, a_kc, b_kc, out_f32):
-        self.name, self.kc, self.f32 = name, (a_kc, b_kc), out_f32
+    def __init__(self, name, a_kc, b_kc, out_f32, epi=False):
+        # epi: f32 bias per output column + ragged N (the last n-tile may hold fewer than 256 valid columns; N % 16 == 0)
+        self.name, self.kc, self.f32, self.epi = name, (a_kc, b_kc), out_f32, epi
 
     # ---- fragment reads of k-step kk from `stage` into register set st
     def reads(self, kk, stage, st):
@@ -154,8 +162,12 @@ class Kernel:
         for op, (rs, ptr, row0, ld) in enumerate(((RA, S_A, t + 8, S_LDA), (RB, S_B, t + 9, S_LDB))):
             if self.kc[op]:     # panel rows row0 .. row0 + 255, all of K: base + row0 * ld; range 255 ld + K bytes
                 r += [f"s_mul_i32 s{t+10}, s{row0}, s{ld}", f"s_mul_hi_u32 s{t+11}, s{row0}, s{ld}",
-                      f"s_add_u32 s{rs}, s{ptr}, s{t+10}", f"s_addc_u32 s{rs+1}, s{ptr+1}, s{t+11}", f"s_and_b32 s{rs+1}, s{rs+1}, 0xffff",
-                      f"s_mul_i32 s{rs+2}, s{ld}, 255", f"s_add_u32 s{rs+2}, s{rs+2}, s{S_K}"]
+                      f"s_add_u32 s{rs}, s{ptr}, s{t+10}", f"s_addc_u32 s{rs+1}, s{ptr+1}, s{t+11}", f"s_and_b32 s{rs+1}, s{rs+1}, 0xffff"]
+                if self.epi and op == 1:    # ragged N: rows past N read as zeros (range = (rows - 1) ld + K bytes)
+                    r += [f"s_sub_u32 s{S_NREMN}, s{S_N}, s{row0}", f"s_min_u32 s{t+10}, s{S_NREMN}, 256", f"s_sub_u32 s{t+10}, s{t+10}, 1",
+                          f"s_mul_i32 s{rs+2}, s{ld}, s{t+10}", f"s_add_u32 s{rs+2}, s{rs+2}, s{S_K}"]
+                else:
+                    r += [f"s_mul_i32 s{rs+2}, s{ld}, 255", f"s_add_u32 s{rs+2}, s{rs+2}, s{S_K}"]
             else:               # panel columns row0 .. row0 + 255 of all K rows: base + row0 * 2; range (K - 1) ld + 512 bytes
                 r += [f"s_lshl_b32 s{t+10}, s{row0}, 1",
                       f"s_add_u32 s{rs}, s{ptr}, s{t+10}", f"s_addc_u32 s{rs+1}, s{ptr+1}, 0", f"s_and_b32 s{rs+1}, s{rs+1}, 0xffff",
@@ -227,6 +239,8 @@ class Kernel:
         E(f"\ts_load_dwordx2 s[{S_MAGL}:{S_MAGL+1}], {S_KARG}, 0x40")
         E(f"\ts_load_dwordx2 s[{S_ONE}:{S_ONE+1}], {S_KARG}, 0x48")
         E(f"\ts_load_dword s{S_G}, {S_KARG}, 0x50")
+        if self.epi:
+            E(f"\ts_load_dwordx2 s[{RBI}:{RBI+1}], {S_KARG}, 0x60")
         E(f"\tv_and_b32 v{V_LANE}, 63, v{V_TID}")
         E(f"\tv_lshrrev_b32 v{V_T}, 6, v{V_TID}")
         E("\ts_nop 1")                                           # VALU write -> v_readfirstlane of the same VGPR: wait state
@@ -262,6 +276,10 @@ class Kernel:
         E(f"\ts_mul_i32 s{RC+2}, s{S_LDC}, 255")
         E(f"\ts_add_u32 s{RC+2}, s{RC+2}, {1024 if self.f32 else 512}")
         E(f"\ts_mov_b32 s{RCN+2}, s{RC+2}")
+        if self.epi:
+            E(f"\ts_and_b32 s{RBI+1}, s{RBI+1}, 0xffff")
+            E(f"\ts_lshl_b32 s{RBI+2}, s{S_N}, 2")
+            E(f"\ts_mov_b32 s{RBI+3}, 0x00020000")
         for x in self.setup(S_TDMA):
             L(x)
         # ---- DMA lane offsets and piece offsets
@@ -362,6 +380,11 @@ class Kernel:
         E(f"\tv_add_u32 v{V_E}, v{V_E}, v{V_E+1}")
         E(f"\tv_add_u32 v{V_CO}, s{t+14}, v{V_E}")
         E(f"\ts_lshl_b32 s{S_C16}, s{S_LDC}, 4")
+        if self.epi:
+            E(f"\tv_lshrrev_b32 v{V_NCOL}, 4, v{V_LANE}")
+            E(f"\tv_lshlrev_b32 v{V_NCOL}, 2, v{V_NCOL}")
+            E(f"\ts_lshl_b32 s{t+14}, s{t+13}, 7")
+            E(f"\tv_add_u32 v{V_NCOL}, s{t+14}, v{V_NCOL}")
         # ---- prologue: k-tiles 0 and 1 of the first tile in flight, accumulators cleared
         for stage in (0, 1):
             for m0w, ld in self.dma(stage):
@@ -374,6 +397,8 @@ class Kernel:
             E(f"\tv_accvgpr_write_b32 a{a}, 0")
         for r in range(3):
             E(f"\ts_mov_b32 s{RC+r}, s{RCN+r}")
+        if self.epi:
+            E(f"\ts_mov_b32 s{S_NREM}, s{S_NREMN}")
         E("\ts_waitcnt vmcnt(16)")
         E("\ts_barrier")
         for x in self.reads(0, 0, 0):
@@ -389,8 +414,23 @@ class Kernel:
         E(f"\ts_cbranch_scc1 .Lloop_{nm}")
         # ---- epilogue.  The stream is two k-tiles into this block's next tile (k-tile 0 landed at the last barrier, k-tile 1
         # is in flight and is waited for, together with these stores, by the vmcnt(0) of the next tile's first barrier)
+        if self.epi:
+            # the lane's bias values: column n0 + wn*128 + 16 fn + 4 g .. + 3 (past N: zeros); n0 = N - S_NREM
+            E(f"\ts_sub_u32 s{t+10}, s{S_N}, s{S_NREM}")
+            E(f"\ts_lshl_b32 s{t+10}, s{t+10}, 2")
+            E(f"\tv_lshlrev_b32 v{V_E}, 2, v{V_NCOL}")
+            for fn in range(8):
+                E(f"\tbuffer_load_dwordx4 v[{V_BIAS+4*fn}:{V_BIAS+4*fn+3}], v{V_E}, s[{RBI}:{RBI+3}], s{t+10} offen offset:{fn*64}")
+            # store offsets with the ragged-N mask folded in: columns >= N go to an out-of-range offset (dropped)
+            E(f"\tv_mov_b32 v{V_E+1}, 0x80000000")
+            for fn in range(8):
+                E(f"\ts_sub_i32 s{t+11}, s{S_NREM}, {16*fn}")
+                E(f"\tv_cmp_gt_i32 vcc, s{t+11}, v{V_NCOL}")
+                E(f"\tv_cndmask_b32 v{V_MOFF+fn}, v{V_E+1}, v{V_CO}, vcc")
         E("\ts_nop 15")
         E("\ts_nop 15")
+        if self.epi:
+            E("\ts_waitcnt vmcnt(0)")      # the bias values (and the stream's k-tile 1, which the next barrier would wait for anyway)
         E(f"\ts_mov_b32 s{S_CROW}, 0")
         tiles = [(fm, fn) for fm in range(8) for fn in range(8)]
 
@@ -408,9 +448,12 @@ class Kernel:
             if self.f32:
                 E(f"\tbuffer_store_dwordx4 v[{cur}:{cur+3}], v{V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*64}")
             else:
+                if self.epi:
+                    for r in range(4):
+                        E(f"\tv_add_f32 v{cur+r}, v{cur+r}, v{V_BIAS+4*fn+r}")
                 E(f"\tv_cvt_pk_bf16_f32 v{cur+4}, v{cur}, v{cur+1}")
                 E(f"\tv_cvt_pk_bf16_f32 v{cur+5}, v{cur+2}, v{cur+3}")
-                E(f"\tbuffer_store_dwordx2 v[{cur+4}:{cur+5}], v{V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*32}")
+                E(f"\tbuffer_store_dwordx2 v[{cur+4}:{cur+5}], v{V_MOFF+fn if self.epi else V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*32}")
             if fn == 7:
                 E(f"\ts_add_u32 s{S_CROW}, s{S_CROW}, s{S_C16}")
         E(f"\ts_add_u32 s{S_TCUR}, s{S_TCUR}, s{S_G}")
@@ -420,11 +463,13 @@ class Kernel:
         E(f".Lnext_{nm}:")     # (register set 0 already holds the next tile's first fragments: the last P1 read them)
         for r in range(3):
             E(f"\ts_mov_b32 s{RC+r}, s{RCN+r}")
+        if self.epi:
+            E(f"\ts_mov_b32 s{S_NREM}, s{S_NREMN}")
         E(f"\ts_branch .Ltile_{nm}")
         E("\t.section\t.rodata,\"a\",@progbits")
         E("\t.p2align\t6, 0x0")
         E(f"\t.amdhsa_kernel {nm}")
-        for k, v in (("group_segment_fixed_size", 131072), ("private_segment_fixed_size", 0), ("kernarg_size", 96),
+        for k, v in (("group_segment_fixed_size", 131072), ("private_segment_fixed_size", 0), ("kernarg_size", 112),
                      ("user_sgpr_count", 2), ("user_sgpr_dispatch_ptr", 0), ("user_sgpr_queue_ptr", 0), ("user_sgpr_kernarg_segment_ptr", 1),
                      ("user_sgpr_dispatch_id", 0), ("user_sgpr_kernarg_preload_length", 0), ("user_sgpr_kernarg_preload_offset", 0),
                      ("user_sgpr_private_segment_size", 0), ("uses_dynamic_stack", 0), ("enable_private_segment", 0),
@@ -442,11 +487,11 @@ class Kernel:
         return f"""  - .agpr_count:     256
     .args:
       - .offset:         0
-        .size:           96
+        .size:           112
         .value_kind:     by_value
     .group_segment_fixed_size: 131072
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 96
+    .kernarg_segment_size: 112
     .max_flat_workgroup_size: 256
     .name:           {self.name}
     .private_segment_fixed_size: 0
@@ -461,7 +506,7 @@ class Kernel:
 
 
 KERNELS = [Kernel("lap_gemm_asm_nt", True, True, False), Kernel("lap_gemm_asm_nn", True, False, False),
-           Kernel("lap_gemm_asm_tn", False, False, True)]
+           Kernel("lap_gemm_asm_tn", False, False, True), Kernel("lap_gemm_asm_nt_bias", True, True, False, epi=True)]
 E('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
 E("\t.amdhsa_code_object_version 6")
 for k in KERNELS:
