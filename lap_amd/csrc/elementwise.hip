@@ -84,38 +84,41 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const bf16* __restrict_
 }
 
 // ----------------------------------------------------------------------- GeGLU
+// (row strides in elements: ld_gu for gu, ld_act for act / dact, ld_dgu for dgu — the consumers of act and dgu are GEMMs that
+// read them through transposing LDS reads, for which a row stride of 32 / 64 KiB is a bad one: lap_geglu_*_ld)
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16* __restrict__ gu, bf16* __restrict__ act,
-                                                        long long nchunk, int H8) {
+                                                        long long nchunk, int H8, long long ld_gu, long long ld_act) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= nchunk) return;
   const long long row = gid / H8;
   const int c = (int)(gid % H8) * 8;
   const long long H = (long long)H8 * 8;
   float g[8], u[8], o[8];
-  ld8(gu + row * 2 * H + c, g);
-  ld8(gu + row * 2 * H + H + c, u);
+  ld8(gu + row * ld_gu + c, g);
+  ld8(gu + row * ld_gu + H + c, u);
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = round_bf16((gelu_tanh_f(g[e]))) * u[e];  // gelu output is a bf16 tensor upstream
-  st8(act + row * H + c, o);
+  st8(act + row * ld_act + c, o);
 }
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16* __restrict__ gu, const bf16* __restrict__ dact,
-                                                        bf16* __restrict__ dgu, long long nchunk, int H8) {
+                                                        bf16* __restrict__ dgu, long long nchunk, int H8, long long ld_gu,
+                                                        long long ld_act, long long ld_dgu) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= nchunk) return;
   const long long row = gid / H8;
   const int c = (int)(gid % H8) * 8;
   const long long H = (long long)H8 * 8;
   float g[8], u[8], d[8], dg[8], du[8];
-  ld8(gu + row * 2 * H + c, g);
-  ld8(gu + row * 2 * H + H + c, u);
-  ld8(dact + row * H + c, d);
+  ld8(gu + row * ld_gu + c, g);
+  ld8(gu + row * ld_gu + H + c, u);
+  ld8(dact + row * ld_act + c, d);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     dg[e] = d[e] * u[e] * gelu_tanh_grad_f(g[e]);
     du[e] = d[e] * round_bf16((gelu_tanh_f(g[e])));
   }
-  st8(dgu + row * 2 * H + c, dg);
-  st8(dgu + row * 2 * H + H + c, du);
+  st8(dgu + row * ld_dgu + c, dg);
+  st8(dgu + row * ld_dgu + H + c, du);
 }
 
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long long n8) {
@@ -565,20 +568,26 @@ extern "C" int lap_rope_split_bwd(const void* dq, const void* dk, const void* dv
   return LAP_OK;
 }
 
-extern "C" int lap_geglu_fwd(const void* gu, void* act, int rows, int H, void* stream) {
-  if (rows <= 0 || H <= 0 || (H & 7)) return LAP_ERR_ARG;
+extern "C" int lap_geglu_fwd_ld(const void* gu, void* act, int rows, int H, int ld_gu, int ld_act, void* stream) {
+  if (rows <= 0 || H <= 0 || (H & 7) || ld_gu < 2 * H || ld_act < H || (ld_gu & 7) || (ld_act & 7)) return LAP_ERR_ARG;
   const long long n = (long long)rows * (H / 8);
-  hipLaunchKernelGGL(geglu_fwd_kernel, flat_grid(n), dim3(256), 0, S_, (const bf16*)gu, (bf16*)act, n, H / 8);
+  hipLaunchKernelGGL(geglu_fwd_kernel, flat_grid(n), dim3(256), 0, S_, (const bf16*)gu, (bf16*)act, n, H / 8, (long long)ld_gu, (long long)ld_act);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_geglu_fwd(const void* gu, void* act, int rows, int H, void* stream) {
+  return lap_geglu_fwd_ld(gu, act, rows, H, 2 * H, H, stream);
+}
+extern "C" int lap_geglu_bwd_ld(const void* gu, const void* dact, void* dgu, int rows, int H, int ld_gu, int ld_dact, int ld_dgu, void* stream) {
+  if (rows <= 0 || H <= 0 || (H & 7) || ld_gu < 2 * H || ld_dact < H || ld_dgu < 2 * H || ((ld_gu | ld_dact | ld_dgu) & 7)) return LAP_ERR_ARG;
+  const long long n = (long long)rows * (H / 8);
+  hipLaunchKernelGGL(geglu_bwd_kernel, flat_grid(n), dim3(256), 0, S_, (const bf16*)gu, (const bf16*)dact, (bf16*)dgu, n,
+                     H / 8, (long long)ld_gu, (long long)ld_dact, (long long)ld_dgu);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
 extern "C" int lap_geglu_bwd(const void* gu, const void* dact, void* dgu, int rows, int H, void* stream) {
-  if (rows <= 0 || H <= 0 || (H & 7)) return LAP_ERR_ARG;
-  const long long n = (long long)rows * (H / 8);
-  hipLaunchKernelGGL(geglu_bwd_kernel, flat_grid(n), dim3(256), 0, S_, (const bf16*)gu, (const bf16*)dact, (bf16*)dgu, n,
-                     H / 8);
-  LAP_CHECK_LAUNCH();
-  return LAP_OK;
+  return lap_geglu_bwd_ld(gu, dact, dgu, rows, H, 2 * H, H, 2 * H, stream);
 }
 extern "C" int lap_gelu_fwd(const void* x, void* y, long long n, void* stream) {
   if (n <= 0 || (n & 7)) return LAP_ERR_ARG;

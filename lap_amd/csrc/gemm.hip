@@ -1483,9 +1483,9 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
       const long long t5 = (long long)(M / 256) * (N / 256);
       const double fill = (double)t5 / (256.0 * ((t5 + 255) / 256));
       // measured against the HIP tiles (tools/bench_asm_gemm.py bench): forward +10-17 % whenever the rounds are filled or the
-      // contraction is short; weight gradient +10 % on wide outputs (down projection: 2048 x 16384), -6 % on tall ones
-      // (gate|up: 32768 x 2048: stays on the ping-pong tile); data gradient: parity (stays on the ping-pong tile)
-      const bool win = (a_kc && b_kc) ? (fill >= 0.8 || K <= 4096) : (!a_kc && !b_kc) ? (fill >= 0.8 && N >= M) : false;
+      // contraction is short; weight gradient +10 % (tall outputs run as the wide product of the swapped operands with
+      // transposed stores, see lap_gemm_asm); data gradient: parity (stays on the ping-pong tile)
+      const bool win = (a_kc && b_kc) ? (fill >= 0.8 || K <= 4096) : (!a_kc && !b_kc) ? fill >= 0.8 : false;
       if (t5 >= 128 && win) return lap_gemm_asm(A, B, C, M, N, K, lda, ldb, ldc, a_kc, b_kc, f32, stream);
     }
   }

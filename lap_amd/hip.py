@@ -87,6 +87,8 @@ SIGNATURES: dict[str, list] = {
     "lap_rope_split_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "lap_geglu_fwd": [_vp, _vp, _i, _i, _vp],
     "lap_geglu_bwd": [_vp, _vp, _vp, _i, _i, _vp],
+    "lap_geglu_fwd_ld": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "lap_geglu_bwd_ld": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "lap_gelu_fwd": [_vp, _vp, _ll, _vp],
     "lap_gelu_bwd": [_vp, _vp, _vp, _ll, _vp],
     "lap_embed_gather": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
@@ -317,16 +319,27 @@ def rope_split_bwd(dq, dk, dv, pos, B, T_seg, T_total, seg_off, NH, HD, q_scale)
     return dqkv
 
 
-def geglu_fwd(gu):
+def _padded_rows(rows, cols, device, pad):
+    """[rows, cols] bf16 view of a buffer whose rows are `pad` elements longer: see lap_geglu_fwd_ld in include/lap_hip.h"""
+    return torch.empty((rows, cols + pad), dtype=torch.bfloat16, device=device)[:, :cols]
+
+
+def _row_pad(cols):
+    """64 elements when the dense row would be a multiple of 16 KiB (the bad strides measured: 32 and 64 KiB), else none"""
+    return 64 if cols * 2 >= 16384 and (cols * 2) % 16384 == 0 else 0
+
+
+def geglu_fwd(gu, pad=False):
     rows, H2 = gu.shape
-    act = torch.empty((rows, H2 // 2), dtype=torch.bfloat16, device=gu.device)
-    call("lap_geglu_fwd", _p(gu), _p(act), rows, H2 // 2)
+    act = _padded_rows(rows, H2 // 2, gu.device, _row_pad(H2 // 2) if pad else 0)
+    call("lap_geglu_fwd_ld", _p(gu), _p(act), rows, H2 // 2, gu.stride(0), act.stride(0))
     return act
 
 
-def geglu_bwd(gu, dact):
-    dgu = torch.empty_like(gu)
-    call("lap_geglu_bwd", _p(gu), _p(dact), _p(dgu), gu.shape[0], gu.shape[1] // 2)
+def geglu_bwd(gu, dact, pad=False):
+    rows, H2 = gu.shape
+    dgu = _padded_rows(rows, H2, gu.device, _row_pad(H2) if pad else 0)
+    call("lap_geglu_bwd_ld", _p(gu), _p(dact), _p(dgu), rows, H2 // 2, gu.stride(0), dact.stride(0), dgu.stride(0))
     return dgu
 
 

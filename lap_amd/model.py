@@ -422,7 +422,7 @@ class LAP:
                 xa[0] = self._lin0(o[0], p + "wo0", residual=x0)
                 hf[0], rstd_f[0] = hip.rmsnorm_fwd(xa[0], scale=self.F(p + "n_ffw"), save_rstd=save)
                 gu[0] = self._lin0(hf[0], p + "wgu0")
-                act[0] = hip.geglu_fwd(gu[0])
+                act[0] = hip.geglu_fwd(gu[0], pad=self.gemm_dtype != "fp8")
                 xn[0] = self._lin0(act[0], p + "wd0", residual=xa[0])
             if x1 is not None:
                 We3 = 3 * e.width
@@ -455,7 +455,7 @@ class LAP:
             if dx0 is not None:
                 self._wgrad(dx0, c["act"][0], p + "wd0")
                 dact = self._dgrad0(dx0, p + "wd0")
-                dgu = hip.geglu_bwd(c["gu"][0], dact)
+                dgu = hip.geglu_bwd(c["gu"][0], dact, pad=self.gemm_dtype != "fp8")
                 del dact
                 self._wgrad(dgu, c["hf"][0], p + "wgu0")
                 dhf = self._dgrad0(dgu, p + "wgu0")

@@ -80,9 +80,11 @@ def acc(fm, fn):
     return (fm * 8 + fn) * 4
 
 
-def mfma(fm, fn, st):
+def mfma(fm, fn, st, swap=False):
+    """D' = B A^T (a lane owns 4 consecutive n of one m); swap: D = A B^T (4 consecutive m of one n: transposed stores)"""
     a = acc(fm, fn)
-    return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a+3}], v[{FB[st]+4*fn}:{FB[st]+4*fn+3}], v[{FA[st]+4*fm}:{FA[st]+4*fm+3}], a[{a}:{a+3}]"
+    x, y = (FA[st] + 4 * fm, FB[st] + 4 * fn) if swap else (FB[st] + 4 * fn, FA[st] + 4 * fm)
+    return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a+3}], v[{x}:{x+3}], v[{y}:{y+3}], a[{a}:{a+3}]"
 
 
 def order():
@@ -95,9 +97,11 @@ def order():
 
 
 class Kernel:
-    def __init__(self, name, a_kc, b_kc, out_f32, epi=False):
+    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False):
         # epi: f32 bias per output column + ragged N (the last n-tile may hold fewer than 256 valid columns; N % 16 == 0)
-        self.name, self.kc, self.f32, self.epi = name, (a_kc, b_kc), out_f32, epi
+        # tout: the product is stored TRANSPOSED (C is [N][ldc]): a tall weight gradient dW [out, in] = dy^T x runs as the wide
+        #       product x^T dy (whose operand panels stream much better, tools/bench_asm_gemm.py) and lands in dW's layout
+        self.name, self.kc, self.f32, self.epi, self.tout = name, (a_kc, b_kc), out_f32, epi, tout
 
     # ---- fragment reads of k-step kk from `stage` into register set st
     def reads(self, kk, stage, st):
@@ -174,7 +178,8 @@ class Kernel:
                       f"s_lshr_b32 s{t+10}, s{S_K}, 1", f"s_sub_u32 s{t+10}, s{t+10}, 1",
                       f"s_mul_i32 s{rs+2}, s{t+10}, s{ld}", f"s_add_u32 s{rs+2}, s{rs+2}, 512"]
         sh = 2 if self.f32 else 1
-        r += [f"s_mul_i32 s{t+10}, s{t+8}, s{S_LDC}", f"s_mul_hi_u32 s{t+11}, s{t+8}, s{S_LDC}", f"s_lshl_b32 s{t+12}, s{t+9}, {sh}",
+        cr, cc = (t + 9, t + 8) if self.tout else (t + 8, t + 9)      # C row / column origin of the tile
+        r += [f"s_mul_i32 s{t+10}, s{cr}, s{S_LDC}", f"s_mul_hi_u32 s{t+11}, s{cr}, s{S_LDC}", f"s_lshl_b32 s{t+12}, s{cc}, {sh}",
               f"s_add_u32 s{t+10}, s{t+10}, s{t+12}", f"s_addc_u32 s{t+11}, s{t+11}, 0",
               f"s_add_u32 s{RCN}, s{S_C}, s{t+10}", f"s_addc_u32 s{RCN+1}, s{S_C+1}, s{t+11}", f"s_and_b32 s{RCN+1}, s{RCN+1}, 0xffff"]
         return r
@@ -199,7 +204,7 @@ class Kernel:
         for slot, txt in side:
             byslot.setdefault(slot, []).append(txt)
         for n, (fm, fn) in enumerate(order()):
-            E("\t" + mfma(fm, fn, st))
+            E("\t" + mfma(fm, fn, st, self.tout))
             for txt in byslot.get(n, []):
                 L(txt)
 
@@ -370,13 +375,15 @@ class Kernel:
                     E(f"\tv_xor_b32 v{VR+f}, {f << 5}, v{V_E+5}")
                     E(f"\tv_add_u32 v{VR+8+f}, {STAGE}, v{VR+f}")
         # ---- epilogue lane offset: m = wm*128 + fm*16 + (l & 15), n = wn*128 + fn*16 + 4 (l >> 4)
+        # (transposed stores: the lane's row is n = wn*128 + fn*16 + (l & 15), its 4 columns m = wm*128 + fm*16 + 4 (l >> 4))
+        wrow, wcol = (t + 13, t + 12) if self.tout else (t + 12, t + 13)
         E(f"\tv_and_b32 v{V_E}, 15, v{V_LANE}")
         E(f"\tv_lshrrev_b32 v{V_E+1}, 4, v{V_LANE}")
-        E(f"\ts_lshl_b32 s{t+14}, s{t+12}, 7")
+        E(f"\ts_lshl_b32 s{t+14}, s{wrow}, 7")
         E(f"\tv_add_u32 v{V_E}, s{t+14}, v{V_E}")
         E(f"\tv_mul_lo_u32 v{V_E}, v{V_E}, s{S_LDC}")
         E(f"\tv_lshlrev_b32 v{V_E+1}, {4 if self.f32 else 3}, v{V_E+1}")      # 4 g elements in bytes
-        E(f"\ts_lshl_b32 s{t+14}, s{t+13}, {9 if self.f32 else 8}")           # wn * 128 elements in bytes
+        E(f"\ts_lshl_b32 s{t+14}, s{wcol}, {9 if self.f32 else 8}")           # w? * 128 elements in bytes
         E(f"\tv_add_u32 v{V_E}, v{V_E}, v{V_E+1}")
         E(f"\tv_add_u32 v{V_CO}, s{t+14}, v{V_E}")
         E(f"\ts_lshl_b32 s{S_C16}, s{S_LDC}, 4")
@@ -432,7 +439,8 @@ class Kernel:
         if self.epi:
             E("\ts_waitcnt vmcnt(0)")      # the bias values (and the stream's k-tile 1, which the next barrier would wait for anyway)
         E(f"\ts_mov_b32 s{S_CROW}, 0")
-        tiles = [(fm, fn) for fm in range(8) for fn in range(8)]
+        # (fr, fc): 16-row group / 16-column group of C; the accumulator tile is (fm, fn) = (fr, fc), or (fc, fr) when transposed
+        tiles = [((fc, fr) if self.tout else (fr, fc)) for fr in range(8) for fc in range(8)]
 
         def rd(n, base):
             a = acc(*tiles[n])
@@ -445,6 +453,7 @@ class Kernel:
             cur = V_E + (n & 1) * 8
             if n + 1 < 64:
                 rd(n + 1, V_E + ((n + 1) & 1) * 8)
+            fn = n & 7          # from here on: the column group of C
             if self.f32:
                 E(f"\tbuffer_store_dwordx4 v[{cur}:{cur+3}], v{V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*64}")
             else:
@@ -506,7 +515,8 @@ class Kernel:
 
 
 KERNELS = [Kernel("lap_gemm_asm_nt", True, True, False), Kernel("lap_gemm_asm_nn", True, False, False),
-           Kernel("lap_gemm_asm_tn", False, False, True), Kernel("lap_gemm_asm_nt_bias", True, True, False, epi=True)]
+           Kernel("lap_gemm_asm_tn", False, False, True), Kernel("lap_gemm_asm_nt_bias", True, True, False, epi=True),
+           Kernel("lap_gemm_asm_tn_t", False, False, True, tout=True)]
 E('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
 E("\t.amdhsa_code_object_version 6")
 for k in KERNELS:
