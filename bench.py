@@ -37,8 +37,8 @@ HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.29 T
 # profiles/r01_gemm_pmc_counters.txt: gate-up forward GEMM M=17920 N=32768 K=2048 (the largest launch of the step),
 # separate --pmc passes: FETCH_SIZE 1,786,773 KB raw x 2 (gfx950 half-count correction for wide coalesced reads,
 # MI355X_MICROARCH.md §HBM) + WRITE_SIZE 1,272,545 KB; algorithmic bytes of that launch: 0.207 GB read + 1.174 GB written
-GEMM_TRAFFIC = {"bytes_per_launch": 2 * 1786772.9e3 + 1272544.9e3, "algorithmic_bytes_per_launch": 73.4e6 + 134.2e6 + 1174.4e6,
-                "shape": "gate-up fwd M=17920 N=32768 K=2048", "source": "profiles/r01_gemm_pmc_counters.txt"}
+GEMM_TRAFFIC = {"bytes_per_launch": 2 * 1752442.9e3 + 1157996.2e3, "algorithmic_bytes_per_launch": 73.4e6 + 134.2e6 + 1174.4e6,
+                "shape": "gate-up fwd M=17920 N=32768 K=2048 (lap_gemm_asm_nt)", "source": "profiles/r02f_gemm_pmc_counters.txt"}
 TRAIN_FLOP_PER_SAMPLE = 8.375e12  # 3 x forward (2.792 TFLOP), recompute not credited
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA
 
@@ -271,7 +271,7 @@ def main():
                         else f"NON-HEADLINE flow test: config {args.config}"),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": 610,
                        "parallelism": f"fsdp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_sp_kernel / gemm_pq_kernel / gemm_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": "lap_gemm_asm_* (csrc/gemm_asm_kernels.s) / gemm_pq_kernel / gemm_sp_kernel / gemm_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", "achieved": round(achieved, 1),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "traffic": GEMM_TRAFFIC["bytes_per_launch"], "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE)",
                          "traffic_shape": GEMM_TRAFFIC["shape"], "traffic_algorithmic_bytes": GEMM_TRAFFIC["algorithmic_bytes_per_launch"],

@@ -1466,6 +1466,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   // below to pay.  tile 14 forces it (tests); LAP_GEMM_NO_ASM=1 disables it (A/B runs).
   {
     static const bool no_asm = getenv("LAP_GEMM_NO_ASM") != nullptr;
+    static const bool no_asm_nn = getenv("LAP_GEMM_NO_ASM_NN") != nullptr;
     const bool plain = !bias && !residual && !(flags & (LAP_GEMM_GELU | LAP_GEMM_ACCUM | LAP_GEMM_PARTIALS)) && alpha == 1.0f && ksplit <= 1 &&
                        lap_gemm_asm_ok(a_kc, b_kc, f32, M, N, K, lda, ldb, ldc);
     // forward + f32 bias per column (Flax Dense of SigLIP: qkv, fc1), N any multiple of 16
@@ -1484,8 +1485,9 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
       const double fill = (double)t5 / (256.0 * ((t5 + 255) / 256));
       // measured against the HIP tiles (tools/bench_asm_gemm.py bench): forward +10-17 % whenever the rounds are filled or the
       // contraction is short; weight gradient +10 % (tall outputs run as the wide product of the swapped operands with
-      // transposed stores, see lap_gemm_asm); data gradient: parity (stays on the ping-pong tile)
-      const bool win = (a_kc && b_kc) ? (fill >= 0.8 || K <= 4096) : (!a_kc && !b_kc) ? fill >= 0.8 : false;
+      // transposed stores, see lap_gemm_asm); data gradient: 0 .. +14 % on short contractions with filled rounds (the
+      // ping-pong tile's rate on a weight with 32 KiB rows varies from box to box), long ones keep the tail split
+      const bool win = (a_kc && b_kc) ? (fill >= 0.8 || K <= 4096) : (!a_kc && !b_kc) ? fill >= 0.8 : (fill >= 0.8 && K <= 4096 && !no_asm_nn);
       if (t5 >= 128 && win) return lap_gemm_asm(A, B, C, M, N, K, lda, ldb, ldc, a_kc, b_kc, f32, stream);
     }
   }
