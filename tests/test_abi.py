@@ -27,3 +27,17 @@ def test_binding_covers_header():
     src = (ROOT / "lap_amd" / "hip.py").read_text()
     bound = set(re.findall(r'"(lap_[a-z0-9_]+)":', src))
     assert bound == _header_names()
+
+
+def test_assembly_kernels_file_is_the_generators_output():
+    """lap_amd/csrc/gemm_asm_kernels.s is generated (tools/gen_gemm_asm.py): the committed file must be what the generator
+    writes with default schedule parameters, so that nobody edits the 16k lines by hand."""
+    import os
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("ASM_")}
+    out = subprocess.run([sys.executable, str(root / "tools" / "gen_gemm_asm.py")], capture_output=True, text=True, check=True, env=env).stdout
+    assert out == (root / "lap_amd" / "csrc" / "gemm_asm_kernels.s").read_text()
