@@ -595,11 +595,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_sp_kernel(GemmParams p) {
   auto rsB = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.B, 0, (int)min((long long)(B_KC ? p.N : p.K) * p.ldb * 2, 0x7fffffffLL), 0x00020000);
   unsigned offA[PC], offB[PC];
+  int kcA[PC], kcB[PC];     // K-contiguous operands: first k of the lane's chunk inside a k-tile (K % 64 != 0: chunks past K read as zeros)
 #pragma unroll
   for (int j = 0; j < PC; ++j) {
     const int ci = (w * PC + j) * 64 + lane;
+    kcA[j] = 0; kcB[j] = 0;
     if (A_KC) {
       const int row = ci >> 3, c = (ci & 7) ^ ((row >> 1) & 7);
+      kcA[j] = c * 8;
       offA[j] = (m0 + row < p.M) ? (unsigned)(((long long)(m0 + row) * p.lda + c * 8) * 2) : OOB;
     } else {
       const int kr = ci >> 5, c = (ci & 31) ^ (mc_swz(kr) << 1);
@@ -607,6 +610,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_sp_kernel(GemmParams p) {
     }
     if (B_KC) {
       const int row = ci >> 3, c = (ci & 7) ^ ((row >> 1) & 7);
+      kcB[j] = c * 8;
       offB[j] = (n0 + row < p.N) ? (unsigned)(((long long)(n0 + row) * p.ldb + c * 8) * 2) : OOB;
     } else {
       const int kr = ci >> 5, c = (ci & 31) ^ (mc_swz(kr) << 1);
@@ -615,16 +619,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_sp_kernel(GemmParams p) {
   }
   const unsigned stepA = A_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.lda * 2);
   const unsigned stepB = B_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.ldb * 2);
-  const int nkt_all = p.K / BK;
+  const int nkt_all = (p.K + BK - 1) / BK;   // (rows of an M- / N-contiguous operand past K lie outside its descriptor: zeros)
   const int kt0 = blockIdx.y * p.ktiles_per_split;
   const int kt1 = min(nkt_all, kt0 + p.ktiles_per_split);
   auto piece = [&](int buf, int kt, int j) {   // j < 4: operand A, else B; past the end: zero fill, keeps the counts uniform
     char* base = smem + buf * STAGE;
     if (j < PC) {
-      const unsigned v = (offA[j] != OOB && kt < kt1) ? offA[j] + (unsigned)kt * stepA : OOB;
+      const unsigned v = (offA[j] != OOB && kt < kt1 && (!A_KC || kt * BK + kcA[j] < p.K)) ? offA[j] + (unsigned)kt * stepA : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(base + (w * PC + j) * 1024), 16, v, 0, 0, 0);
     } else {
-      const unsigned v = (offB[j - PC] != OOB && kt < kt1) ? offB[j - PC] + (unsigned)kt * stepB : OOB;
+      const unsigned v = (offB[j - PC] != OOB && kt < kt1 && (!B_KC || kt * BK + kcB[j - PC] < p.K)) ? offB[j - PC] + (unsigned)kt * stepB : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(base + A_BYTES + (w * PC + j - PC) * 1024), 16, v, 0, 0, 0);
     }
   };
@@ -794,11 +798,14 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmParams p) {
   auto rsB = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.B, 0, (int)min((long long)(B_KC ? p.N : p.K) * p.ldb * 2, 0x7fffffffLL), 0x00020000);
   unsigned offA[PC], offB[PC];
+  int kcA[PC], kcB[PC];     // K-contiguous operands: first k of the lane's chunk inside a k-half (chunks past K read as zeros)
 #pragma unroll
   for (int j = 0; j < PC; ++j) {
     const int ci = (w * PC + j) * 64 + lane;     // 16-byte chunk of one operand's k-half image (1024 chunks)
+    kcA[j] = 0; kcB[j] = 0;
     if (A_KC) {
       const int row = ci >> 2, c = (ci & 3) ^ ((-(row >> 2)) & 3);
+      kcA[j] = c * 8;
       offA[j] = (m0 + row < p.M) ? (unsigned)(((long long)(m0 + row) * p.lda + c * 8) * 2) : OOB;
     } else {
       const int kr = ci >> 5, c = (ci & 31) ^ (mc_swz(kr) << 1);
@@ -806,6 +813,7 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmParams p) {
     }
     if (B_KC) {
       const int row = ci >> 2, c = (ci & 3) ^ ((-(row >> 2)) & 3);
+      kcB[j] = c * 8;
       offB[j] = (n0 + row < p.N) ? (unsigned)(((long long)(n0 + row) * p.ldb + c * 8) * 2) : OOB;
     } else {
       const int kr = ci >> 5, c = (ci & 31) ^ (mc_swz(kr) << 1);
@@ -815,17 +823,17 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmParams p) {
   const unsigned stepA = A_KC ? (unsigned)(KH * 2) : (unsigned)((long long)KH * p.lda * 2);
   const unsigned stepB = B_KC ? (unsigned)(KH * 2) : (unsigned)((long long)KH * p.ldb * 2);
   const int h0 = 2 * blockIdx.y * p.ktiles_per_split;
-  const int h1 = min(p.K / KH, h0 + 2 * p.ktiles_per_split);       // k-halves [h0, h1): an even count (K % 64 == 0)
+  const int h1 = min(2 * ((p.K + 2 * KH - 1) / (2 * KH)), h0 + 2 * p.ktiles_per_split);   // k-halves [h0, h1): an even count (past K: zeros)
   auto pieces = [&](int jh) {   // all 4 pieces of this wave for k-half jh -> slot (jh - h0) & 3; past the end: zero fill
     char* base = smem + ((jh - h0) & (NSLOT - 1)) * SLOT;
 #pragma unroll
     for (int j = 0; j < PC; ++j) {
-      const unsigned v = (offA[j] != OOB && jh < h1) ? offA[j] + (unsigned)jh * stepA : OOB;
+      const unsigned v = (offA[j] != OOB && jh < h1 && (!A_KC || jh * KH + kcA[j] < p.K)) ? offA[j] + (unsigned)jh * stepA : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(base + (w * PC + j) * 1024), 16, v, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < PC; ++j) {
-      const unsigned v = (offB[j] != OOB && jh < h1) ? offB[j] + (unsigned)jh * stepB : OOB;
+      const unsigned v = (offB[j] != OOB && jh < h1 && (!B_KC || jh * KH + kcB[j] < p.K)) ? offB[j] + (unsigned)jh * stepB : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(base + HALF + (w * PC + j) * 1024), 16, v, 0, 0, 0);
     }
   };
@@ -1151,7 +1159,7 @@ int launch_pn(GemmParams p, hipStream_t s) {
 template <bool A_KC, bool B_KC, bool OUT_F32>
 int launch_pq(GemmParams p, hipStream_t s) {
   constexpr int LDS = OUT_F32 ? 128 * (256 * 4 + 16) : 256 * (256 * 2 + 16);   // >= the four 32 KiB slots
-  if (p.K & 63) return LAP_ERR_ARG;
+  if (p.K & 7) return LAP_ERR_ARG;      // (a ragged last k-tile is zero-filled by the kernel)
   auto kern = gemm_pq_kernel<A_KC, B_KC, OUT_F32>;
   p.epi_lds = (!p.part && p.ksplit == 1 && !(OUT_F32 && p.R) && !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) ? 1 : 0;
   static bool done = false;
@@ -1162,7 +1170,7 @@ int launch_pq(GemmParams p, hipStream_t s) {
   }
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
-  const int nkt = p.K / 64;
+  const int nkt = (p.K + 63) / 64;
   p.ktiles_per_split = (nkt + p.ksplit - 1) / p.ksplit;
   const int count = p.tile_count > 0 ? p.tile_count : p.tiles_m * p.tiles_n - p.tile_base;
   hipLaunchKernelGGL(kern, dim3(count, p.ksplit), dim3(512), LDS, s, p);
@@ -1173,7 +1181,7 @@ int launch_pq(GemmParams p, hipStream_t s) {
 template <int WGM, int WGN, bool A_KC, bool B_KC, bool OUT_F32, bool TWOB = false>
 int launch_sp(GemmParams p, hipStream_t s) {
   constexpr int LDS = OUT_F32 ? 128 * (256 * 4 + 16) : 256 * (256 * 2 + 16);   // >= the two operand stages (128 KiB)
-  if (p.K & 63) return LAP_ERR_ARG;
+  if (p.K & 7) return LAP_ERR_ARG;      // (a ragged last k-tile is zero-filled by the kernel)
   auto kern = gemm_sp_kernel<WGM, WGN, A_KC, B_KC, OUT_F32, TWOB>;
   p.epi_lds = (!p.part && p.ksplit == 1 && !(OUT_F32 && p.R) && !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) ? 1 : 0;
   static bool done = false;
@@ -1184,7 +1192,7 @@ int launch_sp(GemmParams p, hipStream_t s) {
   }
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
-  const int nkt = p.K / 64;
+  const int nkt = (p.K + 63) / 64;
   p.ktiles_per_split = (nkt + p.ksplit - 1) / p.ksplit;
   const int count = p.tile_count > 0 ? p.tile_count : p.tiles_m * p.tiles_n - p.tile_base;
   hipLaunchKernelGGL(kern, dim3(count, p.ksplit), dim3(WGM * WGN * 64), LDS, s, p);
@@ -1522,11 +1530,12 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
     }
   }
   if (ksplit == 0 && scratch != nullptr && !tail_tiles) ksplit = pick_ksplit(tile, M, N, K, scratch_bytes, a_kc && b_kc);
-  // K % 64 == 0: the software-pipelined 8-wave kernel (tile 10) for the forward layout, the ping-pong kernel (tile 12) as
+  // K % 8 == 0: the software-pipelined 8-wave kernel (tile 10) for the forward layout, the ping-pong kernel (tile 12) as
   // soon as an operand is M-contiguous (data / weight gradients: +5-11 % measured, tools/bench_kernels.py; on the forward
   // layout its 64-byte k-half rows cost more in LDS-DMA requests than the ping-pong gains); else the 16-wave kernel
   static const bool no_pq = getenv("LAP_GEMM_NO_PINGPONG") != nullptr;   // A/B switch for benchmarks
-  const int big = !(K & 63) ? ((a_kc && b_kc) || no_pq ? 10 : 12) : 5;
+  static const bool no_ktail = getenv("LAP_GEMM_NO_KTAIL") != nullptr;      // A/B switch: ragged K back on the lockstep tile
+  const int big = (!(K & 7) && (!(K & 63) || !no_ktail)) ? ((a_kc && b_kc) || no_pq ? 10 : 12) : 5;
   if (tile == 5) tile = big;
   const bool two_phase = ksplit > 1 && scratch != nullptr;
   if (two_phase && scratch_bytes < (long long)ksplit * M * N * 4) return LAP_ERR_ARG;

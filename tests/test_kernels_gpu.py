@@ -184,6 +184,30 @@ def test_gemm_assembly_bias_kernel_ragged_n_matches_hip_tiles_bitwise(hip):
         assert rel_err(outs[1][:, :N], a.float() @ b.float().t() + bias) < 5e-3
 
 
+def test_gemm_ragged_k_on_the_pipelined_tiles_matches_lockstep_tile_bitwise(hip):
+    """K % 64 != 0 (SigLIP's MLP width 4304 = 67 * 64 + 16) on tiles 10 / 12: the last k-tile's chunks past K are fetched with an
+    out-of-range offset (zeros), so the sums — and the bits — are those of the 16-wave lockstep tile (tile 2) that handled such
+    K before; all three layouts, with epilogue extras."""
+    M, N = 1024, 1152
+    for K in (4304, 88, 200):
+        a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(3)).to(DEV); res = rnd(M, N, seed=4)
+        o10 = hip.linear_fwd(a, b, bias=bias, residual=res, tile=10, ksplit=1)
+        o2 = hip.linear_fwd(a, b, bias=bias, residual=res, tile=2, ksplit=1)
+        assert torch.equal(o10, o2), K
+        assert rel_err(o10, a.float() @ b.float().t() + bias + res.float()) < 5e-3
+        w = rnd(K, N, seed=5)                                   # data gradient: A K-contiguous (ragged), B rows past K out of range
+        assert torch.equal(hip.linear_dgrad(a, w, tile=12, ksplit=1), hip.linear_dgrad(a, w, tile=2, ksplit=1)), K
+        dy, x = rnd(K, M, seed=6), rnd(K, N, seed=7)            # weight gradient: contraction over K rows of both operands
+        g12, g2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+        hip.linear_wgrad(dy, x, g12, tile=12, ksplit=1); hip.linear_wgrad(dy, x, g2, tile=2, ksplit=1)
+        assert torch.equal(g12, g2), K
+        assert rel_err(g12, dy.float().t() @ x.float()) < 1e-5
+    # the automatic choice now takes the pipelined tiles for such K
+    a, b = rnd(2048, 4304, seed=8), rnd(1152, 4304, seed=9)
+    assert torch.equal(hip.linear_fwd(a, b), hip.linear_fwd(a, b, tile=2, ksplit=1)) or rel_err(hip.linear_fwd(a, b), a.float() @ b.float().t()) < 5e-3
+
+
 def test_gemm_tail_split(hip):
     # more than one round of 256x256 tiles with a poorly filled last round: the full rounds run unsplit, the tail
     # tiles are split along K into compact slabs and reduced (partial tiles in M and N included)
