@@ -239,12 +239,13 @@ class FsdpComm(UnitPipeline):
         import os
 
         self.inplace_gather = os.environ.get("LAP_FSDP_INPLACE_GATHER", "1") != "0"
-        # The assembly GEMM kernels are persistent, one block per CU: a collective kernel that holds a few CUs when such a GEMM
-        # starts would leave some of its 256 blocks waiting for a CU and double that GEMM's time.  Under RCCL they therefore
-        # run with 248 blocks (31 per XCD), which leaves one CU per XCD to the 8 collective channels planned in DESIGN.md
-        # section 5.  (Read once by the library at its first assembly launch; an explicit LAP_ASM_BLOCKS wins.)
-        if self.fused and self.world_size > 1:
-            os.environ.setdefault("LAP_ASM_BLOCKS", "248")
+        # The assembly GEMM kernels are persistent, one block per CU, with a static tile list per block: a collective kernel
+        # that holds a few CUs when such a GEMM starts leaves as many of its 256 blocks waiting until other blocks have
+        # finished their whole list — the GEMM takes twice as long.  (Fewer blocks avoid that but quantise badly: 248 blocks
+        # cost 5 % of the step on one GPU.)  The HIP tiles schedule their blocks dynamically and have no such cliff, so under
+        # RCCL the library stays on them unless LAP_GEMM_ASM_WITH_RCCL=1 asks otherwise.  (Read once by the library.)
+        if self.fused and self.world_size > 1 and os.environ.get("LAP_GEMM_ASM_WITH_RCCL") != "1":
+            os.environ.setdefault("LAP_GEMM_NO_ASM", "1")
 
     # ---- gradients
     def _reduce_grads(self, u):
