@@ -208,6 +208,30 @@ def test_gemm_ragged_k_on_the_pipelined_tiles_matches_lockstep_tile_bitwise(hip)
     assert torch.equal(hip.linear_fwd(a, b), hip.linear_fwd(a, b, tile=2, ksplit=1)) or rel_err(hip.linear_fwd(a, b), a.float() @ b.float().t()) < 5e-3
 
 
+def test_gemm_assembly_kernel_replays_from_a_hip_graph(hip):
+    """The assembly kernels are launched through hipModuleLaunchKernel from an embedded code object: a captured launch must
+    replay like any other kernel node (serving with a batch whose prefill rows fill whole 256-tiles takes this route)."""
+    a, b = rnd(2048, 512, seed=1), rnd(1024, 512, seed=2)
+    ref = hip.linear_fwd(a, b, tile=10, ksplit=1)
+    out = torch.zeros_like(ref)
+    hip.linear_fwd(a, b, out)                      # (first use outside capture: the module load is not capturable)
+    torch.cuda.synchronize()
+    out.zero_()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            hip.linear_fwd(a, b, out)
+    torch.cuda.current_stream().wait_stream(side)
+    assert not out.any()                           # capture does not execute
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    a.copy_(rnd(2048, 512, seed=3))
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(out, hip.linear_fwd(a, b, tile=10, ksplit=1))
+
+
 def test_gemm_tail_split(hip):
     # more than one round of 256x256 tiles with a poorly filled last round: the full rounds run unsplit, the tail
     # tiles are split along K into compact slabs and reduced (partial tiles in M and N included)
