@@ -93,6 +93,149 @@ def compute_norm_stats(dataset: EpisodeDataset, *, action_pad_to: int | None = N
     return out
 
 
+# ------------------------------------------------------------------------------ dataset mixture (datasets/dataset_mixer.py)
+# datasets/utils/mixtures.py: named mixtures = (dataset name, sampling weight) lists; the two the reference's LAP configs use
+# plus the single-dataset entries every dataset name implies.
+NAMED_MIXTURES: dict[str, list[tuple[str, float]]] = {
+    "oxe_magic_soup": [
+        ("bc_z", 0.05), ("droid", 2.0), ("fractal20220817_data", 1.0), ("bridge_v2_oxe", 1.0), ("taco_play", 2.0), ("jaco_play", 1.0),
+        ("furniture_bench_dataset_converted_externally_to_rlds", 0.05), ("utaustin_mutex", 1.0), ("berkeley_fanuc_manipulation", 2.0),
+        ("fmb", 0.05), ("berkeley_autolab_ur5", 1.0), ("austin_buds_dataset_converted_externally_to_rlds", 1.0),
+        ("austin_sailor_dataset_converted_externally_to_rlds", 1.0), ("austin_sirius_dataset_converted_externally_to_rlds", 1.0),
+        ("viola", 1.0), ("molmoact_dataset", 1.0)],
+    "libero_finetune": [("libero_10_no_noops", 1.0), ("libero_spatial_no_noops", 1.0), ("libero_object_no_noops", 1.0),
+                        ("libero_goal_no_noops", 1.0)],
+}
+
+
+def resolve_mixture(mix) -> list[tuple[str, float]]:
+    """A named mixture, a single dataset name (weight 1, as the reference's per-dataset entries), or an explicit list."""
+    if isinstance(mix, str):
+        return list(NAMED_MIXTURES.get(mix, [(mix, 1.0)]))
+    return [(str(n), float(w)) for n, w in mix]
+
+
+def mixture_weights(sizes: Sequence[int], weights: Sequence[float], *, balance_weights: bool = True) -> tuple[np.ndarray, int]:
+    """dataset_mixer.py:146-156: `balance_weights` multiplies each mixture weight by its dataset's size (number of transitions),
+    the result is normalised; the effective length of the mixture is the largest size / weight — the number of draws after
+    which the most under-sampled dataset has been seen once in expectation."""
+    sizes, w = np.asarray(sizes, dtype=np.float64), np.asarray(weights, dtype=np.float64)
+    if len(sizes) == 0 or len(sizes) != len(w) or (sizes <= 0).any() or (w <= 0).any():
+        raise ValueError("a mixture needs one positive size and one positive weight per dataset")
+    if balance_weights:
+        w = w * sizes
+    w = w / w.sum()
+    return w, int((sizes / w).max())
+
+
+def global_norm_stats(per_dataset: dict, *, action_dim: int, state_dim: int, state_types: dict | None = None,
+                      exclude: Sequence[str] = ()) -> dict:
+    """datasets/utils/statistics.py:45-236 (GlobalStatisticsBuilder): one set of normalisation statistics for a mixture from the
+    per-dataset ones.  `per_dataset[name][key]` has mean / std / q01 / q99 / min / max vectors and `num_transitions` (key =
+    "actions" or "state").  Mean and variance are the exact moments of the pooled data (weights = transitions, parallel-variance
+    formula), q01 / min are the per-dimension minimum over datasets, q99 / max the maximum — the bounds of the pooled data can
+    only be bracketed, not recovered, from per-dataset quantiles.  Vectors are cut / zero-padded to `action_dim` / `state_dim`
+    (std padded with 0).  States are pooled per state type (`state_types[name]`, e.g. "eef_pose" / "joint_pos"; "none" or
+    missing = skipped) into `state_<type>`; datasets in `exclude` (the VQA sets) contribute nothing."""
+    def pad(v, n, fill=0.0):
+        v = np.asarray(v, dtype=np.float32)[:n]
+        return np.pad(v, (0, n - len(v)), constant_values=fill)
+
+    def pool(names, key, dim):
+        names = [n for n in names if key in per_dataset[n] and per_dataset[n][key].get("num_transitions", 0) > 0]
+        total = sum(int(per_dataset[n][key]["num_transitions"]) for n in names)
+        if total == 0:
+            return None
+        mean = sum(pad(per_dataset[n][key]["mean"], dim) * per_dataset[n][key]["num_transitions"] for n in names) / total
+        var = sum(per_dataset[n][key]["num_transitions"] * (np.square(pad(per_dataset[n][key]["std"], dim)) +
+                                                             np.square(pad(per_dataset[n][key]["mean"], dim) - mean)) for n in names) / total
+        lo = lambda f: np.min([pad(per_dataset[n][key][f], dim) for n in names], axis=0)
+        hi = lambda f: np.max([pad(per_dataset[n][key][f], dim) for n in names], axis=0)
+        return {"mean": mean.astype(np.float32), "std": np.sqrt(var).astype(np.float32), "q01": lo("q01"), "q99": hi("q99"),
+                "min": lo("min"), "max": hi("max"), "num_transitions": total,
+                "num_trajectories": sum(int(per_dataset[n][key].get("num_trajectories", 0)) for n in names)}
+
+    robot = [n for n in per_dataset if n not in set(exclude)]
+    out = {}
+    acts = pool(robot, "actions", action_dim)
+    out["actions"] = acts if acts is not None else {
+        "mean": np.zeros(action_dim, np.float32), "std": np.ones(action_dim, np.float32), "q01": np.zeros(action_dim, np.float32),
+        "q99": np.zeros(action_dim, np.float32), "num_transitions": 0, "num_trajectories": 0}
+    by_type: dict[str, list[str]] = {}
+    for n in robot:
+        t = (state_types or {}).get(n, "eef_pose")
+        if t and t != "none":
+            by_type.setdefault(t, []).append(n)
+    for t, names in by_type.items():
+        st = pool(names, "state", state_dim)
+        if st is not None:
+            out[f"state_{t}"] = st
+    return out
+
+
+class MixtureDataset:
+    """Weighted mixture of episode datasets with the index protocol of `EpisodeDataset` (datasets/dataset_mixer.py:34-240).
+
+    The reference interleaves endlessly repeated, shuffled per-dataset streams with `sample_from_datasets(weights, seed)`: every
+    element of the mixed stream comes from dataset i with probability w_i.  Here element `index` of the mixture is a pure
+    function of (seed, index): a counter-based generator picks the dataset by the same weights and then a transition of it
+    uniformly — the same distribution, random access (what the resumable, rank-sharded `DataLoader` needs) instead of a stream.
+    `len()` is the reference's effective mixture length (`mixture_weights`)."""
+
+    def __init__(self, datasets: dict, mixture, *, balance_weights: bool = True, seed: int = 0):
+        spec = resolve_mixture(mixture)
+        missing = [n for n, _ in spec if n not in datasets]
+        if missing:
+            raise KeyError(f"mixture names datasets that were not provided: {missing}")
+        self.names = [n for n, _ in spec]
+        self.datasets = [datasets[n] for n in self.names]
+        self.sizes = [len(d) for d in self.datasets]
+        self.sample_weights, self.length = mixture_weights(self.sizes, [w for _, w in spec], balance_weights=balance_weights)
+        self._cdf = np.cumsum(self.sample_weights)
+        self.seed = int(seed)
+        horizons = {d.action_horizon for d in self.datasets}
+        if len(horizons) != 1:
+            raise ValueError(f"datasets of one mixture must share the action horizon, got {sorted(horizons)}")
+        self.action_horizon = horizons.pop()
+
+    def __len__(self) -> int:
+        return self.length
+
+    def locate(self, index: int) -> tuple[int, int]:
+        """(dataset position in the mixture, transition index inside it) of mixture element `index`"""
+        u = np.random.Generator(np.random.Philox(key=self.seed, counter=[0, 0, 0, int(index)])).random(2)
+        d = min(int(np.searchsorted(self._cdf, u[0], side="right")), len(self.datasets) - 1)
+        return d, min(int(u[1] * self.sizes[d]), self.sizes[d] - 1)
+
+    def __getitem__(self, index: int) -> dict:
+        d, i = self.locate(index)
+        sample = self.datasets[d][i]
+        if not sample.get("dataset_name"):
+            sample["dataset_name"] = self.names[d]
+        return sample
+
+    @property
+    def episodes(self):      # (compute_norm_stats over the pooled episodes; per-dataset statistics: call it per dataset)
+        return [e for d in self.datasets for e in d.episodes]
+
+
+def compute_mixture_norm_stats(mixture: MixtureDataset, *, action_pad_to: int, state_dim: int, state_types: dict | None = None) -> dict:
+    """Per-dataset statistics (`compute_norm_stats`) pooled by `global_norm_stats`, in the norm_stats.json layout `Normalize` reads
+    ("actions", "state"): the reference normalises every dataset of a mixture with the same global statistics
+    (dataset_mixer.py:166-214)."""
+    per = {}
+    for name, ds in zip(mixture.names, mixture.datasets):
+        st = compute_norm_stats(ds, action_pad_to=action_pad_to)
+        n_tr, n_ep = len(ds), len(ds.episodes)
+        per[name] = {k: {**{f: np.asarray(v[f], dtype=np.float32) for f in v}, "num_transitions": n_tr, "num_trajectories": n_ep} for k, v in st.items()}
+    g = global_norm_stats(per, action_dim=action_pad_to, state_dim=state_dim, state_types=state_types)
+    state = next((g[k] for k in sorted(g) if k.startswith("state_")), None)
+    out = {"actions": {f: np.asarray(g["actions"][f]).tolist() for f in ("mean", "std", "q01", "q99", "min", "max") if f in g["actions"]}}
+    if state is not None:
+        out["state"] = {f: np.asarray(state[f]).tolist() for f in ("mean", "std", "q01", "q99", "min", "max")}
+    return out
+
+
 def _stack(samples: list[dict]) -> dict:
     """jax.tree.map(np.stack) over per-sample dicts (data_loader.py:111-121); None leaves must be None everywhere."""
     first = samples[0]
@@ -161,13 +304,17 @@ class DataLoader:
             yield CoTObservation.from_dict(batch, device=self.device), actions
 
 
-def create_data_loader(config, dataset: EpisodeDataset, tokenizer, *, norm_stats: dict | None = None, shuffle: bool = True, seed: int = 0,
+def create_data_loader(config, dataset: "EpisodeDataset | MixtureDataset", tokenizer, *, norm_stats: dict | None = None, shuffle: bool = True, seed: int = 0,
                        rank: int = 0, world_size: int = 1, num_batches: int | None = None, split: str = "train", device=None) -> DataLoader:
     """datasets/data_loader.py:126-198: per-rank batch = config.batch_size // world_size; the transform stack of
     `training/config.py` (data transforms + Normalize + model transforms) for the LAP model type."""
     mc = config.model
     if norm_stats is None:
-        norm_stats = compute_norm_stats(dataset, action_pad_to=mc.action_dim)
+        if isinstance(dataset, MixtureDataset):     # one set of statistics for the whole mixture (dataset_mixer.py:166-214)
+            state_dim = max(np.asarray(e["state"]).shape[-1] for e in dataset.episodes)
+            norm_stats = compute_mixture_norm_stats(dataset, action_pad_to=mc.action_dim, state_dim=state_dim)
+        else:
+            norm_stats = compute_norm_stats(dataset, action_pad_to=mc.action_dim)
     ntype = getattr(config.data, "action_proprio_normalization_type", "bounds_q99")
     stack = pio.compose([
         pio.CoTInputs(action_dim=mc.action_dim, random_base_prob=getattr(config.data, "random_base_prob", 0.0),

@@ -107,3 +107,77 @@ def test_episode_files_round_trip(tmp_path):
     np.testing.assert_array_equal(ds[7]["observation"]["base_0_rgb"], eps[1]["base_0_rgb"][1])
     with pytest.raises(FileNotFoundError):
         D.EpisodeDataset(tmp_path / "none", action_horizon=4)
+
+
+# ------------------------------------------------------------------------------------------- dataset mixture
+def test_mixture_weights_follow_the_reference_formula():
+    """dataset_mixer.py:146-156: balance -> weight x size, normalise; length = max(size / weight)."""
+    w, n = D.mixture_weights([1000, 250, 50], [1.0, 2.0, 0.05], balance_weights=True)
+    raw = np.array([1000 * 1.0, 250 * 2.0, 50 * 0.05])
+    assert np.allclose(w, raw / raw.sum()) and abs(w.sum() - 1) < 1e-12
+    assert n == int((np.array([1000, 250, 50]) / w).max())
+    w2, n2 = D.mixture_weights([1000, 250, 50], [1.0, 2.0, 0.05], balance_weights=False)
+    assert np.allclose(w2, np.array([1.0, 2.0, 0.05]) / 3.05) and n2 == int((np.array([1000, 250, 50]) / w2).max())
+    with pytest.raises(ValueError):
+        D.mixture_weights([10, 0], [1.0, 1.0])
+    assert D.resolve_mixture("libero_finetune")[0] == ("libero_10_no_noops", 1.0) and D.resolve_mixture("droid") == [("droid", 1.0)]
+    assert dict(D.resolve_mixture("oxe_magic_soup"))["droid"] == 2.0
+
+
+def test_mixture_dataset_draws_by_weight_and_is_a_pure_function_of_seed_and_index(setup):
+    cfg, tok, _ = setup
+    H = cfg.model.action_horizon
+    a = D.EpisodeDataset(_episodes(n=4, T=20, seed=1), action_horizon=H)       # 80 transitions
+    b = D.EpisodeDataset(_episodes(n=2, T=10, seed=2), action_horizon=H)       # 20 transitions
+    for e in b.episodes:
+        e["dataset_name"] = "bridge_v2_oxe"
+    mix = D.MixtureDataset({"droid": a, "bridge_v2_oxe": b}, [("droid", 1.0), ("bridge_v2_oxe", 3.0)], balance_weights=False, seed=5)
+    assert np.allclose(mix.sample_weights, [0.25, 0.75]) and len(mix) == int(max(80 / 0.25, 20 / 0.75))
+    picks = np.array([mix.locate(i) for i in range(4000)])
+    assert abs((picks[:, 0] == 1).mean() - 0.75) < 0.03                         # dataset frequencies = mixture weights
+    inner = picks[picks[:, 0] == 1, 1]
+    assert set(inner) == set(range(20)) and np.bincount(inner).std() / np.bincount(inner).mean() < 0.2   # uniform inside a dataset
+    again = D.MixtureDataset({"droid": a, "bridge_v2_oxe": b}, [("droid", 1.0), ("bridge_v2_oxe", 3.0)], balance_weights=False, seed=5)
+    assert all(again.locate(i) == tuple(picks[i]) for i in range(0, 4000, 97))
+    other = D.MixtureDataset({"droid": a, "bridge_v2_oxe": b}, [("droid", 1.0), ("bridge_v2_oxe", 3.0)], balance_weights=False, seed=6)
+    assert any(other.locate(i) != tuple(picks[i]) for i in range(50))
+    s = mix[3]
+    d, i = mix.locate(3)
+    assert s["dataset_name"] == ["droid", "bridge_v2_oxe"][d] and np.array_equal(s["actions"], [a, b][d][i]["actions"])
+    with pytest.raises(KeyError):
+        D.MixtureDataset({"droid": a}, "libero_finetune")
+    # balanced: weight x size -> every transition of the pool is equally likely
+    bal = D.MixtureDataset({"droid": a, "bridge_v2_oxe": b}, [("droid", 1.0), ("bridge_v2_oxe", 1.0)], balance_weights=True)
+    assert np.allclose(bal.sample_weights, [0.8, 0.2]) and len(bal) == 100
+    # and it feeds the loader like a single dataset (global statistics, resume protocol)
+    loader = D.create_data_loader(cfg, mix, tok, seed=0, num_batches=2)
+    obs, actions = next(iter(loader))
+    assert actions.shape == (cfg.batch_size, H, cfg.model.action_dim) and torch.isfinite(actions).all()
+
+
+def test_global_norm_stats_are_the_pooled_moments_and_bracketing_quantiles():
+    """datasets/utils/statistics.py:94-236: mean / std of a mixture = the exact moments of the pooled transitions; q01 / q99 / min /
+    max bracket the pooled data (min of the lower, max of the upper bounds); VQA sets excluded; states pooled per state type."""
+    rs = np.random.RandomState(0)
+    data = {"droid": rs.normal(0.1, 1.0, (500, 7)), "bridge_v2_oxe": rs.normal(-0.3, 0.4, (120, 7)), "coco_captions": rs.normal(5, 1, (50, 7))}
+    states = {"droid": rs.normal(0, 1, (500, 8)), "bridge_v2_oxe": rs.normal(1, 2, (120, 10)), "coco_captions": rs.normal(0, 1, (50, 8))}
+
+    def stats(x):
+        return {"mean": x.mean(0), "std": x.std(0), "q01": np.quantile(x, 0.01, 0), "q99": np.quantile(x, 0.99, 0), "min": x.min(0), "max": x.max(0),
+                "num_transitions": len(x), "num_trajectories": len(x) // 10}
+    per = {n: {"actions": stats(data[n]), "state": stats(states[n])} for n in data}
+    g = D.global_norm_stats(per, action_dim=9, state_dim=10, state_types={"droid": "eef_pose", "bridge_v2_oxe": "joint_pos", "coco_captions": "none"},
+                            exclude=["coco_captions"])
+    pooled = np.concatenate([data["droid"], data["bridge_v2_oxe"]], 0)
+    assert np.allclose(g["actions"]["mean"][:7], pooled.mean(0), atol=1e-5) and np.allclose(g["actions"]["std"][:7], pooled.std(0), atol=1e-5)
+    assert np.all(g["actions"]["mean"][7:] == 0) and np.all(g["actions"]["std"][7:] == 0)          # padded to action_dim
+    assert g["actions"]["num_transitions"] == 620 and g["actions"]["num_trajectories"] == 62
+    assert np.allclose(g["actions"]["q01"][:7], np.minimum(per["droid"]["actions"]["q01"], per["bridge_v2_oxe"]["actions"]["q01"]))
+    assert np.allclose(g["actions"]["q99"][:7], np.maximum(per["droid"]["actions"]["q99"], per["bridge_v2_oxe"]["actions"]["q99"]))
+    assert np.all(g["actions"]["q01"][:7] <= np.quantile(pooled, 0.01, 0) + 1e-6) and np.all(g["actions"]["q99"][:7] >= np.quantile(pooled, 0.99, 0) - 1e-6)
+    assert np.allclose(g["actions"]["min"][:7], pooled.min(0)) and np.allclose(g["actions"]["max"][:7], pooled.max(0))
+    assert set(g) == {"actions", "state_eef_pose", "state_joint_pos"}
+    assert np.allclose(g["state_eef_pose"]["mean"][:8], states["droid"].mean(0), atol=1e-5) and g["state_eef_pose"]["num_transitions"] == 500
+    assert np.allclose(g["state_joint_pos"]["std"], states["bridge_v2_oxe"].std(0), atol=1e-5)
+    empty = D.global_norm_stats({"coco_captions": per["coco_captions"]}, action_dim=4, state_dim=4, exclude=["coco_captions"])
+    assert empty["actions"]["num_transitions"] == 0 and np.all(empty["actions"]["std"] == 1) and set(empty) == {"actions"}
