@@ -239,13 +239,10 @@ class FsdpComm(UnitPipeline):
         import os
 
         self.inplace_gather = os.environ.get("LAP_FSDP_INPLACE_GATHER", "1") != "0"
-        # The assembly GEMM kernels are persistent, one block per CU, with a static tile list per block: a collective kernel
-        # that holds a few CUs when such a GEMM starts leaves as many of its 256 blocks waiting until other blocks have
-        # finished their whole list — the GEMM takes twice as long.  (Fewer blocks avoid that but quantise badly: 248 blocks
-        # cost 5 % of the step on one GPU.)  The HIP tiles schedule their blocks dynamically and have no such cliff, so under
-        # RCCL the library stays on them unless LAP_GEMM_ASM_WITH_RCCL=1 asks otherwise.  (Read once by the library.)
-        if self.fused and self.world_size > 1 and os.environ.get("LAP_GEMM_ASM_WITH_RCCL") != "1":
-            os.environ.setdefault("LAP_GEMM_NO_ASM", "1")
+        # The assembly GEMM kernels are persistent (one block per CU) but draw their tiles from per-XCD counters, so a collective
+        # kernel that owns a few CUs costs them about what it costs the HIP tiles (tools/probes/coresident.py: +10 % with 16 CUs
+        # taken, against +70 % for static tile lists); they stay on under RCCL.  LAP_GEMM_NO_ASM=1 is the switch if a SCALE run
+        # says otherwise.
 
     # ---- gradients
     def _reduce_grads(self, u):

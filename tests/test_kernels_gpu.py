@@ -142,7 +142,7 @@ def test_gemm_assembly_kernels_match_hip_tiles_bitwise(hip, lay):
     across the tile seam), and row strides larger than the row."""
     a_kc, b_kc, f32 = lay[0] == "n", lay[1] == "t", lay == "tn"
     dt = torch.float32 if f32 else torch.bfloat16
-    for M, N, K, pad in [(256, 512, 256, 0), (2304, 1280, 512, 0), (1024, 768, 1152, 64), (5120, 4096, 384, 0)]:
+    for M, N, K, pad in [(256, 512, 512, 0), (2304, 1280, 512, 0), (1024, 768, 1152, 64), (5120, 4096, 640, 0), (9216, 8192, 512, 0)]:
         a = rnd(M, K + pad, seed=1)[:, :K] if a_kc else rnd(K, M + pad, seed=1)[:, :M]
         b = rnd(N, K + pad, seed=2)[:, :K] if b_kc else rnd(K, N + pad, seed=2)[:, :N]
         outs = []
@@ -163,14 +163,14 @@ def test_gemm_assembly_kernels_match_hip_tiles_bitwise(hip, lay):
         assert torch.equal(o1, o2)
     # epilogue extras are not this kernel's: asking for it explicitly is rejected, the automatic choice falls back
     with pytest.raises(hip.LapHipError):
-        hip.gemm(rnd(256, 256), rnd(512, 256), torch.empty(256, 512, device=DEV, dtype=torch.bfloat16), M=256, N=512, K=256, lda=256, ldb=256,
+        hip.gemm(rnd(256, 512), rnd(512, 512), torch.empty(256, 512, device=DEV, dtype=torch.bfloat16), M=256, N=512, K=512, lda=512, ldb=512,
                  ldc=512, residual=rnd(256, 512), ldr=512, tile=14)
 
 
 def test_gemm_assembly_bias_kernel_ragged_n_matches_hip_tiles_bitwise(hip):
     """lap_gemm_asm_nt_bias: forward + f32 bias per column, N any multiple of 16 (SigLIP qkv N = 3456, fc1 N = 4304): the last
     n-tile's missing rows of B read as zeros and its missing output columns are never stored."""
-    for M, N, K, pad in [(512, 528, 256, 0), (1024, 1152, 1152, 48), (2304, 4304, 384, 0), (768, 3456, 1152, 16)]:
+    for M, N, K, pad in [(512, 528, 512, 0), (1024, 1152, 1152, 48), (2304, 4304, 640, 0), (768, 3456, 1152, 16), (8192, 4304, 512, 0)]:
         a = rnd(M, K + pad, seed=1)[:, :K]
         b = rnd(N, K, seed=2)
         bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(DEV)

@@ -17,7 +17,7 @@ def timeit(fn, n=10):
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "check"
 layouts = sys.argv[2:] or ["nt", "nn", "tn"]
-SH = {"check": [(256, 512, 256), (512, 256, 384), (1024, 768, 1152), (2304, 1280, 512), (4096, 4096, 4096)],
+SH = {"check": [(256, 512, 512), (512, 256, 640), (1024, 768, 1152), (2304, 1280, 512), (4096, 4096, 4096), (9216, 8192, 512)],
       "quick": {"nt": [(17920, 32768, 2048), (4096, 4096, 4096), (8192, 8192, 8192), (17920, 2560, 2048)],
                 "nn": [(17920, 16384, 2048), (4096, 4096, 4096), (8192, 8192, 8192), (17920, 2048, 32768)],
                 "tn": [(32768, 2048, 17920), (2048, 16384, 17920), (4096, 4096, 4096), (8192, 8192, 8192)]},

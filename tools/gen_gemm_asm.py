@@ -3,8 +3,12 @@ operand layout.  The HIP kernels of csrc/gemm.hip stop at 1.15-1.35 PF because h
 fed; here the instruction stream is fixed by this script:
 
   256 x 256 x 64 tile, 4 waves (2 x 2), one per SIMD, each 128 x 128 = 8 x 8 MFMA 16x16x32 tiles in 256 AGPRs;
-  PERSISTENT blocks (one per CU): block b walks tiles t0, t0 + grid, ...; the operand stream (LDS-DMA) runs two k-tiles ahead
-  of the MFMAs and straight across tile seams, so a tile's epilogue overlaps the next tile's first fetches;
+  PERSISTENT blocks (256, one per CU).  Tiles are handed out per XCD: round r of XCD x covers logical tiles r * 256 + 32 x .. + 31;
+  a block's first tile is static (block b: 32 (b % 8) + b / 8), every further one is a ticket of its XCD's counter (the XCD
+  is read from HW_REG_XCC_ID), drawn by wave 0 one k-tile before the operand stream needs it and passed to the other waves
+  through an LDS mailbox — a block that starts late or shares its CU simply takes fewer tiles, and neighbours in the tile
+  order stay on one L2.  The operand stream (LDS-DMA) runs two k-tiles ahead of the MFMAs and straight across tile seams,
+  so a tile's epilogue overlaps the next tile's first fetches;
   LDS: 2 stages x [A tile 32 KiB | B tile 32 KiB].  A K-contiguous operand tile is [256 rows][128 B], 16-byte chunks
   XOR-swizzled with (row >> 1) & 7 and read with ds_read_b128; an M- / N-contiguous operand tile is [64 k-rows][512 B],
   chunks XOR-swizzled with mc_swz(k) << 1 and read with ds_read_b64_tr_b16 (the images of csrc/common.hpp kc_tile_off /
@@ -25,7 +29,7 @@ Kernels: lap_gemm_asm_nt (A [M,K], B [N,K]; bf16 out: forward), lap_gemm_asm_nn 
 gradient), lap_gemm_asm_tn (A [K,M], B [K,N]; f32 out: weight gradient), lap_gemm_asm_nt_bias (forward + f32 bias per
 column, N any multiple of 16: the last n-tile's missing rows of B read as zeros, its missing columns of C are masked out of
 the stores).  Constraints checked by the launcher (csrc/gemm_asm.hip): M % 256 == 0, N % 256 == 0 (plain kernels), K % 128
-== 0, K >= 256, strides % 8 == 0.
+== 0, K >= 512, strides % 8 == 0.
 
 Usage: python tools/gen_gemm_asm.py > lap_amd/csrc/gemm_asm_kernels.s
 """
@@ -48,7 +52,11 @@ S_T = 20                    # s20..s35 scratch (s35: wave id)
 S_W8K = 40                  # wave * 8192: LDS byte base of this wave's DMA pieces
 S_LOOP = 41
 S_TM, S_GML, S_MAGL, S_NT, S_ONE, S_GSH, S_G = 42, 43, 44, 45, 46, 47, 48
-S_TCUR, S_TDMA, S_DLEFT, S_NKT = 50, 51, 52, 53
+S_HAVE, S_TDMA, S_DLEFT, S_NKT = 50, 51, 52, 53      # S_HAVE: the stream has moved on to a valid next tile of this block
+RQ = 8                      # s[8:11]: descriptor of the 8 per-XCD tile counters
+S_XCC, S_XOFF, S_REQ = 3, 49, 59   # XCC id of the CU this block runs on; its counter's byte offset; wave 0: a ticket request is in flight
+V_TK, V_MB = 14, 15         # ticket (wave 0: the atomic's return value); LDS address of the ticket mailbox
+MAILBOX = 131072            # LDS byte offset (behind the two stages)
 S_BUMPA, S_BUMPB = 54, 55   # bytes per k-tile along each operand
 S_C = 56                    # C pointer pair
 RA, RB, RC = 60, 64, 68     # buffer descriptors
@@ -185,15 +193,30 @@ class Kernel:
         return r
 
     def stream_step(self):
-        """after a k-tile's DMA pieces: advance the descriptors; when the tile's last k-tile has been requested, move the
-        stream on to this block's next tile (or park it: every further request then falls outside the range: zero fill)"""
+        """after a k-tile's DMA pieces: advance the descriptors.  One k-tile before the tile's last request wave 0 draws the
+        block's next ticket from its XCD's counter (returned by the time of the next barrier, where it is put into the LDS
+        mailbox); when the last k-tile has been requested every wave reads the mailbox and moves the stream on to that tile
+        (or parks it: every further request then falls outside the range: zero fill)."""
         _uid[0] += 1
         u = _uid[0]
+        t = S_T
         r = self.bump()
-        r += [f"s_sub_u32 s{S_DLEFT}, s{S_DLEFT}, 1", f"s_cmp_lg_u32 s{S_DLEFT}, 0", f"s_cbranch_scc1 .Lstream_done{u}",
-              f"s_add_u32 s{S_TDMA}, s{S_TDMA}, s{S_G}", f"s_cmp_lt_u32 s{S_TDMA}, s{S_NT}", f"s_cbranch_scc0 .Lstream_park{u}"]
+        r += [f"s_sub_u32 s{S_DLEFT}, s{S_DLEFT}, 1",
+              f"s_cmp_lg_u32 s{S_DLEFT}, 1", f"s_cbranch_scc1 .Lno_req{u}",
+              f"s_cmp_lg_u32 s{t+15}, 0", f"s_cbranch_scc1 .Lstream_done{u}",                 # (DLEFT == 1: nothing else to do)
+              "s_mov_b64 exec, 1", f"v_mov_b32 v{V_TK}, 1",
+              f"buffer_atomic_add v{V_TK}, off, s[{RQ}:{RQ+3}], s{S_XOFF} sc0",
+              "s_mov_b64 exec, -1", f"s_mov_b32 s{S_REQ}, 1", f"s_branch .Lstream_done{u}",
+              f".Lno_req{u}:",
+              f"s_cmp_lg_u32 s{S_DLEFT}, 0", f"s_cbranch_scc1 .Lstream_done{u}",
+              f"ds_read_b32 v{V_TK}, v{V_MB}", "s_waitcnt lgkmcnt(0)", f"v_readfirstlane_b32 s{t+10}, v{V_TK}",
+              f"s_add_u32 s{t+10}, s{t+10}, 32",                                               # tickets count from the second round
+              f"s_lshr_b32 s{t+11}, s{t+10}, 5", f"s_lshl_b32 s{t+11}, s{t+11}, 8",            # round * 256
+              f"s_and_b32 s{t+10}, s{t+10}, 31", f"s_add_u32 s{t+11}, s{t+11}, s{t+10}",
+              f"s_lshl_b32 s{t+10}, s{S_XCC}, 5", f"s_add_u32 s{S_TDMA}, s{t+11}, s{t+10}",    # + 32 xcc
+              f"s_cmp_lt_u32 s{S_TDMA}, s{S_NT}", f"s_cbranch_scc0 .Lstream_park{u}"]
         r += self.setup(S_TDMA)
-        r += [f"s_mov_b32 s{S_DLEFT}, s{S_NKT}", f"s_branch .Lstream_done{u}", f".Lstream_park{u}:",
+        r += [f"s_mov_b32 s{S_DLEFT}, s{S_NKT}", f"s_mov_b32 s{S_HAVE}, 1", f"s_branch .Lstream_done{u}", f".Lstream_park{u}:",
               f"s_mov_b32 s{RA+2}, 0", f"s_mov_b32 s{RB+2}, 0", f"s_mov_b32 s{S_STEPA}, 0", f"s_mov_b32 s{S_STEPB}, 0",
               f"s_mov_b32 s{S_DLEFT}, 0x7fffffff", f".Lstream_done{u}:"]
         return r
@@ -215,6 +238,15 @@ class Kernel:
         rs = RS * 16 / len(rd)
         self.phase(0, [(min(int(rs * n), 63), t) for n, t in enumerate(rd)])
         E("\ts_waitcnt vmcnt(0) lgkmcnt(0)")
+        _uid[0] += 1
+        E(f"\ts_cmp_eq_u32 s{S_REQ}, 0")                  # wave 0, a ticket has just come back: into the mailbox before the barrier
+        E(f"\ts_cbranch_scc1 .Lno_pub{_uid[0]}")
+        E("\ts_mov_b64 exec, 1")
+        E(f"\tds_write_b32 v{V_MB}, v{V_TK}")
+        E("\ts_mov_b64 exec, -1")
+        E("\ts_waitcnt lgkmcnt(0)")
+        E(f"\ts_mov_b32 s{S_REQ}, 0")
+        E(f".Lno_pub{_uid[0]}:")
         E("\ts_barrier")
         rd = self.reads(0, stage ^ 1, 0)
         side = [(min(int(rs * n), 63), t) for n, t in enumerate(rd)]
@@ -244,6 +276,8 @@ class Kernel:
         E(f"\ts_load_dwordx2 s[{S_MAGL}:{S_MAGL+1}], {S_KARG}, 0x40")
         E(f"\ts_load_dwordx2 s[{S_ONE}:{S_ONE+1}], {S_KARG}, 0x48")
         E(f"\ts_load_dword s{S_G}, {S_KARG}, 0x50")
+        E(f"\ts_load_dwordx2 s[{RQ}:{RQ+1}], {S_KARG}, 0x70")
+        E(f"\ts_getreg_b32 s{S_XCC}, hwreg(HW_REG_XCC_ID)")
         if self.epi:
             E(f"\ts_load_dwordx2 s[{RBI}:{RBI+1}], {S_KARG}, 0x60")
         E(f"\tv_and_b32 v{V_LANE}, 63, v{V_TID}")
@@ -252,17 +286,24 @@ class Kernel:
         E(f"\tv_readfirstlane_b32 s{W}, v{V_T}")                 # wave id
         E("\ts_nop 4")
         E("\ts_waitcnt lgkmcnt(0)")
-        # ---- this block's first tile: block b runs on XCD b % 8; the blocks of an XCD take consecutive tiles of every round
+        # ---- this block's first tile (static): 32 (b % 8) + b / 8 — the blocks of an XCD (round-robin dispatch) start on
+        # consecutive tiles; every further tile is a ticket of the XCD the block really runs on
         E(f"\ts_and_b32 s{t}, {S_WG}, 7")
-        E(f"\ts_lshr_b32 s{t+1}, s{S_G}, 3")
-        E(f"\ts_mul_i32 s{t}, s{t}, s{t+1}")
+        E(f"\ts_lshl_b32 s{t}, s{t}, 5")
         E(f"\ts_lshr_b32 s{t+1}, {S_WG}, 3")
-        E(f"\ts_add_u32 s{S_TCUR}, s{t}, s{t+1}")
-        E(f"\ts_cmp_lt_u32 s{S_TCUR}, s{S_NT}")
+        E(f"\ts_add_u32 s{S_TDMA}, s{t}, s{t+1}")
+        E(f"\ts_cmp_lt_u32 s{S_TDMA}, s{S_NT}")
         E(f"\ts_cbranch_scc1 .Lhave_work_{nm}")
         E("\ts_endpgm")
         E(f".Lhave_work_{nm}:")
-        E(f"\ts_mov_b32 s{S_TDMA}, s{S_TCUR}")
+        E(f"\ts_and_b32 s{S_XCC}, s{S_XCC}, 7")
+        E(f"\ts_lshl_b32 s{S_XOFF}, s{S_XCC}, 2")
+        E(f"\ts_and_b32 s{RQ+1}, s{RQ+1}, 0xffff")
+        E(f"\ts_mov_b32 s{RQ+2}, 32")
+        E(f"\ts_mov_b32 s{RQ+3}, 0x00020000")
+        E(f"\ts_mov_b32 s{S_HAVE}, 0")
+        E(f"\ts_mov_b32 s{S_REQ}, 0")
+        E(f"\tv_mov_b32 v{V_MB}, {MAILBOX}")
         E(f"\ts_lshl_b32 s{S_LDA}, s{S_LDA}, 1")         # leading dimensions and K in bytes from here on
         E(f"\ts_lshl_b32 s{S_LDB}, s{S_LDB}, 1")
         E(f"\ts_lshl_b32 s{S_LDC}, s{S_LDC}, {2 if self.f32 else 1}")
@@ -465,11 +506,11 @@ class Kernel:
                 E(f"\tbuffer_store_dwordx2 v[{cur+4}:{cur+5}], v{V_MOFF+fn if self.epi else V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*32}")
             if fn == 7:
                 E(f"\ts_add_u32 s{S_CROW}, s{S_CROW}, s{S_C16}")
-        E(f"\ts_add_u32 s{S_TCUR}, s{S_TCUR}, s{S_G}")
-        E(f"\ts_cmp_lt_u32 s{S_TCUR}, s{S_NT}")
+        E(f"\ts_cmp_lg_u32 s{S_HAVE}, 0")
         E(f"\ts_cbranch_scc1 .Lnext_{nm}")
         E("\ts_endpgm")
         E(f".Lnext_{nm}:")     # (register set 0 already holds the next tile's first fragments: the last P1 read them)
+        E(f"\ts_mov_b32 s{S_HAVE}, 0")
         for r in range(3):
             E(f"\ts_mov_b32 s{RC+r}, s{RCN+r}")
         if self.epi:
@@ -478,7 +519,7 @@ class Kernel:
         E("\t.section\t.rodata,\"a\",@progbits")
         E("\t.p2align\t6, 0x0")
         E(f"\t.amdhsa_kernel {nm}")
-        for k, v in (("group_segment_fixed_size", 131072), ("private_segment_fixed_size", 0), ("kernarg_size", 112),
+        for k, v in (("group_segment_fixed_size", 131136), ("private_segment_fixed_size", 0), ("kernarg_size", 128),
                      ("user_sgpr_count", 2), ("user_sgpr_dispatch_ptr", 0), ("user_sgpr_queue_ptr", 0), ("user_sgpr_kernarg_segment_ptr", 1),
                      ("user_sgpr_dispatch_id", 0), ("user_sgpr_kernarg_preload_length", 0), ("user_sgpr_kernarg_preload_offset", 0),
                      ("user_sgpr_private_segment_size", 0), ("uses_dynamic_stack", 0), ("enable_private_segment", 0),
@@ -496,11 +537,11 @@ class Kernel:
         return f"""  - .agpr_count:     256
     .args:
       - .offset:         0
-        .size:           112
+        .size:           128
         .value_kind:     by_value
-    .group_segment_fixed_size: 131072
+    .group_segment_fixed_size: 131136
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 112
+    .kernarg_segment_size: 128
     .max_flat_workgroup_size: 256
     .name:           {self.name}
     .private_segment_fixed_size: 0
