@@ -58,11 +58,11 @@ class UnitPipeline:
         self.lookahead = int(os.environ.get("LAP_OPT_LOOKAHEAD", "3"))
         self._todo_args = None
         # release order = the order in which the forward first needs the units: the store's order, except that the adaRMS
-        # bank (built last) is needed right after the embedding table (embed_suffix), before the first Gemma layer
+        # bank (built last) is needed second — the model issues embed_suffix (on its second stream) ahead of the SigLIP tower
         sched = [u for u in store.units if u.name != "ada"]
         names = [u.name for u in sched]
         if "ada" in store.unit_by_name:
-            sched.insert(names.index("embed") + 1 if "embed" in names else len(sched), store.unit_by_name["ada"])
+            sched.insert(1 if names and names[0] == "small" else 0, store.unit_by_name["ada"])
         self._sched = sched
         self._unit_pos = {u.name: k for k, u in enumerate(sched)}
         self._released = len(sched)      # units _sched[0 : _released] of the current pass are enqueued
@@ -90,12 +90,15 @@ class UnitPipeline:
             torch.cuda.current_stream().wait_event(self._opt_done)
             self._opt_done = None
 
-    def wait_unit(self, name: str):
+    def wait_unit(self, name: str, also=None):
+        """The current stream (and `also`, the model's second stream) waits until the unit's parameters are the updated ones."""
         if self._released < len(self._sched):
             self._release(self._unit_pos[name] + 1 + max(self.lookahead, 1), paced=True)
         ev = self.unit_events.pop(name, None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
+            if also is not None:
+                also.wait_event(ev)
 
     def _reduce_grads(self, u):
         pass  # single rank: gradients are already complete

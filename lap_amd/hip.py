@@ -173,8 +173,8 @@ _NSPLIT_ENV = __import__("os").environ.get("LAP_ATTN_NSPLIT")
 
 
 def _gemm_scratch(device, floats: int = 160 * 1024 * 1024):
-    """Per-device f32 scratch (640 MB) lent to the GEMM for two-phase split-K; all uses are stream-ordered."""
-    key = (device.type, device.index)
+    """Per-stream f32 scratch (640 MB) lent to the GEMM for two-phase split-K; its uses are ordered by that stream."""
+    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
     t = _SCRATCH.get(key)
     if t is None:
         t = torch.empty(floats, dtype=torch.float32, device=device)

@@ -14,12 +14,16 @@ fourth forward pass.
 
 Joint two-expert transformer (gemma.py:455-531): the prefix stream (SigLIP tokens + prompt, width of the VLM)
 and the suffix stream (action tokens, width of the action expert) keep separate activations and weights and
-meet only inside the attention kernel, which takes both as segments.
+meet only inside the attention kernel, which takes both as segments.  In the train step the suffix stream's kernels (1,600 rows:
+poorly filled grids, launch-latency bound) are issued on a second HIP stream and run under the prefix stream's GEMMs; the two
+streams synchronise before and after each layer's attention (`LAP_DUAL_STREAM=0`: everything on one stream).
 """
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 import math
+import os
 
 import torch
 
@@ -35,7 +39,7 @@ class _NullComm:
     """world_size == 1: parameters are always resident, gradients stay where they are written."""
     world_size = 1
 
-    def wait_unit(self, name): pass
+    def wait_unit(self, name, also=None): pass
     def grads_ready(self, name): pass
     def before_backward(self): pass
     def all_reduce_sum(self, t): return t
@@ -74,12 +78,36 @@ class LAP:
         self.ps = store
         self.n_img_tok = (config.image_size // self.s.patch) ** 2
         self.deterministic = True
+        self.dual_stream = os.environ.get("LAP_DUAL_STREAM", "1") != "0"
+        self._sfx = None        # the suffix stream's HIP stream (created on first use)
         if gemm_dtype == "fp8":
             dims = (self.v.width, self.v.num_heads * self.v.head_dim, self.v.mlp_dim, (self.v.num_heads + 2 * self.v.num_kv_heads) * self.v.head_dim)
             if any(d % 128 for d in dims):
                 raise ValueError(f"gemm_dtype='fp8' needs projection dimensions that are multiples of 128, got {dims}")
 
     # ------------------------------------------------------------------ small helpers
+    def _suffix_stream(self, *tensors):
+        """The second HIP stream for the suffix (action-expert) side of a joint layer loop, or None when both streams of
+        activations go down the current one (one of them absent, CPU tensors, stream capture, LAP_DUAL_STREAM=0).  It starts
+        behind everything the current stream has been given so far; `tensors` are marked as used on it."""
+        if not self.dual_stream or any(t is None or not t.is_cuda for t in tensors) or torch.cuda.is_current_stream_capturing():
+            return None
+        if self._sfx is None:
+            self._sfx = torch.cuda.Stream(self.device, priority=-1)   # short kernels: never let them queue behind a full grid
+        self._sfx.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            t.record_stream(self._sfx)
+        return self._sfx
+
+    @staticmethod
+    def _handoff(src, dst, *tensors):
+        """`dst` waits for what `src` has been given so far; `tensors` (allocated on src) are about to be used on dst."""
+        if src is not None and dst is not None:
+            dst.wait_stream(src)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(dst)
+
     def W(self, name):
         return self.ps.w16(name)
 
@@ -352,7 +380,6 @@ class LAP:
         h2 = self._lin32(s1, "act/time_out_w", "act/time_out_b")
         cond = hip.swish_fwd(h2)
         cond16 = hip.cast_f32_to_bf16(cond)
-        self.comm.wait_unit("ada")
         mod = hip.linear_fwd(cond16, self.W("ada/w"), bias=self.F("ada/b"))
         return mod, ((temb, h1, s1, h2, cond16) if save else None)
 
@@ -362,23 +389,35 @@ class LAP:
         xt2 = x_t.reshape(B * S, ad).contiguous()
         return hip.cast_f32_to_bf16(self._lin32(xt2, "act/in_w", "act/in_b")), xt2
 
-    def _embed_suffix(self, x_t: torch.Tensor, time: torch.Tensor, save: bool):
-        x1, xt2 = self._embed_actions(x_t)
-        mod, tctx = self._time_mod(time, save)
+    def _embed_suffix(self, x_t: torch.Tensor, time: torch.Tensor, save: bool, overlap: bool = False):
+        """overlap (train step): the dozen small kernels go to the second HIP stream and run under whatever the current stream was
+        given before (the SigLIP tower); their results are next touched by `_llm_fwd`, which joins the streams."""
+        sfx = self._suffix_stream(x_t, time) if overlap else None
+        self.comm.wait_unit("ada", also=sfx)
+        with (torch.cuda.stream(sfx) if sfx is not None else contextlib.nullcontext()):
+            x1, xt2 = self._embed_actions(x_t)
+            mod, tctx = self._time_mod(time, save)
+        if sfx is not None:
+            mod.record_stream(torch.cuda.current_stream()); x1.record_stream(torch.cuda.current_stream())
         return x1, mod, ((xt2, *tctx) if save else None)
 
     def _embed_suffix_bwd(self, sctx, dx1, dmod):
+        """On the second HIP stream when there is one: it runs under the SigLIP backward that the caller issues next.  The
+        caller joins the streams before it declares the "small" unit's gradients complete."""
         xt2, temb, h1, s1, h2, cond16 = sctx
-        dmod16 = hip.cast_f32_to_bf16(dmod)
-        hip.colsum(dmod, self.G("ada/b"))
-        self._wgrad(dmod16, cond16, "ada/w")
-        dcond = hip.cast_bf16_to_f32(hip.linear_dgrad(dmod16, self.W("ada/w")))
-        self.comm.grads_ready("ada")
-        dh2 = hip.swish_bwd(h2, dcond)
-        ds1 = self._lin32_bwd(s1, dh2, "act/time_out_w", "act/time_out_b")
-        dh1 = hip.swish_bwd(h1, ds1)
-        self._lin32_bwd(temb, dh1, "act/time_in_w", "act/time_in_b", need_dx=False)
-        self._lin32_bwd(xt2, hip.cast_bf16_to_f32(dx1), "act/in_w", "act/in_b", need_dx=False)
+        sfx = self._suffix_stream(dx1, dmod)
+        with (torch.cuda.stream(sfx) if sfx is not None else contextlib.nullcontext()):
+            dmod16 = hip.cast_f32_to_bf16(dmod)
+            hip.colsum(dmod, self.G("ada/b"))
+            self._wgrad(dmod16, cond16, "ada/w")
+            dcond = hip.cast_bf16_to_f32(hip.linear_dgrad(dmod16, self.W("ada/w")))
+            self.comm.grads_ready("ada")       # (its side stream starts behind the CURRENT stream: the one these gradients are on)
+            dh2 = hip.swish_bwd(h2, dcond)
+            ds1 = self._lin32_bwd(s1, dh2, "act/time_out_w", "act/time_out_b")
+            dh1 = hip.swish_bwd(h1, ds1)
+            self._lin32_bwd(temb, dh1, "act/time_in_w", "act/time_in_b", need_dx=False)
+            self._lin32_bwd(xt2, hip.cast_bf16_to_f32(dx1), "act/in_w", "act/in_b", need_dx=False)
+        return sfx
 
     # ================================================================== joint Gemma layers
     def _mod_slot(self, mod, slot):
@@ -395,8 +434,11 @@ class LAP:
         Ttot = pos.shape[1]
         ctx = [] if save else None
         mld = 0 if mod_shared else (mod.stride(0) if mod is not None else 0)  # 0: one modulation row for every sample
+        sfx = self._suffix_stream(x1, mod) if (x0 is not None and x1 is not None) else None
+        main = torch.cuda.current_stream() if sfx is not None else None
+        on_sfx = (lambda: torch.cuda.stream(sfx)) if sfx is not None else contextlib.nullcontext
         for l in (range(v.depth) if layers is None else layers):    # `layers`: test hook (teacher-forced per-layer parity)
-            self.comm.wait_unit(f"llm{l}")
+            self.comm.wait_unit(f"llm{l}", also=sfx)
             p = f"llm/{l}/"
             q = [None, None]; k = [None, None]; vv = [None, None]; h = [None, None]; rstd_a = [None, None]
             if x0 is not None:
@@ -407,38 +449,42 @@ class LAP:
             elif kv_cache is not None:
                 k[0], vv[0] = kv_cache[l]
             if x1 is not None:
-                h[1], rstd_a[1] = hip.rmsnorm_fwd(x1, mod=self._mod_slot(mod, 2 * l), rows_per_sample=n1, save_rstd=save, mod_ld=mld)
-                qkv = hip.linear_fwd(h[1], self.W(p + "wqkv1"))
-                q[1], k[1], vv[1] = hip.rope_split_fwd(qkv, pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
-                del qkv
+                with on_sfx():
+                    h[1], rstd_a[1] = hip.rmsnorm_fwd(x1, mod=self._mod_slot(mod, 2 * l), rows_per_sample=n1, save_rstd=save, mod_ld=mld)
+                    qkv = hip.linear_fwd(h[1], self.W(p + "wqkv1"))
+                    q[1], k[1], vv[1] = hip.rope_split_fwd(qkv, pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
+                    del qkv
+                self._handoff(sfx, main, q[1], k[1], vv[1])
             if cache_out is not None:
                 cache_out.append((k[0], vv[0]))
             qlen = [n0 if x0 is not None else 0, n1 if x1 is not None else 0]
             klen = [k[0].shape[0] // B if k[0] is not None else 0, n1 if x1 is not None else 0]
             o, lse = hip.attention_fwd(q, k, vv, qlen, klen, B, NH, KV, HD, qinfo, kinfo, need_lse=save)
+            self._handoff(main, sfx, o[1])
             xa = [None, None]; y1 = None; hf = [None, None]; rstd_f = [None, None]; gu = [None, None]; act = [None, None]; y1f = None
             xn = [None, None]
+            if x1 is not None:     # (issued first: 8 short kernels that then run under the prefix stream's GEMMs)
+                with on_sfx():
+                    y1 = hip.linear_fwd(o[1], self.W(p + "wo1"))
+                    xa[1] = hip.gated_residual_fwd(x1, y1, self._mod_slot(mod, 2 * l)[:, 2 * e.width:], n1, mld)
+                    hf[1], rstd_f[1] = hip.rmsnorm_fwd(xa[1], mod=self._mod_slot(mod, 2 * l + 1), rows_per_sample=n1, save_rstd=save, mod_ld=mld)
+                    gu[1] = hip.linear_fwd(hf[1], self.W(p + "wgu1"))
+                    act[1] = hip.geglu_fwd(gu[1])
+                    y1f = hip.linear_fwd(act[1], self.W(p + "wd1"))
+                    xn[1] = hip.gated_residual_fwd(xa[1], y1f, self._mod_slot(mod, 2 * l + 1)[:, 2 * e.width:], n1, mld)
             if x0 is not None:
                 xa[0] = self._lin0(o[0], p + "wo0", residual=x0)
                 hf[0], rstd_f[0] = hip.rmsnorm_fwd(xa[0], scale=self.F(p + "n_ffw"), save_rstd=save)
                 gu[0] = self._lin0(hf[0], p + "wgu0")
                 act[0] = hip.geglu_fwd(gu[0], pad=self.gemm_dtype != "fp8")
                 xn[0] = self._lin0(act[0], p + "wd0", residual=xa[0])
-            if x1 is not None:
-                We3 = 3 * e.width
-                y1 = hip.linear_fwd(o[1], self.W(p + "wo1"))
-                xa[1] = hip.gated_residual_fwd(x1, y1, self._mod_slot(mod, 2 * l)[:, 2 * e.width:], n1, mld)
-                hf[1], rstd_f[1] = hip.rmsnorm_fwd(xa[1], mod=self._mod_slot(mod, 2 * l + 1), rows_per_sample=n1, save_rstd=save, mod_ld=mld)
-                gu[1] = hip.linear_fwd(hf[1], self.W(p + "wgu1"))
-                act[1] = hip.geglu_fwd(gu[1])
-                y1f = hip.linear_fwd(act[1], self.W(p + "wd1"))
-                xn[1] = hip.gated_residual_fwd(xa[1], y1f, self._mod_slot(mod, 2 * l + 1)[:, 2 * e.width:], n1, mld)
             if save:
                 ctx.append(dict(x=[x0, x1], h=h, rstd_a=rstd_a, q=q, k=k, v=vv, o=o, lse=lse, xa=xa, y1=y1, hf=hf, rstd_f=rstd_f,
                                 gu=gu, act=act, y1f=y1f))
             x0, x1 = xn
             if collect is not None:
                 collect[f"llm/layer{l:02d}/x0"], collect[f"llm/layer{l:02d}/x1"] = x0, x1
+        self._handoff(sfx, main, x1)
         return x0, x1, ctx
 
     def _llm_bwd(self, ctx, dx0, dx1, mod, dmod, pos, qinfo, kinfo, B, n0, n1):
@@ -447,10 +493,30 @@ class LAP:
         Ttot = pos.shape[1]
         ldm = mod.stride(0)
         zero_do0 = None
+        sfx = self._suffix_stream(dx1, dmod, mod)
+        main = torch.cuda.current_stream() if sfx is not None else None
+        on_sfx = (lambda: torch.cuda.stream(sfx)) if sfx is not None else contextlib.nullcontext
         for l in reversed(range(v.depth)):
             p = f"llm/{l}/"
             c = ctx[l]
             d_o = [None, None]
+            # ---- FFN + attention output, suffix stream: xn = xa + y1f * gate_f  (on the second HIP stream, see the module doc)
+            slot_f, slot_a = 2 * l + 1, 2 * l
+            with on_sfx():
+                gate_f = self._mod_slot(mod, slot_f)[:, 2 * e.width:]
+                dy1f = hip.gated_residual_bwd(dx1, c["y1f"], gate_f, n1, ldm, self._mod_slot(dmod, slot_f)[:, 2 * e.width:], dmod.stride(0))
+                self._wgrad(dy1f, c["act"][1], p + "wd1")
+                dact = hip.linear_dgrad(dy1f, self.W(p + "wd1"))
+                dgu = hip.geglu_bwd(c["gu"][1], dact)
+                self._wgrad(dgu, c["hf"][1], p + "wgu1")
+                dhf = hip.linear_dgrad(dgu, self.W(p + "wgu1"))
+                hip.rmsnorm_bwd(c["xa"][1], dhf, c["rstd_f"][1], mod=self._mod_slot(mod, slot_f), rows_per_sample=n1, dx=dx1,
+                                dmod=self._mod_slot(dmod, slot_f), accum_dx=True)
+                gate_a = self._mod_slot(mod, slot_a)[:, 2 * e.width:]
+                dy1 = hip.gated_residual_bwd(dx1, c["y1"], gate_a, n1, ldm, self._mod_slot(dmod, slot_a)[:, 2 * e.width:], dmod.stride(0))
+                self._wgrad(dy1, c["o"][1], p + "wo1")
+                d_o[1] = hip.linear_dgrad(dy1, self.W(p + "wo1"))
+                del dy1f, dact, dgu, dhf, dy1
             # ---- FFN, prefix stream: xn = xa + act @ wd^T   (dx0 is None: the whole prefix side is frozen)
             if dx0 is not None:
                 self._wgrad(dx0, c["act"][0], p + "wd0")
@@ -468,35 +534,26 @@ class LAP:
                 if zero_do0 is None:
                     zero_do0 = torch.zeros_like(c["o"][0])
                 d_o[0] = zero_do0
-            # ---- FFN, suffix stream: xn = xa + y1f * gate_f
-            slot_f, slot_a = 2 * l + 1, 2 * l
-            gate_f = self._mod_slot(mod, slot_f)[:, 2 * e.width:]
-            dy1f = hip.gated_residual_bwd(dx1, c["y1f"], gate_f, n1, ldm, self._mod_slot(dmod, slot_f)[:, 2 * e.width:], dmod.stride(0))
-            self._wgrad(dy1f, c["act"][1], p + "wd1")
-            dact = hip.linear_dgrad(dy1f, self.W(p + "wd1"))
-            dgu = hip.geglu_bwd(c["gu"][1], dact)
-            self._wgrad(dgu, c["hf"][1], p + "wgu1")
-            dhf = hip.linear_dgrad(dgu, self.W(p + "wgu1"))
-            hip.rmsnorm_bwd(c["xa"][1], dhf, c["rstd_f"][1], mod=self._mod_slot(mod, slot_f), rows_per_sample=n1, dx=dx1,
-                            dmod=self._mod_slot(dmod, slot_f), accum_dx=True)
-            gate_a = self._mod_slot(mod, slot_a)[:, 2 * e.width:]
-            dy1 = hip.gated_residual_bwd(dx1, c["y1"], gate_a, n1, ldm, self._mod_slot(dmod, slot_a)[:, 2 * e.width:], dmod.stride(0))
-            self._wgrad(dy1, c["o"][1], p + "wo1")
-            d_o[1] = hip.linear_dgrad(dy1, self.W(p + "wo1"))
             # ---- attention
+            self._handoff(sfx, main, d_o[1])
             dq, dk, dv = hip.attention_bwd(c["q"], c["k"], c["v"], c["o"], d_o, c["lse"], [n0, n1], [n0, n1], B, NH, KV, HD, qinfo, kinfo,
                                            stop_q1_to_k0=self.config.stop_action_to_vlm_grad)
+            self._handoff(main, sfx, dq[1], dk[1], dv[1])
+            with on_sfx():
+                dqkv = hip.rope_split_bwd(dq[1], dk[1], dv[1], pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
+                self._wgrad(dqkv, c["h"][1], p + "wqkv1")
+                dh = hip.linear_dgrad(dqkv, self.W(p + "wqkv1"))
+                hip.rmsnorm_bwd(c["x"][1], dh, c["rstd_a"][1], mod=self._mod_slot(mod, slot_a), rows_per_sample=n1, dx=dx1,
+                                dmod=self._mod_slot(dmod, slot_a), accum_dx=True)
+                del dqkv, dh
             if dx0 is not None:
                 dqkv = hip.rope_split_bwd(dq[0], dk[0], dv[0], pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5)
                 self._wgrad(dqkv, c["h"][0], p + "wqkv0")
                 dh = self._dgrad0(dqkv, p + "wqkv0")
                 hip.rmsnorm_bwd(c["x"][0], dh, c["rstd_a"][0], scale=self.F(p + "n_attn"), dx=dx0, dscale=self.G(p + "n_attn"), accum_dx=True)
-            dqkv = hip.rope_split_bwd(dq[1], dk[1], dv[1], pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
-            self._wgrad(dqkv, c["h"][1], p + "wqkv1")
-            dh = hip.linear_dgrad(dqkv, self.W(p + "wqkv1"))
-            hip.rmsnorm_bwd(c["x"][1], dh, c["rstd_a"][1], mod=self._mod_slot(mod, slot_a), rows_per_sample=n1, dx=dx1,
-                            dmod=self._mod_slot(dmod, slot_a), accum_dx=True)
+                del dqkv, dh
             ctx[l] = None
+            self._handoff(sfx, main)     # the unit's gradients are complete once both streams are through
             self.comm.grads_ready(f"llm{l}")
         return dx0, dx1
 
@@ -572,9 +629,9 @@ class LAP:
             time = u1.pow(1.0 / 1.5) * 0.999 + 0.001  # Beta(a, 1) by inverse CDF
         noise = noise.to(dev, torch.float32).contiguous(); time = time.to(dev, torch.float32).contiguous()
         x_t, u_t = hip.fm_mix(noise, actions, time)
-        # prefix first: its units (SigLIP blocks) are the first ones the pipelined optimizer releases
+        # suffix first: its small kernels go to the second HIP stream and run under the SigLIP tower issued next
+        x1, mod, sctx = self._embed_suffix(x_t, time, backward, overlap=True)
         x0, Pn, pctx = self._embed_prefix(obs, backward, collect)
-        x1, mod, sctx = self._embed_suffix(x_t, time, backward)
         qinfo, kinfo, pos = self._train_infos(obs, S)
         if collect is not None:
             collect["x0_in"], collect["x1_in"], collect["pos"], collect["mod"] = x0, x1, pos, mod
@@ -701,9 +758,10 @@ class LAP:
             dx0 = torch.zeros((B * Pn, Dv), dtype=torch.bfloat16, device=dev)
             hip.copy_rows_bf16(drows, dx0, R, Lt - 1, Dv, Lt - 1, 0, Pn, Pn - Lt)
         dx0, dx1 = self._llm_bwd(lctx, dx0, dx1, mod, dmod, pos, qinfo, kinfo, B, Pn, S)
-        self._embed_suffix_bwd(sctx, dx1, dmod)
+        sfx = self._embed_suffix_bwd(sctx, dx1, dmod)
         if not skip_prefix:
             self._embed_prefix_bwd(pctx, dx0, B, Pn)
+        self._handoff(sfx, torch.cuda.current_stream() if sfx is not None else None)
         self.comm.grads_ready("small")
         return loss, metrics
 
@@ -748,6 +806,7 @@ class LAP:
         # the adaRMS condition depends on the denoise time only: all steps' modulations in one pass over the adaRMS bank
         # built on the device (no host->device copy: the sampler is captured into a HIP graph and replayed)
         tvec = 1.0 + dt * torch.arange(len(times), dtype=torch.float32, device=dev)
+        self.comm.wait_unit("ada")
         mods, _ = self._time_mod(tvec, False)
         # ... and so are the action tokens' positions: one sin / cos table serves the 10 x 18 fused RoPE kernels
         rope_tab = hip.rope_table(pos_all, B, S, pos_all.shape[1], pos_all.shape[1] - S, self.v.head_dim) if fused else None
