@@ -409,6 +409,46 @@ def test_compute_loss_is_forward_of_loss_and_grad(hip):
     assert a.item() == b.item() and a.item() != c.item()
 
 
+def test_two_stream_schedule_equals_one_stream(hip, monkeypatch):
+    """The action expert's kernels on a second HIP stream (model.py: _suffix_stream) against everything on one stream, LAP-3B
+    widths: same loss bits, same activations, and gradients equal up to the order of the f32 atomics that the norm / modulation
+    backward kernels add with (free in both schedules; what follows them inherits the last-bit noise: 1e-5 relative, and no more
+    tensors affected than between two one-stream runs + 2).  Run five times: a missing join between the streams would show up
+    as a flaky mismatch."""
+    cfg = _full_width_cfg(monkeypatch)
+    P = O.init_params(oracle_cfg(cfg), seed=11)
+    obs, actions, noise, time = make_inputs(cfg, B=3, ragged=True)
+    model = _engine(cfg, P)
+    o = to_observation(obs, DEV)
+
+    def run(dual):
+        model.dual_stream = dual
+        for g in model.ps.grad.values():
+            g.zero_()
+        col = {}
+        loss, _ = model.loss_and_grad(0, o, actions.to(DEV), noise=noise.to(DEV), time=time.to(DEV), collect=col)
+        torch.cuda.synchronize()
+        return loss.item(), {k: col[k].clone() for k in ("x0_out", "x1_out", "v_t")}, {n: model.ps.g(n).detach().clone() for n in model.ps.names()}
+
+    l1, a1, g1 = run(False)
+    assert model._sfx is None
+    _, _, g1b = run(False)
+    noisy = sum(not torch.equal(g1[n], g1b[n]) for n in g1)
+    for _ in range(5):
+        l2, a2, g2 = run(True)
+        assert model._sfx is not None
+        assert l1 == l2
+        for k in a1:
+            assert torch.equal(a1[k], a2[k]), k
+        loose = 0
+        for n in g1:
+            if torch.equal(g1[n], g2[n]):
+                continue
+            loose += 1
+            assert rel(g2[n].float().cpu(), g1[n].float().cpu()) < 1e-5, n
+        assert loose <= noisy + 2, (loose, noisy)
+
+
 def test_train_step_matches_oracle_adamw(hip):
     """One full train step (scripts/train.py:329-419): clip -> AdamW -> EMA, against the oracle's autograd + optax restatement."""
     from lap_amd.config import get_config
