@@ -103,10 +103,13 @@ class UnitPipeline:
     def _reduce_grads(self, u):
         pass  # single rank: gradients are already complete
 
-    def grads_ready(self, name: str):
+    def grads_ready(self, name: str, also=None):
+        """The unit's gradients are complete once the current stream (and `also`, the model's weight-gradient stream) get here."""
         u = self.ps.unit_by_name[name]
         if not self.ps.unit_trainable(u):
             return    # fully frozen unit: no reduction, no norm contribution, no update
+        if also is not None and self.is_cuda:
+            self.side.wait_stream(also)
         with self._on_side():
             self._reduce_grads(u)
             if self.is_cuda:  # (the CPU/gloo tests exercise the collectives only; kernels need a GPU)

@@ -40,7 +40,7 @@ class _NullComm:
     world_size = 1
 
     def wait_unit(self, name, also=None): pass
-    def grads_ready(self, name): pass
+    def grads_ready(self, name, also=None): pass
     def before_backward(self): pass
     def all_reduce_sum(self, t): return t
 
@@ -80,6 +80,15 @@ class LAP:
         self.deterministic = True
         self.dual_stream = os.environ.get("LAP_DUAL_STREAM", "1") != "0"
         self._sfx = None        # the suffix stream's HIP stream (created on first use)
+        # which gradients leave the data-gradient path for a third stream (see _off_path): s SigLIP weights, b biases, q / g the
+        # prefix stream's attention / MLP projections; "1" all, "0" none.  Measured (tools/ab3.sh): sb -2.1 .. -3.3 ms per step,
+        # s -1.3, q 0, all +12.6 — but the compute stream's GEMMs then share the chip (their event-timed rate drops 4 %), so the
+        # default stays off: 1 % of the step does not pay for a blurred roofline figure.
+        mode = os.environ.get("LAP_WGRAD_STREAM", "0")
+        self.wgrad_stream = "" if mode == "0" else mode
+        self._wg = self._wg_obj = self._wg_main = None
+        self._wg_dirty = False
+        self._wg_ev: dict = {}
         if gemm_dtype == "fp8":
             dims = (self.v.width, self.v.num_heads * self.v.head_dim, self.v.mlp_dim, (self.v.num_heads + 2 * self.v.num_kv_heads) * self.v.head_dim)
             if any(d % 128 for d in dims):
@@ -121,7 +130,73 @@ class LAP:
         """Weight gradient dWt = dy^T x into the gradient buffer of `name` — skipped for frozen parameters
         (scripts/train.py:358-361 differentiates w.r.t. the trainable filter only)."""
         if self.ps.is_trainable(name):
-            hip.linear_wgrad(dy, x, self.G(name), **kw)
+            mode = self.wgrad_stream
+            kind = "s" if name.startswith("img/") else ("q" if name.endswith(("wqkv0", "wo0")) else "g")
+            if mode == "1" or kind in mode:
+                with self._off_path(dy, x):
+                    hip.linear_wgrad(dy, x, self.G(name), **kw)
+            else:
+                hip.linear_wgrad(dy, x, self.G(name), **kw)
+
+    def _bgrad(self, dy, name):
+        """Bias gradient = column sums of dy, next to the weight gradient."""
+        mode = self.wgrad_stream
+        if mode == "1" or "b" in mode:
+            with self._off_path(dy):
+                hip.colsum(dy, self.G(name))
+        else:
+            hip.colsum(dy, self.G(name))
+
+    # Nothing in the backward waits for a weight / bias gradient except the optimizer, so the prefix stream's and SigLIP's are
+    # issued on a third HIP stream: the data-gradient chain (the critical path) keeps the compute stream, and the weight-gradient
+    # GEMMs fill the CUs its poorly filled last rounds leave idle.  The compute stream joins before it updates a dy in place and
+    # before a unit's gradients are declared complete.  (LAP_WGRAD_STREAM=0: inline.)
+    @contextlib.contextmanager
+    def _off_path(self, *tensors):
+        wg = self._wg
+        if wg is None or torch.cuda.current_stream() != self._wg_main:
+            yield
+            return
+        wg.wait_stream(self._wg_main)
+        for t in tensors:
+            t.record_stream(wg)
+        with torch.cuda.stream(wg):
+            yield
+        ev = torch.cuda.Event()
+        ev.record(wg)
+        self._wg_ev.setdefault(tensors[0].data_ptr(), []).append(ev)     # keyed by dy: the tensor the path may rewrite
+        self._wg_dirty = True
+
+    def _wg_join(self, dy=None):
+        """The compute stream waits for the off-path readers of `dy` (about to be updated in place), or for all of them."""
+        if self._wg is None or not self._wg_dirty or torch.cuda.current_stream() != self._wg_main:
+            return
+        if dy is not None:
+            for ev in self._wg_ev.pop(dy.data_ptr(), ()):
+                self._wg_main.wait_event(ev)
+        else:
+            self._wg_main.wait_stream(self._wg)
+            self._wg_ev.clear()
+            self._wg_dirty = False
+
+    def _unit_done(self, name):
+        """comm.grads_ready for a unit whose weight gradients may still be in flight on the third stream: the communication /
+        optimizer stream waits for that one too, the compute stream does not."""
+        if self._wg is not None and self._wg_dirty and torch.cuda.current_stream() == self._wg_main:
+            self.comm.grads_ready(name, also=self._wg)
+        else:
+            self.comm.grads_ready(name)
+
+    def _wg_begin(self):
+        """Start of a backward pass on the current stream: weight gradients go off the path from here on."""
+        if self.wgrad_stream and self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            if self._wg_obj is None:
+                self._wg_obj = torch.cuda.Stream(self.device)
+            self._wg, self._wg_main, self._wg_dirty = self._wg_obj, torch.cuda.current_stream(), False
+
+    def _wg_end(self):
+        self._wg_join()
+        self._wg = None
 
     # ---- fp8 routing of the VLM expert's projections (BASELINE.json config 5; csrc/gemm_fp8.hip)
     def _w8_of(self, name):
@@ -246,37 +321,39 @@ class LAP:
         hd = W // s.num_heads
         x, enc, mean, rstd = ctx["final"]
         N = x.shape[0] // T
-        hip.colsum(dtok, self.G("img/head_b"))
+        self._bgrad(dtok, "img/head_b")
         self._wgrad(dtok, enc, "img/head_w")
         denc = hip.linear_dgrad(dtok, self.W("img/head_w"))
-        self.comm.grads_ready("img_head")
+        self._unit_done("img_head")
         dx = hip.layernorm_bwd(x, denc, self.F("img/norm_g"), mean, rstd, self.G("img/norm_g"), self.G("img/norm_b"))
         for l in reversed(range(s.depth)):
             p = f"img/{l}/"
             x, y, mean1, rstd1, qkv, o, lse, x1, y2, mean2, rstd2, h, a = ctx["blocks"][l]
-            hip.colsum(dx, self.G(p + "b2"))
+            self._bgrad(dx, p + "b2")
             self._wgrad(dx, a, p + "w2")
             da = hip.linear_dgrad(dx, self.W(p + "w2"))
             dh = hip.gelu_bwd(h, da)
             del da
-            hip.colsum(dh, self.G(p + "b1"))
+            self._bgrad(dh, p + "b1")
             self._wgrad(dh, y2, p + "w1")
             dy2 = hip.linear_dgrad(dh, self.W(p + "w1"))
             del dh
+            self._wg_join(dx)    # (the fc2 weight / bias gradients read dx)
             hip.layernorm_bwd(x1, dy2, self.F(p + "ln2_g"), mean2, rstd2, self.G(p + "ln2_g"), self.G(p + "ln2_b"), dx=dx, accum_dx=True)
-            hip.colsum(dx, self.G(p + "bo"))
+            self._bgrad(dx, p + "bo")
             self._wgrad(dx, o, p + "wo")
             do = hip.linear_dgrad(dx, self.W(p + "wo"))
             dqkv = torch.empty_like(qkv)
             hip.attention_bwd([qkv[:, :W]], [qkv[:, W:2 * W]], [qkv[:, 2 * W:]], [o], [do], lse, [T], [T], N, s.num_heads, s.num_heads, hd,
                               scale=hd ** -0.5, q_rs=(3 * W, 0), kv_rs=(3 * W, 0),
                               dq_out=[dqkv[:, :W]], dk_out=[dqkv[:, W:2 * W]], dv_out=[dqkv[:, 2 * W:]])
-            hip.colsum(dqkv, self.G(p + "bqkv"))
+            self._bgrad(dqkv, p + "bqkv")
             self._wgrad(dqkv, y, p + "wqkv")
             dy = hip.linear_dgrad(dqkv, self.W(p + "wqkv"))
+            self._wg_join(dx)    # (the out-projection's read dx)
             hip.layernorm_bwd(x, dy, self.F(p + "ln1_g"), mean1, rstd1, self.G(p + "ln1_g"), self.G(p + "ln1_b"), dx=dx, accum_dx=True)
             ctx["blocks"][l] = None
-            self.comm.grads_ready(f"img{l}")
+            self._unit_done(f"img{l}")
         dstem = hip.add_posemb_cast_bwd(dx, self.G("img/pos"), T)     # f32 copy of a bf16 gradient: exact in bf16
         p_hi, p_lo = ctx["patches"]
         gw = self.G("img/stem_w")
@@ -526,6 +603,7 @@ class LAP:
                 self._wgrad(dgu, c["hf"][0], p + "wgu0")
                 dhf = self._dgrad0(dgu, p + "wgu0")
                 del dgu
+                self._wg_join(dx0)   # (the down projection's weight gradient reads dx0)
                 hip.rmsnorm_bwd(c["xa"][0], dhf, c["rstd_f"][0], scale=self.F(p + "n_ffw"), dx=dx0, dscale=self.G(p + "n_ffw"), accum_dx=True)
                 del dhf
                 self._wgrad(dx0, c["o"][0], p + "wo0")
@@ -550,11 +628,12 @@ class LAP:
                 dqkv = hip.rope_split_bwd(dq[0], dk[0], dv[0], pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5)
                 self._wgrad(dqkv, c["h"][0], p + "wqkv0")
                 dh = self._dgrad0(dqkv, p + "wqkv0")
+                self._wg_join(dx0)   # (the out projection's reads dx0)
                 hip.rmsnorm_bwd(c["x"][0], dh, c["rstd_a"][0], scale=self.F(p + "n_attn"), dx=dx0, dscale=self.G(p + "n_attn"), accum_dx=True)
                 del dqkv, dh
             ctx[l] = None
-            self._handoff(sfx, main)     # the unit's gradients are complete once both streams are through
-            self.comm.grads_ready(f"llm{l}")
+            self._handoff(sfx, main)     # the unit's gradients are complete once all streams are through
+            self._unit_done(f"llm{l}")
         return dx0, dx1
 
     def _expert_denoise_fwd(self, x1, mod, pos, qinfo, kinfo, B, Pn, S, cache, rope_tab=None):
@@ -728,6 +807,7 @@ class LAP:
 
         # =============================== backward ===============================
         self.comm.before_backward()
+        self._wg_begin()
         We = self.e.width
         dmod = torch.zeros(mod.shape, dtype=torch.float32, device=dev)
         # action head
@@ -762,6 +842,7 @@ class LAP:
         if not skip_prefix:
             self._embed_prefix_bwd(pctx, dx0, B, Pn)
         self._handoff(sfx, torch.cuda.current_stream() if sfx is not None else None)
+        self._wg_end()
         self.comm.grads_ready("small")
         return loss, metrics
 

@@ -877,3 +877,42 @@ def test_gemm_fp8_matches_quantised_reference(hip, M, N, K):
         assert rel_err(dx, (_e4m3(dy, sd.item()) @ qw) / (sd.item() * sw.item())) < 4e-3
     with pytest.raises(hip.LapHipError):
         hip.gemm_fp8(a8[:, :K - 64].contiguous(), sa, w8[:, :K - 64].contiguous(), sw)      # K % 128 != 0
+
+
+def test_kernels_keep_their_bits_next_to_another_streams_gemm(hip):
+    """Results must not depend on what another stream runs on the same CUs.  They once did: with packed-f32 VALU code in the
+    library (the SLP vectoriser's v_pk_fma_f32 + a plain VALU write to one of its two result registers a few instructions
+    later), layernorm_bwd's row sums came out wrong in lanes 48..55 — a few rows per launch — whenever blocks of the 128 x 128
+    GEMM (64 KiB of LDS: they fit next to it on a CU) were resident; lap_amd/build.py now compiles with -fno-slp-vectorize.
+    D = 1152 / 1536 rows are the shapes that failed 130-150 launches out of 150 (tools/probes/concurrency_stress6.py)."""
+    rows, W, MLP = 1536, 1152, 4304
+    g = torch.Generator(device=DEV).manual_seed(1)
+    rnd = lambda *s: (torch.randn(*s, device=DEV, generator=g) * 0.5).bfloat16()
+    rndf = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    dx, y2, y, dh, h = rnd(rows, W), rnd(rows, W), rnd(rows, W), rnd(rows, MLP), rnd(rows, MLP)
+    gam, bet, mean, rstd = rndf(W), rndf(W), rndf(rows) * 0.01, rndf(rows).abs() + 0.5
+    x2k, sc2k, w1 = rnd(rows, 2048), rndf(2048), rnd(MLP, W)
+    outW = torch.empty(MLP, W, device=DEV)
+    side = torch.cuda.Stream()
+
+    def ln_bwd():
+        d = dx.clone(); dg = torch.zeros(W, device=DEV); db = torch.zeros(W, device=DEV)
+        hip.layernorm_bwd(y2, y, gam, mean, rstd, dg, db, dx=d, accum_dx=True)
+        return d
+
+    def rms_bwd():
+        return hip.rmsnorm_bwd(x2k, x2k, rstd, scale=sc2k, dscale=torch.zeros(2048, device=DEV))
+
+    victims = {"layernorm_bwd": ln_bwd, "layernorm_fwd": lambda: hip.layernorm_fwd(y2, gam, bet)[0], "rmsnorm_bwd": rms_bwd,
+               "rmsnorm_fwd": lambda: hip.rmsnorm_fwd(x2k, scale=sc2k)[0], "gelu_bwd": lambda: hip.gelu_bwd(h, dh),
+               "geglu_fwd": lambda: hip.geglu_fwd(dh), "dgrad": lambda: hip.linear_dgrad(dh, w1)}
+    for name, f in victims.items():
+        ref = f().clone()
+        torch.cuda.synchronize()
+        for rep in range(25):
+            with torch.cuda.stream(side):
+                for _ in range(6):   # the 128 x 128 tile in the weight-gradient layout: the co-runner that exposed it
+                    hip.gemm(dh, y2, outW, M=MLP, N=W, K=rows, lda=MLP, ldb=W, ldc=W, a_kc=False, b_kc=False, tile=6, ksplit=1)
+            out = f()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (name, rep)

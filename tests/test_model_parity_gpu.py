@@ -422,7 +422,7 @@ def test_two_stream_schedule_equals_one_stream(hip, monkeypatch):
     o = to_observation(obs, DEV)
 
     def run(dual):
-        model.dual_stream = dual
+        model.dual_stream, model.wgrad_stream = dual, ("1" if dual else "")   # second stream: action expert; third: weight / bias gradients (all of them)
         for g in model.ps.grad.values():
             g.zero_()
         col = {}
@@ -436,7 +436,7 @@ def test_two_stream_schedule_equals_one_stream(hip, monkeypatch):
     noisy = sum(not torch.equal(g1[n], g1b[n]) for n in g1)
     for _ in range(5):
         l2, a2, g2 = run(True)
-        assert model._sfx is not None
+        assert model._sfx is not None and model._wg_obj is not None
         assert l1 == l2
         for k in a1:
             assert torch.equal(a1[k], a2[k]), k
