@@ -277,6 +277,7 @@ class Kernel:
         E(f"\ts_load_dwordx2 s[{S_ONE}:{S_ONE+1}], {S_KARG}, 0x48")
         E(f"\ts_load_dword s{S_G}, {S_KARG}, 0x50")
         E(f"\ts_load_dwordx2 s[{RQ}:{RQ+1}], {S_KARG}, 0x70")
+        E(f"\ts_load_dwordx2 s[{S_T+12}:{S_T+13}], {S_KARG}, 0x78")     # the counters of this stream's NEXT launch (or 0)
         E(f"\ts_getreg_b32 s{S_XCC}, hwreg(HW_REG_XCC_ID)")
         if self.epi:
             E(f"\ts_load_dwordx2 s[{RBI}:{RBI+1}], {S_KARG}, 0x60")
@@ -286,6 +287,20 @@ class Kernel:
         E(f"\tv_readfirstlane_b32 s{W}, v{V_T}")                 # wave id
         E("\ts_nop 4")
         E("\ts_waitcnt lgkmcnt(0)")
+        # ---- block 0 clears the counters the next launch on this stream will draw from (nobody uses them now: the launch that
+        # did is over, the one that will has not started), so the host does not have to memset between launches
+        E(f"\ts_cmp_lg_u32 {S_WG}, 0")
+        E(f"\ts_cbranch_scc1 .Lzeroed_{nm}")
+        E(f"\ts_cmp_eq_u64 s[{S_T+12}:{S_T+13}], 0")
+        E(f"\ts_cbranch_scc1 .Lzeroed_{nm}")
+        E("\ts_mov_b64 exec, 1")
+        for r in range(16, 21):
+            E(f"\tv_mov_b32 v{r}, 0")
+        E(f"\tglobal_store_dwordx4 v20, v[16:19], s[{S_T+12}:{S_T+13}]")
+        E(f"\tglobal_store_dwordx4 v20, v[16:19], s[{S_T+12}:{S_T+13}] offset:16")
+        E("\ts_waitcnt vmcnt(0)")
+        E("\ts_mov_b64 exec, -1")
+        E(f".Lzeroed_{nm}:")
         # ---- this block's first tile (static): 32 (b % 8) + b / 8 — the blocks of an XCD (round-robin dispatch) start on
         # consecutive tiles; every further tile is a ticket of the XCD the block really runs on
         E(f"\ts_and_b32 s{t}, {S_WG}, 7")
