@@ -56,6 +56,7 @@ class UnitPipeline:
         # units of the current optimizer pass that are scheduled but not yet enqueued (paced release, see module docstring);
         # lookahead 0 = enqueue the whole pass at once
         self.lookahead = int(os.environ.get("LAP_OPT_LOOKAHEAD", "3"))
+        self.pace_in_layer = os.environ.get("LAP_OPT_PACE", "top") == "gemm"
         self._todo_args = None
         # release order = the order in which the forward first needs the units: the store's order, except that the adaRMS
         # bank (built last) is needed second — the model issues embed_suffix (on its second stream) ahead of the SigLIP tower
@@ -93,12 +94,19 @@ class UnitPipeline:
     def wait_unit(self, name: str, also=None):
         """The current stream (and `also`, the model's second stream) waits until the unit's parameters are the updated ones."""
         if self._released < len(self._sched):
-            self._release(self._unit_pos[name] + 1 + max(self.lookahead, 1), paced=True)
+            self._release(self._unit_pos[name] + 1 + (0 if self.pace_in_layer else max(self.lookahead, 1)), paced=True)
         ev = self.unit_events.pop(name, None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
             if also is not None:
                 also.wait_event(ev)
+
+    def pace(self, name: str):
+        """Called by the model in front of a unit's longest MFMA-bound GEMM (LAP_OPT_PACE=gemm): the updates of the next
+        `lookahead` units are released HERE, so that their HBM traffic runs beside that GEMM instead of beside the unit's first
+        (bandwidth-bound) norm kernel."""
+        if self.pace_in_layer and self._released < len(self._sched):
+            self._release(self._unit_pos[name] + 1 + max(self.lookahead, 1), paced=True)
 
     def _reduce_grads(self, u):
         pass  # single rank: gradients are already complete

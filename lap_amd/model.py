@@ -40,6 +40,7 @@ class _NullComm:
     world_size = 1
 
     def wait_unit(self, name, also=None): pass
+    def pace(self, name): pass
     def grads_ready(self, name, also=None): pass
     def before_backward(self): pass
     def all_reduce_sum(self, t): return t
@@ -308,6 +309,7 @@ class LAP:
                                         scale=hd ** -0.5, q_rs=(3 * W, 0), kv_rs=(3 * W, 0), need_lse=save)
         x1 = hip.linear_fwd(o, self.W(p + "wo"), bias=self.F(p + "bo"), residual=x)
         y2, mean2, rstd2 = hip.layernorm_fwd(x1, self.F(p + "ln2_g"), self.F(p + "ln2_b"))
+        self.comm.pace(f"img{l}")
         h = hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"))
         a = hip.gelu_fwd(h)
         x2 = hip.linear_fwd(a, self.W(p + "w2"), bias=self.F(p + "b2"), residual=x1)
@@ -552,6 +554,7 @@ class LAP:
             if x0 is not None:
                 xa[0] = self._lin0(o[0], p + "wo0", residual=x0)
                 hf[0], rstd_f[0] = hip.rmsnorm_fwd(xa[0], scale=self.F(p + "n_ffw"), save_rstd=save)
+                self.comm.pace(f"llm{l}")     # optimizer units released here start under the longest MFMA-bound GEMM of the layer
                 gu[0] = self._lin0(hf[0], p + "wgu0")
                 act[0] = hip.geglu_fwd(gu[0], pad=self.gemm_dtype != "fp8")
                 xn[0] = self._lin0(act[0], p + "wd0", residual=xa[0])
