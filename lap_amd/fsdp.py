@@ -117,7 +117,8 @@ class UnitPipeline:
         if not self.ps.unit_trainable(u):
             return    # fully frozen unit: no reduction, no norm contribution, no update
         if also is not None and self.is_cuda:
-            self.side.wait_stream(also)
+            for st in (also if isinstance(also, (list, tuple)) else [also]):
+                self.side.wait_stream(st)
         with self._on_side():
             self._reduce_grads(u)
             if self.is_cuda:  # (the CPU/gloo tests exercise the collectives only; kernels need a GPU)

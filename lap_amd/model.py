@@ -180,13 +180,13 @@ class LAP:
             self._wg_ev.clear()
             self._wg_dirty = False
 
-    def _unit_done(self, name):
-        """comm.grads_ready for a unit whose weight gradients may still be in flight on the third stream: the communication /
-        optimizer stream waits for that one too, the compute stream does not."""
+    def _unit_done(self, name, sfx=None):
+        """comm.grads_ready for a unit whose gradients may still be in flight on the second (`sfx`) or third stream: the
+        communication / optimizer stream waits for those too, the compute stream does not."""
+        also = [sfx] if sfx is not None else []
         if self._wg is not None and self._wg_dirty and torch.cuda.current_stream() == self._wg_main:
-            self.comm.grads_ready(name, also=self._wg)
-        else:
-            self.comm.grads_ready(name)
+            also.append(self._wg)
+        self.comm.grads_ready(name, also=also or None)
 
     def _wg_begin(self):
         """Start of a backward pass on the current stream: weight gradients go off the path from here on."""
@@ -635,8 +635,9 @@ class LAP:
                 hip.rmsnorm_bwd(c["x"][0], dh, c["rstd_a"][0], scale=self.F(p + "n_attn"), dx=dx0, dscale=self.G(p + "n_attn"), accum_dx=True)
                 del dqkv, dh
             ctx[l] = None
-            self._handoff(sfx, main)     # the unit's gradients are complete once all streams are through
-            self._unit_done(f"llm{l}")
+            self._unit_done(f"llm{l}", sfx)   # complete once both streams are through: the optimizer's stream waits for both, the
+                                             # compute stream goes on (it meets the second stream again at the next attention)
+        self._handoff(sfx, main)
         return dx0, dx1
 
     def _expert_denoise_fwd(self, x1, mod, pos, qinfo, kinfo, B, Pn, S, cache, rope_tab=None):
