@@ -25,7 +25,9 @@ inline dim3 flat_grid(long long n, int per_block = 256) { return dim3((unsigned)
 // gemma.py:216: q *= HD^-0.5 as a bf16 multiply.
 // One thread per (row, 8-wide frequency chunk): sin / cos are evaluated once and reused for the NH query heads and the
 // key head of the row (they only depend on the position and the frequency index), then the value head is copied.
-template <bool BWD>
+// HSPLIT (few rows: serving prefill, 560 rows = 35 blocks walking ten heads one after the other, latency bound): one thread per
+// (row, head, chunk) instead — the same arithmetic, sin / cos evaluated per head.
+template <bool BWD, bool HSPLIT = false>
 __global__ __launch_bounds__(256) void rope_split_kernel(const bf16* __restrict__ a0, const bf16* __restrict__ a1,
                                                          const bf16* __restrict__ a2, const int32_t* __restrict__ pos,
                                                          bf16* __restrict__ o0, bf16* __restrict__ o1,
@@ -33,8 +35,15 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const bf16* __restrict_
                                                          int seg_off, int NH, int HD, float q_scale) {
   // FWD: a0 = qkv, outputs o0 = q, o1 = k, o2 = v.   BWD: a0 = dq, a1 = dk, a2 = dv, output o0 = dqkv.
   const int cph = HD / 16;               // 8-wide frequency chunks per head = threads per row
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long long)rows * cph) return;
+  long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  int h_lo = 0, h_hi = NH + 2;
+  if (HSPLIT) {
+    if (gid >= (long long)rows * cph * (NH + 2)) return;
+    h_lo = (int)(gid % (NH + 2)); h_hi = h_lo + 1;
+    gid /= (NH + 2);
+  } else if (gid >= (long long)rows * cph) {
+    return;
+  }
   const int row = (int)(gid / cph);
   const int c = (int)(gid % cph);
   const int b = row / T_seg, t = row % T_seg;
@@ -45,7 +54,7 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const bf16* __restrict_
 #pragma unroll
   for (int e = 0; e < 8; ++e) rope_sincos(p, c * 8 + e, HD, sn[e], cs[e]);
 #pragma unroll 2
-  for (int h = 0; h < NH + 2; ++h) {
+  for (int h = h_lo; h < h_hi; ++h) {
     const bf16* src;
     if (!BWD) src = a0 + (long long)row * W + h * HD;
     else if (h < NH) src = a0 + (long long)row * NH * HD + h * HD;
@@ -552,8 +561,12 @@ extern "C" int lap_rope_split_fwd(const void* qkv, const int32_t* pos, void* q, 
                                   int T_total, int seg_off, int NH, int HD, float q_scale, void* stream) {
   if (B <= 0 || T_seg <= 0 || (HD & 15) || NH <= 0) return LAP_ERR_ARG;
   const long long n = (long long)B * T_seg * (HD / 16);
-  hipLaunchKernelGGL(rope_split_kernel<false>, flat_grid(n), dim3(256), 0, S_, (const bf16*)qkv, nullptr, nullptr, pos,
-                     (bf16*)q, (bf16*)k, (bf16*)v, B * T_seg, T_seg, T_total, seg_off, NH, HD, q_scale);
+  if (n < 65536)   // fewer than 256 blocks: one thread per head as well
+    hipLaunchKernelGGL((rope_split_kernel<false, true>), flat_grid(n * (NH + 2)), dim3(256), 0, S_, (const bf16*)qkv, nullptr, nullptr, pos,
+                       (bf16*)q, (bf16*)k, (bf16*)v, B * T_seg, T_seg, T_total, seg_off, NH, HD, q_scale);
+  else
+    hipLaunchKernelGGL(rope_split_kernel<false>, flat_grid(n), dim3(256), 0, S_, (const bf16*)qkv, nullptr, nullptr, pos,
+                       (bf16*)q, (bf16*)k, (bf16*)v, B * T_seg, T_seg, T_total, seg_off, NH, HD, q_scale);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

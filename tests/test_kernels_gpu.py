@@ -395,7 +395,8 @@ def _rope_ref(x, pos):  # x [B,T,H,D] f32, pos [B,T]
     return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], -1)
 
 
-@pytest.mark.parametrize("B,T,NH,HD,off,Ttot", [(2, 9, 8, 16, 0, 9), (3, 50, 8, 256, 560, 610)])
+# (the last case has enough rows for the one-thread-per-row-chunk form of the forward kernel; the others take the per-head form)
+@pytest.mark.parametrize("B,T,NH,HD,off,Ttot", [(2, 9, 8, 16, 0, 9), (3, 50, 8, 256, 560, 610), (8, 560, 8, 256, 0, 610)])
 def test_rope_split(hip, B, T, NH, HD, off, Ttot):
     qkv = rnd(B * T, (NH + 2) * HD)
     pos = torch.randint(0, 700, (B, Ttot), dtype=torch.int32, device=DEV)
