@@ -45,3 +45,19 @@ for k, (n, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
 print("# largest gaps")
 for g, a, b in sorted(big, reverse=True)[:25]:
     print(f"{g/1e3:9.1f} us  after {a:60s} before {b}")
+# what the other queues were doing during the gaps in front of one kernel: prof_gaps.py <db> <min_us> <marker> <skip> <kernel substring>
+if len(sys.argv) > 5:
+    target = sys.argv[5]
+    print(f"# other queues during the first gaps in front of {target}")
+    shown = 0
+    end_prev = main[0][2]
+    for name, s, e, _ in main[1:]:
+        if target in name and s - end_prev > thr and shown < 4:
+            shown += 1
+            print(f"  gap {end_prev % 10**9 / 1e3:.1f} .. {s % 10**9 / 1e3:.1f} us ({(s - end_prev) / 1e3:.1f} us)")
+            for q, rs in byq.items():
+                for r in rs:
+                    if r[2] > end_prev - 20e3 and r[1] < s + 5e3 and r[3] != main[0][3]:
+                        print(f"     queue {q}: {r[1] % 10**9 / 1e3:10.1f} .. {r[2] % 10**9 / 1e3:10.1f}  {short(r[0])}")
+        if e > end_prev:
+            end_prev = e
