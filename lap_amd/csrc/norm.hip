@@ -240,16 +240,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const bf16* __restrict__ dy, bf16* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rows, int D, int G, int accum_dx) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [NWAVE][2*D]
+                                                            int rows, int D, int G, int accum_dx, float* __restrict__ dxsum) {
+  // dxsum (optional): column sums of the dx this kernel stores (as stored: bf16-rounded) — the bias gradient of the linear
+  // layer that produced the normalised tensor's input, which would otherwise cost a pass over dx of its own
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [NWAVE][2*D] (+ [NWAVE][D] with dxsum)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r0 = blockIdx.x * G, r1 = min(rows, r0 + G);
-  float gm[NCH][8], dg[NCH][8], db[NCH][8];
+  float gm[NCH][8], dg[NCH][8], db[NCH][8], dxs[NCH][8];
 #pragma unroll
   for (int p = 0; p < NCH; ++p) {
     const int c = (lane + 64 * p) * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { dg[p][e] = 0.f; db[p][e] = 0.f; gm[p][e] = (c < D) ? gamma[c + e] : 0.f; }
+    for (int e = 0; e < 8; ++e) { dg[p][e] = 0.f; db[p][e] = 0.f; dxs[p][e] = 0.f; gm[p][e] = (c < D) ? gamma[c + e] : 0.f; }
   }
   bf16x8 nx[NCH], ndy[NCH];   // one row ahead, as in rmsnorm_bwd_kernel
   float nmu = 0.f, nr = 0.f;
@@ -308,27 +310,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
           for (int e = 0; e < 8; ++e) o[e] += old[e];
         }
         store8(dxr + c, o);
+        if (dxsum) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dxs[p][e] += (float)f2bf(o[e]);
+        }
       }
     }
   }
+  const int NS = dxsum ? 3 : 2;
 #pragma unroll
   for (int p = 0; p < NCH; ++p) {
     const int c = (lane + 64 * p) * 8;
     if (c < D) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        red[w * 2 * D + c + e] = dg[p][e];
-        red[w * 2 * D + D + c + e] = db[p][e];
+        red[w * NS * D + c + e] = dg[p][e];
+        red[w * NS * D + D + c + e] = db[p][e];
+        if (dxsum) red[w * NS * D + 2 * D + c + e] = dxs[p][e];
       }
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+  for (int c = threadIdx.x; c < NS * D; c += 256) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < NWAVE; ++i) t += red[i * 2 * D + c];
+    for (int i = 0; i < NWAVE; ++i) t += red[i * NS * D + c];
     if (c < D) atomicAdd(dgamma + c, t);
-    else atomicAdd(dbeta + (c - D), t);
+    else if (c < 2 * D) atomicAdd(dbeta + (c - D), t);
+    else atomicAdd(dxsum + (c - 2 * D), t);
   }
 }
 
@@ -384,16 +393,22 @@ extern "C" int lap_layernorm_fwd(const void* x, const float* gamma, const float*
   return LAP_OK;
 }
 
-extern "C" int lap_layernorm_bwd(const void* x, const float* gamma, const float* mean, const float* rstd,
-                                 const void* dy, void* dx, float* dgamma, float* dbeta, int rows, int D, int accum_dx,
-                                 void* stream) {
+extern "C" int lap_layernorm_bwd_sum(const void* x, const float* gamma, const float* mean, const float* rstd,
+                                     const void* dy, void* dx, float* dgamma, float* dbeta, float* dxsum, int rows, int D,
+                                     int accum_dx, void* stream) {
   if (rows <= 0 || D <= 0 || (D & 7) || !gamma || !mean || !rstd || !dgamma || !dbeta) return LAP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int G = 16;
   dim3 grid((rows + G - 1) / G);
-  const size_t shm = (size_t)NWAVE * 2 * D * sizeof(float);
+  const size_t shm = (size_t)NWAVE * (dxsum ? 3 : 2) * D * sizeof(float);
+  if (shm > 64 * 1024) return LAP_ERR_ARG;
   DISPATCH_NCH(D, hipLaunchKernelGGL(layernorm_bwd_kernel<NCH>, grid, dim3(256), shm, s, (const bf16*)x, gamma, mean,
-                                     rstd, (const bf16*)dy, (bf16*)dx, dgamma, dbeta, rows, D, G, accum_dx));
+                                     rstd, (const bf16*)dy, (bf16*)dx, dgamma, dbeta, rows, D, G, accum_dx, dxsum));
   LAP_CHECK_LAUNCH();
   return LAP_OK;
+}
+extern "C" int lap_layernorm_bwd(const void* x, const float* gamma, const float* mean, const float* rstd,
+                                 const void* dy, void* dx, float* dgamma, float* dbeta, int rows, int D, int accum_dx,
+                                 void* stream) {
+  return lap_layernorm_bwd_sum(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, nullptr, rows, D, accum_dx, stream);
 }

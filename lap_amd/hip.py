@@ -83,6 +83,7 @@ SIGNATURES: dict[str, list] = {
     "lap_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lap_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "lap_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "lap_layernorm_bwd_sum": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_rope_split_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "lap_rope_split_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "lap_geglu_fwd": [_vp, _vp, _i, _i, _vp],
@@ -293,11 +294,12 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6):
     return y, mean, rstd
 
 
-def layernorm_bwd(x, dy, gamma, mean, rstd, dgamma, dbeta, dx=None, accum_dx=False):
+def layernorm_bwd(x, dy, gamma, mean, rstd, dgamma, dbeta, dx=None, accum_dx=False, dxsum=None):
+    """dxsum: f32 [D] that the column sums of the returned dx are ADDED to (a bias gradient for free), or None."""
     rows, D = x.shape
     if dx is None:
         dx = torch.empty_like(x)
-    call("lap_layernorm_bwd", _p(x), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dx), _p(dgamma), _p(dbeta), rows, D,
+    call("lap_layernorm_bwd_sum", _p(x), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dx), _p(dgamma), _p(dbeta), _p(dxsum), rows, D,
          int(accum_dx))
     return dx
 

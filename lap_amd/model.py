@@ -327,11 +327,18 @@ class LAP:
         self._wgrad(dtok, enc, "img/head_w")
         denc = hip.linear_dgrad(dtok, self.W("img/head_w"))
         self._unit_done("img_head")
-        dx = hip.layernorm_bwd(x, denc, self.F("img/norm_g"), mean, rstd, self.G("img/norm_g"), self.G("img/norm_b"))
+        # Bias gradients = column sums of a dy.  Two of a block's four (fc2's and the out projection's) come out of the LayerNorm
+        # backward that PRODUCES that dy instead of a pass of their own over 38 MB (+1.8 us in that kernel against a 15.5 us
+        # column-sum launch; a GELU backward that sums its columns was 2.3 x slower than the two kernels it replaced).
+        fuse_b = os.environ.get("LAP_FUSE_BGRAD", "1") != "0"
+        last = s.depth - 1
+        dx = hip.layernorm_bwd(x, denc, self.F("img/norm_g"), mean, rstd, self.G("img/norm_g"), self.G("img/norm_b"),
+                               dxsum=self.G(f"img/{last}/b2") if fuse_b else None)
         for l in reversed(range(s.depth)):
             p = f"img/{l}/"
             x, y, mean1, rstd1, qkv, o, lse, x1, y2, mean2, rstd2, h, a = ctx["blocks"][l]
-            self._bgrad(dx, p + "b2")
+            if not fuse_b:
+                self._bgrad(dx, p + "b2")
             self._wgrad(dx, a, p + "w2")
             da = hip.linear_dgrad(dx, self.W(p + "w2"))
             dh = hip.gelu_bwd(h, da)
@@ -341,8 +348,10 @@ class LAP:
             dy2 = hip.linear_dgrad(dh, self.W(p + "w1"))
             del dh
             self._wg_join(dx)    # (the fc2 weight / bias gradients read dx)
-            hip.layernorm_bwd(x1, dy2, self.F(p + "ln2_g"), mean2, rstd2, self.G(p + "ln2_g"), self.G(p + "ln2_b"), dx=dx, accum_dx=True)
-            self._bgrad(dx, p + "bo")
+            hip.layernorm_bwd(x1, dy2, self.F(p + "ln2_g"), mean2, rstd2, self.G(p + "ln2_g"), self.G(p + "ln2_b"), dx=dx, accum_dx=True,
+                              dxsum=self.G(p + "bo") if fuse_b else None)
+            if not fuse_b:
+                self._bgrad(dx, p + "bo")
             self._wgrad(dx, o, p + "wo")
             do = hip.linear_dgrad(dx, self.W(p + "wo"))
             dqkv = torch.empty_like(qkv)
@@ -353,7 +362,8 @@ class LAP:
             self._wgrad(dqkv, y, p + "wqkv")
             dy = hip.linear_dgrad(dqkv, self.W(p + "wqkv"))
             self._wg_join(dx)    # (the out-projection's read dx)
-            hip.layernorm_bwd(x, dy, self.F(p + "ln1_g"), mean1, rstd1, self.G(p + "ln1_g"), self.G(p + "ln1_b"), dx=dx, accum_dx=True)
+            hip.layernorm_bwd(x, dy, self.F(p + "ln1_g"), mean1, rstd1, self.G(p + "ln1_g"), self.G(p + "ln1_b"), dx=dx, accum_dx=True,
+                              dxsum=self.G(f"img/{l - 1}/b2") if (fuse_b and l > 0) else None)
             ctx["blocks"][l] = None
             self._unit_done(f"img{l}")
         dstem = hip.add_posemb_cast_bwd(dx, self.G("img/pos"), T)     # f32 copy of a bf16 gradient: exact in bf16

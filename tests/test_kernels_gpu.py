@@ -382,6 +382,15 @@ def test_layernorm(hip, rows, D):
     dx = hip.layernorm_bwd(x, dy, gamma, mean, rstd, dg, db)
     assert rel_err(dx, xr.grad) < 4e-3
     assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+    # ... with the column sums of the stored dx (a bias gradient) on the side: same dx bits, sums = colsum of that bf16 tensor,
+    # added onto what the buffer holds; also on the accumulate-into-dx form
+    dg2 = torch.zeros(D, device=DEV); db2 = torch.zeros(D, device=DEV); sums = torch.full((D,), 0.5, device=DEV)
+    dx2 = hip.layernorm_bwd(x, dy, gamma, mean, rstd, dg2, db2, dxsum=sums)
+    assert torch.equal(dx2, dx)
+    assert rel_err(sums - 0.5, dx.float().sum(0)) < 1e-5 or (sums - 0.5 - dx.float().sum(0)).abs().max() < 1e-3
+    base = rnd(rows, D, seed=4); acc = base.clone(); sums.zero_()
+    hip.layernorm_bwd(x, dy, gamma, mean, rstd, dg2, db2, dx=acc, accum_dx=True, dxsum=sums)
+    assert (sums - acc.float().sum(0)).abs().max() < 1e-3 * max(1.0, acc.float().sum(0).abs().max().item())
 
 
 # ------------------------------------------------------------------ rope / elementwise
