@@ -4,6 +4,8 @@
 // statistics.  Per-column parameter gradients are accumulated in registers over
 // a group of rows, combined across the 4 waves through LDS and added to HBM with
 // one f32 atomic per column per block.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "../../include/lap_hip.h"
 
@@ -372,7 +374,10 @@ extern "C" int lap_rmsnorm_bwd(const void* x, const float* scale, const void* mo
   if (rows <= 0 || D <= 0 || (D & 7) || !rstd) return LAP_ERR_ARG;
   if (mod ? (!dmod || rows_per_sample <= 0 || rows % rows_per_sample) : (!scale || !dscale)) return LAP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int G = mod ? rows_per_sample : 16;   // 4 rows per wave: >= 1000 blocks at LAP-3B row counts (latency hiding); one f32 atomic per column per block
+  // rows per block (one f32 atomic per column and block): 17,920 x 2048 takes 89.6 / 75.0 / 69.8 / 59.7 / 89.9 us at 8 / 16 / 32 / 64 / 128
+  // (tools/probes/bench_norm_bwd.py; LAP_NORM_BWD_ROWS sweeps it)
+  static const int g_env = getenv("LAP_NORM_BWD_ROWS") ? atoi(getenv("LAP_NORM_BWD_ROWS")) : 64;
+  const int G = mod ? rows_per_sample : g_env;
   dim3 grid((rows + G - 1) / G);
   const size_t shm = (size_t)NWAVE * (mod ? 2 : 1) * D * sizeof(float);
   DISPATCH_NCH(D, hipLaunchKernelGGL(rmsnorm_bwd_kernel<NCH>, grid, dim3(256), shm, s, (const bf16*)x, scale,
@@ -398,7 +403,9 @@ extern "C" int lap_layernorm_bwd_sum(const void* x, const float* gamma, const fl
                                      int accum_dx, void* stream) {
   if (rows <= 0 || D <= 0 || (D & 7) || !gamma || !mean || !rstd || !dgamma || !dbeta) return LAP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int G = 16;
+  // rows per block: 16,384 x 1152 takes 75.9 / 54.8 / 43.2 / 49.0 / 76.8 us at 8 / 16 / 32 / 64 / 128 (three atomics per column and block)
+  static const int g_env = getenv("LAP_NORM_BWD_ROWS") ? atoi(getenv("LAP_NORM_BWD_ROWS")) : 32;
+  const int G = g_env;
   dim3 grid((rows + G - 1) / G);
   const size_t shm = (size_t)NWAVE * (dxsum ? 3 : 2) * D * sizeof(float);
   if (shm > 64 * 1024) return LAP_ERR_ARG;
