@@ -38,6 +38,7 @@ import sys
 
 out = []
 E = out.append
+ST_NT = " nt" if os.environ.get("ASM_STORE_NT", "0") == "1" else ""      # nontemporal C stores (A/B knob)
 
 
 def L(x):
@@ -511,14 +512,14 @@ class Kernel:
                 rd(n + 1, V_E + ((n + 1) & 1) * 8)
             fn = n & 7          # from here on: the column group of C
             if self.f32:
-                E(f"\tbuffer_store_dwordx4 v[{cur}:{cur+3}], v{V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*64}")
+                E(f"\tbuffer_store_dwordx4 v[{cur}:{cur+3}], v{V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*64}{ST_NT}")
             else:
                 if self.epi:
                     for r in range(4):
                         E(f"\tv_add_f32 v{cur+r}, v{cur+r}, v{V_BIAS+4*fn+r}")
                 E(f"\tv_cvt_pk_bf16_f32 v{cur+4}, v{cur}, v{cur+1}")
                 E(f"\tv_cvt_pk_bf16_f32 v{cur+5}, v{cur+2}, v{cur+3}")
-                E(f"\tbuffer_store_dwordx2 v[{cur+4}:{cur+5}], v{V_MOFF+fn if self.epi else V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*32}")
+                E(f"\tbuffer_store_dwordx2 v[{cur+4}:{cur+5}], v{V_MOFF+fn if self.epi else V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*32}{ST_NT}")
             if fn == 7:
                 E(f"\ts_add_u32 s{S_CROW}, s{S_CROW}, s{S_C16}")
         E(f"\ts_cmp_lg_u32 s{S_HAVE}, 0")
