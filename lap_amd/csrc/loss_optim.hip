@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 // Four independent 16-byte loads in flight per thread: a block sweeps contiguous 16 KiB chunks (4 x 4 KiB, thread t takes
 // bytes [16 t, 16 t + 16) of each KiB-quad), so the stream stays page-local; the first version had one load in flight and
 // ran at 1.5 TB/s beside the backward GEMMs it shares the chip with (profiles/r01_bench_n1_kernel_stats.md).
+template <bool NT>
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
   __shared__ float red[4];
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -118,8 +119,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   const int t4 = threadIdx.x * 4;
   for (; base + chunk <= n; base += step) {
     const float* p = x + base + t4;
-    const f32x4 t0 = *reinterpret_cast<const f32x4*>(p), t1 = *reinterpret_cast<const f32x4*>(p + 1024);
-    const f32x4 t2 = *reinterpret_cast<const f32x4*>(p + 2048), t3 = *reinterpret_cast<const f32x4*>(p + 3072);
+    auto ld = [](const float* q) { return NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)) : *reinterpret_cast<const f32x4*>(q); };
+    const f32x4 t0 = ld(p), t1 = ld(p + 1024);
+    const f32x4 t2 = ld(p + 2048), t3 = ld(p + 3072);
     a0 += t0[0] * t0[0] + t0[1] * t0[1] + t0[2] * t0[2] + t0[3] * t0[3];
     a1 += t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2] + t1[3] * t1[3];
     a2 += t2[0] * t2[0] + t2[1] * t2[1] + t2[2] * t2[2] + t2[3] * t2[3];
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // VGPRs per SIMD, so the side-stream optimizer never evicts GEMM blocks of the next forward.  (Measured: the step time
 // does not change versus a 54-VGPR version - the ~26 ms the overlapped optimizer still costs per step is HBM contention
 // of its 38 B / parameter with the GEMMs' operand traffic, not CU occupancy.)
+template <bool NT>
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float* __restrict__ ema,
                       const float* __restrict__ g, bf16* __restrict__ p16, long long n, const float* __restrict__ sc,
                       float b1, float b2, float eps, float wd, float max_norm) {
@@ -152,10 +155,15 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, f
   auto cat = [](const float* base, unsigned byte_off) { return reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(base) + byte_off); };
   for (unsigned o = (blockIdx.x * 256u + threadIdx.x) * 8u; o < nb; o += stride) {
     {   // n is even (unit buffers are padded to multiples of 64 elements; checked by the host wrapper)
-      f32x2 pv = *cat(p, o), mv = *cat(m, o), vv = *cat(v, o);
-      const f32x2 gv = *cat(g, o);
+      // NT: the master values, both moments, the EMA and the gradient are touched once per step — nontemporal, so that the
+      // 36 B / parameter streaming past do not push the GEMMs' operand panels out of the L2 (the bf16 copy is stored normally:
+      // the next forward reads it soon)
+      auto ldf = [](const f32x2* q) { return NT ? __builtin_nontemporal_load(q) : *q; };
+      auto stf = [](f32x2* q, f32x2 val) { if (NT) __builtin_nontemporal_store(val, q); else *q = val; };
+      f32x2 pv = ldf(cat(p, o)), mv = ldf(cat(m, o)), vv = ldf(cat(v, o));
+      const f32x2 gv = ldf(cat(g, o));
       f32x2 ev = {0.f, 0.f};
-      if (ema_on) ev = *cat(ema, o);
+      if (ema_on) ev = ldf(cat(ema, o));
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         float gg = gv[e] * clip;
@@ -166,10 +174,10 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, f
         pv[e] = pv[e] - lr * upd;
         if (ema_on) ev[e] = ed * ev[e] + (1.0f - ed) * pv[e];
       }
-      *at(p, o) = pv;
-      *at(m, o) = mv;
-      *at(v, o) = vv;
-      if (ema_on) *at(ema, o) = ev;
+      stf(at(p, o), pv);
+      stf(at(m, o), mv);
+      stf(at(v, o), vv);
+      if (ema_on) stf(at(ema, o), ev);
       if (p16) { bf16x2 q; q[0] = f2bf(pv[0]); q[1] = f2bf(pv[1]); *reinterpret_cast<bf16x2*>(reinterpret_cast<char*>(p16) + (o >> 1)) = q; }
     }
   }
@@ -294,7 +302,9 @@ extern "C" int lap_argmax_rows_f32(const float* x, int rows, int n, int ld, int*
 extern "C" int lap_sumsq_f32(const float* x, long long n, float* sumsq, void* stream) {
   if (n <= 0) return LAP_ERR_ARG;
   const long long blocks = (n + 4095) / 4096;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, S_, x, n, sumsq);
+  static const bool nt = getenv("LAP_SUMSQ_NT") ? atoi(getenv("LAP_SUMSQ_NT")) != 0 : false;
+  if (nt) hipLaunchKernelGGL(sumsq_kernel<true>, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, S_, x, n, sumsq);
+  else hipLaunchKernelGGL(sumsq_kernel<false>, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, S_, x, n, sumsq);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
@@ -307,8 +317,13 @@ extern "C" int lap_adamw_ema(float* p, float* m, float* v, float* ema, const flo
   for (long long o = 0; o < n; o += CH) {
     const long long cnt = n - o < CH ? n - o : CH;
     const long long blocks = (cnt + 511) / 512;
-    hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, p + o, m + o, v + o,
-                       ema ? ema + o : nullptr, g + o, p16 ? (bf16*)p16 + o : nullptr, cnt, scalars, b1, b2, eps, wd, max_norm);
+    static const bool nt = getenv("LAP_ADAMW_NT") ? atoi(getenv("LAP_ADAMW_NT")) != 0 : true;   // (-1.8 ms per train step: tools/ab3.sh)
+    if (nt)
+      hipLaunchKernelGGL(adamw_ema_kernel<true>, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, p + o, m + o, v + o,
+                         ema ? ema + o : nullptr, g + o, p16 ? (bf16*)p16 + o : nullptr, cnt, scalars, b1, b2, eps, wd, max_norm);
+    else
+      hipLaunchKernelGGL(adamw_ema_kernel<false>, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, p + o, m + o, v + o,
+                         ema ? ema + o : nullptr, g + o, p16 ? (bf16*)p16 + o : nullptr, cnt, scalars, b1, b2, eps, wd, max_norm);
     LAP_CHECK_LAUNCH();
   }
   return LAP_OK;
