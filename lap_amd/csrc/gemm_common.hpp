@@ -25,7 +25,7 @@ struct GemmParams {
   int tile_count;        // host side only: tiles of this launch (0 = all from tile_base)
   int part_compact;      // partial slabs are [ksplit][gridDim.x][256][256] (tail split of the 256x256 kernel)
   int sub256;            // 128x128 launch that covers tiles [tile_base, ..) of the 256x256 grid, 4 blocks (quadrants) per tile
-  int epi_lds;           // bf16 output of the 256x256 kernel goes out through LDS in full 512-byte rows (set by the host)
+  int epi_lds;           // output of the 256x256 kernel goes out through LDS in full rows (set by the host); 2: with nontemporal stores
   int dbg;               // LAP_GEMM_EXPERIMENTAL builds only: ablation bits of gemm_sp_kernel (1: no in-loop LDS-DMA, 2: no MFMA)
   const float* qscale_a; // fp8 kernels: device scalars s_a, s_b the operands were multiplied by before rounding to e4m3;
   const float* qscale_b; //   the product is divided by s_a * s_b (alpha applies on top)
@@ -152,7 +152,12 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, char* smem,
       const int r = id >> 5, c = id & 31;
       const int m = m0 + r, n = n0 + c * 8;
       if (m < p.M && n < p.N)   // N % 8 == 0 on this path: a 16-byte piece is inside or outside as a whole
-        *reinterpret_cast<bf16x8*>((bf16*)p.C + (long long)m * p.ldc + n) = *reinterpret_cast<const bf16x8*>(smem + r * CP + c * 16);
+      {
+        const bf16x8 val = *reinterpret_cast<const bf16x8*>(smem + r * CP + c * 16);
+        bf16x8* dst = reinterpret_cast<bf16x8*>((bf16*)p.C + (long long)m * p.ldc + n);
+        if (p.epi_lds == 2) __builtin_nontemporal_store(val, dst);   // full rows, written once: keep them out of the L2's way
+        else *dst = val;
+      }
     }
   } else {
     constexpr int CP = BN * 4 + 16;   // 1040 B: the 16 lanes of a ds_write_b128 group (16 rows) hit 64 distinct banks
@@ -191,7 +196,8 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, char* smem,
           f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CP + c * 16);
           float* dst = (float*)p.C + (long long)m * p.ldc + n;
           if (p.accum) v += *reinterpret_cast<const f32x4*>(dst);
-          *reinterpret_cast<f32x4*>(dst) = v;
+          if (p.epi_lds == 2) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+          else *reinterpret_cast<f32x4*>(dst) = v;
         }
       }
     }
