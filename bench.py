@@ -27,6 +27,10 @@ import os
 import sys
 import time
 
+# Kernel arguments in device memory: ~1 ms per train step less launch latency on MI300-class parts (interleaved A/B: 310.4 -> 309.3 ms;
+# the replayed serving graph is unaffected).  A HIP runtime setting, read when the runtime starts; an explicit value wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
