@@ -41,7 +41,7 @@ HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.29 T
 # profiles/r01_gemm_pmc_counters.txt: gate-up forward GEMM M=17920 N=32768 K=2048 (the largest launch of the step),
 # separate --pmc passes: FETCH_SIZE 1,786,773 KB raw x 2 (gfx950 half-count correction for wide coalesced reads,
 # MI355X_MICROARCH.md §HBM) + WRITE_SIZE 1,272,545 KB; algorithmic bytes of that launch: 0.207 GB read + 1.174 GB written
-GEMM_TRAFFIC = {"bytes_per_launch": 2 * 1748786.8e3 + 1192260.9e3, "algorithmic_bytes_per_launch": 73.4e6 + 134.2e6 + 1174.4e6,
+GEMM_TRAFFIC = {"bytes_per_launch": 2 * 1749055.3e3 + 1197076.8e3, "algorithmic_bytes_per_launch": 73.4e6 + 134.2e6 + 1174.4e6,
                 "shape": "gate-up fwd M=17920 N=32768 K=2048 (lap_gemm_asm_nt)", "source": "profiles/r02g_gemm_pmc_counters.txt"}
 TRAIN_FLOP_PER_SAMPLE = 8.375e12  # 3 x forward (2.792 TFLOP), recompute not credited
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA
