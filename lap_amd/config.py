@@ -318,8 +318,23 @@ class RLDSDataConfig:
 
 @dataclasses.dataclass(frozen=True)
 class WeightLoaderChoice:
-    kind: str = "none"
+    """weight_loaders.py:622-689.  kinds built here: "none", "checkpoint" (params_path = a checkpoint's `params` item) and
+    "paligemma" — the reference's DEFAULT (weight_loaders.py:648-654), which is what its main `lap` config trains from.  The
+    reference downloads gs://vertex-model-garden-paligemma-us/paligemma/pt_224.npz; there is no network here, so the file is
+    looked up locally: params_path, else $LAP_PALIGEMMA_NPZ, else openpi's download cache
+    ~/.cache/openpi/vertex-model-garden-paligemma-us/paligemma/pt_224.npz — and its absence is an error, never a silent
+    random init."""
+    kind: str = "paligemma"
     params_path: str | None = None
+
+    def resolve_paligemma_path(self) -> pathlib.Path:
+        import os
+
+        cand = self.params_path or os.environ.get("LAP_PALIGEMMA_NPZ")
+        if not cand:
+            cache = os.environ.get("OPENPI_DATA_HOME", "~/.cache/openpi")
+            cand = str(pathlib.Path(cache).expanduser() / "vertex-model-garden-paligemma-us" / "paligemma" / "pt_224.npz")
+        return pathlib.Path(cand).expanduser()
 
 
 # ------------------------------------------------------------------------------ TrainConfig (config.py:507-603)
@@ -432,6 +447,7 @@ _CONFIGS = [
         model=LAPConfig(action_dim=7, action_horizon=50, max_token_len=48, enable_action_training=True,
                         stop_action_to_vlm_grad=False, language_loss_weight=0.4, enable_image_augmentation=False),
         lr_schedule=CosineDecaySchedule(warmup_steps=1000, peak_lr=5e-5, decay_steps=40_000, decay_lr=5e-5),
+        weight_loader=WeightLoaderChoice(kind="none"),   # benchmark: random-init weights of the LAP-3B architecture
         batch_size=32, ema_schedule_choice=EmaScheduleChoice(kind="constant"),
     ),
     TrainConfig(  # tiny model for tests (gemma "dummy" variant gemma.py:60-68, SigLIP "mu")
@@ -440,6 +456,7 @@ _CONFIGS = [
                         vocab_size=512, action_dim=7, action_horizon=10, max_token_len=24, enable_action_training=True,
                         language_loss_weight=0.4, enable_image_augmentation=False),
         lr_schedule=CosineDecaySchedule(warmup_steps=2, peak_lr=1e-3, decay_steps=100, decay_lr=1e-3),
+        weight_loader=WeightLoaderChoice(kind="none"),
         batch_size=2, num_train_steps=10, ema_schedule_choice=EmaScheduleChoice(kind="constant"),
     ),
 ]

@@ -66,22 +66,60 @@ def validate_loaded_params(expected: dict, got: dict, *, allow_partial: bool) ->
     return got
 
 
+def load_paligemma_npz(path, expected: dict) -> dict:
+    """PaliGemmaWeightLoader.load (weight_loaders.py:109-124): the official PaliGemma `.npz` is a flat dict of '/'-joined
+    keys; the subtree under `params` becomes the model's `PaliGemma` subtree, keys the model does not have are dropped and
+    dtypes follow the model (`_merge_params`, :691-719).  Returns {reference path: f32 tensor} for the keys it could take."""
+    import numpy as np
+
+    path = __import__("pathlib").Path(path)
+    if not path.is_file():
+        raise FileNotFoundError(
+            f"PaliGemma checkpoint {path} not found.  The reference downloads gs://vertex-model-garden-paligemma-us/paligemma/"
+            "pt_224.npz (weight_loaders.py:117-119); this engine has no network access: place the file there, or point "
+            "weight_loader.params_path / $LAP_PALIGEMMA_NPZ at it, or choose weight_loader.kind='none' for a random init.")
+    out = {}
+    with np.load(path, allow_pickle=False) as z:
+        for key in z.files:
+            if not key.startswith("params/"):
+                continue
+            ref = "PaliGemma/" + key[len("params/"):]
+            if ref in expected:
+                a = z[key]
+                out[ref] = torch.from_numpy(np.ascontiguousarray(a.astype(np.float32) if a.dtype.kind == "f" or a.dtype.kind == "V" else a))
+    if not out:
+        raise ValueError(f"{path}: no key under 'params/' matches the model's PaliGemma subtree")
+    return out
+
+
 def load_weights(config: TrainConfig, store: ParamStore):
     """The `weight_loader` of the config executed against a freshly initialised store (scripts/train.py:191-199,248-310;
-    weight_loaders.py:55-105,691-719): load the checkpoint's `params` item in the reference's tree layout, keep the
-    keys the model knows (CheckpointWeightLoader drops the rest and casts dtypes), validate, and merge over the init."""
+    weight_loaders.py:55-124,691-719): load a parameter tree in the reference's layout, keep the keys the model knows
+    (`_merge_params` drops the rest and casts dtypes), validate, and merge over the init.
+      checkpoint  a checkpoint's `params` item; missing keys allowed iff `allow_partial_weights` (CheckpointWeightLoader merges
+                  only `.*lora.*` back, so anything else missing reaches `_validate_loaded_params`);
+      paligemma   the PaliGemma `.npz` (the reference's default kind); `missing_regex=".*"` — every key it lacks (the action
+                  expert, the action / time heads) keeps its init regardless of `allow_partial_weights`."""
     from lap_amd import checkpoints as ck
     from lap_amd.params import reference_shapes
 
     wl = config.weight_loader
     if wl.kind == "none":
         return False
-    if wl.kind != "checkpoint":
-        raise NotImplementedError(f"weight loader kind {wl.kind!r} (paligemma / gemma3 .npz loaders are out of scope: SURVEY.md §2)")
     expected = reference_shapes(config.model)
-    loaded = ck.restore_params(wl.params_path)           # '/value' suffixes and the 'params/' prefix are stripped there
-    subset = {k: torch.as_tensor(v) for k, v in loaded.items() if k in expected}     # _merge_params: subset of the model's keys
-    subset = validate_loaded_params(expected, subset, allow_partial=config.allow_partial_weights)
+    if wl.kind == "checkpoint":
+        if not wl.params_path:
+            raise ValueError("--weight-loader.params-path must be set when kind=checkpoint")     # weight_loaders.py:659-661
+        loaded = ck.restore_params(wl.params_path)           # '/value' suffixes and the 'params/' prefix are stripped there
+        subset = {k: torch.as_tensor(v) for k, v in loaded.items() if k in expected}     # _merge_params: subset of the model's keys
+        allow_partial = config.allow_partial_weights
+    elif wl.kind == "paligemma":
+        subset = load_paligemma_npz(wl.resolve_paligemma_path(), expected)
+        allow_partial = True
+    else:
+        raise NotImplementedError(f"weight loader kind {wl.kind!r} (paligemma2 / gemma3 loaders belong to model variants that are "
+                                  "out of scope: SURVEY.md §2)")
+    subset = validate_loaded_params(expected, subset, allow_partial=allow_partial)
     if len(subset) < len(expected):                      # partial: the model's own (random-init) arrays fill the gaps
         base = store.to_reference_tree("master")
         base.update(subset)
@@ -149,16 +187,59 @@ class TrainingStepRunner:
         return state.model.comm.param_sumsq(_is_kernel_param).sqrt().view(())
 
 
+class ValidationStepRunner:
+    """scripts/train.py:422-450: `metrics = runner(rng, state, (observation, actions))` — `compute_loss(..., train=False)` on the
+    live parameters with `fold_in(rng, state.step)` as the key, the loss reported as `val_loss` next to the loss metrics.  No
+    gradients, no optimizer; under FSDP the loss is the all-reduced global value like the train loss."""
+
+    def __init__(self, config: TrainConfig):
+        self.config = config
+
+    @torch.no_grad()
+    def __call__(self, rng, state: TrainState, batch, *, noise=None, time=None) -> dict:
+        observation, actions = batch
+        seed = (int(rng) * 1_000_003 + state.step) if not isinstance(rng, torch.Generator) else rng
+        val_loss, val_metrics = state.model.compute_loss(seed, observation, actions, train=False, noise=noise, time=time)
+        val_metrics = dict(val_metrics)
+        val_metrics["val_loss"] = val_loss
+        return val_metrics
+
+
+def run_validation(runner: ValidationStepRunner, rng, state: TrainState, val_loader, num_batches: int | None = None) -> dict:
+    """The periodic validation pass of the train loop (scripts/train.py:619-660): a FRESH iterator every time, so the same
+    fixed validation subset is scored at every interval; up to `num_batches` batches (default: the loader's
+    `num_val_batches()`, else until it is exhausted); returns the mean of each scalar metric with a `val_` prefix
+    (`val_loss` keeps its name)."""
+    if num_batches is None and hasattr(val_loader, "num_val_batches"):
+        num_batches = int(val_loader.num_val_batches())
+    infos = []
+    for i, batch in enumerate(iter(val_loader)):
+        if num_batches is not None and i >= num_batches:
+            break
+        infos.append(runner(rng, state, batch))
+    if not infos:
+        return {}
+    keys = [k for k, v in infos[0].items() if torch.is_tensor(v) and v.numel() == 1]
+    return {(k if k.startswith("val_") else "val_" + k): float(torch.stack([i[k].float().reshape(()) for i in infos]).mean()) for k in keys}
+
+
 # ====================================================================================== training entry point
 class SyntheticDataLoader:
     """Stand-in for datasets/data_loader.py: seeded batches of the benchmark shape (§8d) with
     the protocol the train loop and the checkpoint code use (`__iter__`, `get_state`, `set_state`).  Rank r of N draws
     batch `N * i + r`, so a resumed run continues with the batches the interrupted run would have seen."""
 
-    def __init__(self, cfg, per_rank_batch: int, device, *, seed: int = 0, rank: int = 0, world_size: int = 1):
+    def __init__(self, cfg, per_rank_batch: int, device, *, seed: int = 0, rank: int = 0, world_size: int = 1,
+                 num_batches: int | None = None):
         self.cfg, self.B, self.device = cfg, per_rank_batch, device
         self.seed, self.rank, self.world = seed, rank, world_size
         self.index = 0
+        self.num_batches = num_batches          # None: endless (train split); n: one pass of n batches per iterator (val split)
+
+    def num_val_batches(self) -> int:
+        if self.num_batches is None:
+            raise ValueError("an endless loader has no validation batch count")
+        return self.num_batches
 
     def get_state(self) -> dict:
         return {"index": self.index, "seed": self.seed}
@@ -167,10 +248,15 @@ class SyntheticDataLoader:
         self.index, self.seed = int(s["index"]), int(s["seed"])
 
     def __iter__(self):
+        if self.num_batches is not None:
+            self.index = 0                        # a fresh iterator scores the same fixed subset again
         return self
 
     def __next__(self):
         from lap_amd.observation import CoTObservation
+
+        if self.num_batches is not None and self.index >= self.num_batches:
+            raise StopIteration
 
         cfg, B, dev = self.cfg, self.B, self.device
         g = torch.Generator(device="cpu").manual_seed(self.seed * 1_000_003 + self.index * self.world + self.rank)
@@ -189,7 +275,7 @@ class SyntheticDataLoader:
         return obs, torch.randn(B, cfg.action_horizon, cfg.action_dim, generator=g).to(dev)
 
 
-def main(config: TrainConfig, *, data_loader=None, device: str | None = None, log=print) -> TrainState:
+def main(config: TrainConfig, *, data_loader=None, val_data_loader=None, device: str | None = None, log=print) -> TrainState:
     """scripts/train.py:422-640 (main): distributed init, train state (+ resume), the step loop with interval logging
     and checkpointing.  One process per GPU; under `torch.distributed.run` the parameters / optimizer / EMA are ZeRO-3
     sharded over all ranks and `batch_size` is the GLOBAL batch (config.py:783)."""
@@ -237,6 +323,14 @@ def main(config: TrainConfig, *, data_loader=None, device: str | None = None, lo
         state = ck.restore_state(mngr, state, data_loader)
         log(f"resumed from step {state.step} ({mngr.directory})")
     runner = TrainingStepRunner(config)
+    val_runner = None
+    if config.use_validation:                            # scripts/train.py:539-571
+        if val_data_loader is None:
+            if not isinstance(data_loader, SyntheticDataLoader):
+                raise ValueError("use_validation=True needs a `val_data_loader` (split='val' of the training data)")
+            val_data_loader = SyntheticDataLoader(config.model, config.batch_size // world, device, seed=config.seed + 7919, rank=rank,
+                                                  world_size=world, num_batches=2)
+        val_runner = ValidationStepRunner(config)
     it = iter(data_loader)
     infos, t_last, start = [], _time.perf_counter(), state.step
     for step in range(start, config.num_train_steps):
@@ -256,6 +350,14 @@ def main(config: TrainConfig, *, data_loader=None, device: str | None = None, lo
                 log(f"step {step + 1}: " + ", ".join(f"{k}={v:.4f}" for k, v in mean.items()) +
                     f" | {len(infos) * config.batch_size / dt:.1f} samples/s")
             infos, t_last = [], _time.perf_counter()
+        if val_runner is not None and (step + 1) % config.val_interval == 0:          # scripts/train.py:619-660
+            vm = run_validation(val_runner, config.seed, state, val_data_loader)
+            if world > 1 and vm:
+                t = torch.tensor(list(vm.values()), device=device)
+                dist.all_reduce(t)
+                vm = {k: float(v) / world for k, v in zip(vm, t)}
+            if rank == 0 and vm:
+                log(f"step {step + 1} validation: " + ", ".join(f"{k}={v:.4f}" for k, v in vm.items()))
         if ((step + 1) % config.save_interval == 0 and step + 1 > start) or last:
             # save_assets callback (training/checkpoints.py:216-285): the loader's normalisation statistics travel with the
             # checkpoint, so the policy built from it un-normalises with the training-time numbers

@@ -147,3 +147,33 @@ def test_frozen_vlm_trains_only_the_action_expert(hip):
         p1, _, _ = O.adamw_step(P[k], Pg[k].grad, torch.zeros_like(P[k]), torch.zeros_like(P[k]), 1, tc.lr_schedule(0), tc.optimizer.b1,
                                 tc.optimizer.b2, tc.optimizer.eps, tc.optimizer.weight_decay, cs)
         assert rel(new[k] - P[k], p1 - P[k]) < 0.15, k
+
+
+def test_validation_step_runner_and_loop(hip, tmp_path):
+    """scripts/train.py:422-450 (ValidationStepRunner) and :539-571,619-660 (the loop's validation branch): the runner returns
+    the loss metrics of `compute_loss(train=False)` plus `val_loss`, touches neither parameters nor optimizer state, scores the
+    same fixed subset every time, and `use_validation` makes the loop report it every `val_interval` steps."""
+    from lap_amd.config import get_config
+    from lap_amd.train import SyntheticDataLoader, ValidationStepRunner, init_train_state, main, run_validation
+
+    tc = dataclasses.replace(get_config("debug"), checkpoint_base_dir=str(tmp_path), batch_size=4, seed=5)
+    state = init_train_state(tc, device="cuda")
+    val = SyntheticDataLoader(tc.model, 4, "cuda", seed=11, num_batches=2)
+    runner = ValidationStepRunner(tc)
+    before = {u.name: state.model.ps.master[u.name].clone() for u in state.model.ps.units}
+    batch = next(iter(val))
+    m = runner(tc.seed, state, batch)
+    seed = tc.seed * 1_000_003 + state.step
+    loss, metrics = state.model.compute_loss(seed, batch[0], batch[1], train=False)
+    assert torch.equal(m["val_loss"], loss) and set(m) == set(metrics) | {"val_loss"}
+    assert all(torch.equal(m[k], metrics[k]) for k in metrics)
+    a = run_validation(runner, tc.seed, state, val)
+    b = run_validation(runner, tc.seed, state, val)          # a fresh iterator: the same two batches again
+    assert a == b and set(a) >= {"val_loss", "val_lang_loss", "val_action_loss"} and val.num_val_batches() == 2
+    torch.cuda.synchronize()
+    assert all(torch.equal(before[u.name], state.model.ps.master[u.name]) for u in state.model.ps.units)
+    lines = []
+    main(dataclasses.replace(tc, exp_name="val", num_train_steps=4, use_validation=True, val_interval=2, log_interval=2, save_interval=100),
+         log=lines.append)
+    vl = [l for l in lines if "validation" in l]
+    assert len(vl) == 2 and vl[0].startswith("step 2 validation: ") and "val_loss=" in vl[0]

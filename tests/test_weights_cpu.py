@@ -85,9 +85,49 @@ def test_weight_loader_merges_checkpoint_over_init(tmp_path, value_suffix):
     with pytest.raises(ValueError, match="missing required keys"):
         load_weights(dataclasses.replace(tc_part, allow_partial_weights=False), ParamStore(cfg, "cpu"))
     with pytest.raises(NotImplementedError):
-        load_weights(dataclasses.replace(tc, weight_loader=WeightLoaderChoice("paligemma")), ps)
-    assert not load_weights(tc, ps)                                              # kind "none"
+        load_weights(dataclasses.replace(tc, weight_loader=WeightLoaderChoice("gemma3", "x")), ps)
+    assert not load_weights(tc, ps)                                              # kind "none" (the debug config says so explicitly)
     assert get_config("lap_libero").weight_loader.kind == "checkpoint"          # training/config.py:776-779
+
+
+def test_paligemma_weight_loader(tmp_path, monkeypatch):
+    """PaliGemmaWeightLoader (weight_loaders.py:109-124) is the reference's DEFAULT loader (:648-654) and what its `lap` config
+    trains from: a flat `.npz` whose `params/...` subtree lands under `PaliGemma/`, everything the file lacks (action expert,
+    heads) keeps its init whatever `allow_partial_weights` says (missing_regex ".*"), foreign keys are dropped, and a missing
+    file is an error — never a silent random init."""
+    assert WeightLoaderChoice().kind == "paligemma" and get_config("lap").weight_loader.kind == "paligemma"
+    tc = _cfg()
+    cfg = tc.model
+    P = O.init_params(oracle_cfg(cfg), seed=9)
+    # what the official checkpoint holds: the VLM (expert 0) and the image tower, bf16 / f32 mixed, plus keys we do not have
+    pg = {k: v for k, v in P.items() if k.startswith("PaliGemma/") and "_1/" not in k and not k.endswith("_1")}
+    assert 0 < len(pg) < len(P)
+    flat = {"params/" + k[len("PaliGemma/"):]: v.numpy() for k, v in pg.items()}
+    flat["params/img/head_extra/kernel"] = np.zeros((2, 2), np.float32)          # not in the model: dropped by _merge_params
+    flat["opt_state/count"] = np.zeros((), np.int32)                              # outside `params`: never looked at
+    some = next(k for k in flat if k.endswith("q_einsum/w"))
+    flat[some] = flat[some].astype(np.float16)                                    # dtype follows the model's (cast on merge)
+    path = tmp_path / "pt_224.npz"
+    np.savez(path, **flat)
+    for choice, env in ((WeightLoaderChoice("paligemma", str(path)), None), (WeightLoaderChoice("paligemma"), str(path))):
+        if env:
+            monkeypatch.setenv("LAP_PALIGEMMA_NPZ", env)
+        ps = ParamStore(cfg, "cpu")
+        ps.init_random(0)
+        init = ps.to_reference_tree("master")
+        assert load_weights(dataclasses.replace(tc, weight_loader=choice, allow_partial_weights=False), ps)
+        back = ps.to_reference_tree("master")
+        for k in P:
+            want = (pg[k].to(torch.float16).float() if "params/" + k[len("PaliGemma/"):] == some else pg[k]) if k in pg else init[k]
+            assert torch.equal(back[k], want), k
+    monkeypatch.delenv("LAP_PALIGEMMA_NPZ")
+    monkeypatch.setenv("OPENPI_DATA_HOME", str(tmp_path / "nothing_here"))
+    with pytest.raises(FileNotFoundError, match="pt_224.npz"):
+        load_weights(dataclasses.replace(tc, weight_loader=WeightLoaderChoice("paligemma")), ParamStore(cfg, "cpu"))
+    bad = dict(flat); bad[some] = np.zeros((3, 3), np.float32)
+    np.savez(tmp_path / "bad.npz", **bad)
+    with pytest.raises(ValueError, match="shape"):
+        load_weights(dataclasses.replace(tc, weight_loader=WeightLoaderChoice("paligemma", str(tmp_path / "bad.npz"))), ParamStore(cfg, "cpu"))
 
 
 def test_freeze_filter_partitions_the_store():
