@@ -296,6 +296,7 @@ def restore_state(checkpoint_manager: CheckpointManager, state, data_loader=None
 def _refresh_mirrors(state):
     """bf16 compute mirrors <- restored f32 masters (all-gathered under FSDP)."""
     ps, comm = state.model.ps, state.model.comm
+    ps.version += 1      # masters / mirrors were written directly: derived copies (the fp8 weight mirrors of LAP._w8_of) are stale
     if ps.world_size == 1:
         ps.refresh_mirror_local()
         return

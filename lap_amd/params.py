@@ -294,6 +294,7 @@ class ParamStore:
 
     def refresh_mirror_local(self):
         """bf16 mirror <- f32 master for world_size == 1 (the optimizer kernel does this itself each step)."""
+        self.version += 1     # derived copies of the weights (fp8 mirrors) are stale from here on
         for u in self.units:
             if u.big and not self.sharded(u):
                 self.full16[u.name].copy_(self.master[u.name])

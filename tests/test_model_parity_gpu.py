@@ -553,6 +553,31 @@ def test_fp8_gemm_path_matches_fp8_emulating_oracle(hip, monkeypatch):
         LAP(debug_model_cfg(), seed=0, device=DEV, gemm_dtype="fp8")
 
 
+def test_fp8_weight_mirrors_follow_a_restore(hip, monkeypatch, tmp_path):
+    """`restore_state` writes masters / bf16 mirrors directly; the e4m3 weight copies cached by `LAP._w8_of` are keyed
+    on `ParamStore.version` and must be re-quantised after it — forward, restore, forward equals a model that always held the
+    restored parameters, bit for bit."""
+    from lap_amd import checkpoints as ck
+    from lap_amd.config import get_config
+    from lap_amd.train import init_train_state
+
+    cfg = _full_width_cfg(monkeypatch, action_dim=7)
+    tc = dataclasses.replace(get_config("debug"), model=cfg, gemm_dtype="fp8", checkpoint_base_dir=str(tmp_path), exp_name="r")
+    obs, actions, noise, time = make_inputs(cfg, B=2, ragged=True)
+    args = (to_observation(obs, DEV), actions.to(DEV))
+    kw = dict(noise=noise.to(DEV), time=time.to(DEV))
+    a = init_train_state(tc, seed=1, device=DEV)
+    mngr, _ = ck.initialize_checkpoint_dir(tc.checkpoint_dir, keep_period=None, overwrite=False, resume=True)
+    ck.save_state(mngr, a, None, 1)
+    la, _ = a.model.compute_loss(0, *args, **kw)
+    b = init_train_state(tc, seed=2, device=DEV)
+    lb, _ = b.model.compute_loss(0, *args, **kw)          # caches the fp8 mirrors of the seed-2 weights
+    b = ck.restore_state(mngr, b, None)
+    lr, _ = b.model.compute_loss(0, *args, **kw)
+    torch.cuda.synchronize()
+    assert lb.item() != la.item() and torch.equal(lr, la), (la.item(), lb.item(), lr.item())
+
+
 def test_vqa_and_prediction_loss_mixing_matches_oracle(hip):
     """lap.py:401-413,472-596: VQA / prediction samples carry their own language-loss weights (per-dataset VQA weights through
     the registry ids) and are excluded from the action loss, whose normaliser becomes the number of action samples; idle
