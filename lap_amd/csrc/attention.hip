@@ -608,6 +608,8 @@ int set_lds(K kernel, int bytes) {
   return 0;
 }
 
+#include "attention_serve.hpp"
+
 // Tuning / test knob (lap_attention_set_variant): -1 = automatic; 0 = generic kernels also for HD = 256;
 // 1 = the HD = 256 LDS-DMA kernels (what automatic picks whenever their LDS info table fits).
 int g_attn_variant = -1;
@@ -757,6 +759,38 @@ extern "C" int lap_attention_fwd(const lap_attn_fwd_args* a, void* stream) {
     case 256: return launch_fwd<256>(p, s);
   }
   return LAP_ERR_ARG;
+}
+
+extern "C" int lap_attention_serve_splits(int k_len0, int k_len1) {
+  if (k_len0 < 0 || k_len1 < 0 || k_len0 + k_len1 == 0) return 0;
+  return serve_splits(k_len0, k_len1).nsplit;
+}
+
+extern "C" int lap_attention_serve(const lap_attn_fwd_args* a, void* stream) {
+  if (!a || !check_common(a->B, a->NH, a->NKV, a->HD, a->q_len, a->k_len)) return LAP_ERR_ARG;
+  if (a->HD != 256 || a->q_len[0] != 0 || a->q_len[1] > 64 || a->lse || !a->q[1] || !a->o[1]) return LAP_ERR_ARG;
+  AttnP p = {};
+  for (int s = 0; s < 2; ++s) {
+    p.q[s] = (const bf16*)a->q[s]; p.o[s] = (bf16*)a->o[s];
+    p.k[s] = (const bf16*)a->k[s]; p.v[s] = (const bf16*)a->v[s];
+    p.qlen[s] = a->q_len[s]; p.klen[s] = a->k_len[s];
+    p.q_rs[s] = a->q_rs[s] ? a->q_rs[s] : a->NH * a->HD;
+    p.o_rs[s] = a->o_rs[s] ? a->o_rs[s] : a->NH * a->HD;
+    p.kv_rs[s] = a->kv_rs[s] ? a->kv_rs[s] : a->NKV * a->HD;
+    if ((p.q_rs[s] | p.o_rs[s] | p.kv_rs[s]) & 7) return LAP_ERR_ARG;
+    if (p.klen[s] && (!p.k[s] || !p.v[s])) return LAP_ERR_ARG;
+    if ((long long)p.klen[s] * p.kv_rs[s] * 2 >= 0x7fffffffLL) return LAP_ERR_ARG;
+  }
+  if ((a->qinfo == nullptr) != (a->kinfo == nullptr)) return LAP_ERR_ARG;
+  p.qinfo = a->qinfo; p.kinfo = a->kinfo; p.scale = a->scale;
+  if (!(a->scale > 0.f)) return LAP_ERR_ARG;
+  const long long need = (long long)a->nsplit * a->B * a->q_len[1] * a->NH * (a->HD + 1);
+  if (a->nsplit < 1 || !a->scratch || a->scratch_floats < need) return LAP_ERR_ARG;
+  p.nsplit = a->nsplit; p.hsplit = 1;
+  p.part = a->scratch;
+  p.lpart = a->scratch + (long long)a->nsplit * a->B * a->q_len[1] * a->NH * a->HD;
+  p.B = a->B; p.NH = a->NH; p.NKV = a->NKV;
+  return launch_serve(p, (hipStream_t)stream);
 }
 
 extern "C" int lap_attention_bwd(const lap_attn_bwd_args* a, void* stream) {

@@ -1266,7 +1266,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
   if (p.gelu) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(p.gelu == 2 ? round_bf16(v[e]) : v[e]);
   }
   if (p.R) {
     bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
@@ -1320,6 +1320,12 @@ int dispatch_tile(const GemmParams& p, int tile, hipStream_t s) {
     case 12: return launch_pq<A_KC, B_KC, OUT_F32>(p, s);
     case 10: return launch_sp<2, 4, A_KC, B_KC, OUT_F32>(p, s);
     case 6: return launch<128, 128, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
+    // serving-prefill shapes (M = 512 / 560 rows, forward layout, bf16 out): see pick_serving_tile
+    case 15: if constexpr (A_KC && B_KC) return launch<320, 256, 2, 4, 64, 2, true, true, OUT_F32>(p, s); else return LAP_ERR_ARG;
+    case 16: if constexpr (A_KC && B_KC) return launch<64, 128, 2, 4, 64, 3, true, true, OUT_F32>(p, s); else return LAP_ERR_ARG;
+    case 17: if constexpr (A_KC && B_KC) return launch<64, 64, 2, 2, 64, 4, true, true, OUT_F32>(p, s); else return LAP_ERR_ARG;
+    case 18: if constexpr (A_KC && B_KC) return launch<128, 64, 4, 2, 64, 3, true, true, OUT_F32>(p, s); else return LAP_ERR_ARG;
+    case 19: if constexpr (A_KC && B_KC) return launch<320, 128, 2, 4, 64, 2, true, true, OUT_F32>(p, s); else return LAP_ERR_ARG;
     case 5: return launch<256, 256, 4, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
     case 2: return launch<256, 256, 2, 4, 64, 2, A_KC, B_KC, OUT_F32>(p, s);
 #ifdef LAP_GEMM_EXPERIMENTAL   // probes kept for the record: build with LAP_GEMM_EXPERIMENTAL=1 python -m lap_amd.build
@@ -1360,7 +1366,7 @@ __global__ __launch_bounds__(256) void splitk_tail_reduce_kernel(GemmParams p, i
   }
   if (p.gelu) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(p.gelu == 2 ? round_bf16(v[e]) : v[e]);
   }
   if (p.R) {
     bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
@@ -1460,7 +1466,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   const bool f32 = flags & LAP_GEMM_OUT_F32;
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
-  if (tile < -1 || tile > 14 || ksplit < 0) return LAP_ERR_ARG;
+  if (tile < -1 || tile > 19 || ksplit < 0) return LAP_ERR_ARG;
   // Few output tiles but a very long contraction (LM-head dgrad: 1504 x 2048 over K = 257152; prefill down
   // projection): the big tile with enough K splits to cover the chip beats the small tile walking all of K.
   if (tile < 0 && ksplit == 0 && scratch != nullptr && K >= 16384 && !(flags & LAP_GEMM_PARTIALS)) {
@@ -1503,6 +1509,21 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
       // ping-pong tile's rate on a weight with 32 KiB rows varies from box to box), long ones keep the tail split
       const bool win = (a_kc && b_kc) ? (fill >= 0.8 || K <= 4096) : (!a_kc && !b_kc) ? fill >= 0.8 : (fill >= 0.8 && K <= 4096 && !no_asm_nn);
       if (t5 >= 128 && win) return lap_gemm_asm(A, B, C, M, N, K, lda, ldb, ldc, a_kc, b_kc, f32, stream);
+    }
+  }
+  // Serving prefill (batch-1 action chunk: 512 SigLIP rows, 560 Gemma rows; forward layout, bf16 out).  Every block of such
+  // a GEMM is bound by what it pulls through its CU's vector-memory path (~45 GB/s), so the tile is the one with the fewest
+  // operand bytes per block that still covers the chip WITHOUT a split-K reduce pass behind it (tools/bench_prefill_gemm.py,
+  // hipGraph-timed, automatic choice -> here): SigLIP qkv 22.8 -> 12.5 us, out 14.7 -> 10.1, fc1 24.5 -> 16.8, head 19.3 ->
+  // 10.1; Gemma qkv 22.2 -> 17.1, out 18.2 -> 17.4, gate|up 90.8 -> 74.2 (a 320-row tile: 560 rows are 2 x 280, not 3 x 256).
+  // Long contractions (SigLIP fc2, Gemma down: K >= 4096) keep their K split.  LAP_GEMM_NO_SERVING_TILES=1: off (A/B).
+  if (tile < 0 && ksplit == 0 && a_kc && b_kc && M > 256 && M <= 768 && !(flags & LAP_GEMM_PARTIALS) && (f32 || !(flags & LAP_GEMM_ACCUM))) {
+    static const bool off = getenv("LAP_GEMM_NO_SERVING_TILES") != nullptr;
+    if (!off) {
+      if (K <= 1536 && N >= 1024) { tile = N >= 3072 ? 16 : 17; ksplit = 1; }     // (also the f32 hi / lo stem products)
+      else if (f32) {}
+      else if (K <= 2560 && N >= 8192 && M > 512 && M <= 640) { tile = 15; ksplit = 1; }
+      else if (K <= 2560 && N >= 2048 && N < 8192) { tile = 16; ksplit = 1; }
     }
   }
   if (tile < 0) tile = pick_tile(M, N, K);
@@ -1550,7 +1571,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C; p.bias = bias; p.R = (const bf16*)residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.alpha = alpha;
   p.bias_kind = bias ? ((flags & LAP_GEMM_BIAS_F32) ? 2 : 1) : 0;
-  p.gelu = (flags & LAP_GEMM_GELU) ? 1 : 0;
+  p.gelu = (flags & LAP_GEMM_GELU) ? ((flags & LAP_GEMM_GELU_BF16) ? 2 : 1) : 0;
   p.accum = (flags & LAP_GEMM_ACCUM) ? 1 : 0;
   p.ksplit = ksplit > 1 ? ksplit : 1;
   p.dbg = g_gemm_dbg;

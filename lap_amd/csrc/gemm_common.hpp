@@ -71,9 +71,9 @@ __device__ __forceinline__ void store_tile4(const GemmParams& p, int m, int n, f
   } else if (p.bias_kind == 2) {
     v += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
   }
-  if (p.gelu) {
+  if (p.gelu) {   // 2: the pre-activation is rounded to bf16 first (= a bf16 Dense output followed by a GELU kernel)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(p.gelu == 2 ? round_bf16(v[e]) : v[e]);
   }
   if (p.R) {
     bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);
@@ -131,7 +131,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams& p, char* smem,
           }
           if (p.gelu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(p.gelu == 2 ? round_bf16(v[e]) : v[e]);
           }
           if (p.R) {
             bf16x4 r = *reinterpret_cast<const bf16x4*>(p.R + (long long)m * p.ldr + n);

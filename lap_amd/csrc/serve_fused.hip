@@ -191,6 +191,94 @@ __global__ __launch_bounds__(256) void reduce_residual_norm_kernel(const float* 
   }
 }
 
+// ---------------------------------------------------------------- reduce (+ f32 bias) (+ residual) -> bf16, then a row norm
+// The serving prefill's consumers (SigLIP fc2 -> next LayerNorm; Gemma out / down projection -> next RMSNorm): the split-K
+// reduce pass, the projection's epilogue and the normalisation that follows it in ONE pass over the rows.  One wave per row
+// (D <= 2048), lane / chunk assignment and operation order of splitk_reduce_kernel (gemm.hip) followed by rmsnorm_fwd_kernel /
+// layernorm_fwd_kernel (norm.hip): the same bits as the three launches it replaces.
+//   xn = bf16(sum_s part[s] (+ bias) (+ residual));  NORM 1: h = xn * rstd * (1 + scale)  (gemma.py:113-131, plain form);
+//   NORM 2: h = (xn - mean) * (rstd * gamma) + beta  (Flax LayerNorm, use_fast_variance);  NORM 0: no h.
+template <int NCH, int NORM>
+__global__ __launch_bounds__(256) void reduce_norm_kernel(const float* __restrict__ part, int ks, const float* __restrict__ bias,
+                                                          const bf16* __restrict__ resid, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, bf16* __restrict__ xn, bf16* __restrict__ hout,
+                                                          int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  const long long slab = (long long)rows * D;
+  float v[NCH][8];
+  float s1 = 0.f, ss = 0.f;
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int c = (lane + 64 * p) * 8;
+    if (c < D) {
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = 0.f;
+      const long long off = (long long)row * D + c;
+      int s = 0;
+      for (; s + 4 <= ks; s += 4) {      // four slabs in flight; additions in slab order (= splitk_reduce_kernel)
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u] = *reinterpret_cast<const f32x4*>(part + (s + u) * slab + off);
+          b[u] = *reinterpret_cast<const f32x4*>(part + (s + u) * slab + off + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { y[e] += a[u][e]; y[4 + e] += b[u][e]; }
+      }
+      for (; s < ks; ++s) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(part + s * slab + off), b = *reinterpret_cast<const f32x4*>(part + s * slab + off + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y[e] += a[e]; y[4 + e] += b[e]; }
+      }
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] += bias[c + e];
+      }
+      if (resid) {
+        float r[8];
+        ld8(resid + off, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] += r[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[p][e] = round_bf16(y[e]);
+      st8(xn + off, v[p]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1 += v[p][e]; ss += v[p][e] * v[p][e]; }
+    }
+  }
+  if (NORM == 0) return;
+  ss = wave_sum(ss);
+  float mean = 0.f, r;
+  if (NORM == 2) {
+    s1 = wave_sum(s1);
+    mean = s1 / (float)D;
+    r = 1.0f / sqrtf(fmaxf(ss / (float)D - mean * mean, 0.f) + eps);
+  } else {
+    r = 1.0f / sqrtf(ss / (float)D + eps);
+  }
+#pragma unroll
+  for (int p = 0; p < NCH; ++p) {
+    const int c = (lane + 64 * p) * 8;
+    if (c < D) {
+      float o[8];
+      if (NORM == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[p][e] - mean) * (r * gamma[c + e]) + beta[c + e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = v[p][e] * r * (1.0f + gamma[c + e]);
+      }
+      st8(hout + (long long)row * D + c, o);
+    }
+  }
+}
+
 }  // namespace
 
 #define S_ ((hipStream_t)stream)
@@ -240,6 +328,30 @@ extern "C" int lap_fused_reduce_residual_norm(const float* partials, int ksplit,
     default: return LAP_ERR_ARG;
   }
 #undef GO
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_fused_reduce_norm(const float* partials, int ksplit, const float* bias, const void* residual, int norm,
+                                     const float* gamma, const float* beta, void* xn, void* h, int rows, int D, float eps,
+                                     void* stream) {
+  if (!partials || ksplit < 1 || !xn || rows <= 0 || D <= 0 || (D & 7) || norm < 0 || norm > 2) return LAP_ERR_ARG;
+  if (norm && (!gamma || !h)) return LAP_ERR_ARG;
+  if (norm == 2 && !beta) return LAP_ERR_ARG;
+  const int nch = (D / 8 + 63) / 64;
+  dim3 grid((rows + 3) / 4);
+#define GO2(N, NM) hipLaunchKernelGGL((reduce_norm_kernel<N, NM>), grid, dim3(256), 0, S_, partials, ksplit, bias, (const bf16*)residual, \
+                                      gamma, beta, (bf16*)xn, (bf16*)h, rows, D, eps)
+#define GO(N) do { if (norm == 0) GO2(N, 0); else if (norm == 1) GO2(N, 1); else GO2(N, 2); } while (0)
+  switch (nch) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 3: GO(3); break;
+    case 4: GO(4); break;
+    default: return LAP_ERR_ARG;
+  }
+#undef GO
+#undef GO2
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

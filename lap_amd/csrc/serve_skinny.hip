@@ -18,6 +18,8 @@
 // Rounding points are the reference's (bf16 GEMM outputs, bf16 norm outputs, f32 statistics); the K summation order differs
 // from the generic GEMM path (8 in-block slices instead of split-K slabs), so the two serving paths agree to bf16
 // rounding noise, not bit for bit (tests/test_model_parity_gpu.py states the bound).
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "../../include/lap_hip.h"
 
@@ -56,6 +58,12 @@ __device__ __forceinline__ bf16x8 ldg8(const __amdgpu_buffer_rsrc_t rs, unsigned
   u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
   return __builtin_bit_cast(bf16x8, v);
 }
+// the weight stream: every byte is used by one launch once (nontemporal: does not displace the L2-resident activations)
+template <bool NT>
+__device__ __forceinline__ bf16x8 ldw8(const __amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, NT ? 2 : 0);
+  return __builtin_bit_cast(bf16x8, v);
+}
 
 // Block = (FT x 16 output features, TT x 16 tokens): grid.x = feature groups, grid.y = token groups.  Measured on MI355X
 // (tools/bench_skinny.py): a block's time is ~2.4 us + (bytes it loads) / ~35 GB/s — the per-CU vector-memory path, not HBM
@@ -63,7 +71,9 @@ __device__ __forceinline__ bf16x8 ldg8(const __amdgpu_buffer_rsrc_t rs, unsigned
 // bytes per block at one round of <= 256 blocks: qkv 32 x 32, gate|up 32 tokens x 64 features, out / down 16 x 16.  The
 // token groups of a chunk re-read the same weight rows; with grid.x a multiple of 8 they share an XCD (block id % 8), so
 // the repeats are L2 hits and HBM sees every weight byte once.
-template <int EPI, bool NORM, int KS, int FT, int TT>   // KS: 32-deep k-steps per wave (K = KS * 32 * SK_WAVES)
+// SHM: every token shares ONE modulation row (mod_ld == 0: the denoise step, where the condition is the step's time) — the
+// prologue then loads scale / shift once per k-slice instead of once per token tile (qkv: 256 -> 132 KB per block).
+template <int EPI, bool NORM, int KS, int FT, int TT, bool SHM = false, bool NT = false>   // KS: 32-deep k-steps per wave (K = KS * 32 * SK_WAVES)
 __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyP p) {
   __shared__ __attribute__((aligned(16))) float part[SK_WAVES][FT * TT][64][4];   // per-wave partial output tiles
   __shared__ float red[SK_WAVES][TT][SK_TOK];
@@ -88,22 +98,23 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyP p) {
     }
     const unsigned woff = (unsigned)(((long long)wrow * p.K + k0) * 2);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) wf[f][s] = ldg8(rsW, woff + s * 64);
+    for (int s = 0; s < KS; ++s) wf[f][s] = ldw8<NT>(rsW, woff + s * 64);
   }
   bf16x8 xf[TT][KS];
-  bf16x8 sc[NORM ? TT : 1][NORM ? KS : 1], sh[NORM ? TT : 1][NORM ? KS : 1];
+  constexpr int MT = NORM ? (SHM ? 1 : TT) : 1;
+  bf16x8 sc[MT][NORM ? KS : 1], sh[MT][NORM ? KS : 1];
 #pragma unroll
   for (int t = 0; t < TT; ++t) {
     const int r = (blockIdx.y * TT + t) * SK_TOK + i;     // this lane's token row of tile t (MFMA column i)
     const unsigned xoff = r < p.M ? (unsigned)(((long long)r * p.ldx + k0) * 2) : 0x80000000u;   // rows past M read as zeros
 #pragma unroll
     for (int s = 0; s < KS; ++s) xf[t][s] = ldg8(rsX, xoff + s * 64);
-    if (NORM) {
-      const bf16* mrow = p.mod + (long long)((r < p.M ? r : 0) / p.rps) * p.mod_ld + k0;
+    if (NORM && (!SHM || t == 0)) {
+      const bf16* mrow = p.mod + (SHM ? 0 : (long long)((r < p.M ? r : 0) / p.rps) * p.mod_ld) + k0;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        sc[t][s] = *reinterpret_cast<const bf16x8*>(mrow + s * 32);
-        sh[t][s] = *reinterpret_cast<const bf16x8*>(mrow + p.K + s * 32);
+        sc[SHM ? 0 : t][s] = *reinterpret_cast<const bf16x8*>(mrow + s * 32);
+        sh[SHM ? 0 : t][s] = *reinterpret_cast<const bf16x8*>(mrow + p.K + s * 32);
       }
     }
   }
@@ -137,7 +148,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyP p) {
       for (int s = 0; s < KS; ++s) {
         bf16x8 h;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = f2bf((float)xf[t][s][e] * rstd * round_bf16(1.0f + (float)sc[t][s][e]) + (float)sh[t][s][e]);
+        for (int e = 0; e < 8; ++e)
+          h[e] = f2bf((float)xf[t][s][e] * rstd * round_bf16(1.0f + (float)sc[SHM ? 0 : t][s][e]) + (float)sh[SHM ? 0 : t][s][e]);
         xf[t][s] = h;
       }
     }
@@ -215,21 +227,31 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyP p) {
   }
 }
 
+// LAP_SKINNY_NT=1: nontemporal weight loads (A/B switch, tools/bench_serve_split.py)
+static bool skinny_nt() {
+  static const bool nt = getenv("LAP_SKINNY_NT") && atoi(getenv("LAP_SKINNY_NT")) != 0;
+  return nt;
+}
+
 template <int EPI, bool NORM, int FT, int TT>
 int launch_skinny(const SkinnyP& p, int n_sub, hipStream_t s) {
   if (n_sub % FT) return LAP_ERR_ARG;
   const dim3 grid(n_sub / FT, (p.M + SK_TOK * TT - 1) / (SK_TOK * TT)), block(SK_WAVES * 64);
+  const bool nt = skinny_nt();
+#define GO_(KS_, SHM_) do { if (nt) hipLaunchKernelGGL((skinny_kernel<EPI, NORM, KS_, FT, TT, SHM_, true>), grid, block, 0, s, p); \
+                           else hipLaunchKernelGGL((skinny_kernel<EPI, NORM, KS_, FT, TT, SHM_, false>), grid, block, 0, s, p); } while (0)
   if constexpr (NORM) {   // the prologue keeps the whole K slice of a wave in registers: K = 1024 only
     if (p.K != 32 * SK_WAVES * 4) return LAP_ERR_ARG;
-    hipLaunchKernelGGL((skinny_kernel<EPI, true, 4, FT, TT>), grid, block, 0, s, p);
+    if (p.mod_ld == 0) GO_(4, true); else GO_(4, false);
   } else {
     switch (p.K / (32 * SK_WAVES)) {
-      case 4: hipLaunchKernelGGL((skinny_kernel<EPI, false, 4, FT, TT>), grid, block, 0, s, p); break;
-      case 8: hipLaunchKernelGGL((skinny_kernel<EPI, false, 8, FT, TT>), grid, block, 0, s, p); break;
-      case 16: hipLaunchKernelGGL((skinny_kernel<EPI, false, 16, FT, TT>), grid, block, 0, s, p); break;
+      case 4: GO_(4, false); break;
+      case 8: GO_(8, false); break;
+      case 16: GO_(16, false); break;
       default: return LAP_ERR_ARG;
     }
   }
+#undef GO_
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

@@ -19,6 +19,7 @@ GEMM_ACCUM = 2
 GEMM_GELU = 4
 GEMM_BIAS_F32 = 8
 GEMM_PARTIALS = 16
+GEMM_GELU_BF16 = 32
 
 
 class LapHipError(RuntimeError):
@@ -109,12 +110,15 @@ SIGNATURES: dict[str, list] = {
     "lap_add_posemb_cast": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_add_posemb_cast_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],
+    "lap_attention_serve_splits": [_i, _i],
+    "lap_attention_serve": [C.POINTER(AttnFwdArgs), _vp],
     "lap_attention_bwd": [C.POINTER(AttnBwdArgs), _vp],
     "lap_attention_set_variant": [_i],
     "lap_rope_table": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "lap_fused_reduce_rope_split": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "lap_fused_reduce_geglu": [_vp, _i, _vp, _i, _i, _vp],
     "lap_fused_reduce_residual_norm": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp],
+    "lap_fused_reduce_norm": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "lap_serve_qkv_rope": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp],
     "lap_serve_gate_up": [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp],
     "lap_serve_proj_residual": [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
@@ -171,6 +175,7 @@ def _req(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
 # ------------------------------------------------------------------------------ GEMM
 _SCRATCH: dict = {}
 _NSPLIT_ENV = __import__("os").environ.get("LAP_ATTN_NSPLIT")
+_SERVE_ATTN = __import__("os").environ.get("LAP_SERVE_ATTN", "1") != "0"     # A/B switch: "0" = the generic key-split kernel
 
 
 def _gemm_scratch(device, floats: int = 160 * 1024 * 1024):
@@ -195,7 +200,7 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, 
     if accum:
         flags |= GEMM_ACCUM
     if gelu:
-        flags |= GEMM_GELU
+        flags |= GEMM_GELU | (GEMM_GELU_BF16 if gelu == "bf16" else 0)   # "bf16": round the pre-activation to bf16 first
     if bias is not None and bias.dtype == torch.float32:
         flags |= GEMM_BIAS_F32
     # the library decides on two-phase split-K itself when it is lent scratch (poorly filled grids, skinny-M serving)
@@ -472,6 +477,16 @@ def attention_fwd(q, k, v, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None,
     lse = torch.empty((B, NH, Tq), dtype=torch.float32, device=dev) if need_lse else None
     a.qinfo, a.kinfo, a.lse = _p(qinfo), _p(kinfo), _p(lse)
     a.scale = float(scale)
+    a.B, a.NH, a.NKV, a.HD = B, NH, NKV, HD
+    # batch-1 denoise step: a handful of suffix queries against [KV cache | fresh keys] -> the load-everything-up-front kernel
+    if _SERVE_ATTN and HD == 256 and a.q_len[0] == 0 and 0 < a.q_len[1] <= 64 and not need_lse and nsplit_hint is None and scale > 0:
+        ns = _fn["lap_attention_serve_splits"](a.k_len[0], a.k_len[1])
+        if 0 < ns <= 16:
+            a.nsplit = ns
+            scratch = torch.empty(ns * B * Tq * NH * (HD + 1), dtype=torch.float32, device=dev)
+            a.scratch, a.scratch_floats = _p(scratch), scratch.numel()
+            _chk(_fn["lap_attention_serve"](C.byref(a), _stream()), "lap_attention_serve")
+            return outs, None
     # few query tiles (serving): split the key tiles over more blocks
     ntq = (a.q_len[0] + 63) // 64 + (a.q_len[1] + 63) // 64
     ntk = (a.k_len[0] + 63) // 64 + (a.k_len[1] + 63) // 64
@@ -592,7 +607,7 @@ def axpy_f32(x, v, dt):
 
 
 # ------------------------------------------------ split-K partials + fused consumers (batch-1 denoise step)
-def linear_partials(x, wt, scratch, ksplit=None):
+def linear_partials(x, wt, scratch, ksplit=None, tile=6):
     """Raw f32 partial products of y = x @ wt^T, [ksplit, M, N] in `scratch` (a 1-D f32 tensor); returns (view, ksplit)."""
     M, K = x.shape
     N = wt.shape[0]
@@ -603,8 +618,17 @@ def linear_partials(x, wt, scratch, ksplit=None):
     if scratch.numel() < need:
         raise ValueError("scratch too small for the requested split")
     call("lap_gemm_bf16_ex", _p(x), _p(wt), None, None, None, M, N, K, x.stride(0), wt.stride(0), N, 0, 1.0, 1, 1,
-         GEMM_OUT_F32 | GEMM_PARTIALS, 6, ksplit, _p(scratch), scratch.numel() * 4)
+         GEMM_OUT_F32 | GEMM_PARTIALS, tile, ksplit, _p(scratch), scratch.numel() * 4)
     return scratch[:need].view(ksplit, M, N), ksplit
+
+
+def fused_reduce_norm(part, ksplit, rows, D, *, bias=None, residual=None, norm=0, gamma=None, beta=None, eps=1e-6):
+    """xn = bf16(sum of the split-K slabs (+ f32 bias) (+ bf16 residual)); h = RMSNorm (norm=1, gamma = the f32 scale) or
+    LayerNorm (norm=2) of xn, or None (norm=0).  One pass: the serving prefill's reduce + epilogue + next norm."""
+    xn = torch.empty((rows, D), dtype=torch.bfloat16, device=part.device)
+    h = torch.empty_like(xn) if norm else None
+    call("lap_fused_reduce_norm", _p(part), ksplit, _p(bias), _p(residual), norm, _p(gamma), _p(beta), _p(xn), _p(h), rows, D, float(eps))
+    return xn, h
 
 
 def augment_images(img, params):

@@ -80,6 +80,10 @@ class LAP:
         self.n_img_tok = (config.image_size // self.s.patch) ** 2
         self.deterministic = True
         self.dual_stream = os.environ.get("LAP_DUAL_STREAM", "1") != "0"
+        # serving prefill on the fused consumers (`_siglip_fwd_serve`, `_llm_prefill`); "0": the generic layer loops (A/B, tests)
+        self.serve_fusions = os.environ.get("LAP_SERVE_FUSIONS", "1") != "0"
+        ks = os.environ.get("LAP_PREFILL_KS", "4,1,8,5").split(",")    # K splits of the prefill's qkv / out / down projections, down's tile
+        self._prefill_ks = tuple(int(k) for k in ks)
         self._sfx = None        # the suffix stream's HIP stream (created on first use)
         # which gradients leave the data-gradient path for a third stream (see _off_path): s SigLIP weights, b biases, q / g the
         # prefix stream's attention / MLP projections; "1" all, "0" none.  Measured (tools/ab3.sh): sb -2.1 .. -3.3 ms per step,
@@ -298,6 +302,45 @@ class LAP:
             collect["img/out"] = tok
         return tok, ctx
 
+    def _siglip_fwd_serve(self, images: torch.Tensor):
+        """The tower of `_siglip_fwd` for the serving prefill (nothing is kept for a backward): same operations and rounding
+        points, fewer launches — GELU in fc1's epilogue (after the bf16 rounding of the Dense output), and fc2's split-K reduce,
+        bias, residual add and the NEXT LayerNorm in one consumer pass (`lap_fused_reduce_norm`).  12 -> 10 launches per block,
+        on block tiles sized for 512 rows (lap_gemm_bf16_ex serving rule)."""
+        s, T = self.s, self.n_img_tok
+        W = s.width
+        hd = W // s.num_heads
+        N = images.shape[0]
+        patches = hip.im2col_patch(images.contiguous(), s.patch)
+        p_hi, p_lo = hip.split_f32_hilo(patches)
+        w_hi, w_lo = hip.split_f32_hilo(self.F("img/stem_w"))
+        stem = torch.empty((p_hi.shape[0], W), dtype=torch.float32, device=p_hi.device)
+        R, Kp = p_hi.shape
+        hip.gemm(p_hi, w_hi, stem, M=R, N=W, K=Kp, lda=Kp, ldb=Kp, ldc=W, bias=self.F("img/stem_b"))
+        hip.gemm(p_hi, w_lo, stem, M=R, N=W, K=Kp, lda=Kp, ldb=Kp, ldc=W, accum=True)
+        hip.gemm(p_lo, w_hi, stem, M=R, N=W, K=Kp, lda=Kp, ldb=Kp, ldc=W, accum=True)
+        x = hip.add_posemb_cast(stem, self.F("img/pos"), T)
+        scratch = hip._gemm_scratch(self.device)
+        self.comm.wait_unit("img0")
+        y, _, _ = hip.layernorm_fwd(x, self.F("img/0/ln1_g"), self.F("img/0/ln1_b"))
+        for l in range(s.depth):
+            p = f"img/{l}/"
+            qkv = hip.linear_fwd(y, self.W(p + "wqkv"), bias=self.F(p + "bqkv"))
+            (o, _), _ = hip.attention_fwd([qkv[:, :W]], [qkv[:, W:2 * W]], [qkv[:, 2 * W:]], [T], [T], N, s.num_heads, s.num_heads, hd,
+                                          scale=hd ** -0.5, q_rs=(3 * W, 0), kv_rs=(3 * W, 0), need_lse=False)
+            x1 = hip.linear_fwd(o, self.W(p + "wo"), bias=self.F(p + "bo"), residual=x)
+            y2, _, _ = hip.layernorm_fwd(x1, self.F(p + "ln2_g"), self.F(p + "ln2_b"))
+            a = hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"), gelu="bf16")
+            part, ks = hip.linear_partials(a, self.W(p + "w2"), scratch)
+            if l + 1 < s.depth:
+                self.comm.wait_unit(f"img{l + 1}")
+                g, b = self.F(f"img/{l + 1}/ln1_g"), self.F(f"img/{l + 1}/ln1_b")
+            else:
+                self.comm.wait_unit("img_head")
+                g, b = self.F("img/norm_g"), self.F("img/norm_b")
+            x, y = hip.fused_reduce_norm(part, ks, x1.shape[0], W, bias=self.F(p + "b2"), residual=x1, norm=2, gamma=g, beta=b)
+        return hip.linear_fwd(y, self.W("img/head_w"), bias=self.F("img/head_b"))
+
     def _siglip_block(self, l, x, N, T, W, hd, ctx, save):
         """One pre-LN encoder block (siglip_gemma3.py:59-167): x + MHA(LN(x)), then + MLP(LN(.))."""
         s = self.s
@@ -310,8 +353,11 @@ class LAP:
         x1 = hip.linear_fwd(o, self.W(p + "wo"), bias=self.F(p + "bo"), residual=x)
         y2, mean2, rstd2 = hip.layernorm_fwd(x1, self.F(p + "ln2_g"), self.F(p + "ln2_b"))
         self.comm.pace(f"img{l}")
-        h = hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"))
-        a = hip.gelu_fwd(h)
+        if save:
+            h = hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"))
+            a = hip.gelu_fwd(h)
+        else:   # nothing keeps the pre-activation: GELU in the GEMM epilogue, after the bf16 rounding of the Dense output (same bits)
+            h, a = None, hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"), gelu="bf16")
         x2 = hip.linear_fwd(a, self.W(p + "w2"), bias=self.F(p + "b2"), residual=x1)
         if save:
             ctx["blocks"].append((x, y, mean1, rstd1, qkv, o, lse, x1, y2, mean2, rstd2, h, a))
@@ -426,7 +472,7 @@ class LAP:
         return (i32(qinfo_p), i32(kinfo_p), ppos, i32(qinfo_s), i32(torch.cat([kinfo_p, kinfo_s], 1)), i32(torch.cat([ppos, spos], 1)))
 
     # ================================================================== embedding of the two streams
-    def _embed_prefix(self, obs: CoTObservation, save: bool, collect=None):
+    def _embed_prefix(self, obs: CoTObservation, save: bool, collect=None, serve: bool = False):
         """lap.py:118-170 -> x0 bf16 [B*Pn, Dv] with rows (b, [img0 | img1 | prompt])."""
         cfg = self.config
         keys = cfg.image_keys
@@ -434,7 +480,10 @@ class LAP:
         T, Lt, Dv = self.n_img_tok, obs.tokenized_prompt.shape[1], self.v.width
         Pn = T * len(keys) + Lt
         images = torch.cat([obs.images[k] for k in keys], 0)
-        tok, ictx = self._siglip_fwd(images, save, collect)
+        if save or collect is not None or not (serve and self.serve_fusions):
+            tok, ictx = self._siglip_fwd(images, save, collect)
+        else:
+            tok, ictx = self._siglip_fwd_serve(images), None
         x0 = torch.empty((B * Pn, Dv), dtype=torch.bfloat16, device=self.device)
         for i in range(len(keys)):
             hip.copy_rows_bf16(tok[i * B * T:(i + 1) * B * T], x0, B * T, T, Dv, T, 0, Pn, i * T)
@@ -576,6 +625,42 @@ class LAP:
                 collect[f"llm/layer{l:02d}/x0"], collect[f"llm/layer{l:02d}/x1"] = x0, x1
         self._handoff(sfx, main, x1)
         return x0, x1, ctx
+
+    def _llm_prefill(self, x0, pos, qinfo, kinfo, B, n0, cache_out):
+        """The prefix-only pass of `_llm_fwd` (x1 = None, nothing saved) for the serving prefill: K / V of every layer go to
+        `cache_out`, the last layer's residual stream is returned.  Same operations and rounding points; the split-K projections
+        leave f32 slabs and their consumers do the rest in one pass each — qkv: reduce + RoPE + head split (sin / cos of the
+        prefix positions from one table for all layers), out / down: reduce + residual + the NEXT RMSNorm — 14 -> 10 launches
+        per layer."""
+        v = self.v
+        NH, HD, KV = v.num_heads, v.head_dim, v.num_kv_heads
+        Ttot = pos.shape[1]
+        Dv = v.width
+        scratch = hip._gemm_scratch(self.device)
+        tab = hip.rope_table(pos, B, n0, Ttot, 0, HD)
+        self.comm.wait_unit("llm0")
+        h, _ = hip.rmsnorm_fwd(x0, scale=self.F("llm/0/n_attn"), save_rstd=False)
+        rows = x0.shape[0]
+        for l in range(v.depth):
+            p = f"llm/{l}/"
+            part, ks = hip.linear_partials(h, self.W(p + "wqkv0"), scratch, ksplit=self._prefill_ks[0])
+            q, k, vv = hip.fused_reduce_rope_split(part, ks, pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5, table=tab)
+            cache_out.append((k, vv))
+            o, _ = hip.attention_fwd([q, None], [k, None], [vv, None], [n0, 0], [n0, 0], B, NH, KV, HD, qinfo, kinfo, need_lse=False)
+            if self._prefill_ks[1] > 1:
+                part, ks = hip.linear_partials(o[0], self.W(p + "wo0"), scratch, ksplit=self._prefill_ks[1])
+                xa, hf = hip.fused_reduce_norm(part, ks, rows, Dv, residual=x0, norm=1, gamma=self.F(p + "n_ffw"))
+            else:   # (measured: the unsplit 64-row tile with the residual epilogue + a norm launch beats split + fused consumer here)
+                xa = hip.linear_fwd(o[0], self.W(p + "wo0"), residual=x0)
+                hf, _ = hip.rmsnorm_fwd(xa, scale=self.F(p + "n_ffw"), save_rstd=False)
+            act = hip.geglu_fwd(hip.linear_fwd(hf, self.W(p + "wgu0")))
+            part, ks = hip.linear_partials(act, self.W(p + "wd0"), scratch, ksplit=self._prefill_ks[2], tile=self._prefill_ks[3])
+            if l + 1 < v.depth:
+                self.comm.wait_unit(f"llm{l + 1}")
+                x0, h = hip.fused_reduce_norm(part, ks, rows, Dv, residual=xa, norm=1, gamma=self.F(f"llm/{l + 1}/n_attn"))
+            else:
+                x0, h = hip.fused_reduce_norm(part, ks, rows, Dv, residual=xa, norm=0)
+        return x0
 
     def _llm_bwd(self, ctx, dx0, dx1, mod, dmod, pos, qinfo, kinfo, B, n0, n1):
         v, e = self.v, self.e
@@ -889,20 +974,22 @@ class LAP:
         if noise is None:
             noise = torch.randn((B, S, ad), generator=_gen(rng, dev), device=dev, dtype=torch.float32)
         x_t = noise.to(dev, torch.float32).contiguous().clone()
-        x0, Pn, _ = self._embed_prefix(obs, False)
+        x0, Pn, _ = self._embed_prefix(obs, False, serve=True)
         qinfo_p, kinfo_p, ppos, qinfo_s, kinfo_all, pos_all = self._serve_infos(obs, S)
         cache = []
-        self._llm_fwd(x0, None, None, ppos, qinfo_p, kinfo_p, B, Pn, 0, False, cache_out=cache)
+        if self.serve_fusions and collect is None and self.gemm_dtype == "bf16":
+            self._llm_prefill(x0, ppos, qinfo_p, kinfo_p, B, Pn, cache)
+        else:
+            self._llm_fwd(x0, None, None, ppos, qinfo_p, kinfo_p, B, Pn, 0, False, cache_out=cache)
         dt = -1.0 / num_steps
         times, t = [], 1.0
         while t >= -dt / 2:  # lap.py:669-674 loop condition, unrolled on the host (the time grid is data independent)
             times.append(t)
             t += dt
-        # the adaRMS condition depends on the denoise time only: all steps' modulations in one pass over the adaRMS bank
-        # built on the device (no host->device copy: the sampler is captured into a HIP graph and replayed)
-        tvec = 1.0 + dt * torch.arange(len(times), dtype=torch.float32, device=dev)
-        self.comm.wait_unit("ada")
-        mods, _ = self._time_mod(tvec, False)
+        # the adaRMS condition depends on the denoise time only: all steps' modulations in one pass over the adaRMS bank —
+        # and on nothing else, so they are computed ONCE per (step count, parameter version) and kept: a captured sampler
+        # (serve.GraphedSampler warms up before it captures) holds no time-MLP kernels at all (-0.25 ms per chunk)
+        mods = self._serve_mods(len(times), dt)
         # ... and so are the action tokens' positions: one sin / cos table serves the 10 x 18 fused RoPE kernels
         rope_tab = hip.rope_table(pos_all, B, S, pos_all.shape[1], pos_all.shape[1] - S, self.v.head_dim) if fused else None
         nslot = 2 * self.v.depth
@@ -927,6 +1014,18 @@ class LAP:
                 collect[f"v_t/{step}"] = v_t.view(B, S, ad).clone()
             hip.axpy_f32(x_t, v_t, dt)
         return x_t
+
+    def _serve_mods(self, nsteps: int, dt: float):
+        """adaRMS modulations of the denoise time grid t_k = 1 + k dt (lap.py:655-660 through `_time_mod`), cached per
+        (nsteps, parameter version).  Never filled during stream capture: the tensor must outlive the graph's replays."""
+        key = (nsteps, float(dt), self.ps.version)
+        ent = self.__dict__.setdefault("_mods_cache", {})
+        if key not in ent:
+            ent.clear()
+            tvec = 1.0 + dt * torch.arange(nsteps, dtype=torch.float32, device=self.device)
+            self.comm.wait_unit("ada")
+            ent[key] = self._time_mod(tvec, False)[0]
+        return ent[key]
 
     EOS_TOKEN = 1   # PaliGemma <eos> (lap.py: self.EOS_TOKEN)
 
@@ -989,7 +1088,7 @@ class LAP:
         self.comm.wait_unit("small")
         obs = preprocess_observation(observation, train=False, image_keys=cfg.image_keys, image_resolution=cfg.image_resolution)
         B = obs.tokenized_prompt.shape[0]
-        x0, Pn, _ = self._embed_prefix(obs, False)
+        x0, Pn, _ = self._embed_prefix(obs, False, serve=True)
         qinfo_p, kinfo_p, ppos = self._serve_infos(obs, 1)[:3]
         prefix_mask, _ = self._prefix_masks(obs)
         ar = torch.arange(Pn, device=dev)
@@ -999,7 +1098,10 @@ class LAP:
         kinfo_prefix = (in_range.to(torch.int32) << 24).contiguous()
         qinfo_d = torch.full((B, 1), (1 << 24) | 0xFFFFFF, dtype=torch.int32, device=dev)
         cache = []
-        xf0, _, _ = self._llm_fwd(x0, None, None, ppos, qinfo_p, kinfo_p, B, Pn, 0, False, cache_out=cache)
+        if self.serve_fusions and self.gemm_dtype == "bf16":
+            xf0 = self._llm_prefill(x0, ppos, qinfo_p, kinfo_p, B, Pn, cache)
+        else:
+            xf0, _, _ = self._llm_fwd(x0, None, None, ppos, qinfo_p, kinfo_p, B, Pn, 0, False, cache_out=cache)
         last = (torch.arange(B, device=dev) * Pn + seqlen - 1)
         logits = self._lm_logits(xf0.index_select(0, last).contiguous())        # decodes the first token (lap.py:716)
         out = torch.zeros((B, max_decoding_steps), dtype=torch.int32, device=dev)

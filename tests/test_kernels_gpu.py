@@ -303,6 +303,37 @@ def test_gemm_epilogues(hip):
     assert rel_err(o32, base) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 4304, 1152), (512, 1152, 4304), (200, 136, 72), (1600, 1024, 1024)])
+def test_gemm_gelu_after_bf16_rounding_equals_dense_then_gelu_kernel(hip, M, N, K):
+    """LAP_GEMM_GELU_BF16: the serving path's fc1 applies the GELU in the GEMM epilogue (direct, staged and split-K reduce
+    epilogues) after rounding the pre-activation to bf16 — the bits of [bf16 Dense output -> gelu_fwd]."""
+    a = rnd(M, K, scale=0.3); w = rnd(N, K, scale=0.3, seed=1); b = rnd(N, dtype=torch.float32, seed=2)
+    two = hip.gelu_fwd(hip.linear_fwd(a, w, bias=b))
+    one = hip.linear_fwd(a, w, bias=b, gelu="bf16")
+    assert torch.equal(one, two)
+    for tile in (5, 6, 0):
+        assert torch.equal(hip.linear_fwd(a, w, bias=b, gelu="bf16", tile=tile), hip.gelu_fwd(hip.linear_fwd(a, w, bias=b, tile=tile)))
+
+
+@pytest.mark.parametrize("tile,M,N,K", [(15, 560, 1024, 2048), (15, 601, 520, 192), (16, 512, 3456, 1152), (16, 560, 2560, 2048), (17, 512, 1152, 1152),
+                                        (17, 77, 200, 72), (18, 560, 2048, 2048), (19, 560, 2048, 4096), (19, 330, 136, 520)])
+def test_gemm_serving_tiles_match_the_default_tiles_bitwise(hip, tile, M, N, K):
+    """Tiles 15-19 (serving prefill: 320-row and 64-row block tiles of the generic kernel) keep the accumulation order of every
+    other tile: same bits as the 128x128 tile, with bias / residual epilogues, ragged edges and as split-K partials."""
+    a = rnd(M, K, scale=0.3); w = rnd(N, K, scale=0.3, seed=1); b = rnd(N, dtype=torch.float32, seed=2); r = rnd(M, N, seed=3)
+    for kw in (dict(), dict(bias=b), dict(bias=b, residual=r), dict(residual=r)):
+        assert torch.equal(hip.linear_fwd(a, w, tile=tile, ksplit=1, **kw), hip.linear_fwd(a, w, tile=6, ksplit=1, **kw)), kw
+    if K % 128 == 0:
+        sc = hip._gemm_scratch(a.device)
+        outs = []
+        for t in (tile, 6):
+            o = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+            hip.call("lap_gemm_bf16_ex", hip._p(a), hip._p(w), hip._p(o), hip._p(b), hip._p(r), M, N, K, K, K, N, N, 1.0, 1, 1, hip.GEMM_BIAS_F32,
+                     t, 2, hip._p(sc), sc.numel() * 4)
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_strided(hip):
     # views into a wider buffer (lda/ldc != row length), as used for fused qkv / gate-up buffers
     M, N, K = 130, 72, 96
@@ -676,6 +707,51 @@ def test_attention_suffix_only_queries(hip):
         assert rel_err(lse2, torch.logsumexp(lg, -1)) < 1e-3
 
 
+@pytest.mark.parametrize("B,NH,NKV,Tp,S,npad", [
+    (1, 8, 1, 560, 50, 0),      # the denoise step: 4 full splits + one of 48 | 50 rows
+    (1, 8, 1, 560, 50, 9),      # ... with a padded prompt tail (masked keys inside the last prefix run)
+    (2, 8, 1, 256, 16, 3),      # prefix = whole splits: the fresh keys get a split of their own
+    (2, 4, 2, 100, 40, 0),      # 100 + 40 rows do not fit one split: [100] [40]; grouped kv heads
+    (3, 8, 1, 77, 1, 5),        # single-token decode (odd prefix length: the fresh key starts at the next even row)
+    (1, 8, 8, 130, 64, 0),      # 64 queries, one kv head per query head
+])
+def test_attention_serve_kernel_matches_reference_and_generic_path(hip, monkeypatch, B, NH, NKV, Tp, S, npad):
+    """lap_attention_serve (csrc/attention_serve.hpp) against the f32 restatement and against the generic key-split kernel it
+    replaces in the denoise step (same arithmetic and rounding points: bf16 probabilities, f32 partials; the split
+    boundaries differ, so the two agree to f32 summation order, not bit for bit)."""
+    HD = 256
+    q1 = rnd(B, S, NH * HD, scale=0.25); k0 = rnd(B, Tp, NKV * HD, scale=0.25, seed=1); k1 = rnd(B, S, NKV * HD, scale=0.25, seed=2)
+    v0 = rnd(B, Tp, NKV * HD, seed=3); v1 = rnd(B, S, NKV * HD, seed=4)
+    kinfo = torch.full((B, Tp + S), 3 << 24, dtype=torch.int32, device=DEV)
+    kinfo[:, Tp:] = (4 << 24) | 0x800001
+    for b in range(B):
+        if npad:
+            kinfo[b, Tp - npad - b:Tp] = 0
+    kinfo[B - 1, 3] = 0                                                     # a hole inside the first split
+    qinfo = torch.full((B, S), (6 << 24) | 0x800001, dtype=torch.int32, device=DEV)
+    args = ([None, q1], [k0, k1], [v0, v1], [0, S], [Tp, S], B, NH, NKV, HD, qinfo, kinfo)
+    assert hip._SERVE_ATTN
+    (_, o1), _ = hip.attention_fwd(*args, need_lse=False)
+    monkeypatch.setattr(hip, "_SERVE_ATTN", False)
+    (_, og), _ = hip.attention_fwd(*args, need_lse=False)
+    monkeypatch.setattr(hip, "_SERVE_ATTN", True)
+    mask = _mask_from_info(qinfo, kinfo)
+    ref = _attn_ref(q1.float().view(B, S, NH, HD), torch.cat([k0, k1], 1).float().view(B, Tp + S, NKV, HD),
+                    torch.cat([v0, v1], 1).float().view(B, Tp + S, NKV, HD), mask, NH, NKV)
+    e_new, e_old = rel_err(o1.view(B, S, NH, HD), ref), rel_err(og.view(B, S, NH, HD), ref)
+    assert e_new < 1e-2 and e_new < 1.2 * e_old + 1e-4, (e_new, e_old)
+    assert rel_err(o1, og) < 6e-3                                           # two bf16 roundings of the same f32 value apart
+    # fully masked keys for one sample's queries: zeros, not NaN
+    kinfo2 = kinfo.clone(); kinfo2[0] = 0
+    (_, o3), _ = hip.attention_fwd([None, q1], [k0, k1], [v0, v1], [0, S], [Tp, S], B, NH, NKV, HD, qinfo, kinfo2, need_lse=False)
+    assert torch.isfinite(o3.float()).all() and o3.view(B, S, -1)[0].abs().sum() == 0
+    # strided K / V (column slices of a wider buffer) and an explicit scale
+    kw = torch.cat([k0, v0], -1).contiguous(); k0s, v0s = kw[..., :NKV * HD], kw[..., NKV * HD:]
+    (_, o4), _ = hip.attention_fwd([None, q1], [k0s, k1], [v0s, v1], [0, S], [Tp, S], B, NH, NKV, HD, qinfo, kinfo, need_lse=False,
+                                   kv_rs=(2 * NKV * HD, 0))
+    assert torch.equal(o4, o1)
+
+
 # ------------------------------------------------------------------ loss / optimizer / misc
 def test_ce_chunks(hip):
     R, V = 37, 1000
@@ -926,3 +1002,29 @@ def test_kernels_keep_their_bits_next_to_another_streams_gemm(hip):
             out = f()
             torch.cuda.synchronize()
             assert torch.equal(out, ref), (name, rep)
+
+
+@pytest.mark.parametrize("rows,D,ks,norm,hb,hr", [(512, 1152, 7, 2, True, True), (560, 2048, 4, 1, False, True), (560, 2048, 8, 0, False, True),
+                                                  (37, 64, 1, 1, True, False), (130, 1024, 3, 2, False, False)])
+def test_fused_reduce_norm_equals_reduce_then_norm_bitwise(hip, rows, D, ks, norm, hb, hr):
+    """lap_fused_reduce_norm (the serving prefill's consumer) = the split-K reduce epilogue followed by the norm kernel, bit for bit."""
+    part = rnd(ks, rows, D, dtype=torch.float32, seed=3)
+    bias = rnd(D, dtype=torch.float32, seed=4) if hb else None
+    res = rnd(rows, D, seed=5) if hr else None
+    g = rnd(D, dtype=torch.float32, seed=6, scale=0.3); b = rnd(D, dtype=torch.float32, seed=7, scale=0.3)
+    xn, h = hip.fused_reduce_norm(part, ks, rows, D, bias=bias, residual=res, norm=norm, gamma=g, beta=b)
+    acc = torch.zeros(rows, D, device=DEV)
+    for s in range(ks):
+        acc = acc + part[s]
+    if hb:
+        acc = acc + bias
+    if hr:
+        acc = acc + res.float()
+    want = acc.bfloat16()
+    assert torch.equal(xn, want)
+    if norm == 1:
+        assert torch.equal(h, hip.rmsnorm_fwd(want, scale=g, save_rstd=False)[0])
+    elif norm == 2:
+        assert torch.equal(h, hip.layernorm_fwd(want, g, b)[0])
+    else:
+        assert h is None
