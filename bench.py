@@ -27,10 +27,6 @@ import os
 import sys
 import time
 
-# Kernel arguments in device memory: ~1 ms per train step less launch latency on MI300-class parts (interleaved A/B: 310.4 -> 309.3 ms;
-# the replayed serving graph is unaffected).  A HIP runtime setting, read when the runtime starts; an explicit value wins.
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -38,9 +34,10 @@ import torch
 
 SERVE_BYTES = 4.79e9 + 10 * 0.86e9 + 10 * 10.3e6   # prefix weights once + 10 x (expert weights + KV)
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
-# profiles/r01_gemm_pmc_counters.txt: gate-up forward GEMM M=17920 N=32768 K=2048 (the largest launch of the step),
-# separate --pmc passes: FETCH_SIZE 1,786,773 KB raw x 2 (gfx950 half-count correction for wide coalesced reads,
-# MI355X_MICROARCH.md §HBM) + WRITE_SIZE 1,272,545 KB; algorithmic bytes of that launch: 0.207 GB read + 1.174 GB written
+# profiles/r02g_gemm_pmc_counters.txt: gate-up forward GEMM M=17920 N=32768 K=2048 (the largest launch of the step, assembly NT kernel),
+# separate --pmc passes: FETCH_SIZE 1,749,055 KB raw x 2 (gfx950 half-count correction for wide coalesced reads,
+# MI355X_MICROARCH.md §HBM) + WRITE_SIZE 1,197,077 KB; algorithmic bytes of that launch: 0.207 GB read + 1.174 GB written.
+# A STATIC figure copied from the committed profile (rocprofv3 cannot run inside this process): `traffic_measured_in_run` is false.
 GEMM_TRAFFIC = {"bytes_per_launch": 2 * 1749055.3e3 + 1197076.8e3, "algorithmic_bytes_per_launch": 73.4e6 + 134.2e6 + 1174.4e6,
                 "shape": "gate-up fwd M=17920 N=32768 K=2048 (lap_gemm_asm_nt)", "source": "profiles/r02g_gemm_pmc_counters.txt"}
 TRAIN_FLOP_PER_SAMPLE = 8.375e12  # 3 x forward (2.792 TFLOP), recompute not credited
@@ -92,11 +89,16 @@ class GemmMeter:
                 self.second_ev.append((s, e))
             else:
                 self.records.append((s, e, 2.0 * M * N * K))
+                sig = (M, N, K, kw.get("lda"), kw.get("ldb"), kw.get("ldc"), bool(kw.get("a_kc", True)), bool(kw.get("b_kc", True)),
+                       None if kw.get("bias") is None else kw["bias"].dtype, kw.get("residual") is not None, kw.get("ldr", 0),
+                       kw.get("gelu", False), bool(kw.get("accum", False)), out.dtype, kw.get("tile", -1), kw.get("ksplit", 0))
+                self.shapes[sig] = self.shapes.get(sig, 0) + 1
             return r
         self.hip.gemm = gemm
         self.main_stream = torch.cuda.current_stream().cuda_stream
         self.second, self.second_ev = [], []
         self.base = None
+        self.shapes = {}
 
     def start(self):
         self.base = torch.cuda.Event(enable_timing=True)
@@ -107,6 +109,44 @@ class GemmMeter:
         t = sum(s.elapsed_time(e) for s, e, _ in self.records) * 1e-3
         fl = sum(f for _, _, f in self.records)
         return len(self.records), t, fl
+
+    def isolated(self, dev, reps: int = 4):
+        """The contention-free rate of the family: every distinct call signature the compute stream issued during the timed steps
+        is re-run ALONE (fresh random operands, `reps` timed launches after two warm-up launches, HIP events on the launch
+        stream, nothing else on the device) and the step's mix is priced with those durations:
+            achieved = sum_shapes count x 2MNK / sum_shapes count x t_isolated.
+        In the step itself the launches share the chip with the optimizer stream, the action expert's stream and the third
+        (weight-gradient) stream — overlap that shortens the step but lengthens every event-timed launch; that figure is
+        reported next to this one as `in_situ_event_timed`."""
+        rnd = lambda *sh: (torch.rand(*sh, device=dev) * 2 - 1).to(torch.bfloat16)
+        tot_t = tot_f = 0.0
+        rows = []
+        for sig, cnt in self.shapes.items():
+            M, N, K, lda, ldb, ldc, a_kc, b_kc, bias_dt, has_res, ldr, gelu, accum, odt, tile, ksplit = sig
+            a = rnd(M if a_kc else K, lda)
+            b = rnd(N if b_kc else K, ldb)
+            out = torch.zeros(M, ldc, dtype=odt, device=dev)
+            bias = None if bias_dt is None else torch.randn(N, device=dev).to(bias_dt)
+            res = rnd(M, ldr) if has_res else None
+            call = lambda: self.orig(a, b, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, a_kc=a_kc, b_kc=b_kc, bias=bias, residual=res,
+                                     ldr=ldr, gelu=gelu, accum=accum, tile=tile, ksplit=ksplit)
+            for _ in range(2):
+                call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) * 1e-3 / reps
+            f = 2.0 * M * N * K
+            tot_t += cnt * t
+            tot_f += cnt * f
+            rows.append((cnt * t, f"{'NT'[0] if a_kc else 'T'}{'T' if b_kc else 'N'} {M}x{N}x{K}", cnt, t, f / t / 1e12))
+            del a, b, out, bias, res
+        rows.sort(reverse=True)
+        return tot_f, tot_t, rows
 
     def union_seconds(self):
         """Length of the union of all GEMM launch intervals, both streams: the time during which the family had a launch in
@@ -222,6 +262,10 @@ def _self_launch(args) -> int:
 
 
 def main():
+    # Kernel arguments in device memory: ~1 ms per train step less launch latency on MI300-class parts (interleaved A/B: 310.4 ->
+    # 309.3 ms; the replayed serving graph is unaffected).  A HIP runtime setting, read when the runtime starts (nothing has
+    # touched the device yet); an explicit value in the environment wins.
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -294,7 +338,12 @@ def main():
         n_launch, t_gemm, fl_gemm = meter.summary()
         samples = args.batch * world * args.steps
         value = samples / dt
-        achieved = fl_gemm / t_gemm / 1e12 if t_gemm > 0 else 0.0
+        in_situ = fl_gemm / t_gemm / 1e12 if t_gemm > 0 else 0.0
+        union_s = meter.union_seconds()
+        second_fl = sum(meter.second)
+        # the family's rate by isolated per-shape timing (see GemmMeter.isolated): the train state stays resident, operands are fresh
+        iso_f, iso_t, iso_rows = meter.isolated(dev)
+        achieved = iso_f / iso_t / 1e12 if iso_t > 0 else 0.0
         out = {
             "metric": "train-step samples/sec LAP-3B bf16", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
@@ -309,16 +358,26 @@ def main():
                        "parallelism": f"fsdp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "kernel": "lap_gemm_asm_* (csrc/gemm_asm_kernels.s) / gemm_pq_kernel / gemm_sp_kernel / gemm_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", "achieved": round(achieved, 1),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         "definition": "sum over the step's GEMM call signatures (compute stream) of count x 2MNK / count x isolated launch "
+                                       "duration, each signature re-run alone in this process with HIP events on the launch stream",
+                         "isolated_gemm_ms_per_step": round(iso_t / max(args.steps, 1) * 1e3, 2),
+                         "distinct_shapes": len(iso_rows),
+                         "top_shapes": [{"shape": nm, "launches_per_step": c // max(args.steps, 1), "us": round(t * 1e6, 1), "TFLOPs": round(r, 0)}
+                                        for _, nm, c, t, r in iso_rows[:8]],
+                         "in_situ_event_timed": {"achieved": round(in_situ, 1), "frac": round(in_situ / MFMA_PEAK_TFLOPS, 4),
+                                                 "gemm_ms_per_step": round(t_gemm / max(args.steps, 1) * 1e3, 2),
+                                                 "note": "HIP events around every compute-stream launch inside the timed steps: includes what the co-running "
+                                                         "optimizer / action-expert / weight-gradient streams cost each launch"},
                          "traffic": GEMM_TRAFFIC["bytes_per_launch"], "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE)",
                          "traffic_shape": GEMM_TRAFFIC["shape"], "traffic_algorithmic_bytes": GEMM_TRAFFIC["algorithmic_bytes_per_launch"],
-                         "traffic_source": GEMM_TRAFFIC["source"],
+                         "traffic_source": GEMM_TRAFFIC["source"], "traffic_measured_in_run": False,
                          "launches_per_step": n_launch // max(args.steps, 1),
                          "second_stream": {"launches_per_step": len(meter.second) // max(args.steps, 1),
-                                           "flop_frac": round(sum(meter.second) / max(fl_gemm + sum(meter.second), 1.0), 4),
-                                           "note": "action-expert GEMMs co-running on a second HIP stream: counted, not in the timed sum"},
-                         "union_of_launch_intervals": {"achieved": round((fl_gemm + sum(meter.second)) / max(meter.union_seconds(), 1e-9) / 1e12, 1),
-                                                       "note": "all GEMM FLOPs of both streams / time during which any GEMM launch was in flight (informative; `achieved` is the per-launch figure)"},
-                         "avg_launch_us": round(t_gemm / max(n_launch, 1) * 1e6, 2),
+                                           "flop_frac": round(second_fl / max(fl_gemm + second_fl, 1.0), 4),
+                                           "note": "action-expert GEMMs co-running on a second HIP stream: counted, not in the timed sums"},
+                         "union_of_launch_intervals": {"achieved": round((fl_gemm + second_fl) / max(union_s, 1e-9) / 1e12, 1),
+                                                       "note": "all GEMM FLOPs of both streams / time during which any GEMM launch was in flight (informative)"},
+                         "avg_launch_us": round(iso_t / max(sum(c for _, _, c, _, _ in iso_rows), 1) * 1e6, 2),
                          "gemm_time_frac_of_step": round(t_gemm / dt, 4),
                          "step_mfu": round(value / world * TRAIN_FLOP_PER_SAMPLE / 1e12 / MFMA_PEAK_TFLOPS, 4)},
             "final_loss": round(loss, 5),

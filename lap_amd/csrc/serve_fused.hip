@@ -279,6 +279,55 @@ __global__ __launch_bounds__(256) void reduce_norm_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------- the sampler's token info words / positions in one launch
+// lap.py:624-654 (prefix: make_attn_mask(prefix_mask, prefix_ar), positions cumsum(mask) - 1; suffix queries see every valid
+// prefix token and all suffix tokens, positions continue after the prefix) as the per-token words of csrc/attention.hip.
+// ~45 tiny torch launches (cat / cumsum / shifts) of 2-10 us each inside the captured sampler before this kernel existed.
+struct ServeInfoP {
+  const unsigned char* img_mask[4];     // bool [B] per image key
+  const unsigned char* prompt_mask;     // bool [B][Lt]
+  const unsigned char* langact;         // bool [B][Lt] or null (ar mask of the prompt tokens)
+  int32_t *qinfo_p, *kinfo_p, *ppos, *qinfo_s, *kinfo_all, *pos_all;
+  int n_img, T, Lt, S, suffix_idx;
+};
+__global__ __launch_bounds__(64) void serve_infos_kernel(ServeInfoP p) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int Pn = p.n_img * p.T + p.Lt, Tk = Pn + p.S;
+  int run_m = 0, run_a = 0;
+  for (int t0 = 0; t0 < Pn; t0 += 64) {
+    const int t = t0 + lane;
+    int m = 0, a = 0;
+    if (t < Pn) {
+      if (t < p.n_img * p.T) m = p.img_mask[t / p.T][b] != 0;
+      else {
+        m = p.prompt_mask[(long long)b * p.Lt + t - p.n_img * p.T] != 0;
+        a = p.langact ? (p.langact[(long long)b * p.Lt + t - p.n_img * p.T] != 0) : 0;
+      }
+    }
+    int cm = m, ca = a;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int um = __shfl_up(cm, o, 64), ua = __shfl_up(ca, o, 64);
+      if (lane >= o) { cm += um; ca += ua; }
+    }
+    cm += run_m; ca += run_a;
+    if (t < Pn) {
+      const int kw = ((m | (m << 1)) << 24) | ca, qw = (m << 24) | ca;
+      p.qinfo_p[(long long)b * Pn + t] = qw;
+      p.kinfo_p[(long long)b * Pn + t] = kw;
+      p.ppos[(long long)b * Pn + t] = cm - 1;
+      p.kinfo_all[(long long)b * Tk + t] = kw;
+      p.pos_all[(long long)b * Tk + t] = cm - 1;
+    }
+    run_m = __shfl(cm, 63, 64); run_a = __shfl(ca, 63, 64);
+  }
+  for (int s = lane; s < p.S; s += 64) {
+    p.qinfo_s[(long long)b * p.S + s] = (6 << 24) | p.suffix_idx;
+    p.kinfo_all[(long long)b * Tk + Pn + s] = (4 << 24) | p.suffix_idx;
+    p.pos_all[(long long)b * Tk + Pn + s] = run_m + s;
+  }
+}
+
 }  // namespace
 
 #define S_ ((hipStream_t)stream)
@@ -352,6 +401,25 @@ extern "C" int lap_fused_reduce_norm(const float* partials, int ksplit, const fl
   }
 #undef GO
 #undef GO2
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_serve_infos(const void* const* img_masks, int n_img, int T_img, const void* prompt_mask, const void* langact_mask,
+                               int B, int Lt, int S, int suffix_idx, int32_t* qinfo_p, int32_t* kinfo_p, int32_t* ppos,
+                               int32_t* qinfo_s, int32_t* kinfo_all, int32_t* pos_all, void* stream) {
+  if (!img_masks || n_img < 0 || n_img > 4 || T_img <= 0 || !prompt_mask || B <= 0 || Lt <= 0 || S <= 0 || !qinfo_p || !kinfo_p || !ppos ||
+      !qinfo_s || !kinfo_all || !pos_all)
+    return LAP_ERR_ARG;
+  ServeInfoP p = {};
+  for (int i = 0; i < n_img; ++i) {
+    if (!img_masks[i]) return LAP_ERR_ARG;
+    p.img_mask[i] = (const unsigned char*)img_masks[i];
+  }
+  p.prompt_mask = (const unsigned char*)prompt_mask; p.langact = (const unsigned char*)langact_mask;
+  p.qinfo_p = qinfo_p; p.kinfo_p = kinfo_p; p.ppos = ppos; p.qinfo_s = qinfo_s; p.kinfo_all = kinfo_all; p.pos_all = pos_all;
+  p.n_img = n_img; p.T = T_img; p.Lt = Lt; p.S = S; p.suffix_idx = suffix_idx;
+  hipLaunchKernelGGL(serve_infos_kernel, dim3(B), dim3(64), 0, S_, p);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

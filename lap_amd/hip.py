@@ -119,6 +119,7 @@ SIGNATURES: dict[str, list] = {
     "lap_fused_reduce_geglu": [_vp, _i, _vp, _i, _i, _vp],
     "lap_fused_reduce_residual_norm": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp],
     "lap_fused_reduce_norm": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "lap_serve_infos": [C.POINTER(_vp), _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "lap_serve_qkv_rope": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp],
     "lap_serve_gate_up": [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp],
     "lap_serve_proj_residual": [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
@@ -620,6 +621,22 @@ def linear_partials(x, wt, scratch, ksplit=None, tile=6):
     call("lap_gemm_bf16_ex", _p(x), _p(wt), None, None, None, M, N, K, x.stride(0), wt.stride(0), N, 0, 1.0, 1, 1,
          GEMM_OUT_F32 | GEMM_PARTIALS, tile, ksplit, _p(scratch), scratch.numel() * 4)
     return scratch[:need].view(ksplit, M, N), ksplit
+
+
+def serve_infos(img_masks, T_img, prompt_mask, langact_mask, S, suffix_idx):
+    """Token info words / positions of the sampler (lap.py:624-654) in one launch: (qinfo_p, kinfo_p, ppos, qinfo_s, kinfo_all,
+    pos_all), int32; masks are torch.bool tensors on the device."""
+    B, Lt = prompt_mask.shape
+    for t in (*img_masks, prompt_mask, *(() if langact_mask is None else (langact_mask,))):
+        if t.dtype != torch.bool or not t.is_contiguous() or not t.is_cuda:
+            raise TypeError("serve_infos: contiguous cuda bool masks")
+    Pn = len(img_masks) * T_img + Lt
+    dev = prompt_mask.device
+    mk = lambda n: torch.empty((B, n), dtype=torch.int32, device=dev)
+    outs = (mk(Pn), mk(Pn), mk(Pn), mk(S), mk(Pn + S), mk(Pn + S))
+    arr = (_vp * max(len(img_masks), 1))(*[_p(t) for t in img_masks])
+    call("lap_serve_infos", arr, len(img_masks), T_img, _p(prompt_mask), _p(langact_mask), B, Lt, S, suffix_idx, *[_p(t) for t in outs])
+    return outs
 
 
 def fused_reduce_norm(part, ksplit, rows, D, *, bias=None, residual=None, norm=0, gamma=None, beta=None, eps=1e-6):

@@ -86,10 +86,11 @@ class LAP:
         self._prefill_ks = tuple(int(k) for k in ks)
         self._sfx = None        # the suffix stream's HIP stream (created on first use)
         # which gradients leave the data-gradient path for a third stream (see _off_path): s SigLIP weights, b biases, q / g the
-        # prefix stream's attention / MLP projections; "1" all, "0" none.  Measured (tools/ab3.sh): sb -2.1 .. -3.3 ms per step,
-        # s -1.3, q 0, all +12.6 — but the compute stream's GEMMs then share the chip (their event-timed rate drops 4 %), so the
-        # default stays off: 1 % of the step does not pay for a blurred roofline figure.
-        mode = os.environ.get("LAP_WGRAD_STREAM", "0")
+        # prefix stream's attention / MLP projections; "1" all, "0" none.  Measured (tools/ab3.sh, interleaved on one box): sb
+        # -2.1 .. -3.3 ms per step in round 2 and -2.6 ms in round 3 (310.0 -> 307.4), s -1.3, q 0, all +12.6.  Default "sb":
+        # step time is the decision variable (the compute stream's GEMMs then share the chip, so their EVENT-timed rate drops
+        # by 4 % — bench.py's roofline figure is computed from isolated per-shape times for that reason).
+        mode = os.environ.get("LAP_WGRAD_STREAM", "sb")
         self.wgrad_stream = "" if mode == "0" else mode
         self._wg = self._wg_obj = self._wg_main = None
         self._wg_dirty = False
@@ -457,6 +458,12 @@ class LAP:
     def _serve_infos(self, obs: CoTObservation, S: int):
         """sample_actions masks (lap.py:624-654): prefix attends per make_attn_mask(prefix_mask, prefix_ar); suffix
         queries see every valid prefix token and all suffix tokens; suffix positions follow sum(prefix_mask)."""
+        keys = self.config.image_keys
+        if (self.serve_fusions and obs.tokenized_prompt_mask.is_cuda and len(keys) <= 4
+                and all(obs.image_masks[k].dtype == torch.bool for k in keys) and obs.tokenized_prompt_mask.dtype == torch.bool):
+            la = obs.tokenized_langact_mask
+            return hip.serve_infos([obs.image_masks[k].contiguous() for k in keys], self.n_img_tok, obs.tokenized_prompt_mask.contiguous(),
+                                   None if la is None else la.to(torch.bool).contiguous(), S, SUFFIX_IDX_BASE + 1)
         prefix_mask, prefix_ar = self._prefix_masks(obs)
         B, Pn = prefix_mask.shape
         dev = prefix_mask.device

@@ -12,8 +12,6 @@ from __future__ import annotations
 import dataclasses
 import os
 
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory: ~1 ms per step less launch latency (see bench.py)
-
 import torch
 
 from lap_amd import hip
@@ -286,6 +284,9 @@ def main(config: TrainConfig, *, data_loader=None, val_data_loader=None, device:
 
     from lap_amd import checkpoints as ck
 
+    # kernel arguments in device memory: ~1 ms per step less launch latency (see bench.py); only effective if the HIP runtime
+    # has not started yet in this process, harmless otherwise; an explicit value in the environment wins
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1028,3 +1028,31 @@ def test_fused_reduce_norm_equals_reduce_then_norm_bitwise(hip, rows, D, ks, nor
         assert torch.equal(h, hip.layernorm_fwd(want, g, b)[0])
     else:
         assert h is None
+
+
+@pytest.mark.parametrize("B,n_img,T,Lt,S,with_la", [(1, 2, 256, 48, 50, False), (3, 2, 16, 24, 10, True), (2, 3, 70, 130, 1, True)])
+def test_serve_infos_kernel_equals_the_torch_construction(hip, B, n_img, T, Lt, S, with_la):
+    """lap_serve_infos = LAP._serve_infos' torch construction (lap.py:624-654), bit for bit, with masked images, padding and ar tokens."""
+    g = torch.Generator().manual_seed(B * 100 + Lt)
+    img = [(torch.rand(B, generator=g) > 0.3).to(DEV) for _ in range(n_img)]
+    pmask = torch.ones(B, Lt, dtype=torch.bool)
+    la = torch.zeros(B, Lt, dtype=torch.bool)
+    for b in range(B):
+        npad = (5 * b + 2) % 7
+        pmask[b, Lt - npad:] = False
+        la[b, Lt - npad - 6:Lt - npad] = True
+    pmask, la = pmask.to(DEV), la.to(DEV)
+    SUF = 0x800001
+    got = hip.serve_infos(img, T, pmask, la if with_la else None, S, SUF)
+    prefix_mask = torch.cat([m[:, None].expand(B, T) for m in img] + [pmask], 1)
+    ar = torch.cat([torch.zeros(B, n_img * T, dtype=torch.bool, device=DEV), la if with_la else torch.zeros_like(la)], 1)
+    cs = torch.cumsum(ar.to(torch.int32), 1)
+    pm = prefix_mask.to(torch.int32)
+    kinfo_p = ((pm | (pm << 1)) << 24) | cs
+    qinfo_p = (pm << 24) | cs
+    s_idx = torch.full((B, S), SUF, dtype=torch.int32, device=DEV)
+    ppos = torch.cumsum(pm, 1) - 1
+    spos = pm.sum(-1, keepdim=True) + torch.arange(S, dtype=torch.int32, device=DEV)[None]
+    want = (qinfo_p, kinfo_p, ppos, (6 << 24) | s_idx, torch.cat([kinfo_p, (4 << 24) | s_idx], 1), torch.cat([ppos, spos], 1))
+    for a, w in zip(got, want):
+        assert a.dtype == torch.int32 and torch.equal(a, w.to(torch.int32))

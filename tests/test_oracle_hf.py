@@ -164,3 +164,91 @@ def test_oracle_bf16_mode_close_to_f32_and_sampler_uses_cache():
     (_, o1), _ = O.gemma_forward(P, CFG, [pt, st], pos, full, [None, cond])
     v = o1[:, -CFG.action_horizon:] @ P["action_out_proj/kernel"] + P["action_out_proj/bias"]
     assert torch.allclose(v, col["v_t/0"], atol=1e-4, rtol=1e-4)
+
+
+def test_prefix_path_matches_hf_paligemma_end_to_end():
+    """The one cross-check of the WHOLE prefix path that does not rest on recall: HuggingFace
+    `PaliGemmaForConditionalGeneration` (tiny config, shared random weights) against the oracle's
+    `embed_prefix -> gemma_forward(prefix only) -> Embedder.decode` (lap.py:118-170,209-260; gemma.py:148-154,455-531):
+    image tokens enter unscaled, text embeddings x sqrt(width), image + prompt tokens attend bidirectionally, language-action
+    tokens causally (make_attn_mask over `tokenized_langact_mask` = HF's token_type_ids == 1 suffix), padding is masked out,
+    the LM head is the transposed embedding table.  Two image keys per sample, ragged padding."""
+    pytest.importorskip("transformers")
+    from transformers import PaliGemmaConfig, PaliGemmaForConditionalGeneration
+    from transformers.models.gemma.configuration_gemma import GemmaConfig
+    from transformers.models.siglip.configuration_siglip import SiglipVisionConfig
+
+    c, s = CFG.vlm, CFG.img
+    IMG_TOK = CFG.vocab_size - 1
+    tcfg = GemmaConfig(vocab_size=CFG.vocab_size, hidden_size=c.width, intermediate_size=c.mlp_dim, num_hidden_layers=c.depth,
+                       num_attention_heads=c.num_heads, num_key_value_heads=c.num_kv_heads, head_dim=c.head_dim,
+                       hidden_act="gelu_pytorch_tanh", hidden_activation="gelu_pytorch_tanh", rms_norm_eps=1e-6,
+                       rope_theta=10000.0, attention_bias=False, attention_dropout=0.0, max_position_embeddings=1024)
+    vcfg = SiglipVisionConfig(hidden_size=s.width, intermediate_size=s.mlp_dim, num_hidden_layers=s.depth,
+                              num_attention_heads=s.num_heads, image_size=CFG.image_size, patch_size=s.patch,
+                              layer_norm_eps=1e-6, hidden_act="gelu_pytorch_tanh", attention_dropout=0.0,
+                              projection_dim=c.width, vision_use_head=False)
+    hc = PaliGemmaConfig(vision_config=vcfg, text_config=tcfg, image_token_index=IMG_TOK, projection_dim=c.width, hidden_size=c.width,
+                         vocab_size=CFG.vocab_size)
+    hc._attn_implementation = "eager"
+    tcfg._attn_implementation = "eager"; vcfg._attn_implementation = "eager"
+    model = PaliGemmaForConditionalGeneration(hc).eval().float()
+    P = O.init_params(CFG, seed=6)
+    vt = model.model.vision_tower
+    vm = vt.vision_model if hasattr(vt, "vision_model") else vt
+    lm = model.model.language_model
+    blk, lay = "PaliGemma/img/Transformer/encoderblock", "PaliGemma/llm/layers"
+    with torch.no_grad():
+        vm.embeddings.patch_embedding.weight.copy_(P["PaliGemma/img/embedding/kernel"].permute(3, 2, 0, 1))
+        vm.embeddings.patch_embedding.bias.copy_(P["PaliGemma/img/embedding/bias"])
+        vm.embeddings.position_embedding.weight.copy_(P["PaliGemma/img/pos_embedding"][0])
+        for l, hl in enumerate(vm.encoder.layers):
+            hl.layer_norm1.weight.copy_(P[f"{blk}/LayerNorm_0/scale"][l]); hl.layer_norm1.bias.copy_(P[f"{blk}/LayerNorm_0/bias"][l])
+            hl.layer_norm2.weight.copy_(P[f"{blk}/LayerNorm_1/scale"][l]); hl.layer_norm2.bias.copy_(P[f"{blk}/LayerNorm_1/bias"][l])
+            for nm, proj in (("query", hl.self_attn.q_proj), ("key", hl.self_attn.k_proj), ("value", hl.self_attn.v_proj)):
+                proj.weight.copy_(P[f"{blk}/MultiHeadDotProductAttention_0/{nm}/kernel"][l].reshape(s.width, -1).t())
+                proj.bias.copy_(P[f"{blk}/MultiHeadDotProductAttention_0/{nm}/bias"][l].reshape(-1))
+            hl.self_attn.out_proj.weight.copy_(P[f"{blk}/MultiHeadDotProductAttention_0/out/kernel"][l].reshape(-1, s.width).t())
+            hl.self_attn.out_proj.bias.copy_(P[f"{blk}/MultiHeadDotProductAttention_0/out/bias"][l])
+            hl.mlp.fc1.weight.copy_(P[f"{blk}/MlpBlock_0/Dense_0/kernel"][l].t()); hl.mlp.fc1.bias.copy_(P[f"{blk}/MlpBlock_0/Dense_0/bias"][l])
+            hl.mlp.fc2.weight.copy_(P[f"{blk}/MlpBlock_0/Dense_1/kernel"][l].t()); hl.mlp.fc2.bias.copy_(P[f"{blk}/MlpBlock_0/Dense_1/bias"][l])
+        vm.post_layernorm.weight.copy_(P["PaliGemma/img/Transformer/encoder_norm/scale"])
+        vm.post_layernorm.bias.copy_(P["PaliGemma/img/Transformer/encoder_norm/bias"])
+        model.model.multi_modal_projector.linear.weight.copy_(P["PaliGemma/img/head/kernel"].t())
+        model.model.multi_modal_projector.linear.bias.copy_(P["PaliGemma/img/head/bias"])
+        lm.embed_tokens.weight.copy_(P["PaliGemma/llm/embedder/input_embedding"])
+        for l, hl in enumerate(lm.layers):
+            hl.self_attn.q_proj.weight.copy_(P[f"{lay}/attn/q_einsum/w"][l].permute(0, 2, 1).reshape(-1, c.width))
+            hl.self_attn.k_proj.weight.copy_(P[f"{lay}/attn/kv_einsum/w"][l][0].permute(0, 2, 1).reshape(-1, c.width))
+            hl.self_attn.v_proj.weight.copy_(P[f"{lay}/attn/kv_einsum/w"][l][1].permute(0, 2, 1).reshape(-1, c.width))
+            hl.self_attn.o_proj.weight.copy_(P[f"{lay}/attn/attn_vec_einsum/w"][l].reshape(-1, c.width).t())
+            hl.mlp.gate_proj.weight.copy_(P[f"{lay}/mlp/gating_einsum"][l][0].t())
+            hl.mlp.up_proj.weight.copy_(P[f"{lay}/mlp/gating_einsum"][l][1].t())
+            hl.mlp.down_proj.weight.copy_(P[f"{lay}/mlp/linear"][l].t())
+            hl.input_layernorm.weight.copy_(P[f"{lay}/pre_attention_norm/scale"][l])
+            hl.post_attention_layernorm.weight.copy_(P[f"{lay}/pre_ffw_norm/scale"][l])
+        lm.norm.weight.copy_(P["PaliGemma/llm/final_norm/scale"])
+        model.lm_head.weight.copy_(P["PaliGemma/llm/embedder/input_embedding"])          # tied head (gemma.py:153-154)
+    B, L = 2, CFG.max_token_len
+    g = torch.Generator().manual_seed(2)
+    keys = CFG.image_keys
+    T = (CFG.image_size // s.patch) ** 2
+    obs = dict(images={k: torch.rand(B, CFG.image_size, CFG.image_size, 3, generator=g) * 2 - 1 for k in keys},
+               image_masks={k: torch.ones(B, dtype=torch.bool) for k in keys},
+               tokenized_prompt=torch.randint(0, IMG_TOK, (B, L), generator=g),
+               tokenized_prompt_mask=torch.tensor([[True] * L, [True] * (L - 5) + [False] * 5]),
+               tokenized_langact_mask=torch.tensor([[False] * (L - 7) + [True] * 7, [False] * (L - 11) + [True] * 6 + [False] * 5]))
+    pt, pm, pa = O.embed_prefix(P, CFG, obs)
+    pos = torch.cumsum(pm.long(), 1) - 1
+    (ours, _), _ = O.gemma_forward(P, CFG, [pt, None], pos, O.make_attn_mask(pm, pa), [None, None])
+    logits = ours @ P["PaliGemma/llm/embedder/input_embedding"].t()
+    # HF inputs: [image placeholders of every key | prompt]; pixel_values sample-major, key-minor (the scatter order)
+    ids = torch.cat([torch.full((B, len(keys) * T), IMG_TOK), obs["tokenized_prompt"]], 1)
+    pix = torch.stack([obs["images"][k] for k in keys], 1).reshape(B * len(keys), CFG.image_size, CFG.image_size, 3).permute(0, 3, 1, 2)
+    tt = torch.cat([torch.zeros(B, len(keys) * T, dtype=torch.long), obs["tokenized_langact_mask"].long()], 1)
+    with torch.no_grad():
+        ref = model(input_ids=ids, pixel_values=pix, attention_mask=pm.long(), token_type_ids=tt, position_ids=pos).logits
+    assert ref.shape == logits.shape
+    # (padding rows attend to nothing in the oracle and to something arbitrary in HF: compare valid positions only)
+    d = (logits - ref)[pm]
+    assert d.abs().max() < 2e-4 * max(1.0, ref[pm].abs().max().item()), d.abs().max()
