@@ -344,6 +344,9 @@ def main():
         # the family's rate by isolated per-shape timing (see GemmMeter.isolated): the train state stays resident, operands are fresh
         iso_f, iso_t, iso_rows = meter.isolated(dev)
         achieved = iso_f / iso_t / 1e12 if iso_t > 0 else 0.0
+        if os.environ.get("LAP_BENCH_SHAPES"):      # the whole table, for tools / profiles (stderr: stdout carries the one JSON line)
+            for tt, nm, c, t, r in iso_rows:
+                print(f"  {nm:28s} x{c // max(args.steps, 1):3d}  {t * 1e6:8.1f} us  {r:7.0f} TF/s  {tt / max(args.steps, 1) * 1e3:7.2f} ms/step", file=sys.stderr)
         out = {
             "metric": "train-step samples/sec LAP-3B bf16", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,

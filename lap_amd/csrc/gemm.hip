@@ -1511,6 +1511,31 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
       if (t5 >= 128 && win) return lap_gemm_asm(A, B, C, M, N, K, lda, ldb, ldc, a_kc, b_kc, f32, stream);
     }
   }
+  // N = 256 j + 128 with many rows (SigLIP's width 1152 at B x 512 rows: out / fc2 forward, qkv / fc1 data gradients): the 256-wide
+  // tiling needs j + 1 column tiles of which the last is half empty, e.g. 64 x 4.5 -> 320 tile slots = two rounds of the chip for
+  // 1.13 rounds of work.  Cut the product along N instead: columns [0, 256 j) are whole tiles (64 x 4 = exactly one round at
+  // B = 32, and a plain / bias-only product of that shape is eligible for the assembly kernels), the last 128 columns a second,
+  // small product on the 128 x 128 tile.  Same bits (every output element keeps its accumulation order).
+  // tools/bench_nsplit.py (isolated, us): fc2 forward K = 4304 240 -> 200, qkv data gradient K = 3456 141 -> 122, fc1 data gradient
+  // K = 4304 172 -> 159; K = 1152 (out projection) loses 4 us to the second launch, so short contractions stay whole.  The tail
+  // product re-reads all of A for 128 columns, which is what keeps the gain below the 1.5 / 2 rounds it removes.
+  // LAP_GEMM_NO_NSPLIT=1: off (A/B).
+  if (tile < 0 && ksplit == 0 && (N & 255) == 128 && N >= 640 && N <= 2048 + 128 && M >= 4096 && K >= 2048 && !(flags & LAP_GEMM_PARTIALS)) {
+    static const bool off = getenv("LAP_GEMM_NO_NSPLIT") != nullptr;
+    const long long tm = (M + 255) / 256, t_all = tm * (N / 256 + 1), t_whole = tm * (N / 256);
+    const double fill_all = (double)t_all / (256.0 * ((t_all + 255) / 256)), fill_whole = (double)t_whole / (256.0 * ((t_whole + 255) / 256));
+    if (!off && fill_all < 0.8 && fill_whole >= 0.9) {
+      const int N0 = N - 128;
+      const int esz = f32 ? 4 : 2;
+      const char* Bp = (const char*)B;
+      const void* B1 = b_kc ? (const void*)(Bp + (long long)N0 * ldb * 2) : (const void*)(Bp + (long long)N0 * 2);
+      const void* bias1 = bias ? (const void*)((const char*)bias + (long long)N0 * ((flags & LAP_GEMM_BIAS_F32) ? 4 : 2)) : nullptr;
+      const void* res1 = residual ? (const void*)((const char*)residual + (long long)N0 * 2) : nullptr;
+      void* C1 = (void*)((char*)C + (long long)N0 * esz);
+      if (int rc = lap_gemm_bf16_ex(A, B, C, bias, residual, M, N0, K, lda, ldb, ldc, ldr, alpha, a_kc, b_kc, flags, -1, 0, scratch, scratch_bytes, stream)) return rc;
+      return lap_gemm_bf16_ex(A, B1, C1, bias1, res1, M, 128, K, lda, ldb, ldc, ldr, alpha, a_kc, b_kc, flags, -1, 0, scratch, scratch_bytes, stream);
+    }
+  }
   // Serving prefill (batch-1 action chunk: 512 SigLIP rows, 560 Gemma rows; forward layout, bf16 out).  Every block of such
   // a GEMM is bound by what it pulls through its CU's vector-memory path (~45 GB/s), so the tile is the one with the fewest
   // operand bytes per block that still covers the chip WITHOUT a split-K reduce pass behind it (tools/bench_prefill_gemm.py,

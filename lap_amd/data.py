@@ -201,9 +201,13 @@ class MixtureDataset:
     def __len__(self) -> int:
         return self.length
 
+    def set_epoch(self, epoch: int):
+        """The draws are a pure function of (seed, epoch, index): a resumed loader reproduces them, a new epoch re-samples."""
+        self.epoch = int(epoch)
+
     def locate(self, index: int) -> tuple[int, int]:
         """(dataset position in the mixture, transition index inside it) of mixture element `index`"""
-        u = np.random.Generator(np.random.Philox(key=self.seed, counter=[0, 0, 0, int(index)])).random(2)
+        u = np.random.Generator(np.random.Philox(key=self.seed, counter=[0, 0, int(getattr(self, "epoch", 0)), int(index)])).random(2)
         d = min(int(np.searchsorted(self._cdf, u[0], side="right")), len(self.datasets) - 1)
         return d, min(int(u[1] * self.sizes[d]), self.sizes[d] - 1)
 
@@ -286,9 +290,19 @@ class DataLoader:
     # ---- iteration
     def _indices(self, batch_index: int) -> np.ndarray:
         epoch, within = divmod(batch_index, self.per_epoch)
-        order = np.random.RandomState(self.seed + 7919 * epoch).permutation(len(self.dataset)) if self.shuffle else np.arange(len(self.dataset))
+        if self.shuffle:
+            # one permutation per EPOCH, kept until the epoch changes (a mixture's effective length is 20-40x its transitions:
+            # rebuilding it for every batch cost seconds and gigabytes)
+            if getattr(self, "_order_epoch", None) != epoch:
+                self._order, self._order_epoch = np.random.RandomState(self.seed + 7919 * epoch).permutation(len(self.dataset)), epoch
+            order = self._order
+        else:
+            order = np.arange(len(self.dataset))
         g0 = within * self.batch_size * self.world + self.rank * self.batch_size
-        return order[g0:g0 + self.batch_size]
+        idx = order[g0:g0 + self.batch_size]
+        if hasattr(self.dataset, "set_epoch"):
+            self.dataset.set_epoch(epoch)      # a mixture draws NEW samples every epoch (the reference's stream never repeats a finite set)
+        return idx
 
     def __iter__(self):
         produced = 0

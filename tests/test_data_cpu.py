@@ -181,3 +181,66 @@ def test_global_norm_stats_are_the_pooled_moments_and_bracketing_quantiles():
     assert np.allclose(g["state_joint_pos"]["std"], states["bridge_v2_oxe"].std(0), atol=1e-5)
     empty = D.global_norm_stats({"coco_captions": per["coco_captions"]}, action_dim=4, state_dim=4, exclude=["coco_captions"])
     assert empty["actions"]["num_transitions"] == 0 and np.all(empty["actions"]["std"] == 1) and set(empty) == {"actions"}
+
+
+# ------------------------------------------------------------------------------ offline RLDS exporter (lap_amd/rlds_export.py)
+def test_rlds_export_rotation_helpers_match_scipy():
+    """rotation_utils.py:84-160,453-471 and transforms.py:103-133 restated in numpy, against scipy's rotations."""
+    from scipy.spatial.transform import Rotation
+
+    from lap_amd import rlds_export as R
+
+    g = np.random.default_rng(0)
+    eul = np.stack([g.uniform(-3, 3, 64), g.uniform(-1.4, 1.4, 64), g.uniform(-3, 3, 64)], -1)
+    want = Rotation.from_euler("xyz", eul).as_matrix()                      # extrinsic xyz = Rz Ry Rx
+    assert np.allclose(R.euler_to_rotation_matrix(eul), want, atol=1e-12)
+    assert np.allclose(R.rotation_matrix_to_euler(want), eul, atol=1e-9)
+    e1, e2 = eul[:32], eul[32:]
+    rel = R.euler_diff(e1, e2)
+    assert np.allclose(Rotation.from_euler("xyz", e2).as_matrix() @ Rotation.from_euler("xyz", rel).as_matrix(),
+                       Rotation.from_euler("xyz", e1).as_matrix(), atol=1e-9)
+    rv = g.normal(size=(64, 3)) * g.uniform(0.0, 2.5, (64, 1))
+    rv[0] = 0.0                                                             # zero rotation: the x-axis fallback
+    assert np.allclose(Rotation.from_euler("xyz", R.axis_angle_to_extrinsic_xyz_euler(rv)).as_matrix(), Rotation.from_rotvec(rv).as_matrix(), atol=1e-9)
+
+
+def test_rlds_export_libero_and_droid_record_to_episode():
+    """transforms.py:1453-1481 (LIBERO) and :757-790 (DROID) on hand-built trajectories, through `episode_from_rlds` into the
+    episode store and out of `EpisodeDataset` as the sample the train loader sees."""
+    from lap_amd import data as D, rlds_export as R
+
+    T = 6
+    g = np.random.default_rng(1)
+    img = g.integers(0, 255, (T, 8, 8, 3), dtype=np.uint8)
+    # LIBERO: state [xyz, axis-angle, 2 finger joints]; action gripper -1 (open) .. +1 (close)
+    rot = np.array([[0.0, 0.0, 0.1 * t] for t in range(T)])                 # pure yaw, 0.1 rad per step
+    st = np.concatenate([np.arange(T)[:, None] * np.array([[0.01, 0.0, -0.02]]), rot, np.full((T, 1), 0.02), np.full((T, 1), -0.02)], 1)
+    act = np.concatenate([g.normal(size=(T, 6)), np.array([[-1.0], [-1.0], [0.3], [1.0], [1.0], [-0.5]])], 1)
+    traj = {"observation": {"image": img, "wrist_image": img[::-1].copy(), "state": st}, "action": act,
+            "language_instruction": np.array([b"put the bowl on the plate"] * T)}
+    ep = R.episode_from_rlds("libero_10_no_noops", traj)
+    assert ep["prompt"] == "put the bowl on the plate" and ep["dataset_name"] == "libero_10_no_noops"
+    assert ep["base_0_rgb"].dtype == np.uint8 and np.array_equal(ep["left_wrist_0_rgb"], img[::-1])
+    assert np.allclose(ep["state"][:, :3], st[:, :3]) and np.allclose(ep["state"][:, 3:6], rot, atol=1e-7)      # yaw-only: euler = axis-angle
+    assert np.allclose(ep["state"][:, 6], 0.5)                                                                 # 0.02 / 0.04
+    want_grip = 1.0 - np.clip(act[:, -1], 0, 1)                                                                # 1 = open
+    assert np.allclose(ep["actions"][:, 6], want_grip)
+    assert np.allclose(ep["actions"][:-1, :3], [[0.01, 0.0, -0.02]] * (T - 1), atol=1e-7) and np.allclose(ep["actions"][:-1, 3:6], [[0, 0, 0.1]] * (T - 1), atol=1e-6)
+    assert np.allclose(ep["actions"][-1, :6], 0.0)                                                             # zero-padded last step
+    assert R.episode_from_rlds("libero_10_no_noops", dict(traj, language_instruction=np.array([b""] * T))) is None
+    ds = D.EpisodeDataset([ep], action_horizon=4)
+    s = ds[1]
+    assert s["actions"].shape == (4, 7) and np.allclose(s["language_actions"][:3], 4 * np.array([0.01, 0.0, -0.02]), atol=1e-6)   # steps 1..4
+    assert np.isclose(s["language_actions"][5], 0.4, atol=1e-5) and s["language_actions"][6] == 0.0 and s["has_wrist_image"]     # gripper of step 4: closed
+    # DROID: gripper_position 0 open .. 1 closed, rank-1; in-between values take the next decided step
+    cart = np.concatenate([np.arange(T)[:, None] * np.array([[0.0, 0.02, 0.0]]), np.zeros((T, 3))], 1)
+    gp = np.array([0.0, 0.1, 0.45, 0.55, 0.9, 1.0])
+    dtraj = {"observation": {"exterior_image_1_left": img, "wrist_image_left": img, "cartesian_position": cart, "gripper_position": gp},
+             "action_dict": {"gripper_position": gp[:, None]}, "language_instruction": b"open the drawer"}
+    de = R.episode_from_rlds("droid", dtraj)
+    assert np.allclose(de["state"][:, 6], [1, 1, 1, 0, 0, 0]) and np.allclose(de["actions"][:, 6], [1, 1, 1, 0, 0, 0])
+    assert np.allclose(de["actions"][:-1, 1], 0.02) and np.allclose(de["actions"][-1, :6], 0)
+    b = R.binarize_gripper_actions(np.array([0.5, 0.5, 0.99, 0.5, 0.01, 0.5]))                                  # default threshold 0.95
+    assert np.allclose(b, [1, 1, 1, 0, 0, 0.5])                                                                # the tail keeps the last raw value
+    with pytest.raises(KeyError):
+        R.episode_from_rlds("bridge_v2_oxe", traj)

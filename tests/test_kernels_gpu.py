@@ -1056,3 +1056,15 @@ def test_serve_infos_kernel_equals_the_torch_construction(hip, B, n_img, T, Lt, 
     want = (qinfo_p, kinfo_p, ppos, (6 << 24) | s_idx, torch.cat([kinfo_p, (4 << 24) | s_idx], 1), torch.cat([ppos, spos], 1))
     for a, w in zip(got, want):
         assert a.dtype == torch.int32 and torch.equal(a, w.to(torch.int32))
+
+
+def test_gemm_n_split_of_half_filled_last_column_tile_keeps_the_bits(hip):
+    """N = 1152 at 16,384 rows (SigLIP at B = 32) runs as [0, 1024) + [1024, 1152) (lap_gemm_bf16_ex): every output element keeps
+    its accumulation order, so the result equals the un-split 256 x 256 tiling bit for bit — forward with f32 bias and residual,
+    forward with bias (whole-tile part on the assembly kernel), plain data gradient."""
+    M, N, K = 16384, 1152, 2048
+    a = rnd(M, K, scale=0.3); w = rnd(N, K, scale=0.3, seed=1); b = rnd(N, dtype=torch.float32, seed=2); r = rnd(M, N, seed=3)
+    for kw in (dict(bias=b, residual=r), dict(bias=b), dict()):
+        assert torch.equal(hip.linear_fwd(a, w, **kw), hip.linear_fwd(a, w, tile=5, **kw)), list(kw)
+    wt = rnd(K, N, scale=0.3, seed=4)
+    assert torch.equal(hip.linear_dgrad(a, wt), hip.linear_dgrad(a, wt, tile=5))

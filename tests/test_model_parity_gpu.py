@@ -284,12 +284,112 @@ def test_full_depth_lap3b_forward_and_sampler_match_oracle(hip):
     assert torch.equal(generic, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused="partials"))
     err, base = rel(out, ref), rel(ref16, ref)
     assert rel(generic, ref) < max(FREE_RUN_RATIO * base, 5e-3) and rel(out, generic) < max(FREE_RUN_RATIO * base, 5e-3)
+    # BASELINE config 4 at the real size: the hipGraph-captured sampler replays to the eager sampler's bits (twice: no state leak)
+    from lap_amd.serve import GraphedSampler
+
+    gs = GraphedSampler(model, 1, 10).capture()
+    g1 = gs(o, noise.to(DEV)).clone()
+    g2 = gs(o, noise.to(DEV)).clone()
+    assert torch.equal(g1, out) and torch.equal(g2, out)
+    del gs
     print(f"full depth: oracle {t_oracle:.0f} s; loss {loss.item():.5f} / f32 {loss32.item():.5f} / bf16 {loss16.item():.5f}; "
           f"free-running worst layer vs bf16 oracle {w16:.2e}, vs f32 {w32:.2e}; teacher-forced worst layer {wtf:.2e}; "
           f"sampler {err:.2e} (bf16 oracle {base:.2e})")
     for k, e32, b, e16 in report[::6]:
         print(f"  {k:22s} engine-f32 {e32:.2e}  bf16oracle-f32 {b:.2e}  engine-bf16oracle {e16:.2e}")
     assert out.shape == (1, 50, 7) and err < max(FREE_RUN_RATIO * base, 5e-3), (err, base)
+
+
+def test_full_depth_lap3b_training_gradients_match_oracle(hip):
+    """The real LAP-3B (27 + 18 layers, 257,152-word vocabulary), B = 2, `loss_and_grad` on the DEFAULT schedule (action expert
+    on the second stream, SigLIP weight / bias gradients on the third) against the f32 oracle's autograd: the loss, both
+    per-sample losses and EVERY gradient tensor of the reference's tree (scripts/train.py:329-361).  The 2-layer slices cover
+    every kernel shape; this covers the full-depth backward — the activation stash of 45 layers, the stream schedule and the
+    accumulation of 18 + 27 layers of rounding noise into the early layers' gradients (bound: the slices' 5e-2 per tensor)."""
+    import time as _t
+
+    from lap_amd.config import get_config
+    from lap_amd.model import LAP
+    from lap_amd.params import engine_to_reference
+
+    cfg = get_config("lap_bench").model
+    oc = oracle_cfg(cfg)
+    B = 2
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(32, nthr))
+    try:
+        t0 = _t.perf_counter()
+        P = O.init_params(oc, seed=23)
+        obs, actions, noise, time = make_inputs(cfg, B=B, ragged=True)
+        Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        loss32, m32 = O.compute_loss(Pg, oc, obs, actions, noise, time)
+        loss32.backward()
+        g32 = {k: v.grad for k, v in Pg.items()}
+        del Pg
+        t_oracle = _t.perf_counter() - t0
+    finally:
+        torch.set_num_threads(nthr)
+    model = LAP(cfg, params=P, device=DEV)
+    del P
+    assert model.dual_stream and model.wgrad_stream == "sb"          # the defaults bench.py runs with
+    for g in model.ps.grad.values():
+        g.zero_()
+    col = {}
+    loss, _ = model.loss_and_grad(0, to_observation(obs, DEV), actions.to(DEV), noise=noise.to(DEV), time=time.to(DEV), collect=col)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss32.item()) / abs(loss32.item()) < 5e-3, (loss.item(), loss32.item())
+    assert rel(col["per_sample_action"], m32["per_sample_action"]) < 2e-2 and rel(col["per_sample_lang"], m32["per_sample_lang"]) < 2e-2
+    gref = engine_to_reference(cfg, {name: model.ps.g(name).detach().float().cpu() for name in model.ps.names()})
+    worst = []
+    for k, g in g32.items():
+        if g is None:
+            continue
+        r = rel(gref[k], g)
+        worst.append((r, k))
+        assert r < 5e-2 or (gref[k] - g).abs().max() < 1e-4, (k, r)
+    worst.sort(reverse=True)
+    assert len(worst) == len(g32)
+    print(f"full-depth training parity: oracle {t_oracle:.0f} s; loss {loss.item():.5f} vs f32 {loss32.item():.5f}; {len(worst)} gradient "
+          f"tensors, worst relative L2: " + ", ".join(f"{k.split('PaliGemma/')[-1]} {r:.1e}" for r, k in worst[:4]))
+
+
+def test_full_size_train_steps_do_not_depend_on_the_stream_schedule(hip, monkeypatch):
+    """Three consecutive LAP-3B train steps at B = 32 (the benchmark's step: forward, backward, clip, AdamW, EMA) on the default
+    schedule — second stream, third stream, optimizer paced under the next forward's GEMMs — against everything on one stream
+    with the whole optimizer pass enqueued at once.  Step 0's loss is bit-equal (the forward does not depend on the schedule);
+    later losses see parameters whose gradients carried f32-atomics-order noise in a handful of small tensors (norm scales,
+    modulation, biases: free in BOTH schedules, `test_two_stream_schedule_equals_one_stream`), so they are compared to the
+    spread two identical one-stream runs show between themselves."""
+    import dataclasses as dc
+
+    from lap_amd.config import get_config
+    from lap_amd.train import SyntheticDataLoader, TrainingStepRunner, init_train_state
+
+    tc = dc.replace(get_config("lap_bench"), batch_size=32, seed=3)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        state = init_train_state(tc, device=DEV)
+        runner = TrainingStepRunner(tc)
+        it = iter(SyntheticDataLoader(tc.model, 32, DEV, seed=5))
+        losses = []
+        for step in range(3):
+            state, info = runner(tc.seed, state, next(it), step)
+            losses.append(info["loss"].item())
+        torch.cuda.synchronize()
+        del state
+        torch.cuda.empty_cache()
+        return losses
+
+    one = {"LAP_DUAL_STREAM": "0", "LAP_WGRAD_STREAM": "0", "LAP_OPT_PACE": "top", "LAP_OPT_LOOKAHEAD": "0"}
+    dflt = {"LAP_DUAL_STREAM": "1", "LAP_WGRAD_STREAM": "sb", "LAP_OPT_PACE": "gemm", "LAP_OPT_LOOKAHEAD": "5"}
+    a, a2, b = run(one), run(one), run(dflt)
+    assert a[0] == a2[0] == b[0], (a, a2, b)
+    spread = max(abs(x - y) / abs(x) for x, y in zip(a[1:], a2[1:]))
+    for x, y in zip(a[1:], b[1:]):
+        assert abs(x - y) / abs(x) <= max(4 * spread, 2e-6), (a, a2, b)
+    print(f"3 steps at B=32: one stream {a} / again {a2} / default schedule {b}")
 
 
 def test_graphed_sampler_replay_equals_eager_and_oracle(hip):
