@@ -58,7 +58,8 @@ def synthetic_batch(cfg, B, device, seed):
         tokenized_prompt=torch.randint(0, cfg.vocab_size, (B, L), generator=g, dtype=torch.int32).to(device),
         tokenized_prompt_mask=torch.ones(B, L, dtype=torch.bool, device=device),
         tokenized_langact_mask=la.to(device), token_loss_mask=torch.ones(B, L, dtype=torch.bool, device=device),
-        sample_mask=torch.ones(B, dtype=torch.bool, device=device))
+        sample_mask=torch.ones(B, dtype=torch.bool, device=device),
+        loss_rows_max=int(la[:, 1:].sum(-1).max()))     # host-side hint the data loaders attach: 16 loss-carrying tokens per sample
     actions = torch.randn(B, cfg.action_horizon, cfg.action_dim, generator=g).to(device)
     return obs, actions
 

@@ -304,6 +304,7 @@ def _refresh_mirrors(state):
         if ps.sharded(u):
             a, b = ps.shard_range(u)
             ps.full16[u.name][a:b].copy_(ps.master[u.name])
+    ps.refresh_lo_shard()
     comm.start_param_gather()
     comm.synchronize()
 

@@ -1515,7 +1515,8 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   // tiling needs j + 1 column tiles of which the last is half empty, e.g. 64 x 4.5 -> 320 tile slots = two rounds of the chip for
   // 1.13 rounds of work.  Cut the product along N instead: columns [0, 256 j) are whole tiles (64 x 4 = exactly one round at
   // B = 32, and a plain / bias-only product of that shape is eligible for the assembly kernels), the last 128 columns a second,
-  // small product on the 128 x 128 tile.  Same bits (every output element keeps its accumulation order).
+  // small product on the 128 x 128 tile (with its automatic K split: those 128 columns see another f32 summation order,
+  // everything else keeps its bits).
   // tools/bench_nsplit.py (isolated, us): fc2 forward K = 4304 240 -> 200, qkv data gradient K = 3456 141 -> 122, fc1 data gradient
   // K = 4304 172 -> 159; K = 1152 (out projection) loses 4 us to the second launch, so short contractions stay whole.  The tail
   // product re-reads all of A for 128 columns, which is what keeps the gain below the 1.5 / 2 rounds it removes.

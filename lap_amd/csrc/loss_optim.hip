@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void ce_update_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void ce_grad_kernel(const float* __restrict__ logits, int ldl,
                                                       const int32_t* __restrict__ target, const float* __restrict__ m,
                                                       const float* __restrict__ l, const float* __restrict__ wgt,
-                                                      bf16* __restrict__ dlogits, int ldd, int v0, int vc) {
+                                                      bf16* __restrict__ dlogits, bf16* __restrict__ dlo, int ldd, int v0, int vc) {
   const int r = blockIdx.y;
   const int v = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (v >= vc) return;
@@ -73,7 +73,11 @@ __global__ __launch_bounds__(256) void ce_grad_kernel(const float* __restrict__ 
   for (int e = 0; e < n; ++e) {
     float p = (wr != 0.f) ? __expf(x[e] - lse) : 0.f;
     if (v + e == t) p -= 1.0f;
-    d[e] = f2bf(wr * p);
+    const float dv = wr * p;
+    d[e] = f2bf(dv);
+    // the f32 cotangent as two bf16 planes (hi + lo carries 16 mantissa bits): gemma.py:153-154 keeps the logits — and with them
+    // their gradient — in f32, the GEMMs that consume it here are bf16 MFMA products with f32 accumulation
+    if (dlo) dlo[(long long)r * ldd + v + e] = f2bf(dv - round_bf16(dv));
   }
 }
 
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // of its 38 B / parameter with the GEMMs' operand traffic, not CU occupancy.)
 template <bool NT>
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float* __restrict__ ema,
-                      const float* __restrict__ g, bf16* __restrict__ p16, long long n, const float* __restrict__ sc,
+                      const float* __restrict__ g, bf16* __restrict__ p16, bf16* __restrict__ p16lo, long long n, const float* __restrict__ sc,
                       float b1, float b2, float eps, float wd, float max_norm) {
   const float gnorm = sqrtf(sc[0]);
   // optax.clip_by_global_norm: g if norm < max_norm else g / norm * max_norm
@@ -179,6 +183,10 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, f
       stf(at(v, o), vv);
       if (ema_on) stf(at(ema, o), ev);
       if (p16) { bf16x2 q; q[0] = f2bf(pv[0]); q[1] = f2bf(pv[1]); *reinterpret_cast<bf16x2*>(reinterpret_cast<char*>(p16) + (o >> 1)) = q; }
+      if (p16lo) {   // the residual plane of the embedding table (hi + lo = 16 mantissa bits of the f32 value: the LM head's f32 operand)
+        bf16x2 q; q[0] = f2bf(pv[0] - round_bf16(pv[0])); q[1] = f2bf(pv[1] - round_bf16(pv[1]));
+        *reinterpret_cast<bf16x2*>(reinterpret_cast<char*>(p16lo) + (o >> 1)) = q;
+      }
     }
   }
 }
@@ -289,7 +297,15 @@ extern "C" int lap_ce_chunk_grad(const float* logits, int ldl, const int32_t* ta
                                  const float* w, void* dlogits, int ldd, int rows, int v0, int vc, void* stream) {
   if (rows <= 0 || vc <= 0) return LAP_ERR_ARG;
   dim3 grid((vc + 1023) / 1024, rows);
-  hipLaunchKernelGGL(ce_grad_kernel, grid, dim3(256), 0, S_, logits, ldl, target, m, l, w, (bf16*)dlogits, ldd, v0, vc);
+  hipLaunchKernelGGL(ce_grad_kernel, grid, dim3(256), 0, S_, logits, ldl, target, m, l, w, (bf16*)dlogits, (bf16*)nullptr, ldd, v0, vc);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+extern "C" int lap_ce_chunk_grad_hilo(const float* logits, int ldl, const int32_t* target, const float* m, const float* l,
+                                      const float* w, void* dlogits_hi, void* dlogits_lo, int ldd, int rows, int v0, int vc, void* stream) {
+  if (rows <= 0 || vc <= 0 || !dlogits_hi || !dlogits_lo) return LAP_ERR_ARG;
+  dim3 grid((vc + 1023) / 1024, rows);
+  hipLaunchKernelGGL(ce_grad_kernel, grid, dim3(256), 0, S_, logits, ldl, target, m, l, w, (bf16*)dlogits_hi, (bf16*)dlogits_lo, ldd, v0, vc);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
@@ -308,9 +324,8 @@ extern "C" int lap_sumsq_f32(const float* x, long long n, float* sumsq, void* st
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
-extern "C" int lap_adamw_ema(float* p, float* m, float* v, float* ema, const float* g, void* p16, long long n,
-                             const float* scalars, float b1, float b2, float eps, float wd, float max_norm,
-                             void* stream) {
+static int adamw_launch(float* p, float* m, float* v, float* ema, const float* g, void* p16, void* p16lo, long long n,
+                        const float* scalars, float b1, float b2, float eps, float wd, float max_norm, void* stream) {
   if (n <= 0 || (n & 1) || !scalars) return LAP_ERR_ARG;
   static const long long cap = getenv("LAP_ADAMW_BLOCKS") ? atoll(getenv("LAP_ADAMW_BLOCKS")) : 4096;   // tuning knob (tools/ab_bench.sh)
   const long long CH = 1LL << 29;
@@ -320,13 +335,26 @@ extern "C" int lap_adamw_ema(float* p, float* m, float* v, float* ema, const flo
     static const bool nt = getenv("LAP_ADAMW_NT") ? atoi(getenv("LAP_ADAMW_NT")) != 0 : true;   // (-1.8 ms per train step: tools/ab3.sh)
     if (nt)
       hipLaunchKernelGGL(adamw_ema_kernel<true>, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, p + o, m + o, v + o,
-                         ema ? ema + o : nullptr, g + o, p16 ? (bf16*)p16 + o : nullptr, cnt, scalars, b1, b2, eps, wd, max_norm);
+                         ema ? ema + o : nullptr, g + o, p16 ? (bf16*)p16 + o : nullptr, p16lo ? (bf16*)p16lo + o : nullptr, cnt, scalars, b1, b2,
+                         eps, wd, max_norm);
     else
       hipLaunchKernelGGL(adamw_ema_kernel<false>, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, p + o, m + o, v + o,
-                         ema ? ema + o : nullptr, g + o, p16 ? (bf16*)p16 + o : nullptr, cnt, scalars, b1, b2, eps, wd, max_norm);
+                         ema ? ema + o : nullptr, g + o, p16 ? (bf16*)p16 + o : nullptr, p16lo ? (bf16*)p16lo + o : nullptr, cnt, scalars, b1, b2,
+                         eps, wd, max_norm);
     LAP_CHECK_LAUNCH();
   }
   return LAP_OK;
+}
+extern "C" int lap_adamw_ema(float* p, float* m, float* v, float* ema, const float* g, void* p16, long long n,
+                             const float* scalars, float b1, float b2, float eps, float wd, float max_norm,
+                             void* stream) {
+  return adamw_launch(p, m, v, ema, g, p16, nullptr, n, scalars, b1, b2, eps, wd, max_norm, stream);
+}
+extern "C" int lap_adamw_ema_hilo(float* p, float* m, float* v, float* ema, const float* g, void* p16, void* p16lo, long long n,
+                                  const float* scalars, float b1, float b2, float eps, float wd, float max_norm,
+                                  void* stream) {
+  if (!p16 || !p16lo) return LAP_ERR_ARG;
+  return adamw_launch(p, m, v, ema, g, p16, p16lo, n, scalars, b1, b2, eps, wd, max_norm, stream);
 }
 extern "C" int lap_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                             int ldb, int ldc, float alpha, int a_kc, int b_kc, int accum, void* stream) {

@@ -175,10 +175,12 @@ class UnitPipeline:
             for u in self._sched[self._released:upto]:
                 lo, _ = ps.shard_range(u)
                 ema = ps.ema.get(u.name)
+                lo16 = ps.lo16.get(u.name)
                 for a, b in ps.local_train_ranges(u):   # shard coordinates; frozen tensors are skipped altogether
                     p16 = ps.full16[u.name][lo + a:lo + b] if u.big else None
                     hip.adamw_ema(ps.master[u.name][a:b], ps.m[u.name][a:b], ps.v[u.name][a:b], ema[a:b] if ema is not None else None,
-                                  ps.gshard[u.name][a:b], p16, self.scal, opt.b1, opt.b2, opt.eps, opt.weight_decay, opt.clip_gradient_norm)
+                                  ps.gshard[u.name][a:b], p16, self.scal, opt.b1, opt.b2, opt.eps, opt.weight_decay, opt.clip_gradient_norm,
+                                  p16lo=lo16[lo + a:lo + b] if lo16 is not None else None)
                 if ps.unit_trainable(u):
                     self._after_unit_update(u)
                 if self.is_cuda:
@@ -279,6 +281,9 @@ class FsdpComm(UnitPipeline):
             full = self.ps.full16[u.name]
             a, b = self.ps.shard_range(u)
             self._all_gather(full, full[a:b])
+            lo = self.ps.lo16.get(u.name)      # the embedding table's residual plane travels like the mirror (+1.05 GB per step)
+            if lo is not None:
+                self._all_gather(lo, lo[a:b])
 
     def start_param_gather(self):
         """Stand-alone gather of every bf16 mirror (tests / after loading weights)."""

@@ -128,6 +128,8 @@ SIGNATURES: dict[str, list] = {
     "lap_serve_final_euler": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
     "lap_ce_chunk_update": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_ce_chunk_grad": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lap_ce_chunk_grad_hilo": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lap_adamw_ema_hilo": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _vp],
     "lap_sumsq_f32": [_vp, _ll, _vp, _vp],
     "lap_argmax_rows_f32": [_vp, _i, _i, _i, _vp, _vp],
     "lap_adamw_ema": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _vp],
@@ -204,8 +206,10 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, 
         flags |= GEMM_GELU | (GEMM_GELU_BF16 if gelu == "bf16" else 0)   # "bf16": round the pre-activation to bf16 first
     if bias is not None and bias.dtype == torch.float32:
         flags |= GEMM_BIAS_F32
-    # the library decides on two-phase split-K itself when it is lent scratch (poorly filled grids, skinny-M serving)
-    scratch = _gemm_scratch(a.device) if (ksplit == 0 and not accum) else None
+    # the library decides on two-phase split-K itself when it is lent scratch (poorly filled grids, skinny-M serving); an
+    # accumulating product gets it too when its output is small and its contraction long (the LM head's hi / lo data gradients:
+    # 16 output tiles over K = 257,152 — unsplit that is 16 CUs walking 4,018 k-tiles; the reduce pass adds onto C)
+    scratch = _gemm_scratch(a.device) if (ksplit == 0 and (not accum or (K >= 16384 and M * N <= (1 << 22)))) else None
     call("lap_gemm_bf16_ex", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, ldc, ldr, float(alpha),
          int(a_kc), int(b_kc), flags, tile, ksplit, _p(scratch), scratch.numel() * 4 if scratch is not None else 0)
     return out
@@ -553,17 +557,28 @@ def ce_chunk_update(logits, target, m, l, tl, v0):
     call("lap_ce_chunk_update", _p(logits), logits.stride(0), _p(target), _p(m), _p(l), _p(tl), rows, v0, vc)
 
 
-def ce_chunk_grad(logits, target, m, l, w, dlogits, v0):
+def ce_chunk_grad(logits, target, m, l, w, dlogits, v0, dlogits_lo=None):
+    """dlogits (bf16) = w * (softmax - onehot); with `dlogits_lo` also the bf16 residual plane (hi + lo ~ the f32 value)."""
     rows, vc = logits.shape
-    call("lap_ce_chunk_grad", _p(logits), logits.stride(0), _p(target), _p(m), _p(l), _p(w), _p(dlogits),
-         dlogits.stride(0), rows, v0, vc)
+    if dlogits_lo is None:
+        call("lap_ce_chunk_grad", _p(logits), logits.stride(0), _p(target), _p(m), _p(l), _p(w), _p(dlogits),
+             dlogits.stride(0), rows, v0, vc)
+    else:
+        if dlogits_lo.stride(0) != dlogits.stride(0):
+            raise ValueError("hi / lo planes must share the row stride")
+        call("lap_ce_chunk_grad_hilo", _p(logits), logits.stride(0), _p(target), _p(m), _p(l), _p(w), _p(dlogits), _p(dlogits_lo),
+             dlogits.stride(0), rows, v0, vc)
 
 
 def sumsq_f32(x, out):
     call("lap_sumsq_f32", _p(x), x.numel(), _p(out))
 
 
-def adamw_ema(p, m, v, ema, g, p16, scalars, b1, b2, eps, wd, max_norm):
+def adamw_ema(p, m, v, ema, g, p16, scalars, b1, b2, eps, wd, max_norm, p16lo=None):
+    if p16lo is not None:
+        call("lap_adamw_ema_hilo", _p(p), _p(m), _p(v), _p(ema), _p(g), _p(p16), _p(p16lo), p.numel(), _p(scalars), float(b1), float(b2),
+             float(eps), float(wd), float(max_norm))
+        return
     call("lap_adamw_ema", _p(p), _p(m), _p(v), _p(ema), _p(g), _p(p16), p.numel(), _p(scalars), float(b1), float(b2),
          float(eps), float(wd), float(max_norm))
 

@@ -827,12 +827,39 @@ class LAP:
         # ---- language loss (lap.py:209-289): rows Pn-Lt .. Pn-2 predict tokens 1 .. Lt-1
         Lt = obs.tokenized_prompt.shape[1]
         Dv, V = self.v.width, cfg.vocab_size
-        R = B * (Lt - 1)
-        rows = torch.empty((R, Dv), dtype=torch.bfloat16, device=dev)
-        hip.copy_rows_bf16(xf0, rows, R, Lt - 1, Dv, Pn, Pn - Lt, Lt - 1, 0)
+        loss_mask = obs.tokenized_langact_mask[:, 1:] & obs.tokenized_prompt_mask[:, 1:]
+        if obs.token_loss_mask is not None:
+            loss_mask = loss_mask & obs.token_loss_mask[:, 1:]
+        lm_bool = loss_mask if obs.sample_mask is None else loss_mask & obs.sample_mask[:, None]
+        lm = lm_bool.to(torch.float32)
+        cnt = torch.clamp(lm.sum(-1), min=1.0)
+        # Only rows whose loss mask is set matter (the reference multiplies the other rows' cross entropy by 0): with the host
+        # hint `loss_rows_max` the head runs on that many rows per sample — the masked ones first (stable order), padded with
+        # rows of weight 0 — instead of all Lt - 1 (BASELINE shapes: 16 of 47).  A hint smaller than a sample's count would drop
+        # tokens silently, so the device-side check turns the loss into NaN instead (no host sync).
+        n_sel = observation.loss_rows_max if observation.loss_rows_max is not None else obs.loss_rows_max
+        sel = None
+        if n_sel is not None and 0 < n_sel < Lt - 1 and os.environ.get("LAP_LM_ALL_ROWS", "0") != "1":
+            sel = torch.sort((~lm_bool).to(torch.uint8), dim=1, stable=True).indices[:, :n_sel]          # [B, n_sel] in 0 .. Lt-2
+            hint_too_small = (lm.sum(-1) > n_sel).any()
+            Ls = n_sel
+            rowid = (torch.arange(B, device=dev) * Pn + (Pn - Lt))[:, None] + sel
+            rows = xf0.index_select(0, rowid.view(-1))
+            targets = obs.tokenized_prompt[:, 1:].gather(1, sel).to(torch.int32).contiguous().view(-1)
+            lm_s = lm.gather(1, sel)
+        else:
+            Ls = Lt - 1
+            rows = torch.empty((B * Ls, Dv), dtype=torch.bfloat16, device=dev)
+            hip.copy_rows_bf16(xf0, rows, B * Ls, Ls, Dv, Pn, Pn - Lt, Ls, 0)
+            targets = obs.tokenized_prompt[:, 1:].to(torch.int32).contiguous().view(-1)
+            lm_s = lm
+        R = B * Ls
         pl, rstd_pl = hip.rmsnorm_fwd(rows, scale=self.F("llm/final_norm"), save_rstd=backward)
-        table16 = self.W("llm/embed")
-        targets = obs.tokenized_prompt[:, 1:].to(torch.int32).contiguous().view(-1)
+        # Embedder.decode (gemma.py:153-154) multiplies the bf16 pre-logits by the F32 table: table = hi + lo, two bf16 planes
+        # (16 mantissa bits; the products are exact in the f32 accumulator) -> logits to ~2^-17 of the f32 product
+        table16, table_lo = self.W("llm/embed"), self.ps.w16lo("llm/embed")
+        if os.environ.get("LAP_LM_NO_LO", "0") == "1":       # A/B switch: the bf16 mirror alone (the pre-round-3 dtype flow)
+            table_lo = None
         # vocab chunks: one when [R, V] bf16 stays below the 2 GiB buffer-descriptor range of the GEMM (B <= 32 here)
         vc_max = max(1024, (int(1.5e9) // (2 * R)) // 1024 * 1024)
         chunks = [(v0, min(vc_max, V - v0)) for v0 in range(0, V, vc_max)]
@@ -842,17 +869,14 @@ class LAP:
         for v0, vc in chunks:
             lg = torch.empty((R, vc), dtype=torch.float32, device=dev)
             hip.gemm(pl, table16[v0:v0 + vc], lg, M=R, N=vc, K=Dv, lda=Dv, ldb=Dv, ldc=vc)
+            if table_lo is not None:
+                hip.gemm(pl, table_lo[v0:v0 + vc], lg, M=R, N=vc, K=Dv, lda=Dv, ldb=Dv, ldc=vc, accum=True)
             hip.ce_chunk_update(lg, targets, m, lsum, tl, v0)
             logit_chunks.append(lg if backward else None)
-        nll = (m + torch.log(lsum) - tl).view(B, Lt - 1)
-        loss_mask = obs.tokenized_langact_mask[:, 1:] & obs.tokenized_prompt_mask[:, 1:]
-        if obs.token_loss_mask is not None:
-            loss_mask = loss_mask & obs.token_loss_mask[:, 1:]
-        lm = loss_mask.to(torch.float32)
-        if obs.sample_mask is not None:
-            lm = lm * obs.sample_mask[:, None].to(torch.float32)
-        cnt = torch.clamp(lm.sum(-1), min=1.0)
-        lang_loss = (nll * lm).sum(-1) / cnt
+        nll = (m + torch.log(lsum) - tl).view(B, Ls)
+        lang_loss = (nll * lm_s).sum(-1) / cnt
+        if sel is not None:
+            lang_loss = torch.where(hint_too_small, torch.full_like(lang_loss, float("nan")), lang_loss)
         # ---- action loss (lap.py:291-301)
         pre1, rstd_p1 = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=backward)
         pre1f = hip.cast_bf16_to_f32(pre1)
@@ -923,26 +947,39 @@ class LAP:
         skip_prefix = self._prefix_frozen()
         dx0 = None
         if not skip_prefix:
-            # language head: dlogits = w * (softmax - onehot); w = d loss / d nll
-            w = (wl[:, None] * lm / cnt[:, None] / n_active).contiguous().view(-1)
-            dpl32 = torch.empty((R, Dv), dtype=torch.float32, device=dev) if len(chunks) > 1 else None
+            # language head: dlogits = w * (softmax - onehot); w = d loss / d nll.  The cotangent of the f32 logits stays f32 in the
+            # reference (d pre_logits = dlogits . table, d table = dlogits^T . pre_logits in f32): dlogits = dh + dl (two bf16
+            # planes), table = hi + lo -> dh.hi + dl.hi + dh.lo (dl.lo is 2^-16 of the sum) and (dh + dl)^T . pre_logits
+            w = (wl[:, None] * lm_s / cnt[:, None] / n_active).contiguous().view(-1)
+            hilo = table_lo is not None
+            # hi / lo planes stacked along the rows, [dh; dl]: ONE weight-gradient product over 2R rows against [pl; pl] (the f32
+            # [V, D] output is written once instead of accumulated onto), ONE data-gradient product [dh; dl] . hi (the table plane
+            # is read once), plus dh . lo onto its first half
+            RR = 2 * R if hilo else R
+            pl2 = torch.cat([pl, pl], 0) if hilo else pl
+            dpl32 = torch.empty((RR, Dv), dtype=torch.float32, device=dev) if (len(chunks) > 1 or hilo) else None
             gE = self.G("llm/embed")
             for ci, (v0, vc) in enumerate(chunks):
-                dlogits = torch.empty((R, vc), dtype=torch.bfloat16, device=dev)
-                hip.ce_chunk_grad(logit_chunks[ci], targets, m, lsum, w, dlogits, v0)
+                dlogits = torch.empty((RR, vc), dtype=torch.bfloat16, device=dev)
+                hip.ce_chunk_grad(logit_chunks[ci], targets, m, lsum, w, dlogits[:R], v0, dlogits_lo=dlogits[R:] if hilo else None)
                 logit_chunks[ci] = None
                 if self.ps.is_trainable("llm/embed"):
-                    hip.linear_wgrad(dlogits, pl, gE[v0:v0 + vc])
+                    hip.linear_wgrad(dlogits, pl2, gE[v0:v0 + vc])
                 if dpl32 is None:
                     dpl = hip.linear_dgrad(dlogits, table16[v0:v0 + vc])
                 else:
                     hip.linear_dgrad(dlogits, table16[v0:v0 + vc], out=dpl32, accum=ci > 0)
+                    if hilo:
+                        hip.linear_dgrad(dlogits[:R], table_lo[v0:v0 + vc], out=dpl32[:R], accum=True)
                 del dlogits
             if dpl32 is not None:
-                dpl = hip.cast_f32_to_bf16(dpl32)
+                dpl = hip.cast_f32_to_bf16(dpl32[:R] + dpl32[R:] if hilo else dpl32)
             drows = hip.rmsnorm_bwd(rows, dpl, rstd_pl, scale=self.F("llm/final_norm"), dscale=self.G("llm/final_norm"))
             dx0 = torch.zeros((B * Pn, Dv), dtype=torch.bfloat16, device=dev)
-            hip.copy_rows_bf16(drows, dx0, R, Lt - 1, Dv, Lt - 1, 0, Pn, Pn - Lt)
+            if sel is not None:
+                dx0.index_copy_(0, rowid.view(-1), drows)
+            else:
+                hip.copy_rows_bf16(drows, dx0, R, Lt - 1, Dv, Lt - 1, 0, Pn, Pn - Lt)
         dx0, dx1 = self._llm_bwd(lctx, dx0, dx1, mod, dmod, pos, qinfo, kinfo, B, Pn, S)
         sfx = self._embed_suffix_bwd(sctx, dx1, dmod)
         if not skip_prefix:
@@ -1072,6 +1109,9 @@ class LAP:
         V, Dv = self.config.vocab_size, self.v.width
         lg = torch.empty((rows.shape[0], V), dtype=torch.float32, device=self.device)
         hip.gemm(pl, self.W("llm/embed"), lg, M=rows.shape[0], N=V, K=Dv, lda=Dv, ldb=Dv, ldc=V)
+        lo = self.ps.w16lo("llm/embed")      # the f32 table as hi + lo (see _loss_impl)
+        if lo is not None:
+            hip.gemm(pl, lo, lg, M=rows.shape[0], N=V, K=Dv, lda=Dv, ldb=Dv, ldc=V, accum=True)
         return lg
 
     def sample_tokens(self, rng, observation, *, max_decoding_steps: int = 390, temperature: float = 0.0, collect=None):

@@ -43,6 +43,11 @@ class CoTObservation:
     is_vqa_sample: torch.Tensor | None = None
     is_prediction_sample: torch.Tensor | None = None
     vqa_dataset_id: torch.Tensor | None = None
+    # Engine hint, a HOST int (not a reference field): an upper bound on the number of loss-carrying token positions per sample
+    # of this batch (langact & prompt & loss masks, positions 1..L-1).  With it the language head computes logits for that many
+    # rows per sample instead of all L-1 (lap.py:221-260 computes them all and multiplies by the mask); set by `from_dict` and the
+    # loaders from the host-side masks.  A bound that is too small poisons the loss with NaN (checked on the device, no sync).
+    loss_rows_max: int | None = None
 
     @classmethod
     def from_dict(cls, data: dict, device=None) -> "CoTObservation":
@@ -59,7 +64,17 @@ class CoTObservation:
         cot = data.get("extras", {}).get("cot", {}) if isinstance(data.get("extras"), dict) else {}
         g = lambda k: data.get(k, cot.get(k))
         b = lambda k: _t(g(k), torch.bool, device)
+        hint = None
+        la, pm, tl = g("tokenized_langact_mask"), data.get("tokenized_prompt_mask"), g("token_loss_mask")
+        if la is not None and pm is not None and not (isinstance(la, torch.Tensor) and la.is_cuda):   # host-side masks: count here
+            import numpy as np
+
+            m = np.asarray(la, dtype=bool) & np.asarray(pm, dtype=bool)
+            if tl is not None:
+                m = m & np.asarray(tl, dtype=bool)
+            hint = int(m[:, 1:].sum(-1).max()) if m.ndim == 2 and m.shape[1] > 1 else None
         return cls(
+            loss_rows_max=hint,
             images=images,
             image_masks={k: _t(v, torch.bool, device) for k, v in data.get("image_mask", {}).items()},
             state=_t(data.get("state"), torch.float32, device),

@@ -125,6 +125,9 @@ class ParamStore:
         self.tensor_unit = {t.name: u for u in self.units for t in u.tensors}
         self.tensor_spec = {t.name: t for u in self.units for t in u.tensors}
         self.full16: dict[str, torch.Tensor] = {}   # unit -> bf16 mirror [padded numel] (big units)
+        # unit -> bf16 residual plane, lo = bf16(master - float(mirror)): only the embedding table has one.  The LM head multiplies
+        # by the F32 table (gemma.py:153-154); hi + lo carries 16 of its mantissa bits into two bf16 MFMA products (model.py)
+        self.lo16: dict[str, torch.Tensor] = {}
         self.master: dict[str, torch.Tensor] = {}   # unit -> f32 master (this rank's shard for big units if N>1)
         self.m: dict[str, torch.Tensor] = {}
         self.v: dict[str, torch.Tensor] = {}
@@ -142,6 +145,8 @@ class ParamStore:
             self.master[u.name] = z(sh)
             if u.big:
                 self.full16[u.name] = z(n, torch.bfloat16)
+                if u.name == "embed":
+                    self.lo16[u.name] = z(n, torch.bfloat16)
             if with_grads:
                 self.grad[u.name] = z(n)
                 self.gshard[u.name] = self.grad[u.name] if self.sharded(u) is False else z(sh)
@@ -263,6 +268,8 @@ class ParamStore:
         self.master[u.name].copy_(full[a:b])
         if u.big:
             self.full16[u.name].copy_(full)  # dtype cast
+            if u.name in self.lo16:
+                self.lo16[u.name].copy_(full - self.full16[u.name].to(torch.float32))
 
     def init_random(self, seed: int = 0):
         """Reference initialisers in distribution family (lecun-normal GEMMs, zeros for norm scales / adaRMS,
@@ -298,6 +305,19 @@ class ParamStore:
         for u in self.units:
             if u.big and not self.sharded(u):
                 self.full16[u.name].copy_(self.master[u.name])
+        self.refresh_lo_shard()
+
+    def refresh_lo_shard(self):
+        """Residual plane of this rank's slice of the embedding table from its f32 master slice and the bf16 mirror (after the
+        masters were written directly: checkpoint restore).  Under FSDP the caller gathers the plane like the mirror."""
+        for name, lo in self.lo16.items():
+            a, b = self.shard_range(self.unit_by_name[name])
+            lo[a:b].copy_(self.master[name] - self.full16[name][a:b].to(torch.float32))
+
+    def w16lo(self, name: str) -> torch.Tensor | None:
+        """The bf16 residual plane of a matrix that has one (the embedding table), or None."""
+        u = self.tensor_unit[name]
+        return self._view(self.lo16[u.name], name) if u.name in self.lo16 else None
 
     def load_reference_tree(self, P: dict):
         """Fill from a parameter tree in the reference's names / layouts (see module docstring and
@@ -322,7 +342,7 @@ class ParamStore:
         import torch.distributed as dist
 
         self.quiesce()
-        src = self.master if which == "master" else self.ema
+        src = {"master": self.master, "ema": self.ema, "m": self.m, "v": self.v}[which]
         out = {}
         for u in self.units:
             buf = src[u.name]

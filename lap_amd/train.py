@@ -269,7 +269,7 @@ class SyntheticDataLoader:
             tokenized_prompt=torch.randint(0, cfg.vocab_size, (B, L), generator=g, dtype=torch.int32).to(dev),
             tokenized_prompt_mask=torch.ones(B, L, dtype=torch.bool, device=dev),
             tokenized_langact_mask=la.to(dev), token_loss_mask=torch.ones(B, L, dtype=torch.bool, device=dev),
-            sample_mask=torch.ones(B, dtype=torch.bool, device=dev))
+            sample_mask=torch.ones(B, dtype=torch.bool, device=dev), loss_rows_max=int(la[:, 1:].sum(-1).max()))
         return obs, torch.randn(B, cfg.action_horizon, cfg.action_dim, generator=g).to(dev)
 
 

@@ -1059,12 +1059,18 @@ def test_serve_infos_kernel_equals_the_torch_construction(hip, B, n_img, T, Lt, 
 
 
 def test_gemm_n_split_of_half_filled_last_column_tile_keeps_the_bits(hip):
-    """N = 1152 at 16,384 rows (SigLIP at B = 32) runs as [0, 1024) + [1024, 1152) (lap_gemm_bf16_ex): every output element keeps
-    its accumulation order, so the result equals the un-split 256 x 256 tiling bit for bit — forward with f32 bias and residual,
-    forward with bias (whole-tile part on the assembly kernel), plain data gradient."""
+    """N = 1152 at 16,384 rows (SigLIP at B = 32) runs as [0, 1024) + [1024, 1152) (lap_gemm_bf16_ex): the whole-tile part keeps
+    every element's accumulation order (bit-equal to the un-split 256 x 256 tiling); the 128-column tail runs on the 128 x 128
+    tile with its automatic K split, i.e. the same products in a different f32 summation order (one bf16 rounding apart at
+    most) — forward with f32 bias and residual, forward with bias (whole-tile part on the assembly kernel), plain data gradient."""
     M, N, K = 16384, 1152, 2048
     a = rnd(M, K, scale=0.3); w = rnd(N, K, scale=0.3, seed=1); b = rnd(N, dtype=torch.float32, seed=2); r = rnd(M, N, seed=3)
+
+    def check(got, want):
+        assert torch.equal(got[:, :1024], want[:, :1024])
+        assert rel_err(got[:, 1024:], want[:, 1024:]) < 3e-3 and (got[:, 1024:] != want[:, 1024:]).float().mean() < 0.2
+
     for kw in (dict(bias=b, residual=r), dict(bias=b), dict()):
-        assert torch.equal(hip.linear_fwd(a, w, **kw), hip.linear_fwd(a, w, tile=5, **kw)), list(kw)
+        check(hip.linear_fwd(a, w, **kw), hip.linear_fwd(a, w, tile=5, **kw))
     wt = rnd(K, N, scale=0.3, seed=4)
-    assert torch.equal(hip.linear_dgrad(a, wt), hip.linear_dgrad(a, wt, tile=5))
+    check(hip.linear_dgrad(a, wt), hip.linear_dgrad(a, wt, tile=5))

@@ -392,6 +392,49 @@ def test_full_size_train_steps_do_not_depend_on_the_stream_schedule(hip, monkeyp
     print(f"3 steps at B=32: one stream {a} / again {a2} / default schedule {b}")
 
 
+def test_language_head_on_loss_rows_only_equals_all_rows(hip):
+    """`CoTObservation.loss_rows_max` (host hint): the language head runs on the loss-carrying rows only (lap.py:221-260 computes
+    every row and multiplies by the mask).  Every kept row's logits are the same GEMM rows, so losses and metrics agree to the
+    f32 summation order of the per-sample sums (1e-6), gradients to that of the head's weight gradient (fewer zero rows in
+    its contraction); a hint below a sample's count poisons the loss with NaN instead of dropping tokens."""
+    import dataclasses as dc
+
+    cfg = debug_model_cfg()
+    oc = oracle_cfg(cfg)
+    P = O.init_params(oc, seed=19)
+    obs, actions, noise, time = make_inputs(cfg, B=3, ragged=True)
+    model = _engine(cfg, P)
+    o = to_observation(obs, DEV)
+    lmask = (obs["tokenized_langact_mask"] & obs["tokenized_prompt_mask"] & obs["token_loss_mask"])[:, 1:]
+    n_max = int(lmask.sum(-1).max())
+    assert 0 < n_max < cfg.max_token_len - 1
+
+    def run(ob):
+        for g in model.ps.grad.values():
+            g.zero_()
+        col = {}
+        loss, met = model.loss_and_grad(0, ob, actions.to(DEV), noise=noise.to(DEV), time=time.to(DEV), collect=col)
+        torch.cuda.synchronize()
+        return loss.clone(), {k: v.clone() for k, v in met.items()}, col["per_sample_lang"].clone(), {n: model.ps.g(n).detach().clone() for n in model.ps.names()}
+
+    l_all, m_all, ps_all, g_all = run(o)
+    for hint in (n_max, n_max + 3):
+        l_sel, m_sel, ps_sel, g_sel = run(dc.replace(o, loss_rows_max=hint))
+        close = lambda a, b: torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+        assert close(l_sel, l_all) and close(ps_sel, ps_all) and all(close(m_sel[k], m_all[k]) for k in m_all)
+        for n in g_all:
+            assert torch.equal(g_sel[n], g_all[n]) or rel(g_sel[n], g_all[n]) < 2e-5, n
+    l_bad, _, _, _ = run(dc.replace(o, loss_rows_max=n_max - 1))
+    assert torch.isnan(l_bad)
+    # from_dict derives the hint from host-side masks
+    from lap_amd.observation import CoTObservation
+
+    d = {"image": {k: v.numpy() for k, v in obs["images"].items()}, "image_mask": {k: v.numpy() for k, v in obs["image_masks"].items()},
+         "tokenized_prompt": obs["tokenized_prompt"].numpy(), "tokenized_prompt_mask": obs["tokenized_prompt_mask"].numpy(),
+         "tokenized_langact_mask": obs["tokenized_langact_mask"].numpy(), "token_loss_mask": obs["token_loss_mask"].numpy()}
+    assert CoTObservation.from_dict(d, device="cpu").loss_rows_max == n_max
+
+
 def test_graphed_sampler_replay_equals_eager_and_oracle(hip):
     """BASELINE config 4: the hipGraph-captured batch-1 sampler (serve.GraphedSampler).  Capture once, replay for two
     DIFFERENT requests: every replay must equal the eager sampler bit for bit (same kernels, same order) and agree
@@ -574,12 +617,35 @@ def test_train_step_matches_oracle_adamw(hip):
     new = state2.model.ps.to_reference_tree("master")
     ema = state2.model.ps.to_reference_tree("ema")
     d, on = tc.get_ema_decay_for_step(0)
+    # (1) The optimizer arithmetic, EVERY tensor, tight: clip -> AdamW -> EMA applied to the ENGINE's own gradients must be the
+    # oracle's optax restatement of the same gradients (f32 kernel with 1-ulp rcp / sqrt vs torch f32: 2e-5 on the update).
+    # The gradients themselves are held to 5e-2 per tensor by the gradient tests above; comparing the END-TO-END update against
+    # the oracle's gradients is inherently loose on the first Adam step (update = lr * g / (|g| + eps) ~ lr * sign(g): every
+    # element whose gradient is bf16 noise flips by 2 lr), which is what the old 15 % bound on four tensors absorbed.
+    ps = state2.model.ps
+    g_eng = engine_to_reference(cfg, {name: ps.g(name).detach().float().cpu() for name in ps.names()})
+    gn_eng = torch.sqrt(sum((g.double() ** 2).sum() for g in g_eng.values())).item()
+    assert abs(info["grad_norm"].item() - gn_eng) / gn_eng < 1e-5
+    cs_e = O.clip_scale(gn_eng, tc.optimizer.clip_gradient_norm)
+    m_eng, v_eng = ps.to_reference_tree("m"), ps.to_reference_tree("v")
+    worst = 0.0
+    for k in P:
+        p1, m1, v1 = O.adamw_step(P[k], g_eng[k], torch.zeros_like(P[k]), torch.zeros_like(P[k]), 1, lr, tc.optimizer.b1,
+                                  tc.optimizer.b2, tc.optimizer.eps, tc.optimizer.weight_decay, cs_e)
+        du, dr = new[k] - P[k], p1 - P[k]
+        if dr.norm() > 0:
+            # elements with |g| ~ eps * sqrt(1 - b2) sit on the knee of g / (|g| + eps): compare where the update is well conditioned
+            big = g_eng[k].abs() * cs_e > 1e-5
+            e = rel(du[big], dr[big]) if big.any() else 0.0
+            worst = max(worst, e)
+            assert e < 2e-5, (k, e)
+        assert rel(m_eng[k], m1) < 1e-6 and rel(v_eng[k], v1) < 1e-6, k
+        assert on and rel(ema[k], d * P[k] + (1 - d) * new[k]) < 1e-6, k
+    # (2) end to end against the oracle's own gradients: a sanity bound only (see above)
     for k in ("PaliGemma/llm/layers/mlp/linear", "PaliGemma/img/head/kernel", "action_out_proj/kernel", "PaliGemma/llm/layers/pre_ffw_norm/scale"):
         p1, _, _ = O.adamw_step(P[k], Pg[k].grad, torch.zeros_like(P[k]), torch.zeros_like(P[k]), 1, lr, tc.optimizer.b1,
                                 tc.optimizer.b2, tc.optimizer.eps, tc.optimizer.weight_decay, cs)
-        # first Adam step moves every weight by ~lr * sign(g): compare the update, not the weight
-        assert rel(new[k] - P[k], p1 - P[k]) < 0.15, k
-        assert on and rel(ema[k], d * P[k] + (1 - d) * new[k]) < 1e-6, k
+        assert rel(new[k] - P[k], p1 - P[k]) < 0.25, k
     assert state2.step == 1
 
 
