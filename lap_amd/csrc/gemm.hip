@@ -112,7 +112,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
       const int row = BK == 64 ? ci >> 3 : ci >> 2, pc = BK == 64 ? ci & 7 : ci & 3;
       const int c = BK == 64 ? pc ^ ((row >> 1) & 7) : pc ^ ((-(row >> 2)) & 3);
       kidxB[j] = c * 8;
-      offB[j] = (n0 + row < p.N) ? (unsigned)(((long long)(n0 + row) * p.ldb + c * 8) * 2) : OOB;
+      int brow = n0 + row;
+      if constexpr (BM == 320 && BN == 256 && !OUT_F32) {
+        // GeGLU pairing: wave column group wn (64 tile columns) = 32 gate columns + the 32 up columns of the same features
+        if (p.geglu) brow = ((row & 63) < 32 ? 0 : p.N / 2) + tn * 128 + (row >> 6) * 32 + (row & 31);
+      }
+      offB[j] = (brow < p.N) ? (unsigned)(((long long)brow * p.ldb + c * 8) * 2) : OOB;
     } else {
       constexpr int CPR = BN / 8;
       const int kr = ci / CPR, pc = ci % CPR;
@@ -213,6 +218,25 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
   const int li = lane & 15, lg = lane >> 4;
   if constexpr (BM == 256 && BN == 256 && NW == 16) {
     if (p.epi_lds) { staged_epilogue<NW, WTM, WTN, OUT_F32>(p, smem, acc, wm, wn, m0, n0, tid, lane); return; }
+  }
+  if constexpr (BM == 320 && BN == 256 && !OUT_F32) {
+    if (p.geglu) {   // fragments j = 0, 1: gate columns; j = 2, 3: the up columns of the same features (csrc/elementwise.hip geglu_fwd's bits)
+      static_assert(FN == 4, "GeGLU pairing assumes 64-column wave tiles");
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + li;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int gc = tn * 128 + wn * 32 + j * 16 + 4 * lg;
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(round_bf16(gelu_tanh_f(round_bf16(acc[i][j][e]))) * round_bf16(acc[i][j + 2][e]));
+          *reinterpret_cast<bf16x4*>((bf16*)p.C + (long long)m * p.ldc + gc) = o;
+        }
+      }
+      return;
+    }
   }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
@@ -1467,6 +1491,11 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   if ((flags & LAP_GEMM_ACCUM) && !f32) return LAP_ERR_ARG;
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
   if (tile < -1 || tile > 19 || ksplit < 0) return LAP_ERR_ARG;
+  if (flags & LAP_GEMM_GEGLU) {   // gate|up projection + GeGLU in one launch (serving prefill): the 320-row tile only
+    if (!a_kc || !b_kc || f32 || bias || residual || (flags & ~LAP_GEMM_GEGLU) || (N & 255) || M > 640 || alpha != 1.0f || ksplit > 1 || (tile >= 0 && tile != 15))
+      return LAP_ERR_ARG;
+    tile = 15; ksplit = 1;
+  }
   // Few output tiles but a very long contraction (LM-head dgrad: 1504 x 2048 over K = 257152; prefill down
   // projection): the big tile with enough K splits to cover the chip beats the small tile walking all of K.
   if (tile < 0 && ksplit == 0 && scratch != nullptr && K >= 16384 && !(flags & LAP_GEMM_PARTIALS)) {
@@ -1599,6 +1628,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   p.bias_kind = bias ? ((flags & LAP_GEMM_BIAS_F32) ? 2 : 1) : 0;
   p.gelu = (flags & LAP_GEMM_GELU) ? ((flags & LAP_GEMM_GELU_BF16) ? 2 : 1) : 0;
   p.accum = (flags & LAP_GEMM_ACCUM) ? 1 : 0;
+  p.geglu = (flags & LAP_GEMM_GEGLU) ? 1 : 0;
   p.ksplit = ksplit > 1 ? ksplit : 1;
   p.dbg = g_gemm_dbg;
   p.part = two_phase ? (float*)scratch : nullptr;

@@ -25,6 +25,8 @@ struct GemmParams {
   int tile_count;        // host side only: tiles of this launch (0 = all from tile_base)
   int part_compact;      // partial slabs are [ksplit][gridDim.x][256][256] (tail split of the 256x256 kernel)
   int sub256;            // 128x128 launch that covers tiles [tile_base, ..) of the 256x256 grid, 4 blocks (quadrants) per tile
+  int geglu;             // tile 15 only: N = 2H rows of B are [gate | up]; a block computes 128 gate + the matching 128 up columns and
+                         // stores act = bf16(bf16(gelu(gate)) * up) [M][ldc] (gemma.py:303-312): the serving prefill's gate|up + GeGLU
   int epi_lds;           // output of the 256x256 kernel goes out through LDS in full rows (set by the host); 2: with nontemporal stores
   int dbg;               // LAP_GEMM_EXPERIMENTAL builds only: ablation bits of gemm_sp_kernel (1: no in-loop LDS-DMA, 2: no MFMA)
   const float* qscale_a; // fp8 kernels: device scalars s_a, s_b the operands were multiplied by before rounding to e4m3;

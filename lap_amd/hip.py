@@ -20,6 +20,7 @@ GEMM_GELU = 4
 GEMM_BIAS_F32 = 8
 GEMM_PARTIALS = 16
 GEMM_GELU_BF16 = 32
+GEMM_GEGLU = 64
 
 
 class LapHipError(RuntimeError):
@@ -224,6 +225,16 @@ def linear_fwd(x, wt, out=None, *, bias=None, residual=None, gelu=False, out_dty
     return gemm(x, wt, out, M=M, N=N, K=K, lda=x.stride(0), ldb=wt.stride(0), ldc=out.stride(0), bias=bias,
                 residual=residual, ldr=(residual.stride(0) if residual is not None else 0), gelu=gelu, tile=tile,
                 ksplit=ksplit)
+
+
+def linear_geglu(x, wgu):
+    """act[M, H] = GeGLU(x @ wgu[2H, in]^T): the gate|up projection and lap_geglu_fwd in one launch (serving prefill, M <= 640)."""
+    M, K = x.shape
+    H = wgu.shape[0] // 2
+    act = torch.empty((M, H), dtype=torch.bfloat16, device=x.device)
+    call("lap_gemm_bf16_ex", _p(x), _p(wgu), _p(act), None, None, M, 2 * H, K, x.stride(0), wgu.stride(0), H, 0, 1.0, 1, 1, GEMM_GEGLU, -1, 0,
+         None, 0)
+    return act
 
 
 def linear_dgrad(dy, wt, out=None, *, out_dtype=torch.bfloat16, accum=False, tile=-1, ksplit=0):

@@ -82,6 +82,11 @@ class LAP:
         self.dual_stream = os.environ.get("LAP_DUAL_STREAM", "1") != "0"
         # serving prefill on the fused consumers (`_siglip_fwd_serve`, `_llm_prefill`); "0": the generic layer loops (A/B, tests)
         self.serve_fusions = os.environ.get("LAP_SERVE_FUSIONS", "1") != "0"
+        # first denoise step on a second stream beside the prefill (it needs layer l's K / V only at its layer l).  Measured, hipGraph
+        # replay, same box, interleaved: 15.65 -> 16.30 ms per chunk — the step's 110 short kernels take CUs from the prefill's
+        # load-bound GEMMs for longer than they save.  Kept as a switch, OFF by default.
+        self.serve_overlap = os.environ.get("LAP_SERVE_OVERLAP", "0") != "0"
+        self._den = None
         ks = os.environ.get("LAP_PREFILL_KS", "4,1,8,5").split(",")    # K splits of the prefill's qkv / out / down projections, down's tile
         self._prefill_ks = tuple(int(k) for k in ks)
         self._sfx = None        # the suffix stream's HIP stream (created on first use)
@@ -633,7 +638,7 @@ class LAP:
         self._handoff(sfx, main, x1)
         return x0, x1, ctx
 
-    def _llm_prefill(self, x0, pos, qinfo, kinfo, B, n0, cache_out):
+    def _llm_prefill(self, x0, pos, qinfo, kinfo, B, n0, cache_out, kv_events=None):
         """The prefix-only pass of `_llm_fwd` (x1 = None, nothing saved) for the serving prefill: K / V of every layer go to
         `cache_out`, the last layer's residual stream is returned.  Same operations and rounding points; the split-K projections
         leave f32 slabs and their consumers do the rest in one pass each — qkv: reduce + RoPE + head split (sin / cos of the
@@ -653,6 +658,10 @@ class LAP:
             part, ks = hip.linear_partials(h, self.W(p + "wqkv0"), scratch, ksplit=self._prefill_ks[0])
             q, k, vv = hip.fused_reduce_rope_split(part, ks, pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5, table=tab)
             cache_out.append((k, vv))
+            if kv_events is not None:     # layer l's K / V exist from here on: the first denoise step may use them (sample_actions)
+                ev = torch.cuda.Event()
+                ev.record()
+                kv_events.append(ev)
             o, _ = hip.attention_fwd([q, None], [k, None], [vv, None], [n0, 0], [n0, 0], B, NH, KV, HD, qinfo, kinfo, need_lse=False)
             if self._prefill_ks[1] > 1:
                 part, ks = hip.linear_partials(o[0], self.W(p + "wo0"), scratch, ksplit=self._prefill_ks[1])
@@ -660,7 +669,10 @@ class LAP:
             else:   # (measured: the unsplit 64-row tile with the residual epilogue + a norm launch beats split + fused consumer here)
                 xa = hip.linear_fwd(o[0], self.W(p + "wo0"), residual=x0)
                 hf, _ = hip.rmsnorm_fwd(xa, scale=self.F(p + "n_ffw"), save_rstd=False)
-            act = hip.geglu_fwd(hip.linear_fwd(hf, self.W(p + "wgu0")))
+            if rows <= 640 and (v.mlp_dim & 127) == 0:    # gate|up projection + GeGLU in one launch (the 320-row tile's paired epilogue)
+                act = hip.linear_geglu(hf, self.W(p + "wgu0"))
+            else:
+                act = hip.geglu_fwd(hip.linear_fwd(hf, self.W(p + "wgu0")))
             part, ks = hip.linear_partials(act, self.W(p + "wd0"), scratch, ksplit=self._prefill_ks[2], tile=self._prefill_ks[3])
             if l + 1 < v.depth:
                 self.comm.wait_unit(f"llm{l + 1}")
@@ -770,7 +782,7 @@ class LAP:
             x, h = hip.fused_reduce_residual_norm(part, ks, xa, slot(2 * l + 1)[:, 2 * We:], 0, slot(2 * l + 2), 0, S)
         return h   # slot 2L is final_norm_1: h == final adaRMS norm of the last layer's output
 
-    def _expert_denoise_skinny(self, x1, mod, qinfo, kinfo, B, Pn, S, cache, rope_tab):
+    def _expert_denoise_skinny(self, x1, mod, qinfo, kinfo, B, Pn, S, cache, rope_tab, kv_events=None):
         """The same 18 layers on the skinny-M fused projections (csrc/serve_skinny.hip): five launches per layer —
         [adaRMS + qkv + RoPE/split] -> attention -> [out-proj + gated residual] -> [adaRMS + gate|up + GeGLU] ->
         [down-proj + gated residual] — with no f32 partial slabs in between.  Returns the last layer's residual stream
@@ -785,6 +797,9 @@ class LAP:
             p = f"llm/{l}/"
             q, k, vv = hip.serve_qkv_rope(x, slot(2 * l), 0, S, self.W(p + "wqkv1"), rope_tab, NH, HD, HD ** -0.5)
             ck, cv = cache[l]
+            if kv_events is not None:     # running beside the prefill (first denoise step): layer l's cache is ready at its event
+                torch.cuda.current_stream().wait_event(kv_events[l])
+                ck.record_stream(torch.cuda.current_stream()); cv.record_stream(torch.cuda.current_stream())
             o, _ = hip.attention_fwd([None, q], [ck, k], [cv, vv], [0, S], [Pn, S], B, NH, KV, HD, qinfo, kinfo, need_lse=False)
             xa = hip.serve_proj_residual(o[1], self.W(p + "wo1"), x, slot(2 * l)[:, 2 * We:], 0, S)
             act = hip.serve_gate_up(xa, slot(2 * l + 1), 0, S, self.W(p + "wgu1"))
@@ -1020,11 +1035,6 @@ class LAP:
         x_t = noise.to(dev, torch.float32).contiguous().clone()
         x0, Pn, _ = self._embed_prefix(obs, False, serve=True)
         qinfo_p, kinfo_p, ppos, qinfo_s, kinfo_all, pos_all = self._serve_infos(obs, S)
-        cache = []
-        if self.serve_fusions and collect is None and self.gemm_dtype == "bf16":
-            self._llm_prefill(x0, ppos, qinfo_p, kinfo_p, B, Pn, cache)
-        else:
-            self._llm_fwd(x0, None, None, ppos, qinfo_p, kinfo_p, B, Pn, 0, False, cache_out=cache)
         dt = -1.0 / num_steps
         times, t = [], 1.0
         while t >= -dt / 2:  # lap.py:669-674 loop condition, unrolled on the host (the time grid is data independent)
@@ -1036,14 +1046,38 @@ class LAP:
         mods = self._serve_mods(len(times), dt)
         # ... and so are the action tokens' positions: one sin / cos table serves the 10 x 18 fused RoPE kernels
         rope_tab = hip.rope_table(pos_all, B, S, pos_all.shape[1], pos_all.shape[1] - S, self.v.head_dim) if fused else None
+        cache = []
+        fast_prefill = self.serve_fusions and collect is None and self.gemm_dtype == "bf16"
+        # The first denoise step needs layer l's K / V only when it reaches layer l: it is issued on a second stream and runs
+        # beside the prefill's layers l+1 .. (whose big GEMMs leave CUs idle at their tails), joined before step 1.
+        overlap = fast_prefill and fused == "skinny" and self.serve_overlap and dev.type == "cuda" and len(times) > 1
+        kv_events = [] if overlap else None
+        if overlap:
+            if self._den is None:
+                self._den = torch.cuda.Stream(dev)
+            start = torch.cuda.Event()
+            start.record()
+        if fast_prefill:
+            self._llm_prefill(x0, ppos, qinfo_p, kinfo_p, B, Pn, cache, kv_events=kv_events)
+        else:
+            self._llm_fwd(x0, None, None, ppos, qinfo_p, kinfo_p, B, Pn, 0, False, cache_out=cache)
         nslot = 2 * self.v.depth
         for step in range(len(times)):
             mod = mods[step:step + 1]
             if fused == "skinny":
-                x1 = hip.serve_embed_actions(x_t.view(B * S, ad), self.F("act/in_w"), self.F("act/in_b"))
-                xf1 = self._expert_denoise_skinny(x1, mod, qinfo_s, kinfo_all, B, Pn, S, cache, rope_tab)
-                v_t = torch.empty((B * S, ad), dtype=torch.float32, device=dev) if collect is not None else None
-                hip.serve_final_euler(xf1, self._mod_slot(mod, nslot), 0, S, self.F("act/out_w"), self.F("act/out_b"), x_t.view(B * S, ad), dt, v_t)
+                side = overlap and step == 0
+                main = torch.cuda.current_stream() if side else None
+                if side:
+                    self._den.wait_event(start)
+                    for tns in (x_t, mods, rope_tab, qinfo_s, kinfo_all):
+                        tns.record_stream(self._den)
+                with (torch.cuda.stream(self._den) if side else contextlib.nullcontext()):
+                    x1 = hip.serve_embed_actions(x_t.view(B * S, ad), self.F("act/in_w"), self.F("act/in_b"))
+                    xf1 = self._expert_denoise_skinny(x1, mod, qinfo_s, kinfo_all, B, Pn, S, cache, rope_tab, kv_events=kv_events if side else None)
+                    v_t = torch.empty((B * S, ad), dtype=torch.float32, device=dev) if collect is not None else None
+                    hip.serve_final_euler(xf1, self._mod_slot(mod, nslot), 0, S, self.F("act/out_w"), self.F("act/out_b"), x_t.view(B * S, ad), dt, v_t)
+                if side:
+                    main.wait_stream(self._den)
                 if collect is not None:
                     collect[f"v_t/{step}"] = v_t.view(B, S, ad)
                 continue

@@ -1074,3 +1074,10 @@ def test_gemm_n_split_of_half_filled_last_column_tile_keeps_the_bits(hip):
         check(hip.linear_fwd(a, w, **kw), hip.linear_fwd(a, w, tile=5, **kw))
     wt = rnd(K, N, scale=0.3, seed=4)
     check(hip.linear_dgrad(a, wt), hip.linear_dgrad(a, wt, tile=5))
+
+
+@pytest.mark.parametrize("M,H,K", [(560, 16384, 2048), (601, 256, 192), (320, 128, 64)])
+def test_gemm_geglu_epilogue_equals_projection_then_geglu_kernel(hip, M, H, K):
+    """LAP_GEMM_GEGLU (serving prefill): gate|up projection + GeGLU in one launch = linear_fwd then geglu_fwd, bit for bit."""
+    x = rnd(M, K, scale=0.3); w = rnd(2 * H, K, scale=0.3, seed=1)
+    assert torch.equal(hip.linear_geglu(x, w), hip.geglu_fwd(hip.linear_fwd(x, w, tile=6)))
