@@ -168,26 +168,26 @@ class GemmMeter:
 
 
 def cpu_baseline(cores: int):
-    """CPU oracle (f32, torch CPU autograd) on a bounded slice: LAP-3B widths, BASELINE shapes, NL of 18 joint Gemma
-    layers + NL of 27 SigLIP blocks + a 16k-row vocabulary slice; forward + backward; samples/s extrapolated by the FLOP
-    ratio of the full model to the slice.  The slice grows (2 layers x batch 1 -> 6 layers x batch 2) until the timed
-    region is of the order of 10 s on the host at hand."""
+    """CPU oracle (oracle/lap_oracle.py: f32, torch CPU autograd; kind "port" — the reference's JAX-CPU path cannot be installed
+    offline) on the host cores: ONE full train-step forward + backward of the real LAP-3B (27 SigLIP blocks, 18 joint Gemma
+    layers, 257,152-word vocabulary) at batch 1 on the benchmark's shapes — the smallest whole unit of the metric, no
+    extrapolation.  Hosts with too little memory for the f32 parameters + gradients (27 GB + activations)
+    fall back to a 6-layer slice extrapolated by the forward-FLOP ratio, and say so."""
     from oracle import lap_oracle as O
 
     torch.set_num_threads(cores)
-    V = 16384
-    Tp, S = 560, 50
+    try:
+        import psutil
+        free_gb = psutil.virtual_memory().available / 2 ** 30
+    except Exception:   # noqa: BLE001
+        free_gb = 0.0
+    Tp, S, L = 560, 50, 48
     w_sig_l, w_vlm_l, w_exp_l = 412.4e6 / 27, 1.982e9 / 18, 0.311e9 / 18
     f_full = 2.792e12
-    for NL, B in ((2, 1), (6, 2)):
-        O.GEMMA["gemma_2b_slice"] = O.GemmaCfg(2048, NL, 16384, 8, 1, 256)
-        O.GEMMA["gemma_300m_slice"] = O.GemmaCfg(1024, NL, 4096, 8, 1, 256)
-        O.SIGLIP["So400m/14_slice"] = O.SiglipCfg(1152, NL, 4304, 16)
-        oc = O.OracleCfg(paligemma_variant="gemma_2b_slice", action_expert_variant="gemma_300m_slice", siglip_variant="So400m/14_slice",
-                         action_horizon=50, max_token_len=48, vocab_size=V, language_loss_weight=0.4)
+
+    def run(oc, B, V):
         P = O.init_params(oc, 0)
         g = torch.Generator().manual_seed(0)
-        L = 48
         la = torch.zeros(B, L, dtype=torch.bool); la[:, L - 16:] = True
         obs = dict(images={k: torch.rand(B, 224, 224, 3, generator=g) * 2 - 1 for k in oc.image_keys},
                    image_masks={k: torch.ones(B, dtype=torch.bool) for k in oc.image_keys},
@@ -198,17 +198,29 @@ def cpu_baseline(cores: int):
         t0 = time.perf_counter()
         loss, _ = O.compute_loss(Pg, oc, obs, actions, noise, t)
         loss.backward()
-        dt = time.perf_counter() - t0
-        del P, Pg, loss
-        if dt >= 6.0:
-            break
-    # forward FLOPs per sample of the slice vs the full model (SURVEY.md 8d formula)
+        return time.perf_counter() - t0
+
+    if free_gb >= 96:
+        oc = O.OracleCfg(paligemma_variant="gemma_2b", action_expert_variant="gemma_300m", siglip_variant="So400m/14",
+                         action_horizon=50, max_token_len=L, vocab_size=257152, language_loss_weight=0.4)
+        dt = run(oc, 1, 257152)
+        return {"value": round(1.0 / dt, 6), "unit": "samples/s", "cores": cores, "kind": "port",
+                "sample": f"oracle f32 forward + backward (torch CPU autograd) of the full LAP-3B at batch 1, benchmark shapes: one sample in {dt:.1f} s on "
+                          f"{cores} threads (optimizer update not included: < 1 % of the step's FLOPs); stand-in for the reference's JAX-CPU path, "
+                          f"which cannot be installed offline"}
+    NL, B, V = 6, 2, 16384
+    O.GEMMA["gemma_2b_slice"] = O.GemmaCfg(2048, NL, 16384, 8, 1, 256)
+    O.GEMMA["gemma_300m_slice"] = O.GemmaCfg(1024, NL, 4096, 8, 1, 256)
+    O.SIGLIP["So400m/14_slice"] = O.SiglipCfg(1152, NL, 4304, 16)
+    oc = O.OracleCfg(paligemma_variant="gemma_2b_slice", action_expert_variant="gemma_300m_slice", siglip_variant="So400m/14_slice",
+                     action_horizon=50, max_token_len=L, vocab_size=V, language_loss_weight=0.4)
+    dt = run(oc, B, V)
     f_slice = 2 * (2 * 256 * NL * w_sig_l + NL * 4 * 256 ** 2 * 1152) + 2 * Tp * NL * w_vlm_l + NL * 4 * Tp ** 2 * 2048 \
         + 2 * S * NL * w_exp_l + NL * 4 * S * (Tp + S) * 2048 + 2 * 47 * 2048 * V
     return {"value": round(B / (dt * f_full / f_slice), 6), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle f32 fwd+bwd, batch {B}, LAP-3B widths, {NL}/18 Gemma layers + {NL}/27 SigLIP blocks + 16k-row vocab slice "
-                      f"({dt:.1f} s), extrapolated by forward-FLOP ratio {f_full / f_slice:.1f}x; stand-in for the reference's JAX-CPU "
-                      f"path, which cannot be installed offline"}
+            "sample": f"host has {free_gb:.0f} GB free (< 96): oracle f32 fwd+bwd, batch {B}, LAP-3B widths, {NL}/18 Gemma layers + {NL}/27 SigLIP blocks "
+                      f"+ 16k-row vocab slice ({dt:.1f} s), extrapolated by forward-FLOP ratio {f_full / f_slice:.1f}x; stand-in for the reference's "
+                      f"JAX-CPU path, which cannot be installed offline"}
 
 
 def serve_latency(cfg, dev, reps: int = 20):
@@ -391,9 +403,9 @@ def main():
             torch.cuda.empty_cache()
             out["serve"] = serve_latency(tc.model, dev)
         if world == 1 and not args.no_cpu_baseline:
-            # 16 host threads: torch-CPU matmuls of this size stop scaling well beyond that (256 threads on the
-            # GPU box took 166 s for the same slice)
-            out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))
+            # 32 host threads: torch-CPU matmuls of this size stop scaling (and get slower) well beyond that (256 threads on
+            # the GPU box took 166 s for a 6-layer slice that 16 threads finish in 9 s)
+            out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

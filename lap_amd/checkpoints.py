@@ -156,9 +156,13 @@ def _all_ok(ok: bool, device) -> bool:
 
 
 def _save_once(mngr: CheckpointManager, state, data_loader, step: int, norm_stats, asset_id):
-    """One save attempt.  Every rank runs the same sequence of collectives whatever happens to its own file I/O: local
-    failures are caught, agreed on with `_all_ok`, and re-raised on ALL ranks, so the caller's retry loop iterates in
-    lock-step (a rank retrying alone would leave barrier / all-gather counts mismatched and hang the job)."""
+    """One save attempt.  Every rank runs the same sequence of collectives whatever happens to its own FILE I/O: such local
+    failures (directory setup, tensor / json writes, the commit rename) are caught, agreed on with `_all_ok`, and re-raised on
+    ALL ranks, so the caller's retry loop iterates in lock-step (a rank retrying alone would leave barrier / all-gather counts
+    mismatched and hang the job).  NOT recoverable, by construction: a failure INSIDE the collective phase in between (the
+    stream synchronisation and the all-gathers of `to_reference_tree`: a HIP error surfacing at the sync, host memory exhausted
+    while gathering the f32 tree) — the other ranks are already inside the collective, so that exception propagates and the job
+    has to be restarted from the previous checkpoint."""
     ps = state.model.ps
     rank, world = ps.rank, ps.world_size
     final = mngr.step_dir(step)
