@@ -53,30 +53,31 @@ __global__ __launch_bounds__(512) void attn_serve_kernel(AttnP p, ServeSplits sp
   const int srow0 = sp.sfx_row0;
 
   // ---- every DMA piece of the block, back to back (piece = 2 rows of 512 B; 8 K + 8 V pieces per wave)
-  {
     const long long kvoff0 = (long long)b * p.klen[0] * p.kv_rs[0] + hk * HD, kvoff1 = (long long)b * p.klen[1] * p.kv_rs[1] + hk * HD;
     const auto rsK0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k[0] + kvoff0), 0, seg_records(p.klen[0], p.kv_rs[0], HD), 0x00020000);
     const auto rsV0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.v[0] + kvoff0), 0, seg_records(p.klen[0], p.kv_rs[0], HD), 0x00020000);
     const auto rsK1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k[1] + kvoff1), 0, seg_records(p.klen[1], p.kv_rs[1], HD), 0x00020000);
     const auto rsV1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.v[1] + kvoff1), 0, seg_records(p.klen[1], p.kv_rs[1], HD), 0x00020000);
     const int rb0 = p.kv_rs[0] * 2, rb1 = p.kv_rs[1] * 2;
+    // K pieces now; the V pieces are issued behind the query / info loads (below), so that `vmcnt(8)` — everything but the 8 youngest
+    // operations — means "K image, queries and info words are here" and the scores + softmax run while the V image is still landing
+    auto issue = [&](int kv) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int pc = w * 8 + j;                       // wave uniform
-      const int row = 2 * pc + (lane >> 5);
-      const int col = ((lane & 31) ^ C::swz(row)) << 4;
-      char* dst = smem + pc * 1024;
-      if (has_sfx && 2 * pc >= srow0) {               // rows past the segment end read as zeros (num_records)
-        const unsigned off = (unsigned)((row - srow0) * rb1 + col);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK1, (LDS_PTR(void))(dst + KOFF), 16, off, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV1, (LDS_PTR(void))(dst + VOFF), 16, off, 0, 0, 0);
-      } else {
-        const unsigned off = row < np ? (unsigned)((pbase + row) * rb0 + col) : DMA_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK0, (LDS_PTR(void))(dst + KOFF), 16, off, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV0, (LDS_PTR(void))(dst + VOFF), 16, off, 0, 0, 0);
+      for (int j = 0; j < 8; ++j) {
+        const int pc = w * 8 + j;                       // wave uniform
+        const int row = 2 * pc + (lane >> 5);
+        const int col = ((lane & 31) ^ C::swz(row)) << 4;
+        char* dst = smem + pc * 1024 + (kv ? VOFF : KOFF);
+        if (has_sfx && 2 * pc >= srow0) {               // rows past the segment end read as zeros (num_records)
+          const unsigned off = (unsigned)((row - srow0) * rb1 + col);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(kv ? rsV1 : rsK1, (LDS_PTR(void))dst, 16, off, 0, 0, 0);
+        } else {
+          const unsigned off = row < np ? (unsigned)((pbase + row) * rb0 + col) : DMA_OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(kv ? rsV0 : rsK0, (LDS_PTR(void))dst, 16, off, 0, 0, 0);
+        }
       }
-    }
-  }
+    };
+    issue(0);
   // ---- my query row, its info word, and the keys' info words (in flight together with the DMA)
   const int qt = w & 3, dh = w >> 2;
   const int myq = qt * 16 + i;
@@ -85,15 +86,21 @@ __global__ __launch_bounds__(512) void attn_serve_kernel(AttnP p, ServeSplits sp
   load_row_frags<HD>(p.q[1] + (b * (long long)S + myq) * p.q_rs[1] + h * HD, vq, lane, qf);
   const int qi = !vq ? 0 : (p.qinfo ? p.qinfo[(long long)b * S + myq] : 0x7fffffff);
   const int qcls = qi >> 24, qidx = qi & 0xffffff;
+  int kword = 0;
   if (threadIdx.x < SV_KEYS) {
     const int r = threadIdx.x;
     int joint = -1;                                   // index into the sample's [prefix | suffix] key list
     if (has_sfx && r >= srow0) { if (r - srow0 < S) joint = Pn + r - srow0; }
     else if (r < np) joint = pbase + r;
-    sKw[r] = joint < 0 ? 0 : (p.kinfo ? p.kinfo[(long long)b * Tk + joint] : 0x7f000000);
+    kword = joint < 0 ? 0 : (p.kinfo ? p.kinfo[(long long)b * Tk + joint] : 0x7f000000);
   }
-  wait_vm0();
-  __syncthreads();
+  issue(1);
+  if (threadIdx.x < SV_KEYS) sKw[threadIdx.x] = kword;
+  // all but the 8 V pieces just issued (vector memory operations return in order) + my info word in LDS; a bare barrier: the
+  // fence of __syncthreads() would drain the V pieces as well
+  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 
   // ---- S^T = K Q^T over the block's 128 keys; lane owns query column i and keys 16 t + 4 g + r
   const char* kp[C::KREGS];
@@ -129,6 +136,9 @@ __global__ __launch_bounds__(512) void attn_serve_kernel(AttnP p, ServeSplits sp
       l += sc[t][r];
     }
   l = sum_over_groups(l);
+  wait_vm0();          // the V image
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   // ---- O^T = V^T P^T for this wave's 8 column fragments (columns 128 dh .. 128 dh + 127)
   f32x4 acc[8];
 #pragma unroll
