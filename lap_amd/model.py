@@ -224,6 +224,10 @@ class LAP:
             x8, sx = hip.quantize_fp8(x)
             w8, _, sw = self._w8_of(name)
             return hip.gemm_fp8(x8, sx, w8, sw, residual=residual)
+        if residual is not None and os.environ.get("LAP_UNFUSED_RESIDUAL", "0") == "1":
+            # measurement switch: the reference rounds the projection to bf16 and then the sum to bf16
+            # (gemma.py:285,582-583); the fused epilogue adds in f32 and rounds once
+            return hip.add_bf16(residual, hip.linear_fwd(x, self.W(name)))
         return hip.linear_fwd(x, self.W(name), residual=residual)
 
     def _dgrad0(self, dy, name):
