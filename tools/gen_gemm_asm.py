@@ -38,7 +38,10 @@ import sys
 
 out = []
 E = out.append
-ST_NT = " nt" if os.environ.get("ASM_STORE_NT", "0") == "1" else ""      # nontemporal C stores (A/B knob)
+STAGED = os.environ.get("ASM_EPI", "staged") == "staged"     # C leaves through a per-wave LDS buffer as full 256-byte rows
+# nontemporal C stores: full rows stream past the L2 (+5 % at K = 2048, +12 % at 8192^3); as 32-byte pieces they cost 15-25 %
+ST_NT = " nt" if os.environ.get("ASM_STORE_NT", "1" if STAGED else "0") == "1" else ""
+ABL = set(os.environ.get("ASM_ABL", "").split("+")) - {""}              # timing ablations (WRONG results): nodma nowait nobar noread noepi
 
 
 def L(x):
@@ -57,7 +60,8 @@ S_HAVE, S_TDMA, S_DLEFT, S_NKT = 50, 51, 52, 53      # S_HAVE: the stream has mo
 RQ = 8                      # s[8:11]: descriptor of the 8 per-XCD tile counters
 S_XCC, S_XOFF, S_REQ = 3, 49, 59   # XCC id of the CU this block runs on; its counter's byte offset; wave 0: a ticket request is in flight
 V_TK, V_MB = 14, 15         # ticket (wave 0: the atomic's return value); LDS address of the ticket mailbox
-MAILBOX = 131072            # LDS byte offset (behind the two stages)
+CSTAGE = 131072             # LDS byte offset of the epilogue's staging buffers: 4 KiB per wave ([16 rows][256 B], chunks XOR row)
+MAILBOX = 131072 + 16384    # LDS byte offset of the ticket mailbox (behind the stages and the staging buffers)
 S_BUMPA, S_BUMPB = 54, 55   # bytes per k-tile along each operand
 S_C = 56                    # C pointer pair
 RA, RB, RC = 60, 64, 68     # buffer descriptors
@@ -71,6 +75,10 @@ RBI = 36                    # s[36:39]: bias descriptor (epilogue variant; the p
 V_MOFF = 112                # v112..v119 (fragment set 1, idle during the epilogue): store offsets per fn with the ragged-N mask
 V_NCOL = 13                 # epilogue variant: wn*128 + 4 g (column of the lane's first output inside the tile)
 V_BIAS = 192                # v192..v223: the lane's 8 x 4 bias values of the tile
+V_SW, V_SR = 10, 11         # staged epilogue: the lane's write / read-back address in its wave's staging buffer (fc = 0 / j = 0)
+V_WA, V_RD = 120, 128       # v120..v127 / v128..v131 (fragment set 1, idle during the epilogue): the same per fc / per j
+V_CS = 132                  # v132..v163: two sets of 4 x 4 read-back registers
+V_COM = 164                 # epilogue variant: V_CO with the ragged-N mask folded in
 V_TID, V_LANE = 0, 1
 V_DA, V_DB = 2, 6           # DMA lane offsets: up to 4 classes of pieces per operand
 V_T = 10                    # v10, v11 scratch; v12: epilogue lane offset
@@ -230,6 +238,9 @@ class Kernel:
         for n, (fm, fn) in enumerate(order()):
             E("\t" + mfma(fm, fn, st, self.tout))
             for txt in byslot.get(n, []):
+                if ("nodma" in ABL and ("lds" in txt.split() or txt.startswith("s_add_u32 m0") or txt == "s_nop 0")) or \
+                        ("noread" in ABL and txt.startswith("ds_read_b")):
+                    continue
                 L(txt)
 
     def ktile(self, stage):
@@ -237,8 +248,15 @@ class Kernel:
         DS = int(os.environ.get("ASM_DMA_STRIDE", "4"))         # MFMAs between two DMA pieces
         rd = self.reads(1, stage, 1)
         rs = RS * 16 / len(rd)
-        self.phase(0, [(min(int(rs * n), 63), t) for n, t in enumerate(rd)])
-        E("\ts_waitcnt vmcnt(0) lgkmcnt(0)")
+        side0 = [(min(int(rs * n), 63), t) for n, t in enumerate(rd)]
+        pieces = self.dma(stage)
+        if "spread" in ABL:       # timing only (races on the stage being read): half of the DMA pieces issued in P0
+            for n, (m0w, ld) in enumerate(pieces[:8]):
+                side0 += [(3 + n * 8, m0w), (3 + n * 8, "s_nop 0"), (3 + n * 8, ld)]
+            pieces = pieces[8:]
+            DS = 8
+        self.phase(0, side0)
+        E("\ts_waitcnt lgkmcnt(0)" if "nowait" in ABL else ("\ts_waitcnt vmcnt(8) lgkmcnt(0)" if "spread" in ABL else "\ts_waitcnt vmcnt(0) lgkmcnt(0)"))
         _uid[0] += 1
         E(f"\ts_cmp_eq_u32 s{S_REQ}, 0")                  # wave 0, a ticket has just come back: into the mailbox before the barrier
         E(f"\ts_cbranch_scc1 .Lno_pub{_uid[0]}")
@@ -248,15 +266,153 @@ class Kernel:
         E("\ts_waitcnt lgkmcnt(0)")
         E(f"\ts_mov_b32 s{S_REQ}, 0")
         E(f".Lno_pub{_uid[0]}:")
-        E("\ts_barrier")
+        if "nobar" not in ABL:
+            E("\ts_barrier")
         rd = self.reads(0, stage ^ 1, 0)
         side = [(min(int(rs * n), 63), t) for n, t in enumerate(rd)]
-        for n, (m0w, ld) in enumerate(self.dma(stage)):
+        for n, (m0w, ld) in enumerate(pieces):
             slot = min(1 + n * DS, 62)
             side += [(slot, m0w), (slot, "s_nop 0"), (slot, ld)]
         side += [(63, t) for t in self.stream_step()]
         self.phase(1, side)
         E("\ts_waitcnt lgkmcnt(0)")
+
+    def epilogue_direct(self):
+        """the accumulator tiles stored straight from registers: 16 rows x 32 (bf16) / 64 (f32) bytes per instruction"""
+        t = S_T
+        if self.epi:
+            # the lane's bias values: column n0 + wn*128 + 16 fn + 4 g .. + 3 (past N: zeros); n0 = N - S_NREM
+            E(f"\ts_sub_u32 s{t+10}, s{S_N}, s{S_NREM}")
+            E(f"\ts_lshl_b32 s{t+10}, s{t+10}, 2")
+            E(f"\tv_lshlrev_b32 v{V_E}, 2, v{V_NCOL}")
+            for fn in range(8):
+                E(f"\tbuffer_load_dwordx4 v[{V_BIAS+4*fn}:{V_BIAS+4*fn+3}], v{V_E}, s[{RBI}:{RBI+3}], s{t+10} offen offset:{fn*64}")
+            # store offsets with the ragged-N mask folded in: columns >= N go to an out-of-range offset (dropped)
+            E(f"\tv_mov_b32 v{V_E+1}, 0x80000000")
+            for fn in range(8):
+                E(f"\ts_sub_i32 s{t+11}, s{S_NREM}, {16*fn}")
+                E(f"\tv_cmp_gt_i32 vcc, s{t+11}, v{V_NCOL}")
+                E(f"\tv_cndmask_b32 v{V_MOFF+fn}, v{V_E+1}, v{V_CO}, vcc")
+        E("\ts_nop 15")
+        E("\ts_nop 15")
+        if self.epi:
+            E("\ts_waitcnt vmcnt(0)")      # the bias values (and the stream's k-tile 1, which the next barrier would wait for anyway)
+        E(f"\ts_mov_b32 s{S_CROW}, 0")
+        # (fr, fc): 16-row group / 16-column group of C; the accumulator tile is (fm, fn) = (fr, fc), or (fc, fr) when transposed
+        tiles = [((fc, fr) if self.tout else (fr, fc)) for fr in range(8) for fc in range(8)]
+
+        def rd(n, base):
+            a = acc(*tiles[n])
+            for r in range(4):
+                E(f"\tv_accvgpr_read_b32 v{base+r}, a{a+r}")
+            for r in range(4):
+                E(f"\tv_accvgpr_write_b32 a{a+r}, 0")
+        if "noepi" not in ABL:
+            rd(0, V_E)
+        for n, (fm, fn) in enumerate(tiles if "noepi" not in ABL else []):
+            cur = V_E + (n & 1) * 8
+            if n + 1 < 64:
+                rd(n + 1, V_E + ((n + 1) & 1) * 8)
+            fn = n & 7          # from here on: the column group of C
+            if self.f32:
+                if "nostore" not in ABL:
+                    E(f"\tbuffer_store_dwordx4 v[{cur}:{cur+3}], v{V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*64}{ST_NT}")
+            else:
+                if self.epi:
+                    for r in range(4):
+                        E(f"\tv_add_f32 v{cur+r}, v{cur+r}, v{V_BIAS+4*fn+r}")
+                E(f"\tv_cvt_pk_bf16_f32 v{cur+4}, v{cur}, v{cur+1}")
+                E(f"\tv_cvt_pk_bf16_f32 v{cur+5}, v{cur+2}, v{cur+3}")
+                if "fullline" in ABL and not self.epi:
+                    if n & 1:
+                        E(f"\tbuffer_store_dwordx4 v[{cur}:{cur+3}], v{V_NCOL}, s[{RC}:{RC+3}], s{S_CROW} offen{ST_NT}")
+                        E(f"\ts_add_u32 s{S_CROW}, s{S_CROW}, s{S_NREM}")
+                elif "nostore" not in ABL:
+                    E(f"\tbuffer_store_dwordx2 v[{cur+4}:{cur+5}], v{V_MOFF+fn if self.epi else V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*32}{ST_NT}")
+            if fn == 7 and not ("fullline" in ABL and not self.epi and not self.f32):
+                E(f"\ts_add_u32 s{S_CROW}, s{S_CROW}, s{S_C16}")
+
+    def epilogue_staged(self):
+        """each 16-row group of the wave's C tile goes through the wave's 4 KiB staging buffer and leaves as 4 rows x 256
+        contiguous bytes per store instruction (the direct form writes 16 rows x 32 bytes: partial lines the L2 has to merge,
+        and keeps in place of operand panels).  LDS operations of one wave execute in order, so one buffer is enough: the
+        read-back of unit u is queued before the writes of unit u + 1; the stores of unit u are issued behind the writes and
+        reads of unit u + 1 (lgkmcnt counts them out)."""
+        t = S_T
+        tiles = lambda fr, fc: (fc, fr) if self.tout else (fr, fc)
+        nfc = 4 if self.f32 else 8                  # accumulator tiles per unit (one staging buffer)
+        units = [(fr, h) for fr in range(8) for h in range(2 if self.f32 else 1)]
+        if self.epi:
+            # the lane's bias values: column n0 + wn*128 + 16 fn + 4 g .. + 3 (past N: zeros); n0 = N - S_NREM
+            E(f"\ts_sub_u32 s{t+10}, s{S_N}, s{S_NREM}")
+            E(f"\ts_lshl_b32 s{t+10}, s{t+10}, 2")
+            E(f"\tv_lshlrev_b32 v{V_E}, 2, v{V_NCOL}")
+            for fn in range(8):
+                E(f"\tbuffer_load_dwordx4 v[{V_BIAS+4*fn}:{V_BIAS+4*fn+3}], v{V_E}, s[{RBI}:{RBI+3}], s{t+10} offen offset:{fn*64}")
+            # ragged N: the lane stores columns wn*128 + (l & 15) * 8 .. + 7 of the tile; past N -> an out-of-range offset (dropped)
+            E(f"\tv_and_b32 v{V_E+1}, 15, v{V_LANE}")
+            E(f"\tv_lshlrev_b32 v{V_E+1}, 3, v{V_E+1}")
+            E(f"\tv_and_b32 v{V_E+2}, -128, v{V_NCOL}")                 # wn * 128
+            E(f"\tv_add_u32 v{V_E+1}, v{V_E+1}, v{V_E+2}")
+            E(f"\tv_mov_b32 v{V_E+2}, 0x80000000")
+            E(f"\tv_cmp_gt_i32 vcc, s{S_NREM}, v{V_E+1}")
+            E(f"\tv_cndmask_b32 v{V_COM}, v{V_E+2}, v{V_CO}, vcc")
+        for fc in range(nfc):
+            E(f"\tv_xor_b32 v{V_WA+fc}, {fc * (64 if self.f32 else 32)}, v{V_SW}")
+        for j in range(4):
+            E(f"\tv_xor_b32 v{V_RD+j}, {j * 64}, v{V_SR}")
+        E("\ts_nop 15")
+        E("\ts_nop 15")
+        if self.epi:
+            E("\ts_waitcnt vmcnt(0)")      # the bias values (and the stream's k-tile 1, which the next barrier would wait for anyway)
+        vco = V_COM if self.epi else V_CO
+
+        def rd(fr, fc, base):
+            a = acc(*tiles(fr, fc))
+            for r in range(4):
+                E(f"\tv_accvgpr_read_b32 v{base+r}, a{a+r}")
+            for r in range(4):
+                E(f"\tv_accvgpr_write_b32 a{a+r}, 0")
+
+        def stores(u):
+            fr, h = units[u]
+            cs = V_CS + (u & 1) * 16
+            for j in range(4):      # rows fr*16 + 4 j .. + 3
+                off = f" offset:{h*256}" if h else ""
+                if "nostore" not in ABL:
+                    E(f"\tbuffer_store_dwordx4 v[{cs+4*j}:{cs+4*j+3}], v{vco}, s[{RC}:{RC+3}], s{t + 4*(fr & 1) + j} offen{off}{ST_NT}")
+
+        seq = [(fr, h, fcl) for fr, h in units for fcl in range(nfc)]
+        rd(seq[0][0], seq[0][1] * 4 + seq[0][2], V_E)
+        for n, (fr, h, fcl) in enumerate(seq):
+            u = fr * (2 if self.f32 else 1) + h
+            fc = h * 4 + fcl
+            cur = V_E + (n & 1) * 8
+            if fcl == 0 and h == 0:     # soffsets of this row group's four stores: (fr*16 + 4 j) rows of C
+                b = t + 4 * (fr & 1)
+                E(f"\ts_mul_i32 s{b}, s{S_C16}, {4*fr}")
+                for j in range(1, 4):
+                    E(f"\ts_add_u32 s{b+j}, s{b+j-1}, s{S_C16}")
+            if n + 1 < len(seq):
+                rd(seq[n+1][0], seq[n+1][1] * 4 + seq[n+1][2], V_E + ((n + 1) & 1) * 8)
+            if self.f32:
+                E(f"\tds_write_b128 v{V_WA+fcl}, v[{cur}:{cur+3}]")
+            else:
+                if self.epi:
+                    for r in range(4):
+                        E(f"\tv_add_f32 v{cur+r}, v{cur+r}, v{V_BIAS+4*fc+r}")
+                E(f"\tv_cvt_pk_bf16_f32 v{cur+4}, v{cur}, v{cur+1}")
+                E(f"\tv_cvt_pk_bf16_f32 v{cur+5}, v{cur+2}, v{cur+3}")
+                E(f"\tds_write_b64 v{V_WA+fcl}, v[{cur+4}:{cur+5}]")
+            if fcl == nfc - 1:          # the unit is written: queue its read-back, then store the previous unit
+                cs = V_CS + (u & 1) * 16
+                for j in range(4):
+                    E(f"\tds_read_b128 v[{cs+4*j}:{cs+4*j+3}], v{V_RD+j} offset:{j*1024}")
+                if u > 0:
+                    E(f"\ts_waitcnt lgkmcnt({nfc + 4})")
+                    stores(u - 1)
+        E("\ts_waitcnt lgkmcnt(0)")
+        stores(len(units) - 1)
 
     def emit(self):
         nm = self.name
@@ -431,19 +587,70 @@ class Kernel:
                 for f in range(8):
                     E(f"\tv_xor_b32 v{VR+f}, {f << 5}, v{V_E+5}")
                     E(f"\tv_add_u32 v{VR+8+f}, {STAGE}, v{VR+f}")
-        # ---- epilogue lane offset: m = wm*128 + fm*16 + (l & 15), n = wn*128 + fn*16 + 4 (l >> 4)
-        # (transposed stores: the lane's row is n = wn*128 + fn*16 + (l & 15), its 4 columns m = wm*128 + fm*16 + 4 (l >> 4))
+        # ---- epilogue lane offsets
         wrow, wcol = (t + 13, t + 12) if self.tout else (t + 12, t + 13)
-        E(f"\tv_and_b32 v{V_E}, 15, v{V_LANE}")
-        E(f"\tv_lshrrev_b32 v{V_E+1}, 4, v{V_LANE}")
-        E(f"\ts_lshl_b32 s{t+14}, s{wrow}, 7")
-        E(f"\tv_add_u32 v{V_E}, s{t+14}, v{V_E}")
-        E(f"\tv_mul_lo_u32 v{V_E}, v{V_E}, s{S_LDC}")
-        E(f"\tv_lshlrev_b32 v{V_E+1}, {4 if self.f32 else 3}, v{V_E+1}")      # 4 g elements in bytes
-        E(f"\ts_lshl_b32 s{t+14}, s{wcol}, {9 if self.f32 else 8}")           # w? * 128 elements in bytes
-        E(f"\tv_add_u32 v{V_E}, v{V_E}, v{V_E+1}")
-        E(f"\tv_add_u32 v{V_CO}, s{t+14}, v{V_E}")
-        E(f"\ts_lshl_b32 s{S_C16}, s{S_LDC}, 4")
+        if STAGED:
+            # accumulator tile (fr, fc) of the wave: lane (i = l & 15, g = l >> 4) holds C row fr*16 + i, columns fc*16 + 4 g .. + 3.
+            # Staging buffer of the wave: [16 rows][256 B], 16-byte chunk c of row r at chunk c ^ r.  bf16: one buffer = a whole row
+            # group (128 columns), the lane's 8 bytes of tile fc are chunk 2 fc + (g >> 1), half g & 1; f32: one buffer = half a
+            # row group (64 columns), the lane's 16 bytes of tile fc (fc & 3) are chunk 4 (fc & 3) + g.  Read back as 4 rows x 256 B
+            # per instruction: lane -> row 4 j + (l >> 4), chunk l & 15; stored as 4 full rows of 256 contiguous bytes.
+            E(f"\tv_and_b32 v{V_E}, 15, v{V_LANE}")                      # i
+            E(f"\tv_lshrrev_b32 v{V_E+1}, 4, v{V_LANE}")                 # g
+            if self.f32:
+                E(f"\tv_xor_b32 v{V_E+2}, v{V_E+1}, v{V_E}")             # g ^ i
+                E(f"\tv_lshlrev_b32 v{V_E+2}, 4, v{V_E+2}")
+            else:
+                E(f"\tv_lshrrev_b32 v{V_E+2}, 1, v{V_E+1}")              # g >> 1
+                E(f"\tv_xor_b32 v{V_E+2}, v{V_E+2}, v{V_E}")
+                E(f"\tv_lshlrev_b32 v{V_E+2}, 4, v{V_E+2}")
+                E(f"\tv_and_b32 v{V_E+3}, 1, v{V_E+1}")
+                E(f"\tv_lshlrev_b32 v{V_E+3}, 3, v{V_E+3}")
+                E(f"\tv_add_u32 v{V_E+2}, v{V_E+2}, v{V_E+3}")
+            E(f"\tv_lshlrev_b32 v{V_E+3}, 8, v{V_E}")                    # i * 256
+            E(f"\tv_add_u32 v{V_E+2}, v{V_E+2}, v{V_E+3}")
+            E(f"\ts_lshl_b32 s{t+14}, s{W}, 12")
+            E(f"\ts_add_u32 s{t+14}, s{t+14}, {CSTAGE}")
+            E(f"\tv_add_u32 v{V_SW}, s{t+14}, v{V_E+2}")
+            E(f"\tv_xor_b32 v{V_E+2}, v{V_E}, v{V_E+1}")                 # (l & 15) ^ (l >> 4)
+            E(f"\tv_lshlrev_b32 v{V_E+2}, 4, v{V_E+2}")
+            E(f"\tv_lshlrev_b32 v{V_E+3}, 8, v{V_E+1}")                  # (l >> 4) * 256
+            E(f"\tv_add_u32 v{V_E+2}, v{V_E+2}, v{V_E+3}")
+            E(f"\tv_add_u32 v{V_SR}, s{t+14}, v{V_E+2}")
+            # store offset: row w?*128 + (l >> 4), bytes w?*(128 elements) + (l & 15) * 16
+            E(f"\ts_lshl_b32 s{t+14}, s{wrow}, 7")
+            E(f"\tv_add_u32 v{V_E+1}, s{t+14}, v{V_E+1}")
+            E(f"\tv_mul_lo_u32 v{V_E+1}, v{V_E+1}, s{S_LDC}")
+            E(f"\tv_lshlrev_b32 v{V_E}, 4, v{V_E}")
+            E(f"\ts_lshl_b32 s{t+14}, s{wcol}, {9 if self.f32 else 8}")
+            E(f"\tv_add_u32 v{V_E}, v{V_E}, v{V_E+1}")
+            E(f"\tv_add_u32 v{V_CO}, s{t+14}, v{V_E}")
+            E(f"\ts_lshl_b32 s{S_C16}, s{S_LDC}, 2")                     # FOUR rows of C in bytes
+        else:
+            # m = wm*128 + fm*16 + (l & 15), n = wn*128 + fn*16 + 4 (l >> 4)
+            # (transposed stores: the lane's row is n = wn*128 + fn*16 + (l & 15), its 4 columns m = wm*128 + fm*16 + 4 (l >> 4))
+            E(f"\tv_and_b32 v{V_E}, 15, v{V_LANE}")
+            E(f"\tv_lshrrev_b32 v{V_E+1}, 4, v{V_LANE}")
+            E(f"\ts_lshl_b32 s{t+14}, s{wrow}, 7")
+            E(f"\tv_add_u32 v{V_E}, s{t+14}, v{V_E}")
+            E(f"\tv_mul_lo_u32 v{V_E}, v{V_E}, s{S_LDC}")
+            E(f"\tv_lshlrev_b32 v{V_E+1}, {4 if self.f32 else 3}, v{V_E+1}")      # 4 g elements in bytes
+            E(f"\ts_lshl_b32 s{t+14}, s{wcol}, {9 if self.f32 else 8}")           # w? * 128 elements in bytes
+            E(f"\tv_add_u32 v{V_E}, v{V_E}, v{V_E+1}")
+            E(f"\tv_add_u32 v{V_CO}, s{t+14}, v{V_E}")
+            E(f"\ts_lshl_b32 s{S_C16}, s{S_LDC}, 4")
+        if "fullline" in ABL and not self.epi and not self.f32:
+            # timing only: lane l -> row wm*128 + (l >> 4), bytes wn*256 + (l & 15) * 16: one instruction = 4 rows x 256 B
+            E(f"\tv_lshrrev_b32 v{V_E}, 4, v{V_LANE}")
+            E(f"\ts_lshl_b32 s{t+14}, s{t+12}, 7")
+            E(f"\tv_add_u32 v{V_E}, s{t+14}, v{V_E}")
+            E(f"\tv_mul_lo_u32 v{V_E}, v{V_E}, s{S_LDC}")
+            E(f"\tv_and_b32 v{V_E+1}, 15, v{V_LANE}")
+            E(f"\tv_lshlrev_b32 v{V_E+1}, 4, v{V_E+1}")
+            E(f"\ts_lshl_b32 s{t+14}, s{t+13}, 8")
+            E(f"\tv_add_u32 v{V_E}, v{V_E}, v{V_E+1}")
+            E(f"\tv_add_u32 v{V_NCOL}, s{t+14}, v{V_E}")
+            E(f"\ts_lshl_b32 s{S_NREM}, s{S_LDC}, 2")          # 4 rows of C in bytes
         if self.epi:
             E(f"\tv_lshrrev_b32 v{V_NCOL}, 4, v{V_LANE}")
             E(f"\tv_lshlrev_b32 v{V_NCOL}, 2, v{V_NCOL}")
@@ -478,50 +685,10 @@ class Kernel:
         E(f"\ts_cbranch_scc1 .Lloop_{nm}")
         # ---- epilogue.  The stream is two k-tiles into this block's next tile (k-tile 0 landed at the last barrier, k-tile 1
         # is in flight and is waited for, together with these stores, by the vmcnt(0) of the next tile's first barrier)
-        if self.epi:
-            # the lane's bias values: column n0 + wn*128 + 16 fn + 4 g .. + 3 (past N: zeros); n0 = N - S_NREM
-            E(f"\ts_sub_u32 s{t+10}, s{S_N}, s{S_NREM}")
-            E(f"\ts_lshl_b32 s{t+10}, s{t+10}, 2")
-            E(f"\tv_lshlrev_b32 v{V_E}, 2, v{V_NCOL}")
-            for fn in range(8):
-                E(f"\tbuffer_load_dwordx4 v[{V_BIAS+4*fn}:{V_BIAS+4*fn+3}], v{V_E}, s[{RBI}:{RBI+3}], s{t+10} offen offset:{fn*64}")
-            # store offsets with the ragged-N mask folded in: columns >= N go to an out-of-range offset (dropped)
-            E(f"\tv_mov_b32 v{V_E+1}, 0x80000000")
-            for fn in range(8):
-                E(f"\ts_sub_i32 s{t+11}, s{S_NREM}, {16*fn}")
-                E(f"\tv_cmp_gt_i32 vcc, s{t+11}, v{V_NCOL}")
-                E(f"\tv_cndmask_b32 v{V_MOFF+fn}, v{V_E+1}, v{V_CO}, vcc")
-        E("\ts_nop 15")
-        E("\ts_nop 15")
-        if self.epi:
-            E("\ts_waitcnt vmcnt(0)")      # the bias values (and the stream's k-tile 1, which the next barrier would wait for anyway)
-        E(f"\ts_mov_b32 s{S_CROW}, 0")
-        # (fr, fc): 16-row group / 16-column group of C; the accumulator tile is (fm, fn) = (fr, fc), or (fc, fr) when transposed
-        tiles = [((fc, fr) if self.tout else (fr, fc)) for fr in range(8) for fc in range(8)]
-
-        def rd(n, base):
-            a = acc(*tiles[n])
-            for r in range(4):
-                E(f"\tv_accvgpr_read_b32 v{base+r}, a{a+r}")
-            for r in range(4):
-                E(f"\tv_accvgpr_write_b32 a{a+r}, 0")
-        rd(0, V_E)
-        for n, (fm, fn) in enumerate(tiles):
-            cur = V_E + (n & 1) * 8
-            if n + 1 < 64:
-                rd(n + 1, V_E + ((n + 1) & 1) * 8)
-            fn = n & 7          # from here on: the column group of C
-            if self.f32:
-                E(f"\tbuffer_store_dwordx4 v[{cur}:{cur+3}], v{V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*64}{ST_NT}")
-            else:
-                if self.epi:
-                    for r in range(4):
-                        E(f"\tv_add_f32 v{cur+r}, v{cur+r}, v{V_BIAS+4*fn+r}")
-                E(f"\tv_cvt_pk_bf16_f32 v{cur+4}, v{cur}, v{cur+1}")
-                E(f"\tv_cvt_pk_bf16_f32 v{cur+5}, v{cur+2}, v{cur+3}")
-                E(f"\tbuffer_store_dwordx2 v[{cur+4}:{cur+5}], v{V_MOFF+fn if self.epi else V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*32}{ST_NT}")
-            if fn == 7:
-                E(f"\ts_add_u32 s{S_CROW}, s{S_CROW}, s{S_C16}")
+        if STAGED:
+            self.epilogue_staged()
+        else:
+            self.epilogue_direct()
         E(f"\ts_cmp_lg_u32 s{S_HAVE}, 0")
         E(f"\ts_cbranch_scc1 .Lnext_{nm}")
         E("\ts_endpgm")
@@ -535,7 +702,7 @@ class Kernel:
         E("\t.section\t.rodata,\"a\",@progbits")
         E("\t.p2align\t6, 0x0")
         E(f"\t.amdhsa_kernel {nm}")
-        for k, v in (("group_segment_fixed_size", 131136), ("private_segment_fixed_size", 0), ("kernarg_size", 128),
+        for k, v in (("group_segment_fixed_size", MAILBOX + 64), ("private_segment_fixed_size", 0), ("kernarg_size", 128),
                      ("user_sgpr_count", 2), ("user_sgpr_dispatch_ptr", 0), ("user_sgpr_queue_ptr", 0), ("user_sgpr_kernarg_segment_ptr", 1),
                      ("user_sgpr_dispatch_id", 0), ("user_sgpr_kernarg_preload_length", 0), ("user_sgpr_kernarg_preload_offset", 0),
                      ("user_sgpr_private_segment_size", 0), ("uses_dynamic_stack", 0), ("enable_private_segment", 0),
@@ -555,7 +722,7 @@ class Kernel:
       - .offset:         0
         .size:           128
         .value_kind:     by_value
-    .group_segment_fixed_size: 131136
+    .group_segment_fixed_size: {MAILBOX + 64}
     .kernarg_segment_align: 8
     .kernarg_segment_size: 128
     .max_flat_workgroup_size: 256
