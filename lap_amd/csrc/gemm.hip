@@ -1522,6 +1522,27 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
     const bool biased = a_kc && b_kc && !f32 && bias && (flags & LAP_GEMM_BIAS_F32) && !residual &&
                         !(flags & (LAP_GEMM_GELU | LAP_GEMM_ACCUM | LAP_GEMM_PARTIALS)) && alpha == 1.0f && ksplit <= 1 &&
                         lap_gemm_asm_bias_ok(M, N, K, lda, ldb, ldc) && !((uintptr_t)bias & 15);
+    // forward + bf16 residual with C's leading dimension (+ optional f32 bias): out / down projections of a block
+    const bool resid = a_kc && b_kc && !f32 && residual && ldr == ldc && !((uintptr_t)residual & 15) &&
+                       (!bias || ((flags & LAP_GEMM_BIAS_F32) && !((uintptr_t)bias & 15))) &&
+                       !(flags & (LAP_GEMM_GELU | LAP_GEMM_ACCUM | LAP_GEMM_PARTIALS)) && alpha == 1.0f && ksplit <= 1 &&
+                       lap_gemm_asm_res_ok(bias != nullptr, M, N, K, lda, ldb, ldc);
+    if (tile == 14 && resid) return lap_gemm_asm_res(A, B, C, (const float*)bias, residual, M, N, K, lda, ldb, ldc, stream);
+    if (tile < 0 && resid && !no_asm) {
+      static const bool no_res = getenv("LAP_GEMM_NO_ASM_RES") != nullptr;      // A/B switch
+      const long long tm = M / 256, tn = (N + 255) / 256, t5 = tm * tn, rounds = t5 / 256;
+      const double fill = (double)t5 / (256.0 * ((t5 + 255) / 256));
+      if (!no_res && t5 >= 128 && (fill >= 0.8 || (bias && K <= 2048))) return lap_gemm_asm_res(A, B, C, (const float*)bias, residual, M, N, K, lda, ldb, ldc, stream);
+      // (the M cut of the plain products below, with the residual rows following the cut)
+      static const bool no_msplit = getenv("LAP_GEMM_NO_MSPLIT") != nullptr;
+      if (!no_res && !no_msplit && !bias && ksplit == 0 && scratch != nullptr && K <= 4096 && rounds >= 1 && fill < 0.8 && (rounds * 256) % tn == 0) {
+        const int M0 = (int)(rounds * 256 / tn) * 256;
+        if (int rc = lap_gemm_asm_res(A, B, C, nullptr, residual, M0, N, K, lda, ldb, ldc, stream)) return rc;
+        return lap_gemm_bf16_ex((const char*)A + (long long)M0 * lda * 2, B, (char*)C + (long long)M0 * ldc * 2, nullptr,
+                                (const char*)residual + (long long)M0 * ldr * 2, M - M0, N, K, lda, ldb, ldc, ldr, 1.0f, a_kc, b_kc, flags, -1, 0,
+                                scratch, scratch_bytes, stream);
+      }
+    }
     if (tile == 14 && biased) return lap_gemm_asm_bias(A, B, C, (const float*)bias, M, N, K, lda, ldb, ldc, stream);
     if (tile < 0 && biased && !no_asm) {
       const long long t5 = (long long)(M / 256) * ((N + 255) / 256);
@@ -1529,6 +1550,26 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
       if (t5 >= 128 && fill >= 0.8) return lap_gemm_asm_bias(A, B, C, (const float*)bias, M, N, K, lda, ldb, ldc, stream);
     }
     if (tile == 14) return plain ? lap_gemm_asm(A, B, C, M, N, K, lda, ldb, ldc, a_kc, b_kc, f32, stream) : LAP_ERR_ARG;
+    // M = 17,920 rows x N = 2,048 columns are 70 x 8 = 560 tiles: 2.19 rounds of the chip.  The persistent kernel would run a
+    // third round for 48 tiles; the HIP tile splits those 48 along K.  Same cut here, made along M: rows [0, 64 x 256) are
+    // exactly two rounds for the assembly kernel, the last 1,536 rows a product of their own on the automatic route (its
+    // K split covers the chip).  tools/bench_msplit.py (isolated, us): qkv data gradient K = 2560 195 -> 152, out data gradient
+    // K = 2048 161 -> 124, plain forward K = 2048 129 -> 121; long contractions lose (K = 32768 data gradient 1738 -> 1778, K =
+    // 16384 forward 940 -> 1092: the HIP tile's order keeps its operand panels better) and stay on the tail split.
+    // LAP_GEMM_NO_MSPLIT=1: off (A/B).
+    if (tile < 0 && plain && !no_asm && ksplit == 0 && scratch != nullptr && K <= 4096) {
+      static const bool off = getenv("LAP_GEMM_NO_MSPLIT") != nullptr;
+      const long long tm = M / 256, tn = N / 256, t5 = tm * tn, rounds = t5 / 256;
+      const double fill = (double)t5 / (256.0 * ((t5 + 255) / 256));
+      if (!off && rounds >= 1 && fill < 0.8 && (rounds * 256) % tn == 0) {
+        const int M0 = (int)(rounds * 256 / tn) * 256;
+        const int esz = f32 ? 4 : 2;
+        const void* A1 = a_kc ? (const void*)((const char*)A + (long long)M0 * lda * 2) : (const void*)((const char*)A + (long long)M0 * 2);
+        void* C1 = (void*)((char*)C + (long long)M0 * ldc * esz);
+        if (int rc = lap_gemm_asm(A, B, C, M0, N, K, lda, ldb, ldc, a_kc, b_kc, f32, stream)) return rc;
+        return lap_gemm_bf16_ex(A1, B, C1, nullptr, nullptr, M - M0, N, K, lda, ldb, ldc, 0, 1.0f, a_kc, b_kc, flags, -1, 0, scratch, scratch_bytes, stream);
+      }
+    }
     if (tile < 0 && plain && !no_asm) {
       const long long t5 = (long long)(M / 256) * (N / 256);
       const double fill = (double)t5 / (256.0 * ((t5 + 255) / 256));

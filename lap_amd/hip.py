@@ -76,6 +76,8 @@ SIGNATURES: dict[str, list] = {
     "lap_gemm_asm_ok": [_i, _i, _i, _i, _i, _i, _i, _i, _i],
     "lap_gemm_asm_bias": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_asm_bias_ok": [_i, _i, _i, _i, _i, _i],
+    "lap_gemm_asm_res": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "lap_gemm_asm_res_ok": [_i, _i, _i, _i, _i, _i, _i],
     "lap_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "lap_amax_bf16": [_vp, _ll, _i, _ll, _vp, _vp],
     "lap_quantize_fp8": [_vp, _ll, _i, _ll, _vp, _vp, _ll, _vp, _vp],

@@ -161,10 +161,14 @@ def test_gemm_assembly_kernels_match_hip_tiles_bitwise(hip, lay):
         o1 = hip.linear_fwd(a, b)
         o2 = hip.linear_fwd(a, b, tile=10)
         assert torch.equal(o1, o2)
-    # epilogue extras are not this kernel's: asking for it explicitly is rejected, the automatic choice falls back
+    # epilogue extras other than bias / residual are not these kernels': asking for them explicitly is rejected, the automatic choice
+    # falls back (a residual with a leading dimension of its own likewise)
     with pytest.raises(hip.LapHipError):
         hip.gemm(rnd(256, 512), rnd(512, 512), torch.empty(256, 512, device=DEV, dtype=torch.bfloat16), M=256, N=512, K=512, lda=512, ldb=512,
-                 ldc=512, residual=rnd(256, 512), ldr=512, tile=14)
+                 ldc=512, gelu=True, tile=14)
+    with pytest.raises(hip.LapHipError):
+        hip.gemm(rnd(256, 512), rnd(512, 512), torch.empty(256, 512, device=DEV, dtype=torch.bfloat16), M=256, N=512, K=512, lda=512, ldb=512,
+                 ldc=512, residual=rnd(256, 576), ldr=576, tile=14)
 
 
 def test_gemm_assembly_bias_kernel_ragged_n_matches_hip_tiles_bitwise(hip):
@@ -182,6 +186,34 @@ def test_gemm_assembly_bias_kernel_ragged_n_matches_hip_tiles_bitwise(hip):
         assert torch.equal(outs[0], outs[1]), (M, N, K)
         assert (outs[1][:, N:] == 3.0).all()
         assert rel_err(outs[1][:, :N], a.float() @ b.float().t() + bias) < 5e-3
+
+
+def test_gemm_assembly_residual_kernels_match_hip_tiles_bitwise(hip):
+    """lap_gemm_asm_nt_res / lap_gemm_asm_nt_bias_res: forward + bf16 residual (C's leading dimension) added in f32 before the one
+    rounding, with and without the f32 bias / ragged N: the accumulators go through the f32 staging buffer, the sums and the
+    rounding are those of the HIP tiles' epilogue."""
+    for M, N, K, pad, biased in [(512, 512, 512, 0, False), (1024, 768, 1152, 24, False), (2304, 2048, 640, 0, False),
+                                 (512, 528, 512, 0, True), (1024, 1152, 1152, 48, True), (768, 3456, 640, 16, True), (4096, 1152, 1152, 0, True)]:
+        a = rnd(M, K + pad, seed=1)[:, :K]
+        b = rnd(N, K, seed=2)
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(DEV) if biased else None
+        res = rnd(M, N + pad, seed=7)
+        outs = []
+        for tile in (10, 14):
+            out = torch.full((M, N + pad), 3.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm(a, b, out, M=M, N=N, K=K, lda=a.stride(0), ldb=K, ldc=N + pad, bias=bias, residual=res, ldr=N + pad, tile=tile, ksplit=1)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), (M, N, K)
+        assert (outs[1][:, N:] == 3.0).all()
+        ref = a.float() @ b.float().t() + res[:, :N].float() + (bias if biased else 0.0)
+        assert rel_err(outs[1][:, :N], ref) < 5e-3
+    # the automatic route: 70 x 8 tiles are cut along M (two rounds on the assembly kernel + the last 1536 rows on the HIP tile)
+    M, N, K = 17920, 2048, 2048
+    a, b, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(M, N, seed=3)
+    o = hip.linear_fwd(a, b, residual=res)
+    o10 = hip.linear_fwd(a, b, residual=res, tile=10, ksplit=1)
+    assert torch.equal(o[:16384], o10[:16384])
+    assert rel_err(o[16384:], o10[16384:]) < 2e-3
 
 
 def test_gemm_ragged_k_on_the_pipelined_tiles_matches_lockstep_tile_bitwise(hip):

@@ -79,6 +79,9 @@ V_SW, V_SR = 10, 11         # staged epilogue: the lane's write / read-back addr
 V_WA, V_RD = 120, 128       # v120..v127 / v128..v131 (fragment set 1, idle during the epilogue): the same per fc / per j
 V_CS = 132                  # v132..v163: two sets of 4 x 4 read-back registers
 V_COM = 164                 # epilogue variant: V_CO with the ragged-N mask folded in
+V_RS = (112, 168)           # residual variant: two sets of 4 x 2 registers for the residual values
+V_RT = 124                  # v124..v127: the residual widened to f32
+S_RDL, S_RDH = 58, 91       # residual variant: R - C in bytes
 V_TID, V_LANE = 0, 1
 V_DA, V_DB = 2, 6           # DMA lane offsets: up to 4 classes of pieces per operand
 V_T = 10                    # v10, v11 scratch; v12: epilogue lane offset
@@ -114,11 +117,14 @@ def order():
 
 
 class Kernel:
-    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False):
+    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False, res=False):
         # epi: f32 bias per output column + ragged N (the last n-tile may hold fewer than 256 valid columns; N % 16 == 0)
         # tout: the product is stored TRANSPOSED (C is [N][ldc]): a tall weight gradient dW [out, in] = dy^T x runs as the wide
         #       product x^T dy (whose operand panels stream much better, tools/bench_asm_gemm.py) and lands in dW's layout
-        self.name, self.kc, self.f32, self.epi, self.tout = name, (a_kc, b_kc), out_f32, epi, tout
+        # res: + a bf16 residual R [M][ldc] (same leading dimension as C) added in f32 before the one rounding: the accumulators
+        #      are staged as f32 (two 64-column halves per row group), read back 4 columns per lane, and leave as 128-byte rows
+        self.name, self.kc, self.f32, self.epi, self.tout, self.res = name, (a_kc, b_kc), out_f32, epi, tout, res
+        self.st32 = out_f32 or res          # staging buffer holds f32
 
     # ---- fragment reads of k-step kk from `stage` into register set st
     def reads(self, kk, stage, st):
@@ -337,11 +343,13 @@ class Kernel:
         contiguous bytes per store instruction (the direct form writes 16 rows x 32 bytes: partial lines the L2 has to merge,
         and keeps in place of operand panels).  LDS operations of one wave execute in order, so one buffer is enough: the
         read-back of unit u is queued before the writes of unit u + 1; the stores of unit u are issued behind the writes and
-        reads of unit u + 1 (lgkmcnt counts them out)."""
+        reads of unit u + 1 (lgkmcnt counts them out).  Residual variant: the unit's residual values are requested before its
+        accumulators are staged and added (f32) after the read-back, 4 columns per lane -> 4 rows x 128 bytes per store."""
         t = S_T
         tiles = lambda fr, fc: (fc, fr) if self.tout else (fr, fc)
-        nfc = 4 if self.f32 else 8                  # accumulator tiles per unit (one staging buffer)
-        units = [(fr, h) for fr in range(8) for h in range(2 if self.f32 else 1)]
+        nfc = 4 if self.st32 else 8                 # accumulator tiles per unit (one staging buffer)
+        units = [(fr, h) for fr in range(8) for h in range(2 if self.st32 else 1)]
+        RR = t + 8                                  # s[28:31]: residual descriptor of this tile
         if self.epi:
             # the lane's bias values: column n0 + wn*128 + 16 fn + 4 g .. + 3 (past N: zeros); n0 = N - S_NREM
             E(f"\ts_sub_u32 s{t+10}, s{S_N}, s{S_NREM}")
@@ -349,23 +357,36 @@ class Kernel:
             E(f"\tv_lshlrev_b32 v{V_E}, 2, v{V_NCOL}")
             for fn in range(8):
                 E(f"\tbuffer_load_dwordx4 v[{V_BIAS+4*fn}:{V_BIAS+4*fn+3}], v{V_E}, s[{RBI}:{RBI+3}], s{t+10} offen offset:{fn*64}")
-            # ragged N: the lane stores columns wn*128 + (l & 15) * 8 .. + 7 of the tile; past N -> an out-of-range offset (dropped)
+            # ragged N: the lane stores columns wn*128 + (l & 15) * 8 .. + 7 of the tile (residual variant: for each 64-column half
+            # h, wn*128 + 64 h + (l & 15) * 4 .. + 3); past N -> an out-of-range offset (dropped / read as zero)
             E(f"\tv_and_b32 v{V_E+1}, 15, v{V_LANE}")
-            E(f"\tv_lshlrev_b32 v{V_E+1}, 3, v{V_E+1}")
+            E(f"\tv_lshlrev_b32 v{V_E+1}, {2 if self.res else 3}, v{V_E+1}")
             E(f"\tv_and_b32 v{V_E+2}, -128, v{V_NCOL}")                 # wn * 128
             E(f"\tv_add_u32 v{V_E+1}, v{V_E+1}, v{V_E+2}")
             E(f"\tv_mov_b32 v{V_E+2}, 0x80000000")
             E(f"\tv_cmp_gt_i32 vcc, s{S_NREM}, v{V_E+1}")
             E(f"\tv_cndmask_b32 v{V_COM}, v{V_E+2}, v{V_CO}, vcc")
+            if self.res:                # second half: + 64 columns
+                E(f"\ts_sub_i32 s{t+11}, s{S_NREM}, 64")
+                E(f"\tv_cmp_gt_i32 vcc, s{t+11}, v{V_E+1}")
+                E(f"\tv_cndmask_b32 v{V_COM+1}, v{V_E+2}, v{V_CO}, vcc")
+        if self.res:
+            E(f"\ts_add_u32 s{RR}, s{RC}, s{S_RDL}")
+            E(f"\ts_addc_u32 s{RR+1}, s{RC+1}, s{S_RDH}")
+            E(f"\ts_and_b32 s{RR+1}, s{RR+1}, 0xffff")
+            E(f"\ts_mov_b32 s{RR+2}, s{RC+2}")
+            E(f"\ts_mov_b32 s{RR+3}, s{RC+3}")
         for fc in range(nfc):
-            E(f"\tv_xor_b32 v{V_WA+fc}, {fc * (64 if self.f32 else 32)}, v{V_SW}")
+            E(f"\tv_xor_b32 v{V_WA+fc}, {fc * (64 if self.st32 else 32)}, v{V_SW}")
         for j in range(4):
             E(f"\tv_xor_b32 v{V_RD+j}, {j * 64}, v{V_SR}")
         E("\ts_nop 15")
         E("\ts_nop 15")
         if self.epi:
             E("\ts_waitcnt vmcnt(0)")      # the bias values (and the stream's k-tile 1, which the next barrier would wait for anyway)
-        vco = V_COM if self.epi else V_CO
+
+        def vco(h):
+            return (V_COM + (h if self.res else 0)) if self.epi else V_CO
 
         def rd(fr, fc, base):
             a = acc(*tiles(fr, fc))
@@ -374,33 +395,62 @@ class Kernel:
             for r in range(4):
                 E(f"\tv_accvgpr_write_b32 a{a+r}, 0")
 
+        def soff(fr, j):
+            return t + 4 * (fr & 1) + j
+
+        def res_loads(u):
+            fr, h = units[u]
+            rs = V_RS[u & 1]
+            for j in range(4):
+                off = f" offset:{h*128}" if h else ""
+                E(f"\tbuffer_load_dwordx2 v[{rs+2*j}:{rs+2*j+1}], v{vco(h)}, s[{RR}:{RR+3}], s{soff(fr, j)} offen{off}")
+
         def stores(u):
             fr, h = units[u]
             cs = V_CS + (u & 1) * 16
+            if self.res:
+                rs = V_RS[u & 1]
+                # this unit's residual values; issued behind them: the previous unit's 4 stores (not for unit 0), the next unit's 4 loads (not for the last)
+                E(f"\ts_waitcnt vmcnt({4 * ((u > 0) + (u + 1 < len(units)))})")
+                for j in range(4):
+                    c = cs + 4 * j
+                    E(f"\tv_lshlrev_b32 v{V_RT}, 16, v{rs+2*j}")
+                    E(f"\tv_and_b32 v{V_RT+1}, 0xffff0000, v{rs+2*j}")
+                    E(f"\tv_lshlrev_b32 v{V_RT+2}, 16, v{rs+2*j+1}")
+                    E(f"\tv_and_b32 v{V_RT+3}, 0xffff0000, v{rs+2*j+1}")
+                    for r in range(4):
+                        E(f"\tv_add_f32 v{c+r}, v{c+r}, v{V_RT+r}")
+                    E(f"\tv_cvt_pk_bf16_f32 v{c}, v{c}, v{c+1}")
+                    E(f"\tv_cvt_pk_bf16_f32 v{c+1}, v{c+2}, v{c+3}")
+                    off = f" offset:{h*128}" if h else ""
+                    E(f"\tbuffer_store_dwordx2 v[{c}:{c+1}], v{vco(h)}, s[{RC}:{RC+3}], s{soff(fr, j)} offen{off}{ST_NT}")
+                return
             for j in range(4):      # rows fr*16 + 4 j .. + 3
                 off = f" offset:{h*256}" if h else ""
                 if "nostore" not in ABL:
-                    E(f"\tbuffer_store_dwordx4 v[{cs+4*j}:{cs+4*j+3}], v{vco}, s[{RC}:{RC+3}], s{t + 4*(fr & 1) + j} offen{off}{ST_NT}")
+                    E(f"\tbuffer_store_dwordx4 v[{cs+4*j}:{cs+4*j+3}], v{vco(h)}, s[{RC}:{RC+3}], s{soff(fr, j)} offen{off}{ST_NT}")
 
         seq = [(fr, h, fcl) for fr, h in units for fcl in range(nfc)]
         rd(seq[0][0], seq[0][1] * 4 + seq[0][2], V_E)
         for n, (fr, h, fcl) in enumerate(seq):
-            u = fr * (2 if self.f32 else 1) + h
+            u = fr * (2 if self.st32 else 1) + h
             fc = h * 4 + fcl
             cur = V_E + (n & 1) * 8
             if fcl == 0 and h == 0:     # soffsets of this row group's four stores: (fr*16 + 4 j) rows of C
-                b = t + 4 * (fr & 1)
+                b = soff(fr, 0)
                 E(f"\ts_mul_i32 s{b}, s{S_C16}, {4*fr}")
                 for j in range(1, 4):
                     E(f"\ts_add_u32 s{b+j}, s{b+j-1}, s{S_C16}")
+            if fcl == 0 and self.res:
+                res_loads(u)
             if n + 1 < len(seq):
                 rd(seq[n+1][0], seq[n+1][1] * 4 + seq[n+1][2], V_E + ((n + 1) & 1) * 8)
-            if self.f32:
+            if self.epi:
+                for r in range(4):
+                    E(f"\tv_add_f32 v{cur+r}, v{cur+r}, v{V_BIAS+4*fc+r}")
+            if self.st32:
                 E(f"\tds_write_b128 v{V_WA+fcl}, v[{cur}:{cur+3}]")
             else:
-                if self.epi:
-                    for r in range(4):
-                        E(f"\tv_add_f32 v{cur+r}, v{cur+r}, v{V_BIAS+4*fc+r}")
                 E(f"\tv_cvt_pk_bf16_f32 v{cur+4}, v{cur}, v{cur+1}")
                 E(f"\tv_cvt_pk_bf16_f32 v{cur+5}, v{cur+2}, v{cur+3}")
                 E(f"\tds_write_b64 v{V_WA+fcl}, v[{cur+4}:{cur+5}]")
@@ -412,6 +462,8 @@ class Kernel:
                     E(f"\ts_waitcnt lgkmcnt({nfc + 4})")
                     stores(u - 1)
         E("\ts_waitcnt lgkmcnt(0)")
+        if self.res:
+            E("\ts_nop 0")
         stores(len(units) - 1)
 
     def emit(self):
@@ -438,12 +490,17 @@ class Kernel:
         E(f"\ts_getreg_b32 s{S_XCC}, hwreg(HW_REG_XCC_ID)")
         if self.epi:
             E(f"\ts_load_dwordx2 s[{RBI}:{RBI+1}], {S_KARG}, 0x60")
+        if self.res:
+            E(f"\ts_load_dwordx2 s[{S_T+8}:{S_T+9}], {S_KARG}, 0x68")
         E(f"\tv_and_b32 v{V_LANE}, 63, v{V_TID}")
         E(f"\tv_lshrrev_b32 v{V_T}, 6, v{V_TID}")
         E("\ts_nop 1")                                           # VALU write -> v_readfirstlane of the same VGPR: wait state
         E(f"\tv_readfirstlane_b32 s{W}, v{V_T}")                 # wave id
         E("\ts_nop 4")
         E("\ts_waitcnt lgkmcnt(0)")
+        if self.res:
+            E(f"\ts_sub_u32 s{S_RDL}, s{S_T+8}, s{S_C}")
+            E(f"\ts_subb_u32 s{S_RDH}, s{S_T+9}, s{S_C+1}")
         # ---- block 0 clears the counters the next launch on this stream will draw from (nobody uses them now: the launch that
         # did is over, the one that will has not started), so the host does not have to memset between launches
         E(f"\ts_cmp_lg_u32 {S_WG}, 0")
@@ -597,7 +654,7 @@ class Kernel:
             # per instruction: lane -> row 4 j + (l >> 4), chunk l & 15; stored as 4 full rows of 256 contiguous bytes.
             E(f"\tv_and_b32 v{V_E}, 15, v{V_LANE}")                      # i
             E(f"\tv_lshrrev_b32 v{V_E+1}, 4, v{V_LANE}")                 # g
-            if self.f32:
+            if self.st32:
                 E(f"\tv_xor_b32 v{V_E+2}, v{V_E+1}, v{V_E}")             # g ^ i
                 E(f"\tv_lshlrev_b32 v{V_E+2}, 4, v{V_E+2}")
             else:
@@ -621,7 +678,7 @@ class Kernel:
             E(f"\ts_lshl_b32 s{t+14}, s{wrow}, 7")
             E(f"\tv_add_u32 v{V_E+1}, s{t+14}, v{V_E+1}")
             E(f"\tv_mul_lo_u32 v{V_E+1}, v{V_E+1}, s{S_LDC}")
-            E(f"\tv_lshlrev_b32 v{V_E}, 4, v{V_E}")
+            E(f"\tv_lshlrev_b32 v{V_E}, {3 if self.res else 4}, v{V_E}")      # (residual variant: 4 bf16 = 8 bytes per lane)
             E(f"\ts_lshl_b32 s{t+14}, s{wcol}, {9 if self.f32 else 8}")
             E(f"\tv_add_u32 v{V_E}, v{V_E}, v{V_E+1}")
             E(f"\tv_add_u32 v{V_CO}, s{t+14}, v{V_E}")
@@ -740,7 +797,9 @@ class Kernel:
 
 KERNELS = [Kernel("lap_gemm_asm_nt", True, True, False), Kernel("lap_gemm_asm_nn", True, False, False),
            Kernel("lap_gemm_asm_tn", False, False, True), Kernel("lap_gemm_asm_nt_bias", True, True, False, epi=True),
-           Kernel("lap_gemm_asm_tn_t", False, False, True, tout=True)]
+           Kernel("lap_gemm_asm_tn_t", False, False, True, tout=True),
+           Kernel("lap_gemm_asm_nt_res", True, True, False, res=True),
+           Kernel("lap_gemm_asm_nt_bias_res", True, True, False, epi=True, res=True)]
 E('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
 E("\t.amdhsa_code_object_version 6")
 for k in KERNELS:
