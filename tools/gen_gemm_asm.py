@@ -60,6 +60,7 @@ S_HAVE, S_TDMA, S_DLEFT, S_NKT = 50, 51, 52, 53      # S_HAVE: the stream has mo
 RQ = 8                      # s[8:11]: descriptor of the 8 per-XCD tile counters
 S_XCC, S_XOFF, S_REQ = 3, 49, 59   # XCC id of the CU this block runs on; its counter's byte offset; wave 0: a ticket request is in flight
 V_TK, V_MB = 14, 15         # ticket (wave 0: the atomic's return value); LDS address of the ticket mailbox
+RING = os.environ.get("ASM_RING", "1") == "1"                # weight-gradient kernels: LDS as a ring of four half k-tiles
 CSTAGE = 131072             # LDS byte offset of the epilogue's staging buffers: 4 KiB per wave ([16 rows][256 B], chunks XOR row)
 MAILBOX = 131072 + 16384    # LDS byte offset of the ticket mailbox (behind the stages and the staging buffers)
 S_BUMPA, S_BUMPB = 54, 55   # bytes per k-tile along each operand
@@ -117,7 +118,7 @@ def order():
 
 
 class Kernel:
-    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False, res=False):
+    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False, res=False, ring=False):
         # epi: f32 bias per output column + ragged N (the last n-tile may hold fewer than 256 valid columns; N % 16 == 0)
         # tout: the product is stored TRANSPOSED (C is [N][ldc]): a tall weight gradient dW [out, in] = dy^T x runs as the wide
         #       product x^T dy (whose operand panels stream much better, tools/bench_asm_gemm.py) and lands in dW's layout
@@ -125,6 +126,12 @@ class Kernel:
         #      are staged as f32 (two 64-column halves per row group), read back 4 columns per lane, and leave as 128-byte rows
         self.name, self.kc, self.f32, self.epi, self.tout, self.res = name, (a_kc, b_kc), out_f32, epi, tout, res
         self.st32 = out_f32 or res          # staging buffer holds f32
+        # ring: (both operands M- / N-contiguous) the 128 KiB of LDS as a ring of four 32-deep half k-tiles [A 16 KiB | B 16 KiB]
+        # instead of two 64-deep stages: phase p (64 MFMAs on half p) reads the fragments of half p + 1 and requests half p + 4
+        # into the slot half p left, so every phase carries 8 DMA pieces (instead of none / 16) and a request has two phases
+        # to land (counted vmcnt(16) + one barrier per phase)
+        self.ring = ring
+        assert not ring or not (a_kc or b_kc)
 
     # ---- fragment reads of k-step kk from `stage` into register set st
     def reads(self, kk, stage, st):
@@ -153,6 +160,50 @@ class Kernel:
                 lds = stage * STAGE + boff + j * 1024
                 r.append((f"s_add_u32 m0, s{S_W8K}, {lds}", f"buffer_load_dwordx4 v{vd + cls}, s[{rs}:{rs+3}], s{soff+j} offen lds"))
         return r
+
+    def reads_ring(self, slot, st):
+        """fragment reads of the half k-tile in `slot` into register set st (address registers: VR + 8 * (slot >> 1) + f)"""
+        r = []
+        for f in range(8):
+            for F, VR in ((FA, V_RA), (FB, V_RB)):
+                d = F[st] + 4 * f
+                base = (slot & 1) * 32768
+                r.append(f"ds_read_b64_tr_b16 v[{d}:{d+1}], v{VR + 8*(slot >> 1) + f} offset:{base}")
+                r.append(f"ds_read_b64_tr_b16 v[{d+2}:{d+3}], v{VR + 8*(slot >> 1) + f} offset:{base + 2048}")
+        return r
+
+    def dma_ring(self, slot):
+        """8 LDS-DMA pieces of the stream's next half k-tile into `slot`; piece j of wave w: k-rows 8 w + 2 j, + 1 of the half"""
+        r = []
+        for j in range(4):
+            for rs, soff, vd, boff in ((RA, S_OFFA, V_DA, 0), (RB, S_OFFB, V_DB, 16384)):
+                lds = slot * 32768 + boff + j * 1024
+                r.append((f"s_add_u32 m0, s{S_W8K}, {lds}", f"buffer_load_dwordx4 v{vd + (j & 1)}, s[{rs}:{rs+3}], s{soff+j} offen lds"))
+        return r
+
+    def phase_ring(self, p):
+        """phase p of the ring: half p is in register set p & 1"""
+        _uid[0] += 1
+        u = _uid[0]
+        E("\ts_waitcnt vmcnt(16)")                        # this wave's pieces of half p + 1 (behind them: halves p + 2, p + 3)
+        E(f"\ts_cmp_eq_u32 s{S_REQ}, 0")                  # wave 0: the ticket drawn three phases ago is back (16 requests behind it were counted out)
+        E(f"\ts_cbranch_scc1 .Lno_pub{u}")
+        E(f"\ts_sub_u32 s{S_REQ}, s{S_REQ}, 1")
+        E(f"\ts_cmp_lg_u32 s{S_REQ}, 0")
+        E(f"\ts_cbranch_scc1 .Lno_pub{u}")
+        E("\ts_mov_b64 exec, 1")
+        E(f"\tds_write_b32 v{V_MB}, v{V_TK}")
+        E("\ts_mov_b64 exec, -1")
+        E("\ts_waitcnt lgkmcnt(0)")
+        E(f".Lno_pub{u}:")
+        E("\ts_barrier")
+        side = [(2 * n, txt) for n, txt in enumerate(self.reads_ring((p + 1) & 3, (p + 1) & 1))]
+        for n, (m0w, ld) in enumerate(self.dma_ring(p & 3)):
+            slot = 3 + 8 * n
+            side += [(slot, m0w), (slot, "s_nop 0"), (slot, ld)]
+        side += [(63, txt) for txt in self.stream_step()]
+        self.phase(p & 1, side)
+        E("\ts_waitcnt lgkmcnt(0)")
 
     def bump(self):
         r = []
@@ -216,12 +267,13 @@ class Kernel:
         u = _uid[0]
         t = S_T
         r = self.bump()
+        # (ring: a unit is a half k-tile; the ticket is drawn four units before the seam and published three phases later)
         r += [f"s_sub_u32 s{S_DLEFT}, s{S_DLEFT}, 1",
-              f"s_cmp_lg_u32 s{S_DLEFT}, 1", f"s_cbranch_scc1 .Lno_req{u}",
+              f"s_cmp_lg_u32 s{S_DLEFT}, {4 if self.ring else 1}", f"s_cbranch_scc1 .Lno_req{u}",
               f"s_cmp_lg_u32 s{t+15}, 0", f"s_cbranch_scc1 .Lstream_done{u}",                 # (DLEFT == 1: nothing else to do)
               "s_mov_b64 exec, 1", f"v_mov_b32 v{V_TK}, 1",
               f"buffer_atomic_add v{V_TK}, off, s[{RQ}:{RQ+3}], s{S_XOFF} sc0",
-              "s_mov_b64 exec, -1", f"s_mov_b32 s{S_REQ}, 1", f"s_branch .Lstream_done{u}",
+              "s_mov_b64 exec, -1", f"s_mov_b32 s{S_REQ}, {3 if self.ring else 1}", f"s_branch .Lstream_done{u}",
               f".Lno_req{u}:",
               f"s_cmp_lg_u32 s{S_DLEFT}, 0", f"s_cbranch_scc1 .Lstream_done{u}",
               f"ds_read_b32 v{V_TK}, v{V_MB}", "s_waitcnt lgkmcnt(0)", f"v_readfirstlane_b32 s{t+10}, v{V_TK}",
@@ -537,13 +589,13 @@ class Kernel:
         E(f"\ts_lshl_b32 s{S_LDB}, s{S_LDB}, 1")
         E(f"\ts_lshl_b32 s{S_LDC}, s{S_LDC}, {2 if self.f32 else 1}")
         E(f"\ts_lshl_b32 s{S_K}, s{S_K}, 1")
-        E(f"\ts_lshr_b32 s{S_NKT}, s{S_K}, 7")
+        E(f"\ts_lshr_b32 s{S_NKT}, s{S_K}, {6 if self.ring else 7}")      # k-tiles (ring: half k-tiles) per tile
         E(f"\ts_mov_b32 s{S_DLEFT}, s{S_NKT}")
         for op, (bump, ld) in enumerate(((S_BUMPA, S_LDA), (S_BUMPB, S_LDB))):
             if self.kc[op]:
                 E(f"\ts_mov_b32 s{bump}, 128")
             else:
-                E(f"\ts_lshl_b32 s{bump}, s{ld}, 6")
+                E(f"\ts_lshl_b32 s{bump}, s{ld}, {5 if self.ring else 6}")
         E(f"\ts_mov_b32 s{S_STEPA}, s{S_BUMPA}")
         E(f"\ts_mov_b32 s{S_STEPB}, s{S_BUMPB}")
         for rs in (RA, RB, RC, RCN):
@@ -558,7 +610,7 @@ class Kernel:
         for x in self.setup(S_TDMA):
             L(x)
         # ---- DMA lane offsets and piece offsets
-        E(f"\ts_lshl_b32 s{S_W8K}, s{W}, 13")
+        E(f"\ts_lshl_b32 s{S_W8K}, s{W}, {12 if self.ring else 13}")
         for op, (soff, ld, vd) in enumerate(((S_OFFA, S_LDA, V_DA), (S_OFFB, S_LDB, V_DB))):
             if self.kc[op]:
                 # piece j of wave w covers tile rows (8w + j) * 8 .. + 7; lane l: row l >> 3, physical chunk l & 7,
@@ -581,16 +633,23 @@ class Kernel:
                 # piece j of wave w covers k-rows (8w + j) * 2 .. + 1; lane l: row hi = l >> 5, physical chunk l & 31,
                 # logical chunk = physical ^ (mc_swz(k) << 1), mc_swz(k) = (k & 3) | (((k >> 3) & 1) << 2) with
                 # k & 3 = 2 (j & 1) + hi and (k >> 3) & 1 = (j >> 2) & 1: four classes of pieces c = (j & 1) + 2 ((j >> 2) & 1)
-                E(f"\ts_lshl_b32 s{t+12}, s{W}, 4")
-                for j in range(8):
+                # (ring: piece j of wave w covers k-rows 8 w + 2 j, + 1 of the 32-deep half: k & 3 = 2 (j & 1) + hi, (k >> 3) & 1 = w & 1:
+                # two classes of pieces c = j & 1, the wave's parity folded into both)
+                E(f"\ts_lshl_b32 s{t+12}, s{W}, {3 if self.ring else 4}")
+                for j in range(4 if self.ring else 8):
                     E(f"\ts_add_u32 s{t+13}, s{t+12}, {2*j}")
                     E(f"\ts_mul_i32 s{soff+j}, s{t+13}, s{ld}")
                 E(f"\tv_lshrrev_b32 v{V_T}, 5, v{V_LANE}")              # hi
                 E(f"\tv_and_b32 v{V_T+1}, 31, v{V_LANE}")               # physical chunk
                 E(f"\tv_mul_lo_u32 v{V_E+2}, v{V_T}, s{ld}")
-                for c in range(4):
+                if self.ring:
+                    E(f"\ts_and_b32 s{t+13}, s{W}, 1")
+                    E(f"\ts_lshl_b32 s{t+13}, s{t+13}, 2")
+                for c in range(2 if self.ring else 4):
                     swz0 = 2 * (c & 1) + 4 * (c >> 1)                   # + hi
                     E(f"\tv_add_u32 v{V_E}, {swz0}, v{V_T}")
+                    if self.ring:
+                        E(f"\tv_add_u32 v{V_E}, s{t+13}, v{V_E}")
                     E(f"\tv_lshlrev_b32 v{V_E}, 1, v{V_E}")
                     E(f"\tv_xor_b32 v{V_E}, v{V_E}, v{V_T+1}")
                     E(f"\tv_lshlrev_b32 v{V_E}, 4, v{V_E}")
@@ -598,7 +657,7 @@ class Kernel:
         # ---- fragment read addresses; lane (i = l & 15, g = l >> 4)
         E(f"\ts_lshr_b32 s{t+12}, s{W}, 1")                          # wm
         E(f"\ts_and_b32 s{t+13}, s{W}, 1")                           # wn
-        for op, (VR, wreg, boff) in enumerate(((V_RA, t + 12, 0), (V_RB, t + 13, BOFF))):
+        for op, (VR, wreg, boff) in enumerate(((V_RA, t + 12, 0), (V_RB, t + 13, 16384 if self.ring else BOFF))):
             if self.kc[op]:
                 # rows w?*128 + 16 f + i, chunk (4 kk + g) ^ ((i >> 1) & 7): registers VR + 2 stage + kk
                 E(f"\tv_and_b32 v{V_E}, 15, v{V_LANE}")
@@ -713,9 +772,9 @@ class Kernel:
             E(f"\tv_lshlrev_b32 v{V_NCOL}, 2, v{V_NCOL}")
             E(f"\ts_lshl_b32 s{t+14}, s{t+13}, 7")
             E(f"\tv_add_u32 v{V_NCOL}, s{t+14}, v{V_NCOL}")
-        # ---- prologue: k-tiles 0 and 1 of the first tile in flight, accumulators cleared
-        for stage in (0, 1):
-            for m0w, ld in self.dma(stage):
+        # ---- prologue: k-tiles 0 and 1 of the first tile in flight (ring: half k-tiles 0 .. 3), accumulators cleared
+        for stage in ((0, 1, 2, 3) if self.ring else (0, 1)):
+            for m0w, ld in (self.dma_ring(stage) if self.ring else self.dma(stage)):
                 E("\t" + m0w)
                 E("\ts_nop 0")
                 E("\t" + ld)
@@ -727,16 +786,20 @@ class Kernel:
             E(f"\ts_mov_b32 s{RC+r}, s{RCN+r}")
         if self.epi:
             E(f"\ts_mov_b32 s{S_NREM}, s{S_NREMN}")
-        E("\ts_waitcnt vmcnt(16)")
+        E("\ts_waitcnt vmcnt(24)" if self.ring else "\ts_waitcnt vmcnt(16)")
         E("\ts_barrier")
-        for x in self.reads(0, 0, 0):
+        for x in (self.reads_ring(0, 0) if self.ring else self.reads(0, 0, 0)):
             E("\t" + x)
         E("\ts_waitcnt lgkmcnt(0)")
         E(f".Ltile_{nm}:")
-        E(f"\ts_lshr_b32 s{S_LOOP}, s{S_NKT}, 1")
+        E(f"\ts_lshr_b32 s{S_LOOP}, s{S_NKT}, {2 if self.ring else 1}")
         E(f".Lloop_{nm}:")
-        self.ktile(0)
-        self.ktile(1)
+        if self.ring:
+            for ph in range(4):
+                self.phase_ring(ph)
+        else:
+            self.ktile(0)
+            self.ktile(1)
         E(f"\ts_sub_u32 s{S_LOOP}, s{S_LOOP}, 1")
         E(f"\ts_cmp_lg_u32 s{S_LOOP}, 0")
         E(f"\ts_cbranch_scc1 .Lloop_{nm}")
@@ -796,8 +859,8 @@ class Kernel:
 
 
 KERNELS = [Kernel("lap_gemm_asm_nt", True, True, False), Kernel("lap_gemm_asm_nn", True, False, False),
-           Kernel("lap_gemm_asm_tn", False, False, True), Kernel("lap_gemm_asm_nt_bias", True, True, False, epi=True),
-           Kernel("lap_gemm_asm_tn_t", False, False, True, tout=True),
+           Kernel("lap_gemm_asm_tn", False, False, True, ring=RING), Kernel("lap_gemm_asm_nt_bias", True, True, False, epi=True),
+           Kernel("lap_gemm_asm_tn_t", False, False, True, tout=True, ring=RING),
            Kernel("lap_gemm_asm_nt_res", True, True, False, res=True),
            Kernel("lap_gemm_asm_nt_bias_res", True, True, False, epi=True, res=True)]
 E('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
