@@ -37,6 +37,7 @@ class TensorSpec:
     init_std: float  # 0 -> zeros ; <0 -> ones + N(0, |std|) is not used: ones handled by `fill`
     fill: float = 0.0
     offset: int = 0
+    valid: tuple | None = None   # the reference's extent inside `shape` when the engine pads the tensor with zeros (see siglip_mlp_pad)
 
     @property
     def numel(self) -> int:
@@ -55,6 +56,19 @@ def _align(n: int, a: int = 64) -> int:
     return (n + a - 1) // a * a
 
 
+def siglip_mlp_pad(mlp_dim: int) -> int:
+    """The engine's width of the SigLIP MLP: So400m's 4304 (siglip_gemma3.py:35-37) is 16.8 tiles of 256 as an output and 33.6
+    k-tiles of 128 as a contraction, which keeps fc2 forward and both data gradients off the assembly GEMM kernels.  Padded to
+    4352 = 17 x 256 with ZERO rows of fc1 (+ zero bias entries) and zero columns of fc2: gelu(0) = 0 feeds zero products into
+    fc2 (same f32 sums, k ascending), and every gradient of a padded entry is an exact zero, so AdamW (decay * 0 included)
+    leaves them at zero.  The reference tree never sees the padding (reference_to_engine / engine_to_reference).
+    LAP_SIGLIP_PAD=0: off (A/B)."""
+    import os
+    if os.environ.get("LAP_SIGLIP_PAD", "1") == "0" or mlp_dim % 128 == 0 or mlp_dim < 1024:
+        return mlp_dim
+    return _align(mlp_dim, 256)
+
+
 def build_specs(cfg: LAPConfig) -> list[UnitSpec]:
     v, e, s = get_gemma_config(cfg.paligemma_variant), get_gemma_config(cfg.action_expert_variant), get_siglip_config(cfg.siglip_variant)
     if (v.depth, v.num_heads, v.num_kv_heads, v.head_dim) != (e.depth, e.num_heads, e.num_kv_heads, e.head_dim):
@@ -63,6 +77,7 @@ def build_specs(cfg: LAPConfig) -> list[UnitSpec]:
     QKV = (NH + 2 * v.num_kv_heads) * HD
     T = (cfg.image_size // s.patch) ** 2
     pdim = s.patch * s.patch * 3
+    mp = siglip_mlp_pad(s.mlp_dim)
     units: list[UnitSpec] = []
     small = [
         TensorSpec("img/stem_w", (s.width, pdim), pdim ** -0.5),
@@ -73,12 +88,12 @@ def build_specs(cfg: LAPConfig) -> list[UnitSpec]:
         small += [TensorSpec(f"img/{l}/ln1_g", (s.width,), 0.0, 1.0), TensorSpec(f"img/{l}/ln1_b", (s.width,), 0.0),
                   TensorSpec(f"img/{l}/bqkv", (3 * s.width,), 0.0), TensorSpec(f"img/{l}/bo", (s.width,), 0.0),
                   TensorSpec(f"img/{l}/ln2_g", (s.width,), 0.0, 1.0), TensorSpec(f"img/{l}/ln2_b", (s.width,), 0.0),
-                  TensorSpec(f"img/{l}/b1", (s.mlp_dim,), 1e-6), TensorSpec(f"img/{l}/b2", (s.width,), 1e-6)]
+                  TensorSpec(f"img/{l}/b1", (mp,), 1e-6, valid=(s.mlp_dim,)), TensorSpec(f"img/{l}/b2", (s.width,), 1e-6)]
         units.append(UnitSpec(f"img{l}", [
             TensorSpec(f"img/{l}/wqkv", (3 * s.width, s.width), s.width ** -0.5),
             TensorSpec(f"img/{l}/wo", (s.width, s.width), s.width ** -0.5),
-            TensorSpec(f"img/{l}/w1", (s.mlp_dim, s.width), (2.0 / (s.width + s.mlp_dim)) ** 0.5),
-            TensorSpec(f"img/{l}/w2", (s.width, s.mlp_dim), (2.0 / (s.width + s.mlp_dim)) ** 0.5)], True))
+            TensorSpec(f"img/{l}/w1", (mp, s.width), (2.0 / (s.width + s.mlp_dim)) ** 0.5, valid=(s.mlp_dim, s.width)),
+            TensorSpec(f"img/{l}/w2", (s.width, mp), (2.0 / (s.width + s.mlp_dim)) ** 0.5, valid=(s.width, s.mlp_dim))], True))
     small += [TensorSpec("img/norm_g", (s.width,), 0.0, 1.0), TensorSpec("img/norm_b", (s.width,), 0.0),
               TensorSpec("img/head_b", (v.width,), 0.0)]
     units.append(UnitSpec("img_head", [TensorSpec("img/head_w", (v.width, s.width), s.width ** -0.5)], True))
@@ -279,7 +294,11 @@ class ParamStore:
             full = torch.zeros(self.padded(u), dtype=torch.float32, device=self.device)
             for t in u.tensors:
                 v = full[t.offset:t.offset + t.numel]
-                if t.init_std > 0:
+                if t.init_std > 0 and t.valid is not None and tuple(t.valid) != tuple(t.shape):
+                    # (the same draws as the unpadded tensor would get; the padding stays zero)
+                    tmp = torch.empty(t.valid, dtype=torch.float32, device=self.device).normal_(0.0, t.init_std, generator=g)
+                    v.view(t.shape)[tuple(slice(0, n) for n in t.valid)] = tmp
+                elif t.init_std > 0:
                     v.normal_(0.0, t.init_std, generator=g)
                 elif t.fill:
                     v.fill_(t.fill)
@@ -419,6 +438,7 @@ def reference_to_engine(cfg: LAPConfig, P: dict) -> dict[str, torch.Tensor]:
     L, NH, HD = v.depth, v.num_heads, v.head_dim
     out = {}
     pdim = s.patch * s.patch * 3
+    mp = siglip_mlp_pad(s.mlp_dim)
     out["img/stem_w"] = T("PaliGemma/img/embedding/kernel").reshape(pdim, s.width).t().contiguous()
     out["img/stem_b"] = T("PaliGemma/img/embedding/bias")
     out["img/pos"] = T("PaliGemma/img/pos_embedding")[0]
@@ -431,9 +451,10 @@ def reference_to_engine(cfg: LAPConfig, P: dict) -> dict[str, torch.Tensor]:
         out[f"img/{l}/bqkv"] = torch.cat([T(f"{mha}/{n}/bias")[l].reshape(-1) for n in ("query", "key", "value")], 0)
         out[f"img/{l}/wo"] = T(f"{mha}/out/kernel")[l].reshape(s.width, s.width).t().contiguous()
         out[f"img/{l}/bo"] = T(f"{mha}/out/bias")[l]
-        out[f"img/{l}/w1"] = T(f"{blk}/MlpBlock_0/Dense_0/kernel")[l].t().contiguous()
-        out[f"img/{l}/b1"] = T(f"{blk}/MlpBlock_0/Dense_0/bias")[l]
-        out[f"img/{l}/w2"] = T(f"{blk}/MlpBlock_0/Dense_1/kernel")[l].t().contiguous()
+        padz = mp - s.mlp_dim          # zero rows of fc1 / zero bias entries / zero columns of fc2 (siglip_mlp_pad)
+        out[f"img/{l}/w1"] = torch.nn.functional.pad(T(f"{blk}/MlpBlock_0/Dense_0/kernel")[l].t(), (0, 0, 0, padz)).contiguous()
+        out[f"img/{l}/b1"] = torch.nn.functional.pad(T(f"{blk}/MlpBlock_0/Dense_0/bias")[l], (0, padz))
+        out[f"img/{l}/w2"] = torch.nn.functional.pad(T(f"{blk}/MlpBlock_0/Dense_1/kernel")[l].t(), (0, padz)).contiguous()
         out[f"img/{l}/b2"] = T(f"{blk}/MlpBlock_0/Dense_1/bias")[l]
     out["img/norm_g"], out["img/norm_b"] = T("PaliGemma/img/Transformer/encoder_norm/scale"), T("PaliGemma/img/Transformer/encoder_norm/bias")
     out["img/head_w"] = T("PaliGemma/img/head/kernel").t().contiguous()
@@ -489,8 +510,9 @@ def engine_to_reference(cfg: LAPConfig, E: dict) -> dict[str, torch.Tensor]:
         P[f"{mha}/{n}/bias"] = st(lambda l: E[f"img/{l}/bqkv"][j * s.width:(j + 1) * s.width].reshape(s.num_heads, hd))
     P[f"{mha}/out/kernel"] = st(lambda l: E[f"img/{l}/wo"].t().reshape(s.num_heads, hd, s.width))
     P[f"{mha}/out/bias"] = st(lambda l: E[f"img/{l}/bo"])
-    P[f"{blk}/MlpBlock_0/Dense_0/kernel"], P[f"{blk}/MlpBlock_0/Dense_0/bias"] = st(lambda l: E[f"img/{l}/w1"].t()), st(lambda l: E[f"img/{l}/b1"])
-    P[f"{blk}/MlpBlock_0/Dense_1/kernel"], P[f"{blk}/MlpBlock_0/Dense_1/bias"] = st(lambda l: E[f"img/{l}/w2"].t()), st(lambda l: E[f"img/{l}/b2"])
+    md = s.mlp_dim      # (the engine's zero padding of the MLP width stays behind: siglip_mlp_pad)
+    P[f"{blk}/MlpBlock_0/Dense_0/kernel"], P[f"{blk}/MlpBlock_0/Dense_0/bias"] = st(lambda l: E[f"img/{l}/w1"][:md].t()), st(lambda l: E[f"img/{l}/b1"][:md])
+    P[f"{blk}/MlpBlock_0/Dense_1/kernel"], P[f"{blk}/MlpBlock_0/Dense_1/bias"] = st(lambda l: E[f"img/{l}/w2"][:, :md].t()), st(lambda l: E[f"img/{l}/b2"])
     P["PaliGemma/img/Transformer/encoder_norm/scale"], P["PaliGemma/img/Transformer/encoder_norm/bias"] = E["img/norm_g"], E["img/norm_b"]
     P["PaliGemma/img/head/kernel"], P["PaliGemma/img/head/bias"] = E["img/head_w"].t().contiguous(), E["img/head_b"]
     P["PaliGemma/llm/embedder/input_embedding"] = E["llm/embed"]

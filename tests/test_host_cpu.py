@@ -30,10 +30,43 @@ def test_reference_engine_key_map_round_trip():
         ps.load_reference_tree({k: v for k, v in P.items() if "time_mlp_in" not in k})
 
 
+def test_siglip_mlp_padding_is_invisible_in_the_reference_tree(monkeypatch):
+    """An MLP width that is no multiple of 128 (So400m: 4304) is zero-padded inside the engine only: the reference tree goes in
+    and comes out with its own shapes, the padding is exactly zero after a load and after the random init, and the random init
+    draws the same numbers as the unpadded layout would."""
+    import dataclasses
+    from lap_amd import config as C
+    monkeypatch.setitem(C._SIGLIP, "pad-test/14", C.SiglipConfig(32, 2, 1100, 2))
+    cfg = dataclasses.replace(debug_model_cfg(), siglip_variant="pad-test/14")
+    assert PR.siglip_mlp_pad(1100) == 1280 and PR.siglip_mlp_pad(128) == 128 and PR.siglip_mlp_pad(4352) == 4352
+    shapes = PR.reference_shapes(cfg)
+    blk = "PaliGemma/img/Transformer/encoderblock/MlpBlock_0"
+    assert shapes[f"{blk}/Dense_0/kernel"] == (2, 32, 1100) and shapes[f"{blk}/Dense_1/kernel"] == (2, 1100, 32) and shapes[f"{blk}/Dense_0/bias"] == (2, 1100)
+    g = torch.Generator().manual_seed(0)
+    P = {k: torch.randn(sh, generator=g) for k, sh in shapes.items()}
+    E = PR.reference_to_engine(cfg, P)
+    assert E["img/1/w1"].shape == (1280, 32) and E["img/1/b1"].shape == (1280,) and E["img/1/w2"].shape == (32, 1280)
+    assert not E["img/1/w1"][1100:].any() and not E["img/1/b1"][1100:].any() and not E["img/1/w2"][:, 1100:].any()
+    P2 = PR.engine_to_reference(cfg, E)
+    assert all(torch.equal(P[k], P2[k]) for k in P)
+    ps = PR.ParamStore(cfg, device="cpu")
+    ps.init_random(3)
+    w1, w2, b1 = (ps._view(ps.master[ps.tensor_unit[n].name], n) for n in ("img/0/w1", "img/0/w2", "img/0/b1"))
+    assert not w1[1100:].any() and not w2[:, 1100:].any() and not b1[1100:].any() and w1[:1100].abs().min() > 0
+    monkeypatch.setenv("LAP_SIGLIP_PAD", "0")
+    ps0 = PR.ParamStore(cfg, device="cpu")
+    ps0.init_random(3)
+    T0, T1 = ps0.to_reference_tree("master"), ps.to_reference_tree("master")
+    assert all(torch.equal(T0[k], T1[k]) for k in T0)
+
+
 def test_lap3b_parameter_count_and_units():
     units = PR.build_specs(get_config("lap_bench").model)
-    n = sum(t.numel for u in units for t in u.tensors)
+    import math
+    n = sum(math.prod(t.valid or t.shape) for u in units for t in u.tensors)     # the reference's extents (the engine pads SigLIP's MLP width)
     assert abs(n - 3.353e9) < 2e6   # SURVEY.md §8: 3.353 B parameters
+    n_engine = sum(t.numel for u in units for t in u.tensors)
+    assert n_engine - n == 27 * (PR.siglip_mlp_pad(4304) - 4304) * (2 * 1152 + 1) and PR.siglip_mlp_pad(4304) == 4352
     names = [u.name for u in units]
     assert names[0] == "small" and names.count("embed") == 1 and sum(x.startswith("llm") for x in names) == 18
     assert sum(x.startswith("img") and x[3:].isdigit() for x in names) == 27
