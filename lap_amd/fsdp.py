@@ -45,7 +45,16 @@ class UnitPipeline:
     def __init__(self, store: ParamStore):
         self.ps = store
         self.is_cuda = store.device.type == "cuda"
-        self.side = torch.cuda.Stream(device=store.device) if self.is_cuda else None
+        import os
+        # LAP_OPT_PRIORITY=low: the optimizer's stream at the lowest HIP priority — its blocks are dispatched when the compute
+        # stream has none waiting, i.e. under the persistent GEMM blocks rather than beside the bandwidth-bound kernels
+        prio = os.environ.get("LAP_OPT_PRIORITY", "normal")
+        if not self.is_cuda:
+            self.side = None
+        elif prio in ("low", "high"):
+            self.side = hip.stream_with_hip_priority(store.device, prio)
+        else:
+            self.side = torch.cuda.Stream(device=store.device)
         self.unit_events: dict[str, object] = {}
         self.sumsq = torch.zeros(2, dtype=torch.float32, device=store.device)   # [sharded units, replicated unit]
         self.scal = torch.zeros(8, dtype=torch.float32, device=store.device)

@@ -807,3 +807,21 @@ def gemm_fp8(a8, sa, b8, sb, out=None, *, residual=None, out_dtype=torch.bfloat1
     call("lap_gemm_fp8", _p(a8), _p(b8), _p(out), _p(residual), _p(sa), _p(sb), M, N, K, a8.stride(0), b8.stride(0), out.stride(0),
          residual.stride(0) if residual is not None else 0, float(alpha), flags)
     return out
+
+
+def stream_with_hip_priority(device, level: str):
+    """A HIP stream of the LOWEST ("low") or HIGHEST ("high") priority the device offers, wrapped for torch (torch itself only
+    creates streams of normal or higher priority).  hipStreamNonBlocking, like torch's own pool streams.  The wrapper keeps no
+    ownership: the stream lives for the rest of the process (one per pipeline object)."""
+    import ctypes
+    rt = ctypes.CDLL("libamdhip64.so")
+    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+    if rt.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+        raise LapHipError("hipDeviceGetStreamPriorityRange failed")
+    handle = ctypes.c_void_p()
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        rc = rt.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(1), ctypes.c_int(least.value if level == "low" else greatest.value))
+    if rc != 0 or not handle.value:
+        raise LapHipError(f"hipStreamCreateWithPriority failed: {rc}")
+    return torch.cuda.ExternalStream(handle.value, device=dev)
