@@ -1535,7 +1535,8 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
       if (!no_res && t5 >= 128 && (fill >= 0.8 || (bias && K <= 2048))) return lap_gemm_asm_res(A, B, C, (const float*)bias, residual, M, N, K, lda, ldb, ldc, stream);
       // (the M cut of the plain products below, with the residual rows following the cut)
       static const bool no_msplit = getenv("LAP_GEMM_NO_MSPLIT") != nullptr;
-      if (!no_res && !no_msplit && !bias && ksplit == 0 && scratch != nullptr && K <= 4096 && rounds >= 1 && fill < 0.8 && (rounds * 256) % tn == 0) {
+      static const bool longk = getenv("LAP_GEMM_NO_MSPLIT_LONGK") == nullptr;   // (A/B switch, see the plain products below)
+      if (!no_res && !no_msplit && !bias && ksplit == 0 && scratch != nullptr && (K <= 4096 || longk) && rounds >= 1 && fill < 0.8 && (rounds * 256) % tn == 0) {
         const int M0 = (int)(rounds * 256 / tn) * 256;
         if (int rc = lap_gemm_asm_res(A, B, C, nullptr, residual, M0, N, K, lda, ldb, ldc, stream)) return rc;
         return lap_gemm_bf16_ex((const char*)A + (long long)M0 * lda * 2, B, (char*)C + (long long)M0 * ldc * 2, nullptr,
@@ -1554,10 +1555,14 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
     // third round for 48 tiles; the HIP tile splits those 48 along K.  Same cut here, made along M: rows [0, 64 x 256) are
     // exactly two rounds for the assembly kernel, the last 1,536 rows a product of their own on the automatic route (its
     // K split covers the chip).  tools/bench_msplit.py (isolated, us): qkv data gradient K = 2560 195 -> 152, out data gradient
-    // K = 2048 161 -> 124, plain forward K = 2048 129 -> 121; long contractions lose (K = 32768 data gradient 1738 -> 1778, K =
-    // 16384 forward 940 -> 1092: the HIP tile's order keeps its operand panels better) and stay on the tail split.
-    // LAP_GEMM_NO_MSPLIT=1: off (A/B).
-    if (tile < 0 && plain && !no_asm && ksplit == 0 && scratch != nullptr && K <= 4096) {
+    // K = 2048 161 -> 124, plain forward K = 2048 129 -> 121.  LAP_GEMM_NO_MSPLIT=1: off (A/B).
+    // Long contractions with a K-contiguous A (gate|up data gradient K = 32768, down forward + residual K = 16384; the engine pads
+    // A's rows off the 16 KiB stride): isolated the cut is a wash (1726 vs 1762 us, 922 vs 949 us: the last 1536 rows cost 181 /
+    // 100 us on the HIP tile's K split either way), in the train step it is worth 2.8 ms (302.0 -> 299.2 ms, interleaved on
+    // one box) — the assembly kernel's two rounds leave the optimizer stream more of the chip than the HIP tile's.
+    // LAP_GEMM_NO_MSPLIT_LONGK=1: off (A/B).
+    static const bool msplit_longk = getenv("LAP_GEMM_NO_MSPLIT_LONGK") == nullptr;
+    if (tile < 0 && plain && !no_asm && ksplit == 0 && scratch != nullptr && (K <= 4096 || (msplit_longk && a_kc))) {
       static const bool off = getenv("LAP_GEMM_NO_MSPLIT") != nullptr;
       const long long tm = M / 256, tn = N / 256, t5 = tm * tn, rounds = t5 / 256;
       const double fill = (double)t5 / (256.0 * ((t5 + 255) / 256));
