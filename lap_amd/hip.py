@@ -78,6 +78,8 @@ SIGNATURES: dict[str, list] = {
     "lap_gemm_asm_bias_ok": [_i, _i, _i, _i, _i, _i],
     "lap_gemm_asm_res": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_asm_res_ok": [_i, _i, _i, _i, _i, _i, _i],
+    "lap_gemm_asm_geglu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "lap_gemm_asm_geglu_bwd_ok": [_i, _i, _i, _i, _i, _i],
     "lap_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "lap_amax_bf16": [_vp, _ll, _i, _ll, _vp, _vp],
     "lap_quantize_fp8": [_vp, _ll, _i, _ll, _vp, _vp, _ll, _vp, _vp],
@@ -359,6 +361,27 @@ def geglu_fwd(gu, pad=False):
     act = _padded_rows(rows, H2 // 2, gu.device, _row_pad(H2 // 2) if pad else 0)
     call("lap_geglu_fwd_ld", _p(gu), _p(act), rows, H2 // 2, gu.stride(0), act.stride(0))
     return act
+
+
+def dgrad_geglu_bwd_ok(dy, w, gu):
+    """whether linear_dgrad_geglu_bwd takes (dy [M, K], w [K, N], gu [M, 2N] with any row stride >= 2N)"""
+    M, K = dy.shape
+    N = w.shape[1]
+    return (dy.dtype == w.dtype == gu.dtype == torch.bfloat16 and gu.shape == (M, 2 * N) and gu.stride(1) == 1 and dy.stride(1) == 1 and w.stride(1) == 1
+            and bool(_lib.lap_gemm_asm_geglu_bwd_ok(M, N, K, dy.stride(0), w.stride(0), gu.stride(0))))
+
+
+def linear_dgrad_geglu_bwd(dy, w, gu):
+    """dgu = geglu_bwd(gu, dy @ w) in one launch (the down projection's data gradient with the GeGLU backward as its epilogue);
+    dgu gets gu's row stride."""
+    M, K = dy.shape
+    N = w.shape[1]
+    if tuple(gu.shape) != (M, 2 * N) or w.shape[0] != K:
+        raise LapHipError(f"linear_dgrad_geglu_bwd: dy {tuple(dy.shape)}, w {tuple(w.shape)}, gate|up {tuple(gu.shape)} do not fit")
+    ld = gu.stride(0)
+    dgu = torch.empty((M, ld), dtype=torch.bfloat16, device=gu.device)[:, :2 * N]
+    call("lap_gemm_asm_geglu_bwd", _p(dy), _p(w), _p(dgu), _p(gu), M, N, K, dy.stride(0), w.stride(0), ld)
+    return dgu
 
 
 def geglu_bwd(gu, dact, pad=False):

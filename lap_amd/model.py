@@ -82,6 +82,8 @@ class LAP:
         self.dual_stream = os.environ.get("LAP_DUAL_STREAM", "1") != "0"
         # serving prefill on the fused consumers (`_siglip_fwd_serve`, `_llm_prefill`); "0": the generic layer loops (A/B, tests)
         self.serve_fusions = os.environ.get("LAP_SERVE_FUSIONS", "1") != "0"
+        # prefix stream, bf16: d(act) of the down projection goes straight into the GeGLU backward inside the assembly GEMM's epilogue
+        self.fuse_geglu_bwd = os.environ.get("LAP_FUSE_GEGLU_BWD", "1") != "0" and gemm_dtype != "fp8"
         # first denoise step on a second stream beside the prefill (it needs layer l's K / V only at its layer l).  Measured, hipGraph
         # replay, same box, interleaved: 15.65 -> 16.30 ms per chunk — the step's 110 short kernels take CUs from the prefill's
         # load-bound GEMMs for longer than they save.  Kept as a switch, OFF by default.
@@ -218,7 +220,7 @@ class LAP:
             self._w8[name] = ent
         return ent[1:]
 
-    def _lin0(self, x, name, residual=None):
+    def _lin0(self, x, name, residual=None, out=None):
         """y = x @ Wt^T (+ residual) for a prefix-stream projection: bf16 MFMA GEMM, or e4m3 x e4m3 when gemm_dtype == 'fp8'."""
         if self.gemm_dtype == "fp8":
             x8, sx = hip.quantize_fp8(x)
@@ -228,7 +230,7 @@ class LAP:
             # measurement switch: the reference rounds the projection to bf16 and then the sum to bf16
             # (gemma.py:285,582-583); the fused epilogue adds in f32 and rounds once
             return hip.add_bf16(residual, hip.linear_fwd(x, self.W(name)))
-        return hip.linear_fwd(x, self.W(name), residual=residual)
+        return hip.linear_fwd(x, self.W(name), out, residual=residual)
 
     def _dgrad0(self, dy, name):
         """dx = dy @ Wt for a prefix-stream projection (the fp8 route multiplies by the transposed fp8 copy)."""
@@ -630,7 +632,10 @@ class LAP:
                 xa[0] = self._lin0(o[0], p + "wo0", residual=x0)
                 hf[0], rstd_f[0] = hip.rmsnorm_fwd(xa[0], scale=self.F(p + "n_ffw"), save_rstd=save)
                 self.comm.pace(f"llm{l}")     # optimizer units released here start under the longest MFMA-bound GEMM of the layer
-                gu[0] = self._lin0(hf[0], p + "wgu0")
+                gu_out = None
+                if save and self.fuse_geglu_bwd:    # rows padded like d(gate | up): the fused backward kernel shares one row stride
+                    gu_out = hip._padded_rows(hf[0].shape[0], 2 * v.mlp_dim, hf[0].device, hip._row_pad(2 * v.mlp_dim))
+                gu[0] = self._lin0(hf[0], p + "wgu0", out=gu_out)
                 act[0] = hip.geglu_fwd(gu[0], pad=self.gemm_dtype != "fp8")
                 xn[0] = self._lin0(act[0], p + "wd0", residual=xa[0])
             if save:
@@ -718,9 +723,13 @@ class LAP:
             # ---- FFN, prefix stream: xn = xa + act @ wd^T   (dx0 is None: the whole prefix side is frozen)
             if dx0 is not None:
                 self._wgrad(dx0, c["act"][0], p + "wd0")
-                dact = self._dgrad0(dx0, p + "wd0")
-                dgu = hip.geglu_bwd(c["gu"][0], dact, pad=self.gemm_dtype != "fp8")
-                del dact
+                if self.fuse_geglu_bwd and hip.dgrad_geglu_bwd_ok(dx0, self.W(p + "wd0"), c["gu"][0]):
+                    # the down projection's data gradient with the GeGLU backward as its epilogue: d(act) never reaches memory
+                    dgu = hip.linear_dgrad_geglu_bwd(dx0, self.W(p + "wd0"), c["gu"][0])
+                else:
+                    dact = self._dgrad0(dx0, p + "wd0")
+                    dgu = hip.geglu_bwd(c["gu"][0], dact, pad=self.gemm_dtype != "fp8")
+                    del dact
                 self._wgrad(dgu, c["hf"][0], p + "wgu0")
                 dhf = self._dgrad0(dgu, p + "wgu0")
                 del dgu

@@ -216,6 +216,40 @@ def test_gemm_assembly_residual_kernels_match_hip_tiles_bitwise(hip):
     assert rel_err(o[16384:], o10[16384:]) < 2e-3
 
 
+def test_gemm_assembly_dgrad_with_geglu_backward_epilogue(hip):
+    """lap_gemm_asm_nn_geglu_bwd: d(gate | up) = geglu_bwd(gate | up, dy @ W) in one launch.  Same rounding points as the two-launch
+    route (d(act) and gelu(gate) rounded to bf16); the GELU goes through v_exp / v_rcp instead of tanhf, so outputs may differ from
+    the two-launch route by one bf16 step where the f32 values sit on a rounding boundary — and nowhere else."""
+    for M, N, K, pad in [(256, 512, 512, 0), (1024, 768, 640, 64), (2304, 2048, 1152, 64)]:
+        dy = rnd(M, K, seed=1)
+        w = rnd(K, N, seed=2)
+        gu = (rnd(M, 2 * N + pad, seed=3) * 6.0)[:, :2 * N]       # gate values over [-3, 3]: the nonlinear part of the GELU
+        assert hip.dgrad_geglu_bwd_ok(dy, w, gu)
+        dgu = hip.linear_dgrad_geglu_bwd(dy, w, gu)
+        dact = hip.linear_dgrad(dy, w, tile=12, ksplit=1)
+        ref = hip.geglu_bwd(gu, dact)
+        assert dgu.shape == ref.shape and dgu.stride(0) == gu.stride(0)
+        # identical where the GELU is not saturated; in the tails (|gate| > ~4.5) tanhf rounds to -1 / +1 and the two-launch route
+        # returns exact zeros where the sigmoid form keeps the true 1e-7-sized values: below any bf16 step of the tensor
+        mid = (gu[:, :N].float().abs() <= 3.0)
+        mid2 = torch.cat([mid, mid], 1)
+        same = (dgu == ref)[mid2].float().mean().item()
+        assert same > 0.97, (M, N, K, same)
+        d = (dgu.float() - ref.float()).abs()
+        assert (d <= ref.float().abs() * 2.0 ** -7 + 2e-5 * ref.float().abs().max()).all(), (M, N, K, d.max().item())
+        # and both sit on the f32 formula
+        g, u = gu[:, :N].float(), gu[:, N:].float()
+        da = (dy.float() @ w.float()).bfloat16().float()
+        k0, k1 = 0.7978845608028654, 0.044715
+        t = torch.tanh(k0 * (g + k1 * g ** 3))
+        gelu = 0.5 * g * (1 + t)
+        gp = 0.5 * (1 + t) + 0.5 * g * (1 - t * t) * k0 * (1 + 3 * k1 * g * g)
+        want = torch.cat([da * u * gp, da * gelu.bfloat16().float()], 1)
+        assert rel_err(dgu, want) < 5e-3 and abs(rel_err(dgu, want) - rel_err(ref, want)) < 2e-4
+    with pytest.raises(hip.LapHipError):      # gate | up and its gradient share one row stride; rows shorter than 2N are rejected
+        hip.linear_dgrad_geglu_bwd(rnd(256, 512), rnd(512, 512), rnd(256, 1024)[:, :512])
+
+
 def test_gemm_ragged_k_on_the_pipelined_tiles_matches_lockstep_tile_bitwise(hip):
     """K % 64 != 0 (SigLIP's MLP width 4304 = 67 * 64 + 16) on tiles 10 / 12: the last k-tile's chunks past K are fetched with an
     out-of-range offset (zeros), so the sums — and the bits — are those of the 16-wave lockstep tile (tile 2) that handled such

@@ -83,6 +83,10 @@ V_COM = 164                 # epilogue variant: V_CO with the ragged-N mask fold
 V_RS = (112, 168)           # residual variant: two sets of 4 x 2 registers for the residual values
 V_RT = 124                  # v124..v127: the residual widened to f32
 S_RDL, S_RDH = 58, 91       # residual variant: R - C in bytes
+V_COU = 13                  # GeGLU-backward variant: V_CO of the up half (+ N columns)
+V_GUL = 192                 # v192..v223: two sets of 4 x (gate pair, up pair)
+V_GX, V_GU_, V_GX2, V_GP, V_GG, V_GO = 112, 116, 124, 164, 168, 172     # 4 registers each: the arithmetic of one row piece
+V_GK0, V_GK1 = 182, 183     # constants: -2 log2(e) sqrt(2/pi), sqrt(2/pi)
 V_TID, V_LANE = 0, 1
 V_DA, V_DB = 2, 6           # DMA lane offsets: up to 4 classes of pieces per operand
 V_T = 10                    # v10, v11 scratch; v12: epilogue lane offset
@@ -118,13 +122,20 @@ def order():
 
 
 class Kernel:
-    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False, res=False, ring=False):
+    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False, res=False, ring=False, gbwd=False):
         # epi: f32 bias per output column + ragged N (the last n-tile may hold fewer than 256 valid columns; N % 16 == 0)
         # tout: the product is stored TRANSPOSED (C is [N][ldc]): a tall weight gradient dW [out, in] = dy^T x runs as the wide
         #       product x^T dy (whose operand panels stream much better, tools/bench_asm_gemm.py) and lands in dW's layout
         # res: + a bf16 residual R [M][ldc] (same leading dimension as C) added in f32 before the one rounding: the accumulators
         #      are staged as f32 (two 64-column halves per row group), read back 4 columns per lane, and leave as 128-byte rows
         self.name, self.kc, self.f32, self.epi, self.tout, self.res = name, (a_kc, b_kc), out_f32, epi, tout, res
+        # gbwd: the product is d(act) [M][N] of a GeGLU MLP's down projection and never leaves the kernel: the epilogue reads the
+        #       forward's gate | up values GU [M][2N] (C's leading dimension), rounds d(act) to bf16 as the stand-alone product
+        #       would, and stores d(gate) = d(act) * up * gelu'(gate) and d(up) = d(act) * bf16(gelu(gate)) into C [M][2N]
+        #       (csrc/elementwise.hip geglu_bwd_kernel; gemma.py:308-312 backward).  GELU' through v_exp / v_rcp (sigmoid form).
+        self.gbwd = gbwd
+        res = res or gbwd
+        self.res = res
         self.st32 = out_f32 or res          # staging buffer holds f32
         # ring: (both operands M- / N-contiguous) the 128 KiB of LDS as a ring of four 32-deep half k-tiles [A 16 KiB | B 16 KiB]
         # instead of two 64-deep stages: phase p (64 MFMAs on half p) reads the fragments of half p + 1 and requests half p + 4
@@ -293,11 +304,28 @@ class Kernel:
         byslot = {}
         for slot, txt in side:
             byslot.setdefault(slot, []).append(txt)
-        for n, (fm, fn) in enumerate(order()):
-            E("\t" + mfma(fm, fn, st, self.tout))
+        if "m32" in ABL:        # timing only: the phase's 64 MFMA 16x16x32 as 32 MFMA 32x32x16 (same flops, garbage operands)
+            merged = {}
+            for slot, lst in byslot.items():
+                merged.setdefault(slot // 2, []).extend(lst)
+            byslot = merged
+        for n, (fm, fn) in enumerate(order() if "m32" not in ABL else [(k % 4, k // 4 % 4) for k in range(32)]):
+            if "m32" in ABL:
+                a = (n % 16) * 16
+                E(f"\tv_mfma_f32_32x32x16_bf16 a[{a}:{a+15}], v[{FB[st] + 4*fn}:{FB[st] + 4*fn + 3}], v[{FA[st] + 4*fm}:{FA[st] + 4*fm + 3}], a[{a}:{a+15}]")
+            else:
+                E("\t" + mfma(fm, fn, st, self.tout))
             for txt in byslot.get(n, []):
                 if ("nodma" in ABL and ("lds" in txt.split() or txt.startswith("s_add_u32 m0") or txt == "s_nop 0")) or \
                         ("noread" in ABL and txt.startswith("ds_read_b")):
+                    continue
+                if "gll" in ABL and txt.startswith("buffer_load_dwordx4") and txt.endswith("lds"):
+                    # timing only: the same piece as a global_load_lds (no range check: the parked stream reads real memory)
+                    import re as _re
+                    m = _re.match(r"buffer_load_dwordx4 v(\d+), s\[(\d+):(\d+)\], s(\d+) offen lds", txt)
+                    vd, rs, _, soff = (int(x) for x in m.groups())
+                    L(f"v_add_u32 v{V_E+15}, s{soff}, v{vd}")
+                    L(f"global_load_lds_dwordx4 v{V_E+15}, s[{rs}:{rs+1}]")
                     continue
                 L(txt)
 
@@ -428,6 +456,9 @@ class Kernel:
             E(f"\ts_and_b32 s{RR+1}, s{RR+1}, 0xffff")
             E(f"\ts_mov_b32 s{RR+2}, s{RC+2}")
             E(f"\ts_mov_b32 s{RR+3}, s{RC+3}")
+        if self.gbwd:
+            E(f"\tv_mov_b32 v{V_GK0}, 0xc0135761")       # -2 log2(e) sqrt(2/pi) = -2.3022082
+            E(f"\tv_mov_b32 v{V_GK1}, 0x3f4c422a")       # sqrt(2/pi) = 0.7978846
         for fc in range(nfc):
             E(f"\tv_xor_b32 v{V_WA+fc}, {fc * (64 if self.st32 else 32)}, v{V_SW}")
         for j in range(4):
@@ -452,14 +483,72 @@ class Kernel:
 
         def res_loads(u):
             fr, h = units[u]
+            off = f" offset:{h*128}" if h else ""
+            if self.gbwd:       # gate and up values of the unit: 4 row pieces x (4 gate, 4 up) per lane
+                gl = V_GUL + 16 * (u & 1)
+                for j in range(4):
+                    E(f"\tbuffer_load_dwordx2 v[{gl+4*j}:{gl+4*j+1}], v{V_CO}, s[{RR}:{RR+3}], s{soff(fr, j)} offen{off}")
+                    E(f"\tbuffer_load_dwordx2 v[{gl+4*j+2}:{gl+4*j+3}], v{V_COU}, s[{RR}:{RR+3}], s{soff(fr, j)} offen{off}")
+                return
             rs = V_RS[u & 1]
             for j in range(4):
-                off = f" offset:{h*128}" if h else ""
                 E(f"\tbuffer_load_dwordx2 v[{rs+2*j}:{rs+2*j+1}], v{vco(h)}, s[{RR}:{RR+3}], s{soff(fr, j)} offen{off}")
+
+        def geglu_bwd_piece(c, gl):
+            """4 outputs of one row piece: c..c+3 = d(act) (f32, unrounded), gl, gl+1 = 4 gate values (bf16 pairs), gl+2, gl+3 = 4 up values.
+            Leaves d(gate) packed in V_GU_, V_GU_+1 and d(up) packed in V_GG, V_GG+1.  With s = sigmoid(2 k0 (x + k1 x^3)):
+            gelu(x) = x s,  gelu'(x) = s + 2 x s (1 - s) k0 (1 + 3 k1 x^2)."""
+            X, U, X2, P, G, O = V_GX, V_GU_, V_GX2, V_GP, V_GG, V_GO
+            K1P, C3 = "0xbdd2d3e8", "0x3ddb33b6"      # -2 log2(e) k0 k1 = -0.10294324, 3 k0 k1 = 0.10703222
+            E(f"\tv_cvt_pk_bf16_f32 v{P}, v{c}, v{c+1}")             # d(act) as the stand-alone product stores it
+            E(f"\tv_cvt_pk_bf16_f32 v{P+1}, v{c+2}, v{c+3}")
+            for k in range(2):
+                E(f"\tv_lshlrev_b32 v{X+2*k}, 16, v{gl+k}")
+                E(f"\tv_and_b32 v{X+2*k+1}, 0xffff0000, v{gl+k}")
+                E(f"\tv_lshlrev_b32 v{U+2*k}, 16, v{gl+2+k}")
+                E(f"\tv_and_b32 v{U+2*k+1}, 0xffff0000, v{gl+2+k}")
+            for k in range(2):
+                E(f"\tv_lshlrev_b32 v{c+2*k}, 16, v{P+k}")
+                E(f"\tv_and_b32 v{c+2*k+1}, 0xffff0000, v{P+k}")
+            for e in range(4): E(f"\tv_mul_f32 v{X2+e}, v{X+e}, v{X+e}")
+            for e in range(4): E(f"\tv_fmamk_f32 v{P+e}, v{X2+e}, {K1P}, v{V_GK0}")          # -2 log2(e) k0 (1 + k1 x^2)
+            for e in range(4): E(f"\tv_mul_f32 v{P+e}, v{X+e}, v{P+e}")
+            for e in range(4): E(f"\tv_exp_f32 v{P+e}, v{P+e}")                              # exp(-2 u)
+            for e in range(4): E(f"\tv_add_f32 v{P+e}, 1.0, v{P+e}")
+            for e in range(4): E(f"\tv_rcp_f32 v{P+e}, v{P+e}")                              # s
+            for e in range(4): E(f"\tv_fmamk_f32 v{X2+e}, v{X2+e}, {C3}, v{V_GK1}")          # k0 (1 + 3 k1 x^2)
+            for e in range(4): E(f"\tv_mul_f32 v{G+e}, v{X+e}, v{P+e}")                      # gelu
+            for e in range(4): E(f"\tv_sub_f32 v{O+e}, 1.0, v{P+e}")
+            for e in range(4): E(f"\tv_mul_f32 v{O+e}, v{X+e}, v{O+e}")
+            for e in range(4): E(f"\tv_mul_f32 v{O+e}, v{O+e}, v{X2+e}")
+            for e in range(4): E(f"\tv_add_f32 v{O+e}, v{O+e}, v{O+e}")
+            for e in range(4): E(f"\tv_fma_f32 v{O+e}, v{P+e}, v{O+e}, v{P+e}")              # gelu'
+            for e in range(4): E(f"\tv_mul_f32 v{U+e}, v{c+e}, v{U+e}")
+            for e in range(4): E(f"\tv_mul_f32 v{U+e}, v{U+e}, v{O+e}")                      # d(gate)
+            E(f"\tv_cvt_pk_bf16_f32 v{X}, v{G}, v{G+1}")                                      # bf16(gelu)
+            E(f"\tv_cvt_pk_bf16_f32 v{X+1}, v{G+2}, v{G+3}")
+            for k in range(2):
+                E(f"\tv_lshlrev_b32 v{G+2*k}, 16, v{X+k}")
+                E(f"\tv_and_b32 v{G+2*k+1}, 0xffff0000, v{X+k}")
+            for e in range(4): E(f"\tv_mul_f32 v{G+e}, v{c+e}, v{G+e}")                      # d(up)
+            E(f"\tv_cvt_pk_bf16_f32 v{U}, v{U}, v{U+1}")
+            E(f"\tv_cvt_pk_bf16_f32 v{U+1}, v{U+2}, v{U+3}")
+            E(f"\tv_cvt_pk_bf16_f32 v{G}, v{G}, v{G+1}")
+            E(f"\tv_cvt_pk_bf16_f32 v{G+1}, v{G+2}, v{G+3}")
 
         def stores(u):
             fr, h = units[u]
             cs = V_CS + (u & 1) * 16
+            if self.gbwd:
+                gl = V_GUL + 16 * (u & 1)
+                # this unit's gate / up values; issued behind them: the previous unit's 8 stores (not for unit 0), the next unit's 8 loads (not for the last)
+                E(f"\ts_waitcnt vmcnt({8 * ((u > 0) + (u + 1 < len(units)))})")
+                off = f" offset:{h*128}" if h else ""
+                for j in range(4):
+                    geglu_bwd_piece(cs + 4 * j, gl + 4 * j)
+                    E(f"\tbuffer_store_dwordx2 v[{V_GU_}:{V_GU_+1}], v{V_CO}, s[{RC}:{RC+3}], s{soff(fr, j)} offen{off}{ST_NT}")
+                    E(f"\tbuffer_store_dwordx2 v[{V_GG}:{V_GG+1}], v{V_COU}, s[{RC}:{RC+3}], s{soff(fr, j)} offen{off}{ST_NT}")
+                return
             if self.res:
                 rs = V_RS[u & 1]
                 # this unit's residual values; issued behind them: the previous unit's 4 stores (not for unit 0), the next unit's 4 loads (not for the last)
@@ -602,6 +691,9 @@ class Kernel:
             E(f"\ts_mov_b32 s{rs+3}, 0x00020000")
         E(f"\ts_mul_i32 s{RC+2}, s{S_LDC}, 255")
         E(f"\ts_add_u32 s{RC+2}, s{RC+2}, {1024 if self.f32 else 512}")
+        if self.gbwd:      # C (and GU) rows hold 2 N columns: the up half sits N columns behind the gate half
+            E(f"\ts_lshl_b32 s{t+14}, s{S_N}, 1")
+            E(f"\ts_add_u32 s{RC+2}, s{RC+2}, s{t+14}")
         E(f"\ts_mov_b32 s{RCN+2}, s{RC+2}")
         if self.epi:
             E(f"\ts_and_b32 s{RBI+1}, s{RBI+1}, 0xffff")
@@ -741,6 +833,9 @@ class Kernel:
             E(f"\ts_lshl_b32 s{t+14}, s{wcol}, {9 if self.f32 else 8}")
             E(f"\tv_add_u32 v{V_E}, v{V_E}, v{V_E+1}")
             E(f"\tv_add_u32 v{V_CO}, s{t+14}, v{V_E}")
+            if self.gbwd:
+                E(f"\ts_lshl_b32 s{t+14}, s{S_N}, 1")
+                E(f"\tv_add_u32 v{V_COU}, s{t+14}, v{V_CO}")
             E(f"\ts_lshl_b32 s{S_C16}, s{S_LDC}, 2")                     # FOUR rows of C in bytes
         else:
             # m = wm*128 + fm*16 + (l & 15), n = wn*128 + fn*16 + 4 (l >> 4)
@@ -862,7 +957,8 @@ KERNELS = [Kernel("lap_gemm_asm_nt", True, True, False), Kernel("lap_gemm_asm_nn
            Kernel("lap_gemm_asm_tn", False, False, True, ring=RING), Kernel("lap_gemm_asm_nt_bias", True, True, False, epi=True),
            Kernel("lap_gemm_asm_tn_t", False, False, True, tout=True, ring=RING),
            Kernel("lap_gemm_asm_nt_res", True, True, False, res=True),
-           Kernel("lap_gemm_asm_nt_bias_res", True, True, False, epi=True, res=True)]
+           Kernel("lap_gemm_asm_nt_bias_res", True, True, False, epi=True, res=True),
+           Kernel("lap_gemm_asm_nn_geglu_bwd", True, False, False, gbwd=True)]
 E('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
 E("\t.amdhsa_code_object_version 6")
 for k in KERNELS:
