@@ -80,6 +80,8 @@ SIGNATURES: dict[str, list] = {
     "lap_gemm_asm_res_ok": [_i, _i, _i, _i, _i, _i, _i],
     "lap_gemm_asm_geglu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_asm_geglu_bwd_ok": [_i, _i, _i, _i, _i, _i],
+    "lap_gemm_asm_geglu_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "lap_gemm_asm_geglu_fwd_ok": [_i, _i, _i, _i, _i, _i, _i],
     "lap_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "lap_amax_bf16": [_vp, _ll, _i, _ll, _vp, _vp],
     "lap_quantize_fp8": [_vp, _ll, _i, _ll, _vp, _vp, _ll, _vp, _vp],
@@ -361,6 +363,26 @@ def geglu_fwd(gu, pad=False):
     act = _padded_rows(rows, H2 // 2, gu.device, _row_pad(H2 // 2) if pad else 0)
     call("lap_geglu_fwd_ld", _p(gu), _p(act), rows, H2 // 2, gu.stride(0), act.stride(0))
     return act
+
+
+def linear_geglu_train_ok(x, wgu, pad=True):
+    M, K = x.shape
+    N = wgu.shape[0]
+    p = _row_pad(N) if pad else 0
+    pa = _row_pad(N // 2) if pad else 0
+    return (x.dtype == wgu.dtype == torch.bfloat16 and x.stride(1) == 1 and wgu.stride(1) == 1 and N % 256 == 0
+            and bool(_lib.lap_gemm_asm_geglu_fwd_ok(M, N, K, x.stride(0), wgu.stride(0), N + p, N // 2 + pa)))
+
+
+def linear_geglu_train(x, wgu, pad=True):
+    """(gu, act) = (x @ wgu^T, GeGLU(gu)) in one launch, both kept (training: the backward pass reads gu); rows padded off the
+    16 KiB strides like geglu_fwd / geglu_bwd do."""
+    M, K = x.shape
+    N = wgu.shape[0]
+    gu = _padded_rows(M, N, x.device, _row_pad(N) if pad else 0)
+    act = _padded_rows(M, N // 2, x.device, _row_pad(N // 2) if pad else 0)
+    call("lap_gemm_asm_geglu_fwd", _p(x), _p(wgu), _p(gu), _p(act), M, N, K, x.stride(0), wgu.stride(0), gu.stride(0), act.stride(0))
+    return gu, act
 
 
 def dgrad_geglu_bwd_ok(dy, w, gu):

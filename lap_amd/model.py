@@ -84,6 +84,7 @@ class LAP:
         self.serve_fusions = os.environ.get("LAP_SERVE_FUSIONS", "1") != "0"
         # prefix stream, bf16: d(act) of the down projection goes straight into the GeGLU backward inside the assembly GEMM's epilogue
         self.fuse_geglu_bwd = os.environ.get("LAP_FUSE_GEGLU_BWD", "1") != "0" and gemm_dtype != "fp8"
+        self.fuse_geglu_fwd = os.environ.get("LAP_FUSE_GEGLU_FWD", "1") != "0" and gemm_dtype != "fp8"
         # first denoise step on a second stream beside the prefill (it needs layer l's K / V only at its layer l).  Measured, hipGraph
         # replay, same box, interleaved: 15.65 -> 16.30 ms per chunk — the step's 110 short kernels take CUs from the prefill's
         # load-bound GEMMs for longer than they save.  Kept as a switch, OFF by default.
@@ -632,11 +633,15 @@ class LAP:
                 xa[0] = self._lin0(o[0], p + "wo0", residual=x0)
                 hf[0], rstd_f[0] = hip.rmsnorm_fwd(xa[0], scale=self.F(p + "n_ffw"), save_rstd=save)
                 self.comm.pace(f"llm{l}")     # optimizer units released here start under the longest MFMA-bound GEMM of the layer
-                gu_out = None
-                if save and self.fuse_geglu_bwd:    # rows padded like d(gate | up): the fused backward kernel shares one row stride
-                    gu_out = hip._padded_rows(hf[0].shape[0], 2 * v.mlp_dim, hf[0].device, hip._row_pad(2 * v.mlp_dim))
-                gu[0] = self._lin0(hf[0], p + "wgu0", out=gu_out)
-                act[0] = hip.geglu_fwd(gu[0], pad=self.gemm_dtype != "fp8")
+                if save and self.fuse_geglu_fwd and hip.linear_geglu_train_ok(hf[0], self.W(p + "wgu0")):
+                    # gate | up projection with the GeGLU in its epilogue: gu (kept for the backward pass) and act leave one launch
+                    gu[0], act[0] = hip.linear_geglu_train(hf[0], self.W(p + "wgu0"))
+                else:
+                    gu_out = None
+                    if save and self.fuse_geglu_bwd:    # rows padded like d(gate | up): the fused backward kernel shares one row stride
+                        gu_out = hip._padded_rows(hf[0].shape[0], 2 * v.mlp_dim, hf[0].device, hip._row_pad(2 * v.mlp_dim))
+                    gu[0] = self._lin0(hf[0], p + "wgu0", out=gu_out)
+                    act[0] = hip.geglu_fwd(gu[0], pad=self.gemm_dtype != "fp8")
                 xn[0] = self._lin0(act[0], p + "wd0", residual=xa[0])
             if save:
                 ctx.append(dict(x=[x0, x1], h=h, rstd_a=rstd_a, q=q, k=k, v=vv, o=o, lse=lse, xa=xa, y1=y1, hf=hf, rstd_f=rstd_f,

@@ -216,6 +216,32 @@ def test_gemm_assembly_residual_kernels_match_hip_tiles_bitwise(hip):
     assert rel_err(o[16384:], o10[16384:]) < 2e-3
 
 
+def test_gemm_assembly_gate_up_projection_with_geglu_epilogue(hip):
+    """lap_gemm_asm_nt_geglu: (gu, act) = (x W^T, GeGLU(gu)) in one launch, a tile pairing 128 gate columns with their up columns.
+    gu is bit for bit the plain product; act follows geglu_fwd's rounding points with the GELU through v_exp / v_rcp: identical
+    where the GELU is not saturated, below any bf16 step of the tensor in the tails (tanhf rounds to -1 there, the sigmoid form does not)."""
+    for M, F, K, scale in [(256, 256, 512, 0.1), (1024, 640, 640, 0.08), (2304, 2048, 1152, 0.06)]:
+        x = rnd(M, K, seed=1)
+        w = rnd(2 * F, K, seed=2) * scale
+        assert hip.linear_geglu_train_ok(x, w)
+        gu, act = hip.linear_geglu_train(x, w)
+        gu_ref = hip.linear_fwd(x, w, tile=10, ksplit=1)
+        assert torch.equal(gu, gu_ref), (M, F, K)
+        act_ref = hip.geglu_fwd(gu_ref)
+        assert act.shape == act_ref.shape == (M, F)
+        mid = gu_ref[:, :F].float().abs() <= 3.0
+        assert mid.float().mean() > 0.1
+        same = (act == act_ref)[mid].float().mean().item()
+        assert same > 0.97, (M, F, K, same)
+        d = (act.float() - act_ref.float()).abs()
+        assert (d <= act_ref.float().abs() * 2.0 ** -7 + 2e-5 * act_ref.float().abs().max()).all(), (M, F, K, d.max().item())
+    # several tiles per block and the seam between them, a partial last group of m-tiles
+    x, w = rnd(9216, 512, seed=3), rnd(2 * 4096, 512, seed=4) * 0.2
+    gu, act = hip.linear_geglu_train(x, w)
+    assert torch.equal(gu, hip.linear_fwd(x, w, tile=10, ksplit=1))
+    assert rel_err(act, hip.geglu_fwd(gu)) < 1e-3
+
+
 def test_gemm_assembly_dgrad_with_geglu_backward_epilogue(hip):
     """lap_gemm_asm_nn_geglu_bwd: d(gate | up) = geglu_bwd(gate | up, dy @ W) in one launch.  Same rounding points as the two-launch
     route (d(act) and gelu(gate) rounded to bf16); the GELU goes through v_exp / v_rcp instead of tanhf, so outputs may differ from

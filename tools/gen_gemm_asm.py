@@ -62,7 +62,7 @@ S_XCC, S_XOFF, S_REQ = 3, 49, 59   # XCC id of the CU this block runs on; its co
 V_TK, V_MB = 14, 15         # ticket (wave 0: the atomic's return value); LDS address of the ticket mailbox
 RING = os.environ.get("ASM_RING", "1") == "1"                # weight-gradient kernels: LDS as a ring of four half k-tiles
 CSTAGE = 131072             # LDS byte offset of the epilogue's staging buffers: 4 KiB per wave ([16 rows][256 B], chunks XOR row)
-MAILBOX = 131072 + 16384    # LDS byte offset of the ticket mailbox (behind the stages and the staging buffers)
+MAILBOX = 131072 + 24576    # LDS byte offset of the ticket mailbox (behind the stages and the staging buffers)
 S_BUMPA, S_BUMPB = 54, 55   # bytes per k-tile along each operand
 S_C = 56                    # C pointer pair
 RA, RB, RC = 60, 64, 68     # buffer descriptors
@@ -84,6 +84,12 @@ V_RS = (112, 168)           # residual variant: two sets of 4 x 2 registers for 
 V_RT = 124                  # v124..v127: the residual widened to f32
 S_RDL, S_RDH = 58, 91       # residual variant: R - C in bytes
 V_COU = 13                  # GeGLU-backward variant: V_CO of the up half (+ N columns)
+V_CA = 13                   # GeGLU-forward variant: the lane's offset in ACT
+V_GPK = 192                 # GeGLU-forward variant: v192..v199 the unit's 4 gate tiles, packed bf16
+V_AS = 200                  # v200..v215: two sets of 2 x 4 read-back registers of the ACT staging buffer
+V_SWA, V_SRA = 216, 217     # the lane's write / read-back address in its wave's ACT staging buffer (set per epilogue)
+ASTAGE = 131072 + 16384     # LDS byte offset of the ACT staging buffers: 2 KiB per wave ([16 rows][128 B], chunk XOR (row >> 1))
+S_LDACT, S_ACT, S_ACTNL, S_ACTNH = 99, 100, 58, 91     # ACT's leading dimension in bytes; its pointer pair; the next tile's ACT base
 V_GUL = 192                 # v192..v223: two sets of 4 x (gate pair, up pair)
 V_GX, V_GU_, V_GX2, V_GP, V_GG, V_GO = 112, 116, 124, 164, 168, 172     # 4 registers each: the arithmetic of one row piece
 V_GK0, V_GK1 = 182, 183     # constants: -2 log2(e) sqrt(2/pi), sqrt(2/pi)
@@ -122,7 +128,7 @@ def order():
 
 
 class Kernel:
-    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False, res=False, ring=False, gbwd=False):
+    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False, res=False, ring=False, gbwd=False, gfwd=False):
         # epi: f32 bias per output column + ragged N (the last n-tile may hold fewer than 256 valid columns; N % 16 == 0)
         # tout: the product is stored TRANSPOSED (C is [N][ldc]): a tall weight gradient dW [out, in] = dy^T x runs as the wide
         #       product x^T dy (whose operand panels stream much better, tools/bench_asm_gemm.py) and lands in dW's layout
@@ -133,6 +139,10 @@ class Kernel:
         #       forward's gate | up values GU [M][2N] (C's leading dimension), rounds d(act) to bf16 as the stand-alone product
         #       would, and stores d(gate) = d(act) * up * gelu'(gate) and d(up) = d(act) * bf16(gelu(gate)) into C [M][2N]
         #       (csrc/elementwise.hip geglu_bwd_kernel; gemma.py:308-312 backward).  GELU' through v_exp / v_rcp (sigmoid form).
+        # gfwd: (forward layout) B = W [2F][K] holds the gate rows [0, F) and the up rows [F, 2F) of a GeGLU MLP; a tile pairs 128 gate
+        #       columns with their 128 up columns (every wave: 64 + 64), C = gate | up [M][2F] is stored as by the plain kernel and
+        #       ACT [M][F] = bf16(bf16(gelu(gate)) * up) (csrc/elementwise.hip geglu_fwd_kernel; gemma.py:308-312) leaves with it
+        self.gfwd = gfwd
         self.gbwd = gbwd
         res = res or gbwd
         self.res = res
@@ -152,7 +162,9 @@ class Kernel:
             for f in range(8):
                 d = F[st] + 4 * f
                 if self.kc[op]:     # address registers: VR + 2 * stage + kk; fragment f: + 2048 f
-                    ops.append([f"ds_read_b128 v[{d}:{d+3}], v{VR + 2*stage + kk} offset:{f*2048}"])
+                    # (gfwd, B: fragments 0-3 = the wave's 64 gate columns, 4-7 = their up columns, 128 tile rows further)
+                    extra = 8192 if (self.gfwd and op == 1 and f >= 4) else 0
+                    ops.append([f"ds_read_b128 v[{d}:{d+3}], v{VR + 2*stage + kk} offset:{f*2048 + extra}"])
                 else:               # address registers: VR + 8 * stage + f; k-step: + 16384 kk; second half: k-row + 4
                     ops.append([f"ds_read_b64_tr_b16 v[{d}:{d+1}], v{VR + 8*stage + f} offset:{kk*16384}",
                                 f"ds_read_b64_tr_b16 v[{d+2}:{d+3}], v{VR + 8*stage + f} offset:{kk*16384 + 2048}"])
@@ -247,13 +259,16 @@ class Kernel:
              f"s_cselect_b32 s{t+8}, s{t+8}, s{t+14}",
              f"s_add_u32 s{t+8}, s{t+8}, s{t+10}",                # tm
              f"s_lshl_b32 s{t+8}, s{t+8}, 8",                     # m0
-             f"s_lshl_b32 s{t+9}, s{t+9}, 8"]                     # n0
+             f"s_lshl_b32 s{t+9}, s{t+9}, {7 if self.gfwd else 8}"]   # n0 (gfwd: of the gate half; the up half sits N / 2 further)
         for op, (rs, ptr, row0, ld) in enumerate(((RA, S_A, t + 8, S_LDA), (RB, S_B, t + 9, S_LDB))):
             if self.kc[op]:     # panel rows row0 .. row0 + 255, all of K: base + row0 * ld; range 255 ld + K bytes
                 r += [f"s_mul_i32 s{t+10}, s{row0}, s{ld}", f"s_mul_hi_u32 s{t+11}, s{row0}, s{ld}",
                       f"s_add_u32 s{rs}, s{ptr}, s{t+10}", f"s_addc_u32 s{rs+1}, s{ptr+1}, s{t+11}", f"s_and_b32 s{rs+1}, s{rs+1}, 0xffff"]
                 if self.epi and op == 1:    # ragged N: rows past N read as zeros (range = (rows - 1) ld + K bytes)
                     r += [f"s_sub_u32 s{S_NREMN}, s{S_N}, s{row0}", f"s_min_u32 s{t+10}, s{S_NREMN}, 256", f"s_sub_u32 s{t+10}, s{t+10}, 1",
+                          f"s_mul_i32 s{rs+2}, s{ld}, s{t+10}", f"s_add_u32 s{rs+2}, s{rs+2}, s{S_K}"]
+                elif self.gfwd and op == 1:   # rows n0 .. n0 + 127 and N / 2 + n0 .. + 127
+                    r += [f"s_lshr_b32 s{t+10}, s{S_N}, 1", f"s_add_u32 s{t+10}, s{t+10}, 127",
                           f"s_mul_i32 s{rs+2}, s{ld}, s{t+10}", f"s_add_u32 s{rs+2}, s{rs+2}, s{S_K}"]
                 else:
                     r += [f"s_mul_i32 s{rs+2}, s{ld}, 255", f"s_add_u32 s{rs+2}, s{rs+2}, s{S_K}"]
@@ -267,6 +282,10 @@ class Kernel:
         r += [f"s_mul_i32 s{t+10}, s{cr}, s{S_LDC}", f"s_mul_hi_u32 s{t+11}, s{cr}, s{S_LDC}", f"s_lshl_b32 s{t+12}, s{cc}, {sh}",
               f"s_add_u32 s{t+10}, s{t+10}, s{t+12}", f"s_addc_u32 s{t+11}, s{t+11}, 0",
               f"s_add_u32 s{RCN}, s{S_C}, s{t+10}", f"s_addc_u32 s{RCN+1}, s{S_C+1}, s{t+11}", f"s_and_b32 s{RCN+1}, s{RCN+1}, 0xffff"]
+        if self.gfwd:       # ACT tile: rows m0 .., columns n0 ..
+            r += [f"s_mul_i32 s{t+10}, s{cr}, s{S_LDACT}", f"s_mul_hi_u32 s{t+11}, s{cr}, s{S_LDACT}", f"s_lshl_b32 s{t+12}, s{cc}, 1",
+                  f"s_add_u32 s{t+10}, s{t+10}, s{t+12}", f"s_addc_u32 s{t+11}, s{t+11}, 0",
+                  f"s_add_u32 s{S_ACTNL}, s{S_ACT}, s{t+10}", f"s_addc_u32 s{S_ACTNH}, s{S_ACT+1}, s{t+11}", f"s_and_b32 s{S_ACTNH}, s{S_ACTNH}, 0xffff"]
         return r
 
     def stream_step(self):
@@ -459,6 +478,12 @@ class Kernel:
         if self.gbwd:
             E(f"\tv_mov_b32 v{V_GK0}, 0xc0135761")       # -2 log2(e) sqrt(2/pi) = -2.3022082
             E(f"\tv_mov_b32 v{V_GK1}, 0x3f4c422a")       # sqrt(2/pi) = 0.7978846
+        V_WAA, V_SRA1 = 168, 218
+        if self.gfwd:
+            E(f"\tv_mov_b32 v{V_GK0}, 0xc0135761")
+            for fc in range(4):
+                E(f"\tv_xor_b32 v{V_WAA+fc}, {fc * 32}, v{V_SWA}")
+            E(f"\tv_xor_b32 v{V_SRA1}, 64, v{V_SRA}")
         for fc in range(nfc):
             E(f"\tv_xor_b32 v{V_WA+fc}, {fc * (64 if self.st32 else 32)}, v{V_SW}")
         for j in range(4):
@@ -571,6 +596,41 @@ class Kernel:
                 if "nostore" not in ABL:
                     E(f"\tbuffer_store_dwordx4 v[{cs+4*j}:{cs+4*j+3}], v{vco(h)}, s[{RC}:{RC+3}], s{soff(fr, j)} offen{off}{ST_NT}")
 
+        def geglu_fwd_piece(gp, up):
+            """4 outputs: gp, gp+1 = 4 gate values (packed bf16), up, up+1 = 4 up values; leaves bf16(bf16(gelu(gate)) * up) packed in
+            V_GP, V_GP+1.  gelu(x) = x sigmoid(2 k0 (x + k1 x^3))."""
+            X, U, P = V_GX, V_GU_, V_GP
+            K1P = "0xbdd2d3e8"
+            for k in range(2):
+                E(f"\tv_lshlrev_b32 v{X+2*k}, 16, v{gp+k}")
+                E(f"\tv_and_b32 v{X+2*k+1}, 0xffff0000, v{gp+k}")
+                E(f"\tv_lshlrev_b32 v{U+2*k}, 16, v{up+k}")
+                E(f"\tv_and_b32 v{U+2*k+1}, 0xffff0000, v{up+k}")
+            for e in range(4): E(f"\tv_mul_f32 v{P+e}, v{X+e}, v{X+e}")
+            for e in range(4): E(f"\tv_fmamk_f32 v{P+e}, v{P+e}, {K1P}, v{V_GK0}")
+            for e in range(4): E(f"\tv_mul_f32 v{P+e}, v{X+e}, v{P+e}")
+            for e in range(4): E(f"\tv_exp_f32 v{P+e}, v{P+e}")
+            for e in range(4): E(f"\tv_add_f32 v{P+e}, 1.0, v{P+e}")
+            for e in range(4): E(f"\tv_rcp_f32 v{P+e}, v{P+e}")
+            for e in range(4): E(f"\tv_mul_f32 v{P+e}, v{X+e}, v{P+e}")                      # gelu
+            E(f"\tv_cvt_pk_bf16_f32 v{X}, v{P}, v{P+1}")
+            E(f"\tv_cvt_pk_bf16_f32 v{X+1}, v{P+2}, v{P+3}")
+            for k in range(2):
+                E(f"\tv_lshlrev_b32 v{P+2*k}, 16, v{X+k}")
+                E(f"\tv_and_b32 v{P+2*k+1}, 0xffff0000, v{X+k}")
+            for e in range(4): E(f"\tv_mul_f32 v{P+e}, v{P+e}, v{U+e}")
+            E(f"\tv_cvt_pk_bf16_f32 v{P}, v{P}, v{P+1}")
+            E(f"\tv_cvt_pk_bf16_f32 v{P+1}, v{P+2}, v{P+3}")
+
+        def act_soff(fr, j):
+            return t + 8 + 2 * (fr & 1) + j
+
+        def act_stores(u):
+            fr, h = units[u]
+            a = V_AS + (u & 1) * 8
+            for j in range(2):      # rows fr*16 + 8 j .. + 7 of ACT
+                E(f"\tbuffer_store_dwordx4 v[{a+4*j}:{a+4*j+3}], v{V_CA}, s[{RBI}:{RBI+3}], s{act_soff(fr, j)} offen{ST_NT}")
+
         seq = [(fr, h, fcl) for fr, h in units for fcl in range(nfc)]
         rd(seq[0][0], seq[0][1] * 4 + seq[0][2], V_E)
         for n, (fr, h, fcl) in enumerate(seq):
@@ -591,11 +651,34 @@ class Kernel:
                     E(f"\tv_add_f32 v{cur+r}, v{cur+r}, v{V_BIAS+4*fc+r}")
             if self.st32:
                 E(f"\tds_write_b128 v{V_WA+fcl}, v[{cur}:{cur+3}]")
+            elif self.gfwd:
+                if fcl == 0:            # soffsets of the unit's two ACT stores: (fr*16 + 8 j) rows of ACT
+                    E(f"\ts_mul_i32 s{act_soff(fr, 0)}, s{S_LDACT}, {16*fr}")
+                    E(f"\ts_lshl_b32 s{act_soff(fr, 1)}, s{S_LDACT}, 3")
+                    E(f"\ts_add_u32 s{act_soff(fr, 1)}, s{act_soff(fr, 0)}, s{act_soff(fr, 1)}")
+                dst = (V_GPK + 2 * fc) if fc < 4 else (cur + 4)       # the gate tiles wait for their up tiles
+                E(f"\tv_cvt_pk_bf16_f32 v{dst}, v{cur}, v{cur+1}")
+                E(f"\tv_cvt_pk_bf16_f32 v{dst+1}, v{cur+2}, v{cur+3}")
+                E(f"\tds_write_b64 v{V_WA+fcl}, v[{dst}:{dst+1}]")
+                if fc >= 4:
+                    geglu_fwd_piece(V_GPK + 2 * (fc - 4), cur + 4)
+                    E(f"\tds_write_b64 v{V_WAA + fc - 4}, v[{V_GP}:{V_GP+1}]")
             else:
                 E(f"\tv_cvt_pk_bf16_f32 v{cur+4}, v{cur}, v{cur+1}")
                 E(f"\tv_cvt_pk_bf16_f32 v{cur+5}, v{cur+2}, v{cur+3}")
                 E(f"\tds_write_b64 v{V_WA+fcl}, v[{cur+4}:{cur+5}]")
-            if fcl == nfc - 1:          # the unit is written: queue its read-back, then store the previous unit
+            if fcl == nfc - 1 and self.gfwd:    # (12 LDS writes per unit: the previous unit's stores go out before this unit's read-back is queued)
+                if u > 0:
+                    E("\ts_waitcnt lgkmcnt(12)")
+                    stores(u - 1)
+                    act_stores(u - 1)
+                cs = V_CS + (u & 1) * 16
+                for j in range(4):
+                    E(f"\tds_read_b128 v[{cs+4*j}:{cs+4*j+3}], v{V_RD+j} offset:{j*1024}")
+                a = V_AS + (u & 1) * 8
+                E(f"\tds_read_b128 v[{a}:{a+3}], v{V_SRA}")
+                E(f"\tds_read_b128 v[{a+4}:{a+7}], v{V_SRA1} offset:1024")
+            elif fcl == nfc - 1:        # the unit is written: queue its read-back, then store the previous unit
                 cs = V_CS + (u & 1) * 16
                 for j in range(4):
                     E(f"\tds_read_b128 v[{cs+4*j}:{cs+4*j+3}], v{V_RD+j} offset:{j*1024}")
@@ -606,6 +689,8 @@ class Kernel:
         if self.res:
             E("\ts_nop 0")
         stores(len(units) - 1)
+        if self.gfwd:
+            act_stores(len(units) - 1)
 
     def emit(self):
         nm = self.name
@@ -633,6 +718,9 @@ class Kernel:
             E(f"\ts_load_dwordx2 s[{RBI}:{RBI+1}], {S_KARG}, 0x60")
         if self.res:
             E(f"\ts_load_dwordx2 s[{S_T+8}:{S_T+9}], {S_KARG}, 0x68")
+        if self.gfwd:
+            E(f"\ts_load_dwordx2 s[{S_ACT}:{S_ACT+1}], {S_KARG}, 0x68")
+            E(f"\ts_load_dword s{S_LDACT}, {S_KARG}, 0x54")
         E(f"\tv_and_b32 v{V_LANE}, 63, v{V_TID}")
         E(f"\tv_lshrrev_b32 v{V_T}, 6, v{V_TID}")
         E("\ts_nop 1")                                           # VALU write -> v_readfirstlane of the same VGPR: wait state
@@ -678,6 +766,8 @@ class Kernel:
         E(f"\ts_lshl_b32 s{S_LDB}, s{S_LDB}, 1")
         E(f"\ts_lshl_b32 s{S_LDC}, s{S_LDC}, {2 if self.f32 else 1}")
         E(f"\ts_lshl_b32 s{S_K}, s{S_K}, 1")
+        if self.gfwd:
+            E(f"\ts_lshl_b32 s{S_LDACT}, s{S_LDACT}, 1")
         E(f"\ts_lshr_b32 s{S_NKT}, s{S_K}, {6 if self.ring else 7}")      # k-tiles (ring: half k-tiles) per tile
         E(f"\ts_mov_b32 s{S_DLEFT}, s{S_NKT}")
         for op, (bump, ld) in enumerate(((S_BUMPA, S_LDA), (S_BUMPB, S_LDB))):
@@ -694,6 +784,11 @@ class Kernel:
         if self.gbwd:      # C (and GU) rows hold 2 N columns: the up half sits N columns behind the gate half
             E(f"\ts_lshl_b32 s{t+14}, s{S_N}, 1")
             E(f"\ts_add_u32 s{RC+2}, s{RC+2}, s{t+14}")
+        if self.gfwd:      # a tile's up columns sit N / 2 columns (N bytes) behind its gate columns; ACT descriptor: 256 rows x 128 columns
+            E(f"\ts_add_u32 s{RC+2}, s{RC+2}, s{S_N}")
+            E(f"\ts_mul_i32 s{RBI+2}, s{S_LDACT}, 255")
+            E(f"\ts_add_u32 s{RBI+2}, s{RBI+2}, 256")
+            E(f"\ts_mov_b32 s{RBI+3}, 0x00020000")
         E(f"\ts_mov_b32 s{RCN+2}, s{RC+2}")
         if self.epi:
             E(f"\ts_and_b32 s{RBI+1}, s{RBI+1}, 0xffff")
@@ -708,6 +803,12 @@ class Kernel:
                 # piece j of wave w covers tile rows (8w + j) * 8 .. + 7; lane l: row l >> 3, physical chunk l & 7,
                 # logical chunk = physical ^ swz, swz = (row >> 1) & 7 = (l >> 4) [even piece] or (l >> 4) ^ 4 [odd piece]
                 E(f"\ts_lshl_b32 s{t+12}, s{W}, 6")
+                if self.gfwd and op == 1:     # tile rows 128 .. 255 (waves 2, 3) are the up rows: N / 2 - 128 rows further on
+                    E(f"\ts_lshr_b32 s{t+13}, s{S_N}, 1")
+                    E(f"\ts_sub_u32 s{t+13}, s{t+13}, 128")
+                    E(f"\ts_cmp_ge_u32 s{W}, 2")
+                    E(f"\ts_cselect_b32 s{t+13}, s{t+13}, 0")
+                    E(f"\ts_add_u32 s{t+12}, s{t+12}, s{t+13}")
                 for j in range(8):
                     E(f"\ts_add_u32 s{t+13}, s{t+12}, {8*j}")
                     E(f"\ts_mul_i32 s{soff+j}, s{t+13}, s{ld}")
@@ -760,7 +861,7 @@ class Kernel:
                 E(f"\tv_lshlrev_b32 v{V_E+3}, 4, v{V_E+3}")
                 E(f"\tv_lshlrev_b32 v{V_E+4}, 4, v{V_E+4}")
                 E(f"\tv_lshlrev_b32 v{V_E}, 7, v{V_E}")
-                E(f"\ts_lshl_b32 s{t+14}, s{wreg}, 14")
+                E(f"\ts_lshl_b32 s{t+14}, s{wreg}, {13 if (self.gfwd and op == 1) else 14}")    # (gfwd: the wave's 64 gate rows)
                 if boff:
                     E(f"\ts_add_u32 s{t+14}, s{t+14}, {boff}")
                 for kk in (0, 1):
@@ -836,6 +937,51 @@ class Kernel:
             if self.gbwd:
                 E(f"\ts_lshl_b32 s{t+14}, s{S_N}, 1")
                 E(f"\tv_add_u32 v{V_COU}, s{t+14}, v{V_CO}")
+            if self.gfwd:
+                # gate | up stores: lane -> row (l >> 4) (+ wm * 128), chunk l & 15 of the unit's [64 gate | 64 up] columns:
+                # bytes wn*128 + (l & 7) * 16, + N (= N / 2 columns) for the up chunks 8 .. 15.   (v{V_E+1} = row * ldc)
+                E(f"\tv_and_b32 v{V_E}, 7, v{V_LANE}")
+                E(f"\tv_lshlrev_b32 v{V_E}, 4, v{V_E}")
+                E(f"\tv_bfe_u32 v{V_E+2}, v{V_LANE}, 3, 1")
+                E(f"\tv_mul_lo_u32 v{V_E+2}, v{V_E+2}, s{S_N}")
+                E(f"\tv_add_u32 v{V_E}, v{V_E}, v{V_E+2}")
+                E(f"\ts_lshl_b32 s{t+14}, s{wcol}, 7")
+                E(f"\tv_add_u32 v{V_E}, s{t+14}, v{V_E}")
+                E(f"\tv_add_u32 v{V_CO}, v{V_E}, v{V_E+1}")
+                # ACT stores: lane -> row (l >> 3) (+ wm * 128), bytes wn*128 + (l & 7) * 16
+                E(f"\tv_lshrrev_b32 v{V_E+2}, 3, v{V_LANE}")
+                E(f"\ts_lshl_b32 s{t+14}, s{wrow}, 7")
+                E(f"\tv_add_u32 v{V_E+2}, s{t+14}, v{V_E+2}")
+                E(f"\tv_mul_lo_u32 v{V_E+2}, v{V_E+2}, s{S_LDACT}")
+                E(f"\tv_and_b32 v{V_E}, 7, v{V_LANE}")
+                E(f"\tv_lshlrev_b32 v{V_E}, 4, v{V_E}")
+                E(f"\ts_lshl_b32 s{t+14}, s{wcol}, 7")
+                E(f"\tv_add_u32 v{V_E}, s{t+14}, v{V_E}")
+                E(f"\tv_add_u32 v{V_CA}, v{V_E}, v{V_E+2}")
+                # ACT staging buffer of the wave: [16 rows][128 B], 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7).
+                # write: lane (i, g) -> row i, chunk 2 fc + (g >> 1), half g & 1 (fc enters by XOR of fc * 32)
+                E(f"\tv_and_b32 v{V_E}, 15, v{V_LANE}")                      # i
+                E(f"\tv_lshrrev_b32 v{V_E+1}, 4, v{V_LANE}")                 # g
+                E(f"\tv_lshrrev_b32 v{V_E+2}, 1, v{V_E+1}")                  # g >> 1
+                E(f"\tv_bfe_u32 v{V_E+3}, v{V_LANE}, 1, 3")                  # (i >> 1) & 7
+                E(f"\tv_xor_b32 v{V_E+2}, v{V_E+2}, v{V_E+3}")
+                E(f"\tv_lshlrev_b32 v{V_E+2}, 4, v{V_E+2}")
+                E(f"\tv_and_b32 v{V_E+3}, 1, v{V_E+1}")
+                E(f"\tv_lshlrev_b32 v{V_E+3}, 3, v{V_E+3}")
+                E(f"\tv_add_u32 v{V_E+2}, v{V_E+2}, v{V_E+3}")
+                E(f"\tv_lshlrev_b32 v{V_E+3}, 7, v{V_E}")                    # i * 128
+                E(f"\tv_add_u32 v{V_E+2}, v{V_E+2}, v{V_E+3}")
+                E(f"\ts_lshl_b32 s{t+14}, s{W}, 11")
+                E(f"\ts_add_u32 s{t+14}, s{t+14}, {ASTAGE}")
+                E(f"\tv_add_u32 v{V_SWA}, s{t+14}, v{V_E+2}")
+                # read back: lane -> row 8 j + (l >> 3), chunk (l & 7) ^ (l >> 4) ^ 4 j  (j enters by XOR of 64 and + 1024)
+                E(f"\tv_and_b32 v{V_E+2}, 7, v{V_LANE}")
+                E(f"\tv_xor_b32 v{V_E+2}, v{V_E+2}, v{V_E+1}")
+                E(f"\tv_lshlrev_b32 v{V_E+2}, 4, v{V_E+2}")
+                E(f"\tv_lshrrev_b32 v{V_E+3}, 3, v{V_LANE}")
+                E(f"\tv_lshlrev_b32 v{V_E+3}, 7, v{V_E+3}")
+                E(f"\tv_add_u32 v{V_E+2}, v{V_E+2}, v{V_E+3}")
+                E(f"\tv_add_u32 v{V_SRA}, s{t+14}, v{V_E+2}")
             E(f"\ts_lshl_b32 s{S_C16}, s{S_LDC}, 2")                     # FOUR rows of C in bytes
         else:
             # m = wm*128 + fm*16 + (l & 15), n = wn*128 + fn*16 + 4 (l >> 4)
@@ -879,6 +1025,9 @@ class Kernel:
             E(f"\tv_accvgpr_write_b32 a{a}, 0")
         for r in range(3):
             E(f"\ts_mov_b32 s{RC+r}, s{RCN+r}")
+        if self.gfwd:
+            E(f"\ts_mov_b32 s{RBI}, s{S_ACTNL}")
+            E(f"\ts_mov_b32 s{RBI+1}, s{S_ACTNH}")
         if self.epi:
             E(f"\ts_mov_b32 s{S_NREM}, s{S_NREMN}")
         E("\ts_waitcnt vmcnt(24)" if self.ring else "\ts_waitcnt vmcnt(16)")
@@ -911,6 +1060,9 @@ class Kernel:
         E(f"\ts_mov_b32 s{S_HAVE}, 0")
         for r in range(3):
             E(f"\ts_mov_b32 s{RC+r}, s{RCN+r}")
+        if self.gfwd:
+            E(f"\ts_mov_b32 s{RBI}, s{S_ACTNL}")
+            E(f"\ts_mov_b32 s{RBI+1}, s{S_ACTNH}")
         if self.epi:
             E(f"\ts_mov_b32 s{S_NREM}, s{S_NREMN}")
         E(f"\ts_branch .Ltile_{nm}")
@@ -922,7 +1074,7 @@ class Kernel:
                      ("user_sgpr_dispatch_id", 0), ("user_sgpr_kernarg_preload_length", 0), ("user_sgpr_kernarg_preload_offset", 0),
                      ("user_sgpr_private_segment_size", 0), ("uses_dynamic_stack", 0), ("enable_private_segment", 0),
                      ("system_sgpr_workgroup_id_x", 1), ("system_sgpr_workgroup_id_y", 0), ("system_sgpr_workgroup_id_z", 0),
-                     ("system_sgpr_workgroup_info", 0), ("system_vgpr_workitem_id", 0), ("next_free_vgpr", NVGPR + 256), ("next_free_sgpr", 100),
+                     ("system_sgpr_workgroup_info", 0), ("system_vgpr_workitem_id", 0), ("next_free_vgpr", NVGPR + 256), ("next_free_sgpr", 102),
                      ("accum_offset", NVGPR), ("reserve_vcc", 1), ("float_round_mode_32", 0), ("float_round_mode_16_64", 0),
                      ("float_denorm_mode_32", 3), ("float_denorm_mode_16_64", 3), ("dx10_clamp", 1), ("ieee_mode", 1), ("fp16_overflow", 0),
                      ("tg_split", 0), ("exception_fp_ieee_invalid_op", 0), ("exception_fp_denorm_src", 0), ("exception_fp_ieee_div_zero", 0),
@@ -943,7 +1095,7 @@ class Kernel:
     .max_flat_workgroup_size: 256
     .name:           {self.name}
     .private_segment_fixed_size: 0
-    .sgpr_count:     104
+    .sgpr_count:     106
     .sgpr_spill_count: 0
     .symbol:         {self.name}.kd
     .uniform_work_group_size: 1
@@ -958,7 +1110,8 @@ KERNELS = [Kernel("lap_gemm_asm_nt", True, True, False), Kernel("lap_gemm_asm_nn
            Kernel("lap_gemm_asm_tn_t", False, False, True, tout=True, ring=RING),
            Kernel("lap_gemm_asm_nt_res", True, True, False, res=True),
            Kernel("lap_gemm_asm_nt_bias_res", True, True, False, epi=True, res=True),
-           Kernel("lap_gemm_asm_nn_geglu_bwd", True, False, False, gbwd=True)]
+           Kernel("lap_gemm_asm_nn_geglu_bwd", True, False, False, gbwd=True),
+           Kernel("lap_gemm_asm_nt_geglu", True, True, False, gfwd=True)]
 E('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
 E("\t.amdhsa_code_object_version 6")
 for k in KERNELS:
