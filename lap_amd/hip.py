@@ -82,6 +82,8 @@ SIGNATURES: dict[str, list] = {
     "lap_gemm_asm_geglu_bwd_ok": [_i, _i, _i, _i, _i, _i],
     "lap_gemm_asm_geglu_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_asm_geglu_fwd_ok": [_i, _i, _i, _i, _i, _i, _i],
+    "lap_gemm_asm_bias_gelu": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "lap_gemm_asm_gelu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "lap_amax_bf16": [_vp, _ll, _i, _ll, _vp, _vp],
     "lap_quantize_fp8": [_vp, _ll, _i, _ll, _vp, _vp, _ll, _vp, _vp],
@@ -363,6 +365,41 @@ def geglu_fwd(gu, pad=False):
     act = _padded_rows(rows, H2 // 2, gu.device, _row_pad(H2 // 2) if pad else 0)
     call("lap_geglu_fwd_ld", _p(gu), _p(act), rows, H2 // 2, gu.stride(0), act.stride(0))
     return act
+
+
+def linear_bias_gelu_train_ok(x, wt, bias):
+    M, K = x.shape
+    N = wt.shape[0]
+    return (x.dtype == wt.dtype == torch.bfloat16 and bias is not None and bias.dtype == torch.float32 and x.stride(1) == 1 and wt.stride(1) == 1
+            and bool(_lib.lap_gemm_asm_bias_ok(M, N, K, x.stride(0), wt.stride(0), N)))
+
+
+def linear_bias_gelu_train(x, wt, bias):
+    """(h, a) = (x @ wt^T + bias, gelu(h)) in one launch, both kept (training: the backward pass reads h)"""
+    M, K = x.shape
+    N = wt.shape[0]
+    h = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    a = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    call("lap_gemm_asm_bias_gelu", _p(x), _p(wt), _p(h), _p(a), _p(bias), M, N, K, x.stride(0), wt.stride(0), N)
+    return h, a
+
+
+def dgrad_gelu_bwd_ok(dy, w, h):
+    M, K = dy.shape
+    N = w.shape[1]
+    return (dy.dtype == w.dtype == h.dtype == torch.bfloat16 and tuple(h.shape) == (M, N) and h.stride(1) == 1 and dy.stride(1) == 1 and w.stride(1) == 1
+            and w.shape[0] == K and bool(_lib.lap_gemm_asm_ok(1, 0, 0, M, N, K, dy.stride(0), w.stride(0), h.stride(0))))
+
+
+def linear_dgrad_gelu_bwd(dy, w, h):
+    """d(h) = gelu_bwd(h, dy @ w) in one launch (the second Dense's data gradient with the GELU backward as its epilogue)"""
+    M, K = dy.shape
+    N = w.shape[1]
+    if tuple(h.shape) != (M, N) or w.shape[0] != K:
+        raise LapHipError(f"linear_dgrad_gelu_bwd: dy {tuple(dy.shape)}, w {tuple(w.shape)}, h {tuple(h.shape)} do not fit")
+    dh = torch.empty((M, h.stride(0)), dtype=torch.bfloat16, device=h.device)[:, :N]
+    call("lap_gemm_asm_gelu_bwd", _p(dy), _p(w), _p(dh), _p(h), M, N, K, dy.stride(0), w.stride(0), h.stride(0))
+    return dh
 
 
 def linear_geglu_train_ok(x, wgu, pad=True):

@@ -85,6 +85,7 @@ class LAP:
         # prefix stream, bf16: d(act) of the down projection goes straight into the GeGLU backward inside the assembly GEMM's epilogue
         self.fuse_geglu_bwd = os.environ.get("LAP_FUSE_GEGLU_BWD", "1") != "0" and gemm_dtype != "fp8"
         self.fuse_geglu_fwd = os.environ.get("LAP_FUSE_GEGLU_FWD", "1") != "0" and gemm_dtype != "fp8"
+        self.fuse_gelu = os.environ.get("LAP_FUSE_GELU", "1") != "0"      # SigLIP MLP: GELU forward / backward inside the Dense GEMMs
         # first denoise step on a second stream beside the prefill (it needs layer l's K / V only at its layer l).  Measured, hipGraph
         # replay, same box, interleaved: 15.65 -> 16.30 ms per chunk — the step's 110 short kernels take CUs from the prefill's
         # load-bound GEMMs for longer than they save.  Kept as a switch, OFF by default.
@@ -367,8 +368,11 @@ class LAP:
         y2, mean2, rstd2 = hip.layernorm_fwd(x1, self.F(p + "ln2_g"), self.F(p + "ln2_b"))
         self.comm.pace(f"img{l}")
         if save:
-            h = hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"))
-            a = hip.gelu_fwd(h)
+            if self.fuse_gelu and hip.linear_bias_gelu_train_ok(y2, self.W(p + "w1"), self.F(p + "b1")):
+                h, a = hip.linear_bias_gelu_train(y2, self.W(p + "w1"), self.F(p + "b1"))     # fc1 + bias with the GELU in its epilogue
+            else:
+                h = hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"))
+                a = hip.gelu_fwd(h)
         else:   # nothing keeps the pre-activation: GELU in the GEMM epilogue, after the bf16 rounding of the Dense output (same bits)
             h, a = None, hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"), gelu="bf16")
         x2 = hip.linear_fwd(a, self.W(p + "w2"), bias=self.F(p + "b2"), residual=x1)
@@ -399,9 +403,12 @@ class LAP:
             if not fuse_b:
                 self._bgrad(dx, p + "b2")
             self._wgrad(dx, a, p + "w2")
-            da = hip.linear_dgrad(dx, self.W(p + "w2"))
-            dh = hip.gelu_bwd(h, da)
-            del da
+            if self.fuse_gelu and hip.dgrad_gelu_bwd_ok(dx, self.W(p + "w2"), h):
+                dh = hip.linear_dgrad_gelu_bwd(dx, self.W(p + "w2"), h)      # fc2's data gradient with the GELU backward as its epilogue
+            else:
+                da = hip.linear_dgrad(dx, self.W(p + "w2"))
+                dh = hip.gelu_bwd(h, da)
+                del da
             self._bgrad(dh, p + "b1")
             self._wgrad(dh, y2, p + "w1")
             dy2 = hip.linear_dgrad(dh, self.W(p + "w1"))

@@ -216,6 +216,36 @@ def test_gemm_assembly_residual_kernels_match_hip_tiles_bitwise(hip):
     assert rel_err(o[16384:], o10[16384:]) < 2e-3
 
 
+def test_gemm_assembly_gelu_mlp_kernels(hip):
+    """lap_gemm_asm_nt_bias_gelu (h and a = gelu(h) from one launch, the accumulators walked twice) and lap_gemm_asm_nn_gelu_bwd (d(h) =
+    bf16(dy W) * gelu'(h), d(a) never stored): h bit for bit the biased product; a / d(h) follow gelu_fwd / gelu_bwd with the GELU
+    through v_exp / v_rcp (identical where it is not saturated)."""
+    for M, N, K in [(512, 528, 512), (1024, 1152, 640), (2304, 4352, 1152)]:
+        x = rnd(M, K, seed=1)
+        w = rnd(N, K, seed=2) * 0.08
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(DEV) * 0.5
+        assert hip.linear_bias_gelu_train_ok(x, w, bias)
+        h, a = hip.linear_bias_gelu_train(x, w, bias)
+        h_ref = hip.linear_fwd(x, w, bias=bias, tile=10, ksplit=1)
+        assert torch.equal(h, h_ref), (M, N, K)
+        a_ref = hip.gelu_fwd(h_ref)
+        mid = h_ref.float().abs() <= 3.0
+        assert (a == a_ref)[mid].float().mean().item() > 0.97
+        d = (a.float() - a_ref.float()).abs()
+        assert (d <= a_ref.float().abs() * 2.0 ** -7 + 2e-5 * a_ref.float().abs().max()).all(), (M, N, K, d.max().item())
+    for M, N, K in [(512, 512, 512), (1024, 768, 640), (2304, 4352, 1152)]:
+        dy = rnd(M, K, seed=1)
+        w = rnd(K, N, seed=2)
+        h = rnd(M, N, seed=3) * 5.0
+        assert hip.dgrad_gelu_bwd_ok(dy, w, h)
+        dh = hip.linear_dgrad_gelu_bwd(dy, w, h)
+        ref = hip.gelu_bwd(h, hip.linear_dgrad(dy, w, tile=12, ksplit=1))
+        mid = h.float().abs() <= 3.0
+        assert (dh == ref)[mid].float().mean().item() > 0.97
+        d = (dh.float() - ref.float()).abs()
+        assert (d <= ref.float().abs() * 2.0 ** -7 + 2e-5 * ref.float().abs().max()).all(), (M, N, K, d.max().item())
+
+
 def test_gemm_assembly_gate_up_projection_with_geglu_epilogue(hip):
     """lap_gemm_asm_nt_geglu: (gu, act) = (x W^T, GeGLU(gu)) in one launch, a tile pairing 128 gate columns with their up columns.
     gu is bit for bit the plain product; act follows geglu_fwd's rounding points with the GELU through v_exp / v_rcp: identical

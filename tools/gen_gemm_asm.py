@@ -128,7 +128,7 @@ def order():
 
 
 class Kernel:
-    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False, res=False, ring=False, gbwd=False, gfwd=False):
+    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False, res=False, ring=False, gbwd=False, gfwd=False, dgelu=False, gelu=False):
         # epi: f32 bias per output column + ragged N (the last n-tile may hold fewer than 256 valid columns; N % 16 == 0)
         # tout: the product is stored TRANSPOSED (C is [N][ldc]): a tall weight gradient dW [out, in] = dy^T x runs as the wide
         #       product x^T dy (whose operand panels stream much better, tools/bench_asm_gemm.py) and lands in dW's layout
@@ -142,9 +142,14 @@ class Kernel:
         # gfwd: (forward layout) B = W [2F][K] holds the gate rows [0, F) and the up rows [F, 2F) of a GeGLU MLP; a tile pairs 128 gate
         #       columns with their 128 up columns (every wave: 64 + 64), C = gate | up [M][2F] is stored as by the plain kernel and
         #       ACT [M][F] = bf16(bf16(gelu(gate)) * up) (csrc/elementwise.hip geglu_fwd_kernel; gemma.py:308-312) leaves with it
+        # dgelu: the product is d(a) [M][N] of an MLP's second Dense and never leaves the kernel: the epilogue reads the first Dense's
+        #        pre-activation H [M][N] (C's leading dimension) and stores d(h) = bf16(d(a)) * gelu'(h) (csrc/elementwise.hip gelu_bwd_kernel)
+        # gelu:  (with epi) C = H = bf16(x W^T + bias) and a second output A = bf16(gelu(H)) with C's leading dimension (kernarg
+        #        0x68): the accumulators are walked twice, the second pass zeroes them (siglip_gemma3.py MlpBlock; gelu_fwd_kernel)
+        self.dgelu, self.gelu = dgelu, gelu
         self.gfwd = gfwd
         self.gbwd = gbwd
-        res = res or gbwd
+        res = res or gbwd or dgelu
         self.res = res
         self.st32 = out_f32 or res          # staging buffer holds f32
         # ring: (both operands M- / N-contiguous) the 128 KiB of LDS as a ring of four 32-deep half k-tiles [A 16 KiB | B 16 KiB]
@@ -447,7 +452,8 @@ class Kernel:
         t = S_T
         tiles = lambda fr, fc: (fc, fr) if self.tout else (fr, fc)
         nfc = 4 if self.st32 else 8                 # accumulator tiles per unit (one staging buffer)
-        units = [(fr, h) for fr in range(8) for h in range(2 if self.st32 else 1)]
+        units = [(fr, h) for fr in range(8) for h in range(2 if (self.st32 or self.gelu) else 1)]      # (gelu: h = the pass, 0: H, 1: A = gelu(H))
+        two = 2 if (self.st32 or self.gelu) else 1
         RR = t + 8                                  # s[28:31]: residual descriptor of this tile
         if self.epi:
             # the lane's bias values: column n0 + wn*128 + 16 fn + 4 g .. + 3 (past N: zeros); n0 = N - S_NREM
@@ -469,16 +475,19 @@ class Kernel:
                 E(f"\ts_sub_i32 s{t+11}, s{S_NREM}, 64")
                 E(f"\tv_cmp_gt_i32 vcc, s{t+11}, v{V_E+1}")
                 E(f"\tv_cndmask_b32 v{V_COM+1}, v{V_E+2}, v{V_CO}, vcc")
-        if self.res:
+        if self.res or self.gelu:
             E(f"\ts_add_u32 s{RR}, s{RC}, s{S_RDL}")
             E(f"\ts_addc_u32 s{RR+1}, s{RC+1}, s{S_RDH}")
             E(f"\ts_and_b32 s{RR+1}, s{RR+1}, 0xffff")
             E(f"\ts_mov_b32 s{RR+2}, s{RC+2}")
             E(f"\ts_mov_b32 s{RR+3}, s{RC+3}")
-        if self.gbwd:
+        if self.gbwd or self.dgelu:
             E(f"\tv_mov_b32 v{V_GK0}, 0xc0135761")       # -2 log2(e) sqrt(2/pi) = -2.3022082
             E(f"\tv_mov_b32 v{V_GK1}, 0x3f4c422a")       # sqrt(2/pi) = 0.7978846
         V_WAA, V_SRA1 = 168, 218
+        V_KG, GT = V_COM + 1, (182, 183, 190, 191)      # gelu variant: the constant; four temporaries
+        if self.gelu:
+            E(f"\tv_mov_b32 v{V_KG}, 0xc0135761")
         if self.gfwd:
             E(f"\tv_mov_b32 v{V_GK0}, 0xc0135761")
             for fc in range(4):
@@ -496,12 +505,13 @@ class Kernel:
         def vco(h):
             return (V_COM + (h if self.res else 0)) if self.epi else V_CO
 
-        def rd(fr, fc, base):
+        def rd(fr, fc, base, zero=True):
             a = acc(*tiles(fr, fc))
             for r in range(4):
                 E(f"\tv_accvgpr_read_b32 v{base+r}, a{a+r}")
             for r in range(4):
-                E(f"\tv_accvgpr_write_b32 a{a+r}, 0")
+                if zero:
+                    E(f"\tv_accvgpr_write_b32 a{a+r}, 0")
 
         def soff(fr, j):
             return t + 4 * (fr & 1) + j
@@ -509,6 +519,11 @@ class Kernel:
         def res_loads(u):
             fr, h = units[u]
             off = f" offset:{h*128}" if h else ""
+            if self.dgelu:      # pre-activations of the unit: 4 row pieces x 4 values per lane
+                gl = V_GUL + 16 * (u & 1)
+                for j in range(4):
+                    E(f"\tbuffer_load_dwordx2 v[{gl+4*j}:{gl+4*j+1}], v{V_CO}, s[{RR}:{RR+3}], s{soff(fr, j)} offen{off}")
+                return
             if self.gbwd:       # gate and up values of the unit: 4 row pieces x (4 gate, 4 up) per lane
                 gl = V_GUL + 16 * (u & 1)
                 for j in range(4):
@@ -518,6 +533,35 @@ class Kernel:
             rs = V_RS[u & 1]
             for j in range(4):
                 E(f"\tbuffer_load_dwordx2 v[{rs+2*j}:{rs+2*j+1}], v{vco(h)}, s[{RR}:{RR+3}], s{soff(fr, j)} offen{off}")
+
+        def gelu_bwd_piece(c, hl):
+            """4 outputs of one row piece: c..c+3 = d(a) (f32, unrounded), hl, hl+1 = 4 pre-activations (bf16 pairs); leaves
+            d(h) = bf16(d(a)) * gelu'(h) packed in V_GU_, V_GU_+1."""
+            X, U, X2, P, O = V_GX, V_GU_, V_GX2, V_GP, V_GO
+            K1P, C3 = "0xbdd2d3e8", "0x3ddb33b6"
+            E(f"\tv_cvt_pk_bf16_f32 v{P}, v{c}, v{c+1}")
+            E(f"\tv_cvt_pk_bf16_f32 v{P+1}, v{c+2}, v{c+3}")
+            for k in range(2):
+                E(f"\tv_lshlrev_b32 v{X+2*k}, 16, v{hl+k}")
+                E(f"\tv_and_b32 v{X+2*k+1}, 0xffff0000, v{hl+k}")
+            for k in range(2):
+                E(f"\tv_lshlrev_b32 v{c+2*k}, 16, v{P+k}")
+                E(f"\tv_and_b32 v{c+2*k+1}, 0xffff0000, v{P+k}")
+            for e in range(4): E(f"\tv_mul_f32 v{X2+e}, v{X+e}, v{X+e}")
+            for e in range(4): E(f"\tv_fmamk_f32 v{P+e}, v{X2+e}, {K1P}, v{V_GK0}")
+            for e in range(4): E(f"\tv_mul_f32 v{P+e}, v{X+e}, v{P+e}")
+            for e in range(4): E(f"\tv_exp_f32 v{P+e}, v{P+e}")
+            for e in range(4): E(f"\tv_add_f32 v{P+e}, 1.0, v{P+e}")
+            for e in range(4): E(f"\tv_rcp_f32 v{P+e}, v{P+e}")                              # s
+            for e in range(4): E(f"\tv_fmamk_f32 v{X2+e}, v{X2+e}, {C3}, v{V_GK1}")
+            for e in range(4): E(f"\tv_sub_f32 v{O+e}, 1.0, v{P+e}")
+            for e in range(4): E(f"\tv_mul_f32 v{O+e}, v{X+e}, v{O+e}")
+            for e in range(4): E(f"\tv_mul_f32 v{O+e}, v{O+e}, v{X2+e}")
+            for e in range(4): E(f"\tv_add_f32 v{O+e}, v{O+e}, v{O+e}")
+            for e in range(4): E(f"\tv_fma_f32 v{O+e}, v{P+e}, v{O+e}, v{P+e}")              # gelu'
+            for e in range(4): E(f"\tv_mul_f32 v{U+e}, v{c+e}, v{O+e}")
+            E(f"\tv_cvt_pk_bf16_f32 v{U}, v{U}, v{U+1}")
+            E(f"\tv_cvt_pk_bf16_f32 v{U+1}, v{U+2}, v{U+3}")
 
         def geglu_bwd_piece(c, gl):
             """4 outputs of one row piece: c..c+3 = d(act) (f32, unrounded), gl, gl+1 = 4 gate values (bf16 pairs), gl+2, gl+3 = 4 up values.
@@ -564,6 +608,14 @@ class Kernel:
         def stores(u):
             fr, h = units[u]
             cs = V_CS + (u & 1) * 16
+            if self.dgelu:
+                gl = V_GUL + 16 * (u & 1)
+                E(f"\ts_waitcnt vmcnt({4 * ((u > 0) + (u + 1 < len(units)))})")
+                off = f" offset:{h*128}" if h else ""
+                for j in range(4):
+                    gelu_bwd_piece(cs + 4 * j, gl + 4 * j)
+                    E(f"\tbuffer_store_dwordx2 v[{V_GU_}:{V_GU_+1}], v{V_CO}, s[{RC}:{RC+3}], s{soff(fr, j)} offen{off}{ST_NT}")
+                return
             if self.gbwd:
                 gl = V_GUL + 16 * (u & 1)
                 # this unit's gate / up values; issued behind them: the previous unit's 8 stores (not for unit 0), the next unit's 8 loads (not for the last)
@@ -592,9 +644,10 @@ class Kernel:
                     E(f"\tbuffer_store_dwordx2 v[{c}:{c+1}], v{vco(h)}, s[{RC}:{RC+3}], s{soff(fr, j)} offen{off}{ST_NT}")
                 return
             for j in range(4):      # rows fr*16 + 4 j .. + 3
-                off = f" offset:{h*256}" if h else ""
+                off = f" offset:{h*256}" if (h and not self.gelu) else ""
+                dsc = RR if (self.gelu and h) else RC
                 if "nostore" not in ABL:
-                    E(f"\tbuffer_store_dwordx4 v[{cs+4*j}:{cs+4*j+3}], v{vco(h)}, s[{RC}:{RC+3}], s{soff(fr, j)} offen{off}{ST_NT}")
+                    E(f"\tbuffer_store_dwordx4 v[{cs+4*j}:{cs+4*j+3}], v{vco(0 if self.gelu else h)}, s[{dsc}:{dsc+3}], s{soff(fr, j)} offen{off}{ST_NT}")
 
         def geglu_fwd_piece(gp, up):
             """4 outputs: gp, gp+1 = 4 gate values (packed bf16), up, up+1 = 4 up values; leaves bf16(bf16(gelu(gate)) * up) packed in
@@ -631,11 +684,29 @@ class Kernel:
             for j in range(2):      # rows fr*16 + 8 j .. + 7 of ACT
                 E(f"\tbuffer_store_dwordx4 v[{a+4*j}:{a+4*j+3}], v{V_CA}, s[{RBI}:{RBI+3}], s{act_soff(fr, j)} offen{ST_NT}")
 
+        def gelu_packed(pk, X):
+            """pk, pk+1 = 4 bf16 values h -> bf16(gelu(h)) in place; X: four scratch registers"""
+            P = GT
+            for k in range(2):
+                E(f"\tv_lshlrev_b32 v{X+2*k}, 16, v{pk+k}")
+                E(f"\tv_and_b32 v{X+2*k+1}, 0xffff0000, v{pk+k}")
+            for e in range(4): E(f"\tv_mul_f32 v{P[e]}, v{X+e}, v{X+e}")
+            for e in range(4): E(f"\tv_fmamk_f32 v{P[e]}, v{P[e]}, 0xbdd2d3e8, v{V_KG}")
+            for e in range(4): E(f"\tv_mul_f32 v{P[e]}, v{X+e}, v{P[e]}")
+            for e in range(4): E(f"\tv_exp_f32 v{P[e]}, v{P[e]}")
+            for e in range(4): E(f"\tv_add_f32 v{P[e]}, 1.0, v{P[e]}")
+            for e in range(4): E(f"\tv_rcp_f32 v{P[e]}, v{P[e]}")
+            for e in range(4): E(f"\tv_mul_f32 v{P[e]}, v{X+e}, v{P[e]}")
+            E(f"\tv_cvt_pk_bf16_f32 v{pk}, v{P[0]}, v{P[1]}")
+            E(f"\tv_cvt_pk_bf16_f32 v{pk+1}, v{P[2]}, v{P[3]}")
+
+        fc_of = (lambda h, fcl: fcl) if self.gelu else (lambda h, fcl: h * 4 + fcl)
+        zero_of = (lambda h: h == 1) if self.gelu else (lambda h: True)
         seq = [(fr, h, fcl) for fr, h in units for fcl in range(nfc)]
-        rd(seq[0][0], seq[0][1] * 4 + seq[0][2], V_E)
+        rd(seq[0][0], fc_of(seq[0][1], seq[0][2]), V_E, zero_of(seq[0][1]))
         for n, (fr, h, fcl) in enumerate(seq):
-            u = fr * (2 if self.st32 else 1) + h
-            fc = h * 4 + fcl
+            u = fr * two + h
+            fc = fc_of(h, fcl)
             cur = V_E + (n & 1) * 8
             if fcl == 0 and h == 0:     # soffsets of this row group's four stores: (fr*16 + 4 j) rows of C
                 b = soff(fr, 0)
@@ -645,7 +716,7 @@ class Kernel:
             if fcl == 0 and self.res:
                 res_loads(u)
             if n + 1 < len(seq):
-                rd(seq[n+1][0], seq[n+1][1] * 4 + seq[n+1][2], V_E + ((n + 1) & 1) * 8)
+                rd(seq[n+1][0], fc_of(seq[n+1][1], seq[n+1][2]), V_E + ((n + 1) & 1) * 8, zero_of(seq[n+1][1]))
             if self.epi:
                 for r in range(4):
                     E(f"\tv_add_f32 v{cur+r}, v{cur+r}, v{V_BIAS+4*fc+r}")
@@ -666,6 +737,8 @@ class Kernel:
             else:
                 E(f"\tv_cvt_pk_bf16_f32 v{cur+4}, v{cur}, v{cur+1}")
                 E(f"\tv_cvt_pk_bf16_f32 v{cur+5}, v{cur+2}, v{cur+3}")
+                if self.gelu and h == 1:
+                    gelu_packed(cur + 4, cur)
                 E(f"\tds_write_b64 v{V_WA+fcl}, v[{cur+4}:{cur+5}]")
             if fcl == nfc - 1 and self.gfwd:    # (12 LDS writes per unit: the previous unit's stores go out before this unit's read-back is queued)
                 if u > 0:
@@ -716,7 +789,7 @@ class Kernel:
         E(f"\ts_getreg_b32 s{S_XCC}, hwreg(HW_REG_XCC_ID)")
         if self.epi:
             E(f"\ts_load_dwordx2 s[{RBI}:{RBI+1}], {S_KARG}, 0x60")
-        if self.res:
+        if self.res or self.gelu:
             E(f"\ts_load_dwordx2 s[{S_T+8}:{S_T+9}], {S_KARG}, 0x68")
         if self.gfwd:
             E(f"\ts_load_dwordx2 s[{S_ACT}:{S_ACT+1}], {S_KARG}, 0x68")
@@ -727,7 +800,7 @@ class Kernel:
         E(f"\tv_readfirstlane_b32 s{W}, v{V_T}")                 # wave id
         E("\ts_nop 4")
         E("\ts_waitcnt lgkmcnt(0)")
-        if self.res:
+        if self.res or self.gelu:
             E(f"\ts_sub_u32 s{S_RDL}, s{S_T+8}, s{S_C}")
             E(f"\ts_subb_u32 s{S_RDH}, s{S_T+9}, s{S_C+1}")
         # ---- block 0 clears the counters the next launch on this stream will draw from (nobody uses them now: the launch that
@@ -1111,7 +1184,9 @@ KERNELS = [Kernel("lap_gemm_asm_nt", True, True, False), Kernel("lap_gemm_asm_nn
            Kernel("lap_gemm_asm_nt_res", True, True, False, res=True),
            Kernel("lap_gemm_asm_nt_bias_res", True, True, False, epi=True, res=True),
            Kernel("lap_gemm_asm_nn_geglu_bwd", True, False, False, gbwd=True),
-           Kernel("lap_gemm_asm_nt_geglu", True, True, False, gfwd=True)]
+           Kernel("lap_gemm_asm_nt_geglu", True, True, False, gfwd=True),
+           Kernel("lap_gemm_asm_nn_gelu_bwd", True, False, False, dgelu=True),
+           Kernel("lap_gemm_asm_nt_bias_gelu", True, True, False, epi=True, gelu=True)]
 E('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
 E("\t.amdhsa_code_object_version 6")
 for k in KERNELS:
