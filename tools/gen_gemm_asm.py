@@ -147,6 +147,8 @@ class Kernel:
         # gelu:  (with epi) C = H = bf16(x W^T + bias) and a second output A = bf16(gelu(H)) with C's leading dimension (kernarg
         #        0x68): the accumulators are walked twice, the second pass zeroes them (siglip_gemma3.py MlpBlock; gelu_fwd_kernel)
         self.dgelu, self.gelu = dgelu, gelu
+        # (a backward kernel: no optimizer waves to share the register file with; 16 more VGPRs hold a third set of gate | up values)
+        self.nvgpr = 240 if gbwd else NVGPR
         self.gfwd = gfwd
         self.gbwd = gbwd
         res = res or gbwd or dgelu
@@ -516,16 +518,22 @@ class Kernel:
         def soff(fr, j):
             return t + 4 * (fr & 1) + j
 
+        def soffs(fr):
+            b = soff(fr, 0)
+            E(f"\ts_mul_i32 s{b}, s{S_C16}, {4*fr}")
+            for j in range(1, 4):
+                E(f"\ts_add_u32 s{b+j}, s{b+j-1}, s{S_C16}")
+
         def res_loads(u):
             fr, h = units[u]
             off = f" offset:{h*128}" if h else ""
             if self.dgelu:      # pre-activations of the unit: 4 row pieces x 4 values per lane
-                gl = V_GUL + 16 * (u & 1)
+                gl = V_GUL + 8 * (u % 3)
                 for j in range(4):
-                    E(f"\tbuffer_load_dwordx2 v[{gl+4*j}:{gl+4*j+1}], v{V_CO}, s[{RR}:{RR+3}], s{soff(fr, j)} offen{off}")
+                    E(f"\tbuffer_load_dwordx2 v[{gl+2*j}:{gl+2*j+1}], v{V_CO}, s[{RR}:{RR+3}], s{soff(fr, j)} offen{off}")
                 return
             if self.gbwd:       # gate and up values of the unit: 4 row pieces x (4 gate, 4 up) per lane
-                gl = V_GUL + 16 * (u & 1)
+                gl = V_GUL + 16 * (u % 3)
                 for j in range(4):
                     E(f"\tbuffer_load_dwordx2 v[{gl+4*j}:{gl+4*j+1}], v{V_CO}, s[{RR}:{RR+3}], s{soff(fr, j)} offen{off}")
                     E(f"\tbuffer_load_dwordx2 v[{gl+4*j+2}:{gl+4*j+3}], v{V_COU}, s[{RR}:{RR+3}], s{soff(fr, j)} offen{off}")
@@ -609,17 +617,18 @@ class Kernel:
             fr, h = units[u]
             cs = V_CS + (u & 1) * 16
             if self.dgelu:
-                gl = V_GUL + 16 * (u & 1)
-                E(f"\ts_waitcnt vmcnt({4 * ((u > 0) + (u + 1 < len(units)))})")
+                gl = V_GUL + 8 * (u % 3)
+                # this unit's values; issued behind them: the next two units' 4 loads each, the previous two units' 4 stores each
+                E(f"\ts_waitcnt vmcnt({4 * ((u > 1) + (u > 0) + (u + 1 < len(units)) + (u + 2 < len(units)))})")
                 off = f" offset:{h*128}" if h else ""
                 for j in range(4):
-                    gelu_bwd_piece(cs + 4 * j, gl + 4 * j)
+                    gelu_bwd_piece(cs + 4 * j, gl + 2 * j)
                     E(f"\tbuffer_store_dwordx2 v[{V_GU_}:{V_GU_+1}], v{V_CO}, s[{RC}:{RC+3}], s{soff(fr, j)} offen{off}{ST_NT}")
                 return
             if self.gbwd:
-                gl = V_GUL + 16 * (u & 1)
-                # this unit's gate / up values; issued behind them: the previous unit's 8 stores (not for unit 0), the next unit's 8 loads (not for the last)
-                E(f"\ts_waitcnt vmcnt({8 * ((u > 0) + (u + 1 < len(units)))})")
+                gl = V_GUL + 16 * (u % 3)
+                # this unit's gate / up values; issued behind them: the next two units' 8 loads each, the previous two units' 8 stores each
+                E(f"\ts_waitcnt vmcnt({8 * ((u > 1) + (u > 0) + (u + 1 < len(units)) + (u + 2 < len(units)))})")
                 off = f" offset:{h*128}" if h else ""
                 for j in range(4):
                     geglu_bwd_piece(cs + 4 * j, gl + 4 * j)
@@ -708,13 +717,19 @@ class Kernel:
             u = fr * two + h
             fc = fc_of(h, fcl)
             cur = V_E + (n & 1) * 8
-            if fcl == 0 and h == 0:     # soffsets of this row group's four stores: (fr*16 + 4 j) rows of C
-                b = soff(fr, 0)
-                E(f"\ts_mul_i32 s{b}, s{S_C16}, {4*fr}")
-                for j in range(1, 4):
-                    E(f"\ts_add_u32 s{b+j}, s{b+j-1}, s{S_C16}")
-            if fcl == 0 and self.res:
+            ahead = self.gbwd or self.dgelu       # the epilogue's loads run two units ahead (one unit = ~1.4 us: less than a miss)
+            if fcl == 0 and h == 0 and not ahead:     # soffsets of this row group's four stores: (fr*16 + 4 j) rows of C
+                soffs(fr)
+            if fcl == 0 and self.res and not ahead:
                 res_loads(u)
+            if fcl == 0 and ahead:
+                if u == 0:
+                    soffs(0)
+                    res_loads(0)
+                if u + 1 < len(units):
+                    if units[u + 1][1] == 0:
+                        soffs(units[u + 1][0])      # (the set of row group fr + 1 = that of fr - 1: its stores are out)
+                    res_loads(u + 1)
             if n + 1 < len(seq):
                 rd(seq[n+1][0], fc_of(seq[n+1][1], seq[n+1][2]), V_E + ((n + 1) & 1) * 8, zero_of(seq[n+1][1]))
             if self.epi:
@@ -1147,8 +1162,8 @@ class Kernel:
                      ("user_sgpr_dispatch_id", 0), ("user_sgpr_kernarg_preload_length", 0), ("user_sgpr_kernarg_preload_offset", 0),
                      ("user_sgpr_private_segment_size", 0), ("uses_dynamic_stack", 0), ("enable_private_segment", 0),
                      ("system_sgpr_workgroup_id_x", 1), ("system_sgpr_workgroup_id_y", 0), ("system_sgpr_workgroup_id_z", 0),
-                     ("system_sgpr_workgroup_info", 0), ("system_vgpr_workitem_id", 0), ("next_free_vgpr", NVGPR + 256), ("next_free_sgpr", 102),
-                     ("accum_offset", NVGPR), ("reserve_vcc", 1), ("float_round_mode_32", 0), ("float_round_mode_16_64", 0),
+                     ("system_sgpr_workgroup_info", 0), ("system_vgpr_workitem_id", 0), ("next_free_vgpr", self.nvgpr + 256), ("next_free_sgpr", 102),
+                     ("accum_offset", self.nvgpr), ("reserve_vcc", 1), ("float_round_mode_32", 0), ("float_round_mode_16_64", 0),
                      ("float_denorm_mode_32", 3), ("float_denorm_mode_16_64", 3), ("dx10_clamp", 1), ("ieee_mode", 1), ("fp16_overflow", 0),
                      ("tg_split", 0), ("exception_fp_ieee_invalid_op", 0), ("exception_fp_denorm_src", 0), ("exception_fp_ieee_div_zero", 0),
                      ("exception_fp_ieee_overflow", 0), ("exception_fp_ieee_underflow", 0), ("exception_fp_ieee_inexact", 0),
@@ -1173,7 +1188,7 @@ class Kernel:
     .symbol:         {self.name}.kd
     .uniform_work_group_size: 1
     .uses_dynamic_stack: false
-    .vgpr_count:     {NVGPR + 256}
+    .vgpr_count:     {self.nvgpr + 256}
     .vgpr_spill_count: 0
     .wavefront_size: 64"""
 
