@@ -61,6 +61,10 @@ RQ = 8                      # s[8:11]: descriptor of the 8 per-XCD tile counters
 S_XCC, S_XOFF, S_REQ = 3, 49, 59   # XCC id of the CU this block runs on; its counter's byte offset; wave 0: a ticket request is in flight
 V_TK, V_MB = 14, 15         # ticket (wave 0: the atomic's return value); LDS address of the ticket mailbox
 RING = os.environ.get("ASM_RING", "1") == "1"                # weight-gradient kernels: LDS as a ring of four half k-tiles
+# A tile's FIRST k-step (its fragments are in register set 0 when the previous tile's epilogue starts) is issued from that epilogue,
+# each MFMA with C = 0 right behind the read-out of its accumulator tile: no accumulator is ever zeroed, and the matrix pipe works
+# through 64 MFMAs while the epilogue converts, stages and stores.  The tile's own first phase then carries no MFMAs (peeled copy).
+PEEL = os.environ.get("ASM_PEEL", "0") == "1" and STAGED      # (measured: no gain — the epilogue is latency-bound, not issue-bound)
 CSTAGE = 131072             # LDS byte offset of the epilogue's staging buffers: 4 KiB per wave ([16 rows][256 B], chunks XOR row)
 MAILBOX = 131072 + 24576    # LDS byte offset of the ticket mailbox (behind the stages and the staging buffers)
 S_BUMPA, S_BUMPB = 54, 55   # bytes per k-tile along each operand
@@ -111,11 +115,12 @@ def acc(fm, fn):
     return (fm * 8 + fn) * 4
 
 
-def mfma(fm, fn, st, swap=False):
-    """D' = B A^T (a lane owns 4 consecutive n of one m); swap: D = A B^T (4 consecutive m of one n: transposed stores)"""
+def mfma(fm, fn, st, swap=False, czero=False):
+    """D' = B A^T (a lane owns 4 consecutive n of one m); swap: D = A B^T (4 consecutive m of one n: transposed stores);
+    czero: the product alone (C = 0): the first k-step of a tile, issued from the previous tile's epilogue"""
     a = acc(fm, fn)
     x, y = (FA[st] + 4 * fm, FB[st] + 4 * fn) if swap else (FB[st] + 4 * fn, FA[st] + 4 * fm)
-    return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a+3}], v[{x}:{x+3}], v[{y}:{y+3}], a[{a}:{a+3}]"
+    return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a+3}], v[{x}:{x+3}], v[{y}:{y+3}], " + ("0" if czero else f"a[{a}:{a+3}]")
 
 
 def order():
@@ -211,7 +216,7 @@ class Kernel:
                 r.append((f"s_add_u32 m0, s{S_W8K}, {lds}", f"buffer_load_dwordx4 v{vd + (j & 1)}, s[{rs}:{rs+3}], s{soff+j} offen lds"))
         return r
 
-    def phase_ring(self, p):
+    def phase_ring(self, p, first=False):
         """phase p of the ring: half p is in register set p & 1"""
         _uid[0] += 1
         u = _uid[0]
@@ -232,7 +237,7 @@ class Kernel:
             slot = 3 + 8 * n
             side += [(slot, m0w), (slot, "s_nop 0"), (slot, ld)]
         side += [(63, txt) for txt in self.stream_step()]
-        self.phase(p & 1, side)
+        self.phase(p & 1, side, mfmas=not first)
         E("\ts_waitcnt lgkmcnt(0)")
 
     def bump(self):
@@ -325,11 +330,17 @@ class Kernel:
               f"s_mov_b32 s{S_DLEFT}, 0x7fffffff", f".Lstream_done{u}:"]
         return r
 
-    def phase(self, st, side):
-        """64 MFMAs of register set st with the side instructions threaded in: side = list of (slot, text)."""
+    def phase(self, st, side, mfmas=True):
+        """64 MFMAs of register set st with the side instructions threaded in: side = list of (slot, text).
+        mfmas=False: the side instructions alone, in slot order (a tile's first phase: its MFMAs ran in the previous epilogue)."""
         byslot = {}
         for slot, txt in side:
             byslot.setdefault(slot, []).append(txt)
+        if not mfmas:
+            for slot in sorted(byslot):
+                for txt in byslot[slot]:
+                    L(txt)
+            return
         if "m32" in ABL:        # timing only: the phase's 64 MFMA 16x16x32 as 32 MFMA 32x32x16 (same flops, garbage operands)
             merged = {}
             for slot, lst in byslot.items():
@@ -355,7 +366,7 @@ class Kernel:
                     continue
                 L(txt)
 
-    def ktile(self, stage):
+    def ktile(self, stage, first=False):
         RS = float(os.environ.get("ASM_RD_STRIDE", "2"))        # MFMAs between two fragment reads (K-contiguous count)
         DS = int(os.environ.get("ASM_DMA_STRIDE", "4"))         # MFMAs between two DMA pieces
         rd = self.reads(1, stage, 1)
@@ -367,7 +378,7 @@ class Kernel:
                 side0 += [(3 + n * 8, m0w), (3 + n * 8, "s_nop 0"), (3 + n * 8, ld)]
             pieces = pieces[8:]
             DS = 8
-        self.phase(0, side0)
+        self.phase(0, side0, mfmas=not first)
         E("\ts_waitcnt lgkmcnt(0)" if "nowait" in ABL else ("\ts_waitcnt vmcnt(8) lgkmcnt(0)" if "spread" in ABL else "\ts_waitcnt vmcnt(0) lgkmcnt(0)"))
         _uid[0] += 1
         E(f"\ts_cmp_eq_u32 s{S_REQ}, 0")                  # wave 0, a ticket has just come back: into the mailbox before the barrier
@@ -511,8 +522,10 @@ class Kernel:
             a = acc(*tiles(fr, fc))
             for r in range(4):
                 E(f"\tv_accvgpr_read_b32 v{base+r}, a{a+r}")
+            if zero and PEEL:
+                E("\t" + mfma(*tiles(fr, fc), 0, self.tout, czero=True))     # the next tile's first k-step on this accumulator tile
             for r in range(4):
-                if zero:
+                if zero and not PEEL:
                     E(f"\tv_accvgpr_write_b32 a{a+r}, 0")
 
         def soff(fr, j):
@@ -1109,8 +1122,9 @@ class Kernel:
                 E("\t" + ld)
             for x in self.stream_step():
                 L(x)
-        for a in range(256):
-            E(f"\tv_accvgpr_write_b32 a{a}, 0")
+        if not PEEL:
+            for a in range(256):
+                E(f"\tv_accvgpr_write_b32 a{a}, 0")
         for r in range(3):
             E(f"\ts_mov_b32 s{RC+r}, s{RCN+r}")
         if self.gfwd:
@@ -1123,8 +1137,19 @@ class Kernel:
         for x in (self.reads_ring(0, 0) if self.ring else self.reads(0, 0, 0)):
             E("\t" + x)
         E("\ts_waitcnt lgkmcnt(0)")
+        if PEEL:        # the block's first tile: its first k-step here
+            for fm, fn in order():
+                E("\t" + mfma(fm, fn, 0, self.tout, czero=True))
         E(f".Ltile_{nm}:")
         E(f"\ts_lshr_b32 s{S_LOOP}, s{S_NKT}, {2 if self.ring else 1}")
+        if PEEL:        # first loop body of the tile without the MFMAs of its first phase
+            if self.ring:
+                for ph in range(4):
+                    self.phase_ring(ph, first=ph == 0)
+            else:
+                self.ktile(0, first=True)
+                self.ktile(1)
+            E(f"\ts_sub_u32 s{S_LOOP}, s{S_LOOP}, 1")
         E(f".Lloop_{nm}:")
         if self.ring:
             for ph in range(4):
