@@ -64,6 +64,8 @@ RING = os.environ.get("ASM_RING", "1") == "1"                # weight-gradient k
 # A tile's FIRST k-step (its fragments are in register set 0 when the previous tile's epilogue starts) is issued from that epilogue,
 # each MFMA with C = 0 right behind the read-out of its accumulator tile: no accumulator is ever zeroed, and the matrix pipe works
 # through 64 MFMAs while the epilogue converts, stages and stores.  The tile's own first phase then carries no MFMAs (peeled copy).
+# the previous unit's four stores issued one by one between this unit's accumulator tiles instead of back to back (plain kernels)
+STSPREAD = os.environ.get("ASM_STSPREAD", "0") == "1"
 PEEL = os.environ.get("ASM_PEEL", "0") == "1" and STAGED      # (measured: no gain — the epilogue is latency-bound, not issue-bound)
 CSTAGE = 131072             # LDS byte offset of the epilogue's staging buffers: 4 KiB per wave ([16 rows][256 B], chunks XOR row)
 MAILBOX = 131072 + 24576    # LDS byte offset of the ticket mailbox (behind the stages and the staging buffers)
@@ -626,7 +628,7 @@ class Kernel:
             E(f"\tv_cvt_pk_bf16_f32 v{G}, v{G}, v{G+1}")
             E(f"\tv_cvt_pk_bf16_f32 v{G+1}, v{G+2}, v{G+3}")
 
-        def stores(u):
+        def stores(u, js=None):
             fr, h = units[u]
             cs = V_CS + (u & 1) * 16
             if self.dgelu:
@@ -665,7 +667,7 @@ class Kernel:
                     off = f" offset:{h*128}" if h else ""
                     E(f"\tbuffer_store_dwordx2 v[{c}:{c+1}], v{vco(h)}, s[{RC}:{RC+3}], s{soff(fr, j)} offen{off}{ST_NT}")
                 return
-            for j in range(4):      # rows fr*16 + 4 j .. + 3
+            for j in (range(4) if js is None else js):      # rows fr*16 + 4 j .. + 3
                 off = f" offset:{h*256}" if (h and not self.gelu) else ""
                 dsc = RR if (self.gelu and h) else RC
                 if "nostore" not in ABL:
@@ -779,11 +781,18 @@ class Kernel:
                 a = V_AS + (u & 1) * 8
                 E(f"\tds_read_b128 v[{a}:{a+3}], v{V_SRA}")
                 E(f"\tds_read_b128 v[{a+4}:{a+7}], v{V_SRA1} offset:1024")
+            spread = STSPREAD and not self.res and not self.gfwd
+            if spread and u > 0 and (fcl % (nfc // 4)) == nfc // 4 - 1:     # one of the previous unit's stores behind every second (f32: every) tile
+                if fcl == nfc // 4 - 1:
+                    E(f"\ts_waitcnt lgkmcnt({fcl + 1})")          # the previous unit's read-back (this unit's writes so far behind it)
+                stores(u - 1, [fcl // (nfc // 4)])
+            if fcl == nfc - 1 and self.gfwd:
+                pass
             elif fcl == nfc - 1:        # the unit is written: queue its read-back, then store the previous unit
                 cs = V_CS + (u & 1) * 16
                 for j in range(4):
                     E(f"\tds_read_b128 v[{cs+4*j}:{cs+4*j+3}], v{V_RD+j} offset:{j*1024}")
-                if u > 0:
+                if u > 0 and not spread:
                     E(f"\ts_waitcnt lgkmcnt({nfc + 4})")
                     stores(u - 1)
         E("\ts_waitcnt lgkmcnt(0)")
