@@ -66,6 +66,14 @@ RING = os.environ.get("ASM_RING", "1") == "1"                # weight-gradient k
 # through 64 MFMAs while the epilogue converts, stages and stores.  The tile's own first phase then carries no MFMAs (peeled copy).
 # the previous unit's four stores issued one by one between this unit's accumulator tiles instead of back to back (plain kernels)
 STSPREAD = os.environ.get("ASM_STSPREAD", "0") == "1"
+# (packed f32 arithmetic, v_pk_mul / v_pk_fma / v_pk_add_f32, in the fused GeGLU-backward epilogue was tried: 1222 vs 1247 us on a 3 % faster
+# box — nothing; removed again)
+# Persistent blocks start together and every tile takes the same time, so all 256 CUs reach their epilogues at once: C (and the fused
+# epilogues' reads) leave in bursts while the HBM side idles during the main loops.  STAGGER > 0: block b first sleeps
+# (b & 7) / 8 of a tile time (STAGGER x 64 cycles per k-tile and phase step), so the eight XCDs stay an eighth of a tile apart
+# (inside an XCD the blocks must stay in step: they share their operand panels in its L2 — a stagger inside the XCD cost 5-30 %); the tile tickets hand the late starters fewer tiles, so the delay is not paid at the end.
+STAGGER = int(os.environ.get("ASM_STAGGER", "0"))
+WIDE = os.environ.get("ASM_WIDE", "1") == "1"      # residual-type epilogues: 8 columns per lane -> dwordx4 loads / stores (half the VMEM instructions)
 PEEL = os.environ.get("ASM_PEEL", "0") == "1" and STAGED      # (measured: no gain — the epilogue is latency-bound, not issue-bound)
 CSTAGE = 131072             # LDS byte offset of the epilogue's staging buffers: 4 KiB per wave ([16 rows][256 B], chunks XOR row)
 MAILBOX = 131072 + 24576    # LDS byte offset of the ticket mailbox (behind the stages and the staging buffers)
@@ -155,7 +163,7 @@ class Kernel:
         #        0x68): the accumulators are walked twice, the second pass zeroes them (siglip_gemma3.py MlpBlock; gelu_fwd_kernel)
         self.dgelu, self.gelu = dgelu, gelu
         # (a backward kernel: no optimizer waves to share the register file with; 16 more VGPRs hold a third set of gate | up values)
-        self.nvgpr = 240 if gbwd else NVGPR
+        self.nvgpr = 256 if gbwd else NVGPR
         self.gfwd = gfwd
         self.gbwd = gbwd
         res = res or gbwd or dgelu
@@ -479,8 +487,9 @@ class Kernel:
                 E(f"\tbuffer_load_dwordx4 v[{V_BIAS+4*fn}:{V_BIAS+4*fn+3}], v{V_E}, s[{RBI}:{RBI+3}], s{t+10} offen offset:{fn*64}")
             # ragged N: the lane stores columns wn*128 + (l & 15) * 8 .. + 7 of the tile (residual variant: for each 64-column half
             # h, wn*128 + 64 h + (l & 15) * 4 .. + 3); past N -> an out-of-range offset (dropped / read as zero)
-            E(f"\tv_and_b32 v{V_E+1}, 15, v{V_LANE}")
-            E(f"\tv_lshlrev_b32 v{V_E+1}, {2 if self.res else 3}, v{V_E+1}")
+            wide = self.res and WIDE
+            E(f"\tv_and_b32 v{V_E+1}, {7 if wide else 15}, v{V_LANE}")
+            E(f"\tv_lshlrev_b32 v{V_E+1}, {3 if (wide or not self.res) else 2}, v{V_E+1}")
             E(f"\tv_and_b32 v{V_E+2}, -128, v{V_NCOL}")                 # wn * 128
             E(f"\tv_add_u32 v{V_E+1}, v{V_E+1}, v{V_E+2}")
             E(f"\tv_mov_b32 v{V_E+2}, 0x80000000")
@@ -510,7 +519,24 @@ class Kernel:
             E(f"\tv_xor_b32 v{V_SRA1}, 64, v{V_SRA}")
         for fc in range(nfc):
             E(f"\tv_xor_b32 v{V_WA+fc}, {fc * (64 if self.st32 else 32)}, v{V_SW}")
-        for j in range(4):
+        wide = self.res and WIDE
+        if wide:
+            # read back 8 columns per lane: lane -> row 8 j' + (l >> 3), chunks 2 (l & 7) + c (c = 0, 1) of the [16 rows][16 chunks] buffer,
+            # chunk XOR row: V_RD + 2 j' + c (j' = 1: XOR 128, + 2048 in the instruction)
+            E(f"\tv_lshrrev_b32 v{V_E}, 3, v{V_LANE}")
+            E(f"\tv_and_b32 v{V_E+1}, 7, v{V_LANE}")
+            E(f"\tv_lshlrev_b32 v{V_E+1}, 1, v{V_E+1}")
+            E(f"\tv_lshlrev_b32 v{V_E+2}, 8, v{V_E}")
+            E(f"\ts_lshl_b32 s{t+12}, s{t+15}, 12")
+            E(f"\ts_add_u32 s{t+12}, s{t+12}, {CSTAGE}")
+            E(f"\tv_add_u32 v{V_E+2}, s{t+12}, v{V_E+2}")
+            for c in range(2):
+                E(f"\tv_or_b32 v{V_E+3}, {c}, v{V_E+1}")
+                E(f"\tv_xor_b32 v{V_E+3}, v{V_E+3}, v{V_E}")
+                E(f"\tv_lshlrev_b32 v{V_E+3}, 4, v{V_E+3}")
+                E(f"\tv_add_u32 v{V_RD+c}, v{V_E+2}, v{V_E+3}")
+                E(f"\tv_xor_b32 v{V_RD+2+c}, 128, v{V_RD+c}")
+        for j in range(0 if wide else 4):
             E(f"\tv_xor_b32 v{V_RD+j}, {j * 64}, v{V_SR}")
         E("\ts_nop 15")
         E("\ts_nop 15")
@@ -542,6 +568,21 @@ class Kernel:
         def res_loads(u):
             fr, h = units[u]
             off = f" offset:{h*128}" if h else ""
+            if wide:        # two row pieces (rows fr*16 + 8 j' + (l >> 3)) x 8 columns per lane
+                if self.dgelu:
+                    gl = V_GUL + 8 * (u % 3)
+                    for jp in range(2):
+                        E(f"\tbuffer_load_dwordx4 v[{gl+4*jp}:{gl+4*jp+3}], v{V_CO}, s[{RR}:{RR+3}], s{soff(fr, 2*jp)} offen{off}")
+                elif self.gbwd:
+                    gl = V_GUL + 16 * (u % 3)
+                    for jp in range(2):
+                        E(f"\tbuffer_load_dwordx4 v[{gl+8*jp}:{gl+8*jp+3}], v{V_CO}, s[{RR}:{RR+3}], s{soff(fr, 2*jp)} offen{off}")
+                        E(f"\tbuffer_load_dwordx4 v[{gl+8*jp+4}:{gl+8*jp+7}], v{V_COU}, s[{RR}:{RR+3}], s{soff(fr, 2*jp)} offen{off}")
+                else:
+                    rs = V_RS[u & 1]
+                    for jp in range(2):
+                        E(f"\tbuffer_load_dwordx4 v[{rs+4*jp}:{rs+4*jp+3}], v{vco(h)}, s[{RR}:{RR+3}], s{soff(fr, 2*jp)} offen{off}")
+                return
             if self.dgelu:      # pre-activations of the unit: 4 row pieces x 4 values per lane
                 gl = V_GUL + 8 * (u % 3)
                 for j in range(4):
@@ -557,9 +598,9 @@ class Kernel:
             for j in range(4):
                 E(f"\tbuffer_load_dwordx2 v[{rs+2*j}:{rs+2*j+1}], v{vco(h)}, s[{RR}:{RR+3}], s{soff(fr, j)} offen{off}")
 
-        def gelu_bwd_piece(c, hl):
+        def gelu_bwd_piece(c, hl, out=V_GU_):
             """4 outputs of one row piece: c..c+3 = d(a) (f32, unrounded), hl, hl+1 = 4 pre-activations (bf16 pairs); leaves
-            d(h) = bf16(d(a)) * gelu'(h) packed in V_GU_, V_GU_+1."""
+            d(h) = bf16(d(a)) * gelu'(h) packed in out, out+1."""
             X, U, X2, P, O = V_GX, V_GU_, V_GX2, V_GP, V_GO
             K1P, C3 = "0xbdd2d3e8", "0x3ddb33b6"
             E(f"\tv_cvt_pk_bf16_f32 v{P}, v{c}, v{c+1}")
@@ -583,22 +624,23 @@ class Kernel:
             for e in range(4): E(f"\tv_add_f32 v{O+e}, v{O+e}, v{O+e}")
             for e in range(4): E(f"\tv_fma_f32 v{O+e}, v{P+e}, v{O+e}, v{P+e}")              # gelu'
             for e in range(4): E(f"\tv_mul_f32 v{U+e}, v{c+e}, v{O+e}")
-            E(f"\tv_cvt_pk_bf16_f32 v{U}, v{U}, v{U+1}")
-            E(f"\tv_cvt_pk_bf16_f32 v{U+1}, v{U+2}, v{U+3}")
+            E(f"\tv_cvt_pk_bf16_f32 v{out}, v{U}, v{U+1}")
+            E(f"\tv_cvt_pk_bf16_f32 v{out+1}, v{U+2}, v{U+3}")
 
-        def geglu_bwd_piece(c, gl):
+        def geglu_bwd_piece(c, gl, ul=None, outg=V_GU_, outu=V_GG):
             """4 outputs of one row piece: c..c+3 = d(act) (f32, unrounded), gl, gl+1 = 4 gate values (bf16 pairs), gl+2, gl+3 = 4 up values.
             Leaves d(gate) packed in V_GU_, V_GU_+1 and d(up) packed in V_GG, V_GG+1.  With s = sigmoid(2 k0 (x + k1 x^3)):
             gelu(x) = x s,  gelu'(x) = s + 2 x s (1 - s) k0 (1 + 3 k1 x^2)."""
             X, U, X2, P, G, O = V_GX, V_GU_, V_GX2, V_GP, V_GG, V_GO
             K1P, C3 = "0xbdd2d3e8", "0x3ddb33b6"      # -2 log2(e) k0 k1 = -0.10294324, 3 k0 k1 = 0.10703222
+            ul = gl + 2 if ul is None else ul           # (registers of the 4 up values)
             E(f"\tv_cvt_pk_bf16_f32 v{P}, v{c}, v{c+1}")             # d(act) as the stand-alone product stores it
             E(f"\tv_cvt_pk_bf16_f32 v{P+1}, v{c+2}, v{c+3}")
             for k in range(2):
                 E(f"\tv_lshlrev_b32 v{X+2*k}, 16, v{gl+k}")
                 E(f"\tv_and_b32 v{X+2*k+1}, 0xffff0000, v{gl+k}")
-                E(f"\tv_lshlrev_b32 v{U+2*k}, 16, v{gl+2+k}")
-                E(f"\tv_and_b32 v{U+2*k+1}, 0xffff0000, v{gl+2+k}")
+                E(f"\tv_lshlrev_b32 v{U+2*k}, 16, v{ul+k}")
+                E(f"\tv_and_b32 v{U+2*k+1}, 0xffff0000, v{ul+k}")
             for k in range(2):
                 E(f"\tv_lshlrev_b32 v{c+2*k}, 16, v{P+k}")
                 E(f"\tv_and_b32 v{c+2*k+1}, 0xffff0000, v{P+k}")
@@ -623,14 +665,47 @@ class Kernel:
                 E(f"\tv_lshlrev_b32 v{G+2*k}, 16, v{X+k}")
                 E(f"\tv_and_b32 v{G+2*k+1}, 0xffff0000, v{X+k}")
             for e in range(4): E(f"\tv_mul_f32 v{G+e}, v{c+e}, v{G+e}")                      # d(up)
-            E(f"\tv_cvt_pk_bf16_f32 v{U}, v{U}, v{U+1}")
-            E(f"\tv_cvt_pk_bf16_f32 v{U+1}, v{U+2}, v{U+3}")
-            E(f"\tv_cvt_pk_bf16_f32 v{G}, v{G}, v{G+1}")
-            E(f"\tv_cvt_pk_bf16_f32 v{G+1}, v{G+2}, v{G+3}")
+            E(f"\tv_cvt_pk_bf16_f32 v{outg}, v{U}, v{U+1}")
+            E(f"\tv_cvt_pk_bf16_f32 v{outg+1}, v{U+2}, v{U+3}")
+            E(f"\tv_cvt_pk_bf16_f32 v{outu}, v{G}, v{G+1}")
+            E(f"\tv_cvt_pk_bf16_f32 v{outu+1}, v{G+2}, v{G+3}")
 
         def stores(u, js=None):
             fr, h = units[u]
             cs = V_CS + (u & 1) * 16
+            if wide:
+                off = f" offset:{h*128}" if h else ""
+                nu = len(units)
+                if self.dgelu:
+                    gl, OUT = V_GUL + 8 * (u % 3), 216
+                    E(f"\ts_waitcnt vmcnt({2 * ((u > 1) + (u > 0) + (u + 1 < nu) + (u + 2 < nu))})")
+                    for jp in range(2):
+                        for c in range(2):
+                            gelu_bwd_piece(cs + 8 * jp + 4 * c, gl + 4 * jp + 2 * c, OUT + 2 * c)
+                        E(f"\tbuffer_store_dwordx4 v[{OUT}:{OUT+3}], v{V_CO}, s[{RC}:{RC+3}], s{soff(fr, 2*jp)} offen{off}{ST_NT}")
+                elif self.gbwd:
+                    gl, OG, OU = V_GUL + 16 * (u % 3), 240, 244
+                    E(f"\ts_waitcnt vmcnt({4 * ((u > 1) + (u > 0) + (u + 1 < nu) + (u + 2 < nu))})")
+                    for jp in range(2):
+                        for c in range(2):
+                            if "nomath" not in ABL:
+                                geglu_bwd_piece(cs + 8 * jp + 4 * c, gl + 8 * jp + 2 * c, gl + 8 * jp + 4 + 2 * c, OG + 2 * c, OU + 2 * c)
+                        E(f"\tbuffer_store_dwordx4 v[{OG}:{OG+3}], v{V_CO}, s[{RC}:{RC+3}], s{soff(fr, 2*jp)} offen{off}{ST_NT}")
+                        E(f"\tbuffer_store_dwordx4 v[{OU}:{OU+3}], v{V_COU}, s[{RC}:{RC+3}], s{soff(fr, 2*jp)} offen{off}{ST_NT}")
+                else:
+                    rs = V_RS[u & 1]
+                    E(f"\ts_waitcnt vmcnt({2 * ((u > 0) + (u + 1 < nu))})")
+                    for jp in range(2):
+                        c = cs + 8 * jp
+                        for k in range(4):      # 8 residual values of the row piece, two at a time
+                            E(f"\tv_lshlrev_b32 v{V_RT}, 16, v{rs+4*jp+k}")
+                            E(f"\tv_and_b32 v{V_RT+1}, 0xffff0000, v{rs+4*jp+k}")
+                            E(f"\tv_add_f32 v{c+2*k}, v{c+2*k}, v{V_RT}")
+                            E(f"\tv_add_f32 v{c+2*k+1}, v{c+2*k+1}, v{V_RT+1}")
+                        for k in range(4):
+                            E(f"\tv_cvt_pk_bf16_f32 v{c+k}, v{c+2*k}, v{c+2*k+1}")
+                        E(f"\tbuffer_store_dwordx4 v[{c}:{c+3}], v{vco(h)}, s[{RC}:{RC+3}], s{soff(fr, 2*jp)} offen{off}{ST_NT}")
+                return
             if self.dgelu:
                 gl = V_GUL + 8 * (u % 3)
                 # this unit's values; issued behind them: the next two units' 4 loads each, the previous two units' 4 stores each
@@ -791,7 +866,8 @@ class Kernel:
             elif fcl == nfc - 1:        # the unit is written: queue its read-back, then store the previous unit
                 cs = V_CS + (u & 1) * 16
                 for j in range(4):
-                    E(f"\tds_read_b128 v[{cs+4*j}:{cs+4*j+3}], v{V_RD+j} offset:{j*1024}")
+                    ro = (j >> 1) * 2048 if wide else j * 1024
+                    E(f"\tds_read_b128 v[{cs+4*j}:{cs+4*j+3}], v{V_RD+j} offset:{ro}")
                 if u > 0 and not spread:
                     E(f"\ts_waitcnt lgkmcnt({nfc + 4})")
                     stores(u - 1)
@@ -1037,10 +1113,14 @@ class Kernel:
             E(f"\tv_add_u32 v{V_E+2}, v{V_E+2}, v{V_E+3}")
             E(f"\tv_add_u32 v{V_SR}, s{t+14}, v{V_E+2}")
             # store offset: row w?*128 + (l >> 4), bytes w?*(128 elements) + (l & 15) * 16
+            # (residual-type epilogues, wide form: row w?*128 + (l >> 3), bytes w?*256 + (l & 7) * 16: 8 bf16 columns per lane)
+            if self.res and WIDE:
+                E(f"\tv_and_b32 v{V_E}, 7, v{V_LANE}")
+                E(f"\tv_lshrrev_b32 v{V_E+1}, 3, v{V_LANE}")
             E(f"\ts_lshl_b32 s{t+14}, s{wrow}, 7")
             E(f"\tv_add_u32 v{V_E+1}, s{t+14}, v{V_E+1}")
             E(f"\tv_mul_lo_u32 v{V_E+1}, v{V_E+1}, s{S_LDC}")
-            E(f"\tv_lshlrev_b32 v{V_E}, {3 if self.res else 4}, v{V_E}")      # (residual variant: 4 bf16 = 8 bytes per lane)
+            E(f"\tv_lshlrev_b32 v{V_E}, {3 if (self.res and not WIDE) else 4}, v{V_E}")      # (narrow residual variant: 4 bf16 = 8 bytes per lane)
             E(f"\ts_lshl_b32 s{t+14}, s{wcol}, {9 if self.f32 else 8}")
             E(f"\tv_add_u32 v{V_E}, v{V_E}, v{V_E+1}")
             E(f"\tv_add_u32 v{V_CO}, s{t+14}, v{V_E}")
@@ -1123,6 +1203,17 @@ class Kernel:
             E(f"\tv_lshlrev_b32 v{V_NCOL}, 2, v{V_NCOL}")
             E(f"\ts_lshl_b32 s{t+14}, s{t+13}, 7")
             E(f"\tv_add_u32 v{V_NCOL}, s{t+14}, v{V_NCOL}")
+        if STAGGER:
+            E(f"\ts_and_b32 s{t}, {S_WG}, 7")              # the XCD (round-robin dispatch): its 32 blocks stay in step and keep sharing panels in L2
+            E(f"\ts_mul_i32 s{t}, s{t}, s{S_NKT}")
+            E(f"\ts_cmp_eq_u32 s{t}, 0")
+            E(f"\ts_cbranch_scc1 .Lstag_done_{nm}")
+            E(f".Lstag_{nm}:")
+            E(f"\ts_sleep {max(1, (STAGGER + 1) // 2) if self.ring else STAGGER}")
+            E(f"\ts_sub_u32 s{t}, s{t}, 1")
+            E(f"\ts_cmp_lg_u32 s{t}, 0")
+            E(f"\ts_cbranch_scc1 .Lstag_{nm}")
+            E(f".Lstag_done_{nm}:")
         # ---- prologue: k-tiles 0 and 1 of the first tile in flight (ring: half k-tiles 0 .. 3), accumulators cleared
         for stage in ((0, 1, 2, 3) if self.ring else (0, 1)):
             for m0w, ld in (self.dma_ring(stage) if self.ring else self.dma(stage)):
