@@ -166,7 +166,11 @@ class UnitPipeline:
         # the per-unit updates: build_specs puts the small replicated unit first, then forward order
         self._todo_args = opt
         self._released = 0
-        self._release(self.lookahead if (self.lookahead > 0 and self.is_cuda) else len(self._sched), paced=False)
+        import os
+        serial = os.environ.get("LAP_OPT_SERIAL", "0") == "1"     # A/B: the whole pass alone on the chip, the compute stream waits for it
+        self._release(self.lookahead if (self.lookahead > 0 and self.is_cuda and not serial) else len(self._sched), paced=False)
+        if serial and self.is_cuda and self._opt_done is not None:
+            torch.cuda.current_stream().wait_event(self._opt_done)
         if self.is_cuda:
             torch.cuda.current_stream().wait_event(norm_ready)   # so that `gnorm` can be read from the compute stream
             gnorm.record_stream(torch.cuda.current_stream())
