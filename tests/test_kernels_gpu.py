@@ -216,6 +216,46 @@ def test_gemm_assembly_residual_kernels_match_hip_tiles_bitwise(hip):
     assert rel_err(o[16384:], o10[16384:]) < 2e-3
 
 
+def test_gemm_assembly_kernels_repeat_bit_for_bit_under_load(hip):
+    """Race screen (tools/probes/asm_soak.py in short): ring slots, counted vmcnt waits and the staging buffers are correct only if no
+    wave ever reads a slot early — a miss shows up as a rare differing tile, so the same launch is repeated with another GEMM on a
+    second stream and a bandwidth hog in between, and every output must equal the first bit for bit."""
+    side = torch.cuda.Stream()
+    na, nb = rnd(2048, 2048, seed=11), rnd(2048, 2048, seed=12)
+    no = torch.empty(2048, 2048, device=DEV, dtype=torch.bfloat16)
+    hog = torch.zeros(64 << 20, device=DEV)
+
+    def soak(fn, reps=10):
+        ref = fn()
+        ref = [r.clone() for r in (ref if isinstance(ref, tuple) else (ref,))]
+        for i in range(reps):
+            if i % 2 == 0:
+                with torch.cuda.stream(side):
+                    hip.linear_fwd(na, nb, no)
+            else:
+                hog.add_(1.0)
+            out = fn()
+            for o, r in zip(out if isinstance(out, tuple) else (out,), ref):
+                assert torch.equal(o, r)
+        torch.cuda.synchronize()
+
+    M, N, K = 4352, 4096, 512                  # 17 x 16 tiles: more tiles than blocks, a partial last group, K at the minimum
+    x, w, wn, res, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(K, N, seed=3), rnd(M, N, seed=4), torch.randn(N, device=DEV)
+    o = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    soak(lambda: hip.gemm(x, w, o, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=14, ksplit=1).clone())
+    soak(lambda: hip.gemm(x, wn, o, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_kc=False, tile=14, ksplit=1).clone())
+    soak(lambda: hip.gemm(x, w, o, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, residual=res, ldr=N, tile=14, ksplit=1).clone())
+    soak(lambda: hip.linear_bias_gelu_train(x, w, bias))
+    soak(lambda: hip.linear_dgrad_gelu_bwd(x, wn, res))
+    a, b = rnd(2304, 4096 + 64, seed=5)[:, :4096], rnd(2304, 2048, seed=6)     # weight gradient (ring kernel), K = 2304 rows
+    g = torch.empty(4096, 2048, device=DEV)
+    soak(lambda: hip.gemm(a, b, g, M=4096, N=2048, K=2304, lda=a.stride(0), ldb=2048, ldc=2048, a_kc=False, b_kc=False, tile=14, ksplit=1).clone())
+    wg = rnd(2 * 2048, K, seed=7) * 0.05
+    soak(lambda: hip.linear_geglu_train(x, wg))
+    gu = (rnd(M, 2 * 2048 + 64, seed=8) * 4)[:, :2 * 2048]
+    soak(lambda: hip.linear_dgrad_geglu_bwd(x, rnd(K, 2048, seed=9), gu))
+
+
 def test_gemm_assembly_gelu_mlp_kernels(hip):
     """lap_gemm_asm_nt_bias_gelu (h and a = gelu(h) from one launch, the accumulators walked twice) and lap_gemm_asm_nn_gelu_bwd (d(h) =
     bf16(dy W) * gelu'(h), d(a) never stored): h bit for bit the biased product; a / d(h) follow gelu_fwd / gelu_bwd with the GELU
