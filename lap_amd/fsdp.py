@@ -75,6 +75,9 @@ class UnitPipeline:
             sched.insert(1 if names and names[0] == "small" else 0, store.unit_by_name["ada"])
         self._sched = sched
         self._unit_pos = {u.name: k for k, u in enumerate(sched)}
+        import os
+        self.hold_big = os.environ.get("LAP_OPT_HOLD_EMBED", "0") == "1"     # A/B switch (measured: 282.3 vs 282.3 ms: what the tower gains, the wait costs)
+        self._first_big = self._unit_pos.get("embed", len(sched))     # (schedule: small, ada, img..., img_head, embed, llm...)
         self._released = len(sched)      # units _sched[0 : _released] of the current pass are enqueued
         store._quiesce = self.synchronize
 
@@ -115,7 +118,13 @@ class UnitPipeline:
         `lookahead` units are released HERE, so that their HBM traffic runs beside that GEMM instead of beside the unit's first
         (bandwidth-bound) norm kernel."""
         if self.pace_in_layer and self._released < len(self._sched):
-            self._release(self._unit_pos[name] + 1 + max(self.lookahead, 1), paced=True)
+            upto = self._unit_pos[name] + 1 + max(self.lookahead, 1)
+            if self.hold_big and name.startswith("img"):
+                # the SigLIP tower's short kernels crawl beside a big unit's update (its last three blocks took 3.5 ms each instead of 1
+                # beside the embedding table's 20 GB): the lookahead stops at the tower's own units; the table is updated with the
+                # chip to itself when the compute stream asks for it (wait_unit("embed"))
+                upto = min(upto, self._first_big)
+            self._release(upto, paced=True)
 
     def _reduce_grads(self, u):
         pass  # single rank: gradients are already complete
