@@ -64,7 +64,7 @@ class UnitPipeline:
         import os
         # units of the current optimizer pass that are scheduled but not yet enqueued (paced release, see module docstring);
         # lookahead 0 = enqueue the whole pass at once
-        self.lookahead = int(os.environ.get("LAP_OPT_LOOKAHEAD", "5"))
+        self.lookahead = int(os.environ.get("LAP_OPT_LOOKAHEAD", "9"))
         self.pace_in_layer = os.environ.get("LAP_OPT_PACE", "gemm") == "gemm"
         self._todo_args = None
         # release order = the order in which the forward first needs the units: the store's order, except that the adaRMS
