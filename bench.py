@@ -118,6 +118,7 @@ class GemmMeter:
                     self.shapes[sig] = self.shapes.get(sig, 0) + 1
                 return r
             setattr(self.hip, name, fn)
+        wrap("linear_wgrad_sumsq", lambda dy, x, out, ss: (dy.shape[1], x.shape[1], dy.shape[0]))
         wrap("linear_geglu_train", lambda x, w, *a: (x.shape[0], w.shape[0], x.shape[1]))
         wrap("linear_dgrad_geglu_bwd", lambda dy, w, gu: (dy.shape[0], w.shape[1], w.shape[0]))
         wrap("linear_bias_gelu_train", lambda x, w, b: (x.shape[0], w.shape[0], x.shape[1]))
@@ -152,7 +153,11 @@ class GemmMeter:
             if sig[0] == "fused":
                 _, name, M, N, K, lda = sig
                 fn = self.fused_orig[name]
-                if name == "linear_geglu_train":
+                if name == "linear_wgrad_sumsq":     # (lda = the row stride of dy: the engine pads d(gate|up))
+                    dy, x = rnd(K, lda)[:, :M], rnd(K, N)
+                    o, acc = torch.empty(M, N, device=dev), torch.zeros(1, device=dev)
+                    call, label = (lambda: fn(dy, x, o, acc)), f"TN {M}x{N}x{K}"
+                elif name == "linear_geglu_train":
                     x, w = rnd(M, lda)[:, :K], rnd(N, K) * 0.05
                     call, label = (lambda: fn(x, w)), f"NT+GeGLU {M}x{N}x{K}"
                 elif name == "linear_dgrad_geglu_bwd":

@@ -1473,6 +1473,25 @@ extern "C" int lap_gemm_set_debug(int bits) {   // ablation knob; has an effect 
 #endif
 }
 
+// Weight gradient dW [M][N] (f32) = A^T B over K rows (A [K][M], B [K][N]) with its sum of squares folded in where the assembly
+// kernel takes the product (*folded = 1: *sumsq has received sum(dW^2)); every other shape runs as lap_gemm_bf16_ex would run it and
+// leaves the norm to the caller (*folded = 0).  The routing rule is the plain-product rule of lap_gemm_bf16_ex.
+extern "C" int lap_gemm_wgrad_f32(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, float* sumsq,
+                                  int* folded, void* scratch, long long scratch_bytes, void* stream) {
+  if (!folded) return LAP_ERR_ARG;
+  *folded = 0;
+  static const bool no_asm = getenv("LAP_GEMM_NO_ASM") != nullptr;
+  if (sumsq && !no_asm && M > 0 && N > 0 && lap_gemm_asm_ok(0, 0, 1, M, N, K, lda, ldb, ldc)) {
+    const long long t5 = (long long)(M / 256) * (N / 256);
+    const double fill = (double)t5 / (256.0 * ((t5 + 255) / 256));
+    if (t5 >= 128 && fill >= 0.8) {
+      *folded = 1;
+      return lap_gemm_asm_wgrad(A, B, C, M, N, K, lda, ldb, ldc, sumsq, stream);
+    }
+  }
+  return lap_gemm_bf16_ex(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, 1.0f, 0, 0, LAP_GEMM_OUT_F32, -1, 0, scratch, scratch_bytes, stream);
+}
+
 extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const void* bias, const void* residual,
                                 int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
                                 int a_kc, int b_kc, int flags, int tile, int ksplit, void* scratch,

@@ -67,6 +67,11 @@ class UnitPipeline:
         self.lookahead = int(os.environ.get("LAP_OPT_LOOKAHEAD", "9"))
         self.pace_in_layer = os.environ.get("LAP_OPT_PACE", "gemm") == "gemm"
         self._todo_args = None
+        # single rank: a weight gradient is final when its GEMM stores it, so the assembly weight-gradient kernels add its sum of squares
+        # to the norm themselves (lap_gemm_wgrad_f32) and the per-unit pass skips those tensors; under FSDP the norm is that of the
+        # REDUCED gradient and stays a pass over the shard.  LAP_FOLD_SUMSQ=0: off (A/B)
+        self.fold_sumsq = self.is_cuda and self.world_size == 1 and os.environ.get("LAP_FOLD_SUMSQ", "1") != "0"
+        self.folded = set()
         # release order = the order in which the forward first needs the units: the store's order, except that the adaRMS
         # bank (built last) is needed second — the model issues embed_suffix (on its second stream) ahead of the SigLIP tower
         sched = [u for u in store.units if u.name != "ada"]
@@ -93,8 +98,7 @@ class UnitPipeline:
     def begin_step(self):
         """Start of a train step: the replicated f32 unit is needed (and its gradient buffer re-zeroed) first."""
         self.wait_unit("small")
-        with self._on_side(wait_compute=False):
-            self.sumsq.zero_()   # ordered behind the previous optimizer pass on the side stream
+        self.folded = set()      # tensors whose weight-gradient GEMM has already added sum(g^2) to the norm (fold_sumsq)
 
     def before_backward(self):
         """The previous optimizer pass must be done READING the gradient buffers before the backward rewrites them."""
@@ -126,6 +130,24 @@ class UnitPipeline:
                 upto = min(upto, self._first_big)
             self._release(upto, paced=True)
 
+    def _unfolded(self, u, ranges):
+        """`ranges` of the unit's buffer minus the tensors whose sum of squares is already in (single rank: shard = whole unit)"""
+        cut = sorted((t.offset, t.offset + t.numel) for t in u.tensors if t.name in self.folded) if self.folded else []
+        if not cut:
+            return ranges
+        out = []
+        for a, b in ranges:
+            pos = a
+            for ca, cb in cut:
+                if cb <= pos or ca >= b:
+                    continue
+                if ca > pos:
+                    out.append((pos, ca))
+                pos = max(pos, cb)
+            if pos < b:
+                out.append((pos, b))
+        return out
+
     def _reduce_grads(self, u):
         pass  # single rank: gradients are already complete
 
@@ -142,7 +164,7 @@ class UnitPipeline:
             if self.is_cuda:  # (the CPU/gloo tests exercise the collectives only; kernels need a GPU)
                 slot = 0 if (self.ps.sharded(u) or self.world_size == 1) else 1
                 g = self.ps.gshard[name]
-                for a, b in self.ps.local_train_ranges(u):     # one range (the whole shard) unless a freeze filter is set
+                for a, b in self._unfolded(u, self.ps.local_train_ranges(u)):     # one range (the whole shard) unless a freeze filter is set
                     hip.sumsq_f32(g[a:b], self.sumsq[slot:slot + 1])
         self._pending = True
 
@@ -167,6 +189,10 @@ class UnitPipeline:
             self._reduce_norm()
             self.scal.copy_(h, non_blocking=True)
             self.scal[0:1] = self.sumsq[0:1] + self.sumsq[1:2]
+            # the next step's partial sums start from zero HERE: in front of every unit update of this pass on the side stream, so that
+            # any stream that has waited for one of this pass's units (all of them do, in the next forward) is ordered behind the
+            # clearing — the weight-gradient GEMMs add their share from the compute / weight-gradient streams (fold_sumsq)
+            self.sumsq.zero_()
             gnorm = self.scal[0].sqrt()      # a fresh tensor per step: callers keep the infos of many steps
             self.gnorm = gnorm
             if self.is_cuda:

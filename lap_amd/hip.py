@@ -82,6 +82,8 @@ SIGNATURES: dict[str, list] = {
     "lap_gemm_asm_geglu_bwd_ok": [_i, _i, _i, _i, _i, _i],
     "lap_gemm_asm_geglu_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_asm_geglu_fwd_ok": [_i, _i, _i, _i, _i, _i, _i],
+    "lap_gemm_asm_wgrad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "lap_gemm_wgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _ll, _vp],
     "lap_gemm_asm_bias_gelu": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_asm_gelu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
@@ -261,6 +263,20 @@ def linear_wgrad(dy, x, out, *, accum=False, ksplit=0, tile=-1):
     Kin = x.shape[1]
     return gemm(dy, x, out, M=Nout, N=Kin, K=Mrows, lda=dy.stride(0), ldb=x.stride(0), ldc=out.stride(0), a_kc=False,
                 b_kc=False, accum=accum, ksplit=ksplit, tile=tile)
+
+
+def linear_wgrad_sumsq(dy, x, out, sumsq):
+    """dWt[out, in] (f32) = dy^T x like linear_wgrad, and where the assembly kernel takes the product sum(dWt^2) is added to the
+    one-element f32 tensor `sumsq` on the way out; returns whether that happened (else the caller still owes the norm a pass)."""
+    import ctypes
+    Mrows, Nout = dy.shape
+    Kin = x.shape[1]
+    _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(out, torch.float32, "out"); _req(sumsq, torch.float32, "sumsq")
+    folded = ctypes.c_int(0)
+    scratch = _gemm_scratch(dy.device)
+    call("lap_gemm_wgrad_f32", _p(dy), _p(x), _p(out), Nout, Kin, Mrows, dy.stride(0), x.stride(0), out.stride(0), _p(sumsq),
+         ctypes.byref(folded), _p(scratch), scratch.numel() * 4)
+    return bool(folded.value)
 
 
 def split_f32_hilo(x, ld_out=None):

@@ -147,11 +147,19 @@ class LAP:
         if self.ps.is_trainable(name):
             mode = self.wgrad_stream
             kind = "s" if name.startswith("img/") else ("q" if name.endswith(("wqkv0", "wo0")) else "g")
+            fold = not kw and getattr(self.comm, "fold_sumsq", False) and dy.dtype == torch.bfloat16
+
+            def run():
+                if fold:    # the weight gradient and, where the assembly kernel takes it, its share of the gradient norm in one launch
+                    if hip.linear_wgrad_sumsq(dy, x, self.G(name), self.comm.sumsq[0:1]):
+                        self.comm.folded.add(name)
+                else:
+                    hip.linear_wgrad(dy, x, self.G(name), **kw)
             if mode == "1" or kind in mode:
                 with self._off_path(dy, x):
-                    hip.linear_wgrad(dy, x, self.G(name), **kw)
+                    run()
             else:
-                hip.linear_wgrad(dy, x, self.G(name), **kw)
+                run()
 
     def _bgrad(self, dy, name):
         """Bias gradient = column sums of dy, next to the weight gradient."""

@@ -256,6 +256,27 @@ def test_gemm_assembly_kernels_repeat_bit_for_bit_under_load(hip):
     soak(lambda: hip.linear_dgrad_geglu_bwd(x, rnd(K, 2048, seed=9), gu))
 
 
+def test_gemm_weight_gradient_with_folded_sum_of_squares(hip):
+    """lap_gemm_wgrad_f32: dW bit for bit the plain weight gradient; where the assembly kernel takes the product the sum of squares of dW
+    arrives in the norm accumulator from the kernel's epilogue (one atomic per wave), elsewhere the caller is told to run its own pass."""
+    # (folded where the assembly kernel's rule takes the product: whole 256-tiles, >= 128 of them, rounds of the chip >= 80 % filled)
+    for Mrows, Nout, Kin, expect in [(2304, 8192, 8192, True), (17920, 2048, 16384, True), (1152, 16384, 2048, True), (2304, 4096, 2048, False),
+                                     (640, 512, 768, False), (2304, 1152, 4352, False)]:
+        dy, x = rnd(Mrows, Nout + 64, seed=1)[:, :Nout], rnd(Mrows, Kin, seed=2)
+        ref = torch.empty(Nout, Kin, device=DEV)
+        hip.linear_wgrad(dy, x, ref)
+        out = torch.full((Nout, Kin), 7.0, device=DEV)
+        acc = torch.full((1,), 3.0, device=DEV)
+        folded = hip.linear_wgrad_sumsq(dy, x, out, acc)
+        assert folded == expect, (Mrows, Nout, Kin, folded)
+        assert torch.equal(out, ref)
+        if folded:
+            want = 3.0 + (ref.double() ** 2).sum().item()
+            assert abs(acc.item() - want) <= 2e-5 * want, (acc.item(), want)
+        else:
+            assert acc.item() == 3.0
+
+
 def test_gemm_assembly_gelu_mlp_kernels(hip):
     """lap_gemm_asm_nt_bias_gelu (h and a = gelu(h) from one launch, the accumulators walked twice) and lap_gemm_asm_nn_gelu_bwd (d(h) =
     bf16(dy W) * gelu'(h), d(a) never stored): h bit for bit the biased product; a / d(h) follow gelu_fwd / gelu_bwd with the GELU

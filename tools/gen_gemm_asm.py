@@ -98,6 +98,8 @@ V_RS = (112, 168)           # residual variant: two sets of 4 x 2 registers for 
 V_RT = 124                  # v124..v127: the residual widened to f32
 S_RDL, S_RDH = 58, 91       # residual variant: R - C in bytes
 V_COU = 13                  # GeGLU-backward variant: V_CO of the up half (+ N columns)
+V_SS = 13                   # sum-of-squares variant: the lane's running sum over the block's tiles
+S_SSP = 100                 # s[100:101]: where the sum of squares goes (0: nowhere)
 V_CA = 13                   # GeGLU-forward variant: the lane's offset in ACT
 V_GPK = 192                 # GeGLU-forward variant: v192..v199 the unit's 4 gate tiles, packed bf16
 V_AS = 200                  # v200..v215: two sets of 2 x 4 read-back registers of the ACT staging buffer
@@ -143,7 +145,7 @@ def order():
 
 
 class Kernel:
-    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False, res=False, ring=False, gbwd=False, gfwd=False, dgelu=False, gelu=False):
+    def __init__(self, name, a_kc, b_kc, out_f32, epi=False, tout=False, res=False, ring=False, gbwd=False, gfwd=False, dgelu=False, gelu=False, ss=False):
         # epi: f32 bias per output column + ragged N (the last n-tile may hold fewer than 256 valid columns; N % 16 == 0)
         # tout: the product is stored TRANSPOSED (C is [N][ldc]): a tall weight gradient dW [out, in] = dy^T x runs as the wide
         #       product x^T dy (whose operand panels stream much better, tools/bench_asm_gemm.py) and lands in dW's layout
@@ -161,6 +163,11 @@ class Kernel:
         #        pre-activation H [M][N] (C's leading dimension) and stores d(h) = bf16(d(a)) * gelu'(h) (csrc/elementwise.hip gelu_bwd_kernel)
         # gelu:  (with epi) C = H = bf16(x W^T + bias) and a second output A = bf16(gelu(H)) with C's leading dimension (kernarg
         #        0x68): the accumulators are walked twice, the second pass zeroes them (siglip_gemma3.py MlpBlock; gelu_fwd_kernel)
+        # ss: (f32 output, no epilogue extras) the kernel also adds the sum of squares of everything it stores to the f32 word at kernarg 0x68
+        #     (null: no) — a weight gradient's contribution to the global gradient norm (scripts/train.py:363-371 via optax
+        #     clip_by_global_norm), so that no second pass has to read the gradient back.  Per lane across the block's tiles in V_SS,
+        #     one atomic per wave when the block is out of tiles.
+        self.ss = ss
         self.dgelu, self.gelu = dgelu, gelu
         # (a backward kernel: no optimizer waves to share the register file with; 16 more VGPRs hold a third set of gate | up values)
         self.nvgpr = 256 if gbwd else NVGPR
@@ -826,6 +833,9 @@ class Kernel:
                 for r in range(4):
                     E(f"\tv_add_f32 v{cur+r}, v{cur+r}, v{V_BIAS+4*fc+r}")
             if self.st32:
+                if self.ss:
+                    for r in range(4):
+                        E(f"\tv_fmac_f32 v{V_SS}, v{cur+r}, v{cur+r}")
                 E(f"\tds_write_b128 v{V_WA+fcl}, v[{cur}:{cur+3}]")
             elif self.gfwd:
                 if fcl == 0:            # soffsets of the unit's two ACT stores: (fr*16 + 8 j) rows of ACT
@@ -904,6 +914,9 @@ class Kernel:
             E(f"\ts_load_dwordx2 s[{RBI}:{RBI+1}], {S_KARG}, 0x60")
         if self.res or self.gelu:
             E(f"\ts_load_dwordx2 s[{S_T+8}:{S_T+9}], {S_KARG}, 0x68")
+        if self.ss:
+            E(f"\ts_load_dwordx2 s[{S_SSP}:{S_SSP+1}], {S_KARG}, 0x68")
+            E(f"\tv_mov_b32 v{V_SS}, 0")
         if self.gfwd:
             E(f"\ts_load_dwordx2 s[{S_ACT}:{S_ACT+1}], {S_KARG}, 0x68")
             E(f"\ts_load_dword s{S_LDACT}, {S_KARG}, 0x54")
@@ -1268,6 +1281,32 @@ class Kernel:
             self.epilogue_direct()
         E(f"\ts_cmp_lg_u32 s{S_HAVE}, 0")
         E(f"\ts_cbranch_scc1 .Lnext_{nm}")
+        if self.ss:
+            # out of tiles: the wave's 64 running sums through its staging buffer, added up in lane order by every lane, one atomic
+            E(f"\ts_cmp_eq_u64 s[{S_SSP}:{S_SSP+1}], 0")
+            E(f"\ts_cbranch_scc1 .Lno_ss_{nm}")
+            E(f"\ts_lshl_b32 s{t+12}, s{t+15}, 12")
+            E(f"\ts_add_u32 s{t+12}, s{t+12}, {CSTAGE}")
+            E(f"\tv_lshlrev_b32 v{V_E}, 2, v{V_LANE}")
+            E(f"\tv_add_u32 v{V_E}, s{t+12}, v{V_E}")
+            E("\ts_waitcnt lgkmcnt(0)")
+            E(f"\tds_write_b32 v{V_E}, v{V_SS}")
+            E(f"\tv_mov_b32 v{V_E+1}, s{t+12}")
+            E("\ts_waitcnt lgkmcnt(0)")
+            for k in range(16):
+                E(f"\tds_read_b128 v[{V_CS+4*(k % 8)}:{V_CS+4*(k % 8)+3}], v{V_E+1} offset:{16*k}")
+                if k % 8 == 7:
+                    E("\ts_waitcnt lgkmcnt(0)")
+                    if k == 7:
+                        E(f"\tv_mov_b32 v{V_E+2}, 0")
+                    for q in range(32):
+                        E(f"\tv_add_f32 v{V_E+2}, v{V_E+2}, v{V_CS+q}")
+            E(f"\tv_mov_b32 v{V_E+3}, 0")
+            E("\ts_mov_b64 exec, 1")
+            E(f"\tglobal_atomic_add_f32 v{V_E+3}, v{V_E+2}, s[{S_SSP}:{S_SSP+1}]")
+            E("\ts_mov_b64 exec, -1")
+            E("\ts_waitcnt vmcnt(0)")
+            E(f".Lno_ss_{nm}:")
         E("\ts_endpgm")
         E(f".Lnext_{nm}:")     # (register set 0 already holds the next tile's first fragments: the last P1 read them)
         E(f"\ts_mov_b32 s{S_HAVE}, 0")
@@ -1319,8 +1358,8 @@ class Kernel:
 
 
 KERNELS = [Kernel("lap_gemm_asm_nt", True, True, False), Kernel("lap_gemm_asm_nn", True, False, False),
-           Kernel("lap_gemm_asm_tn", False, False, True, ring=RING), Kernel("lap_gemm_asm_nt_bias", True, True, False, epi=True),
-           Kernel("lap_gemm_asm_tn_t", False, False, True, tout=True, ring=RING),
+           Kernel("lap_gemm_asm_tn", False, False, True, ring=RING, ss=True), Kernel("lap_gemm_asm_nt_bias", True, True, False, epi=True),
+           Kernel("lap_gemm_asm_tn_t", False, False, True, tout=True, ring=RING, ss=True),
            Kernel("lap_gemm_asm_nt_res", True, True, False, res=True),
            Kernel("lap_gemm_asm_nt_bias_res", True, True, False, epi=True, res=True),
            Kernel("lap_gemm_asm_nn_geglu_bwd", True, False, False, gbwd=True),
