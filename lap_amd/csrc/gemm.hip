@@ -1594,6 +1594,17 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
         return lap_gemm_bf16_ex(A1, B, C1, nullptr, nullptr, M - M0, N, K, lda, ldb, ldc, 0, 1.0f, a_kc, b_kc, flags, -1, 0, scratch, scratch_bytes, stream);
       }
     }
+    // Ragged M with very many rows (the embedding table's weight gradient: 257,152 = 1004.5 x 256 rows): the whole m-tiles on the
+    // assembly kernel, the last M % 256 rows as a product of their own (weight-gradient layout only: A's tail is a column offset)
+    if (tile < 0 && !no_asm && !a_kc && !b_kc && f32 && (M & 255) && M >= 65536 && !bias && !residual &&
+        !(flags & (LAP_GEMM_GELU | LAP_GEMM_ACCUM | LAP_GEMM_PARTIALS)) && alpha == 1.0f && ksplit == 0) {
+      const int M0 = M & ~255;
+      if (lap_gemm_asm_ok(0, 0, 1, M0, N, K, lda, ldb, ldc)) {
+        if (int rc = lap_gemm_asm(A, B, C, M0, N, K, lda, ldb, ldc, 0, 0, 1, stream)) return rc;
+        return lap_gemm_bf16_ex((const char*)A + (long long)M0 * 2, B, (char*)C + (long long)M0 * ldc * 4, nullptr, nullptr, M - M0, N, K, lda, ldb,
+                                ldc, 0, 1.0f, 0, 0, flags, -1, 0, scratch, scratch_bytes, stream);
+      }
+    }
     if (tile < 0 && plain && !no_asm) {
       const long long t5 = (long long)(M / 256) * (N / 256);
       const double fill = (double)t5 / (256.0 * ((t5 + 255) / 256));

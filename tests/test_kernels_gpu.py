@@ -277,6 +277,19 @@ def test_gemm_weight_gradient_with_folded_sum_of_squares(hip):
             assert acc.item() == 3.0
 
 
+def test_gemm_weight_gradient_with_ragged_m_is_cut_at_the_last_whole_tile(hip):
+    """the embedding table's weight gradient has 257,152 = 1004.5 x 256 rows: the whole m-tiles run on the assembly kernel (bit-equal to the
+    HIP tile), the last 128 rows as a product of their own"""
+    M, N, K = 65536 + 128, 512, 640
+    a, b = rnd(K, M, seed=1), rnd(K, N, seed=2)
+    out = torch.empty(M, N, device=DEV); ref = torch.empty(M, N, device=DEV)
+    hip.gemm(a, b, out, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, a_kc=False, b_kc=False)
+    hip.gemm(a, b, ref, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, a_kc=False, b_kc=False, tile=12, ksplit=1)
+    assert torch.equal(out[:65536], ref[:65536])
+    assert rel_err(out[65536:], ref[65536:]) < 1e-5
+    assert rel_err(out, a.float().t() @ b.float()) < 1e-5
+
+
 def test_gemm_assembly_gelu_mlp_kernels(hip):
     """lap_gemm_asm_nt_bias_gelu (h and a = gelu(h) from one launch, the accumulators walked twice) and lap_gemm_asm_nn_gelu_bwd (d(h) =
     bf16(dy W) * gelu'(h), d(a) never stored): h bit for bit the biased product; a / d(h) follow gelu_fwd / gelu_bwd with the GELU
