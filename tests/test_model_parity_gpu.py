@@ -383,12 +383,14 @@ def test_full_size_train_steps_do_not_depend_on_the_stream_schedule(hip, monkeyp
         return losses
 
     one = {"LAP_DUAL_STREAM": "0", "LAP_WGRAD_STREAM": "0", "LAP_OPT_PACE": "top", "LAP_OPT_LOOKAHEAD": "0"}
-    dflt = {"LAP_DUAL_STREAM": "1", "LAP_WGRAD_STREAM": "sb", "LAP_OPT_PACE": "gemm", "LAP_OPT_LOOKAHEAD": "5"}
+    dflt = {"LAP_DUAL_STREAM": "1", "LAP_WGRAD_STREAM": "sb", "LAP_OPT_PACE": "gemm", "LAP_OPT_LOOKAHEAD": "9"}
     a, a2, b = run(one), run(one), run(dflt)
     assert a[0] == a2[0] == b[0], (a, a2, b)
     spread = max(abs(x - y) / abs(x) for x, y in zip(a[1:], a2[1:]))
     for x, y in zip(a[1:], b[1:]):
-        assert abs(x - y) / abs(x) <= max(4 * spread, 2e-6), (a, a2, b)
+        # (floor: two identical one-stream runs differ by up to ~1e-5 of the step-2 loss — f32 atomics order in the small tensors'
+        # gradients and in the gradient norm's partial sums — but sometimes by nothing at all, which must not turn that into the bound)
+        assert abs(x - y) / abs(x) <= max(4 * spread, 4e-5), (a, a2, b)
     print(f"3 steps at B=32: one stream {a} / again {a2} / default schedule {b}")
 
 
