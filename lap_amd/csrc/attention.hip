@@ -609,6 +609,7 @@ int set_lds(K kernel, int bytes) {
 }
 
 #include "attention_serve.hpp"
+#include "serve_chain.hpp"
 
 // Tuning / test knob (lap_attention_set_variant): -1 = automatic; 0 = generic kernels also for HD = 256;
 // 1 = the HD = 256 LDS-DMA kernels (what automatic picks whenever their LDS info table fits).
@@ -791,6 +792,57 @@ extern "C" int lap_attention_serve(const lap_attn_fwd_args* a, void* stream) {
   p.lpart = a->scratch + (long long)a->nsplit * a->B * a->q_len[1] * a->NH * a->HD;
   p.B = a->B; p.NH = a->NH; p.NKV = a->NKV;
   return launch_serve(p, (hipStream_t)stream);
+}
+
+// ---- the denoise step's 18 layers in one persistent launch (serve_chain.hpp)
+extern "C" int lap_serve_chain_ok(int B, int S, int D, int H, int NH, int HD, int NKV, int prefix_len) {
+  return chain_ok(B, S, D, H, NH, HD, NKV, prefix_len) ? 1 : 0;
+}
+
+extern "C" int lap_serve_chain_counter_words(void) { return CH_CTR_WORDS; }
+
+// 0: every barrier of every launch so far completed; 1: a block gave up waiting (the results of that launch are invalid)
+extern "C" int lap_serve_chain_status(const unsigned* counters, int* status) {
+  if (!counters || !status) return LAP_ERR_ARG;
+  unsigned v = 0;
+  if (hipError_t e = hipMemcpy(&v, counters + CH_CTR_STRIDE * CH_CTR_ERR, sizeof(v), hipMemcpyDeviceToHost); e != hipSuccess) return (int)e;
+  *status = v != 0;
+  return LAP_OK;
+}
+
+extern "C" int lap_serve_chain(const lap_serve_chain_args* a, void* stream) {
+  if (!a || a->depth < 1 || a->depth > CH_MAX_DEPTH || a->depth > LAP_CHAIN_MAX_DEPTH) return LAP_ERR_ARG;
+  if (!chain_ok(a->B, a->S, a->D, a->H, a->NH, a->HD, 1, a->prefix_len)) return LAP_ERR_ARG;
+  if (!a->x_in || !a->x_out || !a->mod || !a->rope_table || !a->q || !a->k || !a->v || !a->o || !a->xa || !a->act || !a->attn_scratch ||
+      !a->counters || (a->mod_slot_stride & 7) || a->mod_slot_stride < 3 * a->D)
+    return LAP_ERR_ARG;
+  if ((a->qinfo == nullptr) != (a->kinfo == nullptr)) return LAP_ERR_ARG;
+  const int M = a->B * a->S, kv_rs = a->kv_rs ? a->kv_rs : a->HD;
+  if ((kv_rs & 7) || (long long)a->prefix_len * kv_rs * 2 >= 0x7fffffffLL) return LAP_ERR_ARG;
+  ChainP c = {};
+  c.depth = a->depth; c.M = M; c.rps = a->S; c.D = a->D; c.H = a->H; c.NH = a->NH; c.HD = a->HD;
+  c.x_in = (const bf16*)a->x_in; c.x_out = (bf16*)a->x_out; c.mod = (const bf16*)a->mod; c.slot_ld = a->mod_slot_stride;
+  for (int l = 0; l < a->depth; ++l) {
+    if (!a->wqkv[l] || !a->wo[l] || !a->wgu[l] || !a->wd[l] || (a->prefix_len > 0 && (!a->cache_k[l] || !a->cache_v[l]))) return LAP_ERR_ARG;
+    if (((uintptr_t)a->wqkv[l] | (uintptr_t)a->wo[l] | (uintptr_t)a->wgu[l] | (uintptr_t)a->wd[l] | (uintptr_t)a->cache_k[l] | (uintptr_t)a->cache_v[l]) & 15)
+      return LAP_ERR_ARG;
+    c.wqkv[l] = (const bf16*)a->wqkv[l]; c.wo[l] = (const bf16*)a->wo[l]; c.wgu[l] = (const bf16*)a->wgu[l]; c.wd[l] = (const bf16*)a->wd[l];
+    c.ck[l] = (const bf16*)a->cache_k[l]; c.cv[l] = (const bf16*)a->cache_v[l];
+  }
+  c.sp = serve_splits(a->prefix_len, a->S);
+  const long long need = (long long)c.sp.nsplit * M * a->NH * (a->HD + 1);
+  if (a->attn_scratch_floats < need) return LAP_ERR_ARG;
+  AttnP& p = c.attn;
+  p.qlen[0] = 0; p.qlen[1] = a->S; p.klen[0] = a->prefix_len; p.klen[1] = a->S;
+  p.q_rs[0] = p.q_rs[1] = a->NH * a->HD; p.o_rs[0] = p.o_rs[1] = a->NH * a->HD; p.kv_rs[0] = kv_rs; p.kv_rs[1] = a->HD;
+  p.qinfo = a->qinfo; p.kinfo = a->kinfo; p.scale = 1.0f;       // (q carries head_dim^-0.5 from the qkv stage, gemma.py:216)
+  p.B = a->B; p.NH = a->NH; p.NKV = 1; p.nsplit = c.sp.nsplit; p.hsplit = 1;
+  p.part = a->attn_scratch; p.lpart = a->attn_scratch + (long long)c.sp.nsplit * M * a->NH * a->HD;
+  c.rope = a->rope_table; c.q_scale = a->q_scale; c.eps = a->eps;
+  c.q = (bf16*)a->q; c.k = (bf16*)a->k; c.v = (bf16*)a->v; c.o = (bf16*)a->o; c.xa = (bf16*)a->xa; c.act = (bf16*)a->act;
+  c.ctrs = a->counters;
+  c.clk = (unsigned long long*)a->debug_clock;
+  return launch_chain(c, (hipStream_t)stream);
 }
 
 extern "C" int lap_attention_bwd(const lap_attn_bwd_args* a, void* stream) {

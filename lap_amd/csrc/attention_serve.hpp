@@ -36,15 +36,35 @@ inline ServeSplits serve_splits(int klen0, int klen1) {
   return s;
 }
 
-__global__ __launch_bounds__(512) void attn_serve_kernel(AttnP p, ServeSplits sp) {
+// device-scope (sc1) f32 accesses for results that blocks of other XCDs read inside the same launch (the persistent chain,
+// serve_chain.hpp; see serve_skinny_body.hpp on COH)
+template <bool COH>
+__device__ __forceinline__ void st_f32x4(float* p, const f32x4& v) {
+  // (s_nop: a VALU write to the data registers of a > 8-byte store needs 2 wait states behind it; the compiler's hazard
+  //  recogniser does not look inside inline assembly — without it a few values per tile were overwritten in flight)
+  if constexpr (COH) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+template <bool COH>
+__device__ __forceinline__ void st_f32(float* p, float v) {
+  if constexpr (COH) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else *p = v;
+}
+
+// One block of the split attention: key split s of head h of sample b.  smem: SV_LDS bytes [K image | V image | info words].
+// COH: q / the fresh keys and values were written, and the partial results will be read, by other blocks of the SAME launch.
+// PHASE 0: the whole block.  The chain splits it at its grid barrier: PHASE 1 issues the DMA pieces that read the CACHED prefix
+// only (they do not depend on the launch's own results) and returns; PHASE 2, behind the barrier, issues the fresh rows and goes on.
+template <bool COH, int PHASE = 0>
+__device__ __forceinline__ void attn_serve_body(const AttnP& p, const ServeSplits& sp, const int s, const int h, const int b, char* smem) {
   using C = DmaCfg<256>;
   constexpr int HD = 256, PITCH = C::PITCH, KS = C::KS;
   constexpr int KOFF = 0, VOFF = SV_KEYS * PITCH;
-  extern __shared__ __attribute__((aligned(16))) char smem[];     // [K image | V image | info words]
   int* sKw = reinterpret_cast<int*>(smem + 2 * SV_KEYS * PITCH);
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));      // (opaque: keeps the chain's layer loop from hoisting this stage's lane arithmetic, serve_skinny_body.hpp)
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
-  const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int hk = h / (p.NH / p.NKV);
   const int S = p.qlen[1], Pn = p.klen[0], Tk = p.klen[0] + p.klen[1];
   const int np = s < sp.nfull ? SV_KEYS : (s == sp.nfull ? sp.rem : 0);     // prefix rows of this split: [0, np)
@@ -69,36 +89,54 @@ __global__ __launch_bounds__(512) void attn_serve_kernel(AttnP p, ServeSplits sp
         const int col = ((lane & 31) ^ C::swz(row)) << 4;
         char* dst = smem + pc * 1024 + (kv ? VOFF : KOFF);
         if (has_sfx && 2 * pc >= srow0) {               // rows past the segment end read as zeros (num_records)
+          if (PHASE == 1) continue;
           const unsigned off = (unsigned)((row - srow0) * rb1 + col);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(kv ? rsV1 : rsK1, (LDS_PTR(void))dst, 16, off, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(kv ? rsV1 : rsK1, (LDS_PTR(void))dst, 16, off, 0, 0, COH ? 16 : 0);
         } else {
+          if (PHASE == 2) continue;
           const unsigned off = row < np ? (unsigned)((pbase + row) * rb0 + col) : DMA_OOB;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(kv ? rsV0 : rsK0, (LDS_PTR(void))dst, 16, off, 0, 0, 0);
         }
       }
     };
+    if (PHASE == 1) {
+      issue(0);
+      issue(1);
+      return;
+    }
+    // the fresh keys / values were written by other XCDs a moment ago and the DMA path does not honour the device-scope bit the
+    // way register loads do (stale lines of this XCD's L2 were observed): drop them first
+    if (COH && has_sfx) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     issue(0);
   // ---- my query row, its info word, and the keys' info words (in flight together with the DMA)
   const int qt = w & 3, dh = w >> 2;
   const int myq = qt * 16 + i;
   const bool vq = myq < S;
   bf16x8 qf[KS];
-  load_row_frags<HD>(p.q[1] + (b * (long long)S + myq) * p.q_rs[1] + h * HD, vq, lane, qf);
+  if constexpr (COH) {
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)p.q[1], 0, (unsigned)((long long)p.B * S * p.q_rs[1] * 2), 0x00020000);
+    const unsigned qoff = vq ? (unsigned)((((long long)b * S + myq) * p.q_rs[1] + h * HD + g * 8) * 2) : DMA_OOB;   // invalid rows read as zeros
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) qf[kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsQ, qoff + kk * 64, 0, 16));
+  } else {
+    load_row_frags<HD>(p.q[1] + (b * (long long)S + myq) * p.q_rs[1] + h * HD, vq, lane, qf);
+  }
   const int qi = !vq ? 0 : (p.qinfo ? p.qinfo[(long long)b * S + myq] : 0x7fffffff);
   const int qcls = qi >> 24, qidx = qi & 0xffffff;
   int kword = 0;
-  if (threadIdx.x < SV_KEYS) {
-    const int r = threadIdx.x;
+  if (tid < SV_KEYS) {
+    const int r = tid;
     int joint = -1;                                   // index into the sample's [prefix | suffix] key list
     if (has_sfx && r >= srow0) { if (r - srow0 < S) joint = Pn + r - srow0; }
     else if (r < np) joint = pbase + r;
     kword = joint < 0 ? 0 : (p.kinfo ? p.kinfo[(long long)b * Tk + joint] : 0x7f000000);
   }
   issue(1);
-  if (threadIdx.x < SV_KEYS) sKw[threadIdx.x] = kword;
+  if (tid < SV_KEYS) sKw[tid] = kword;
   // all but the 8 V pieces just issued (vector memory operations return in order) + my info word in LDS; a bare barrier: the
   // fence of __syncthreads() would drain the V pieces as well
-  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  if (PHASE == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (the prefix images have been landing since before the barrier)
+  else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
@@ -157,18 +195,22 @@ __global__ __launch_bounds__(512) void attn_serve_kernel(AttnP p, ServeSplits sp
   const long long row = ((long long)s * p.B + b) * S + myq;
   float* op = p.part + (row * p.NH + h) * HD + dh * 128;
 #pragma unroll
-  for (int d = 0; d < 8; ++d) *reinterpret_cast<f32x4*>(op + d * 16 + 4 * g) = acc[d] * inv;
-  if (dh == 0 && g == 0) p.lpart[(((long long)s * p.B + b) * p.NH + h) * S + myq] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * LN2 : NEG_BIG;
+  for (int d = 0; d < 8; ++d) st_f32x4<COH>(op + d * 16 + 4 * g, acc[d] * inv);
+  if (dh == 0 && g == 0) st_f32<COH>(p.lpart + (((long long)s * p.B + b) * p.NH + h) * S + myq, l > 0.f ? (m + __builtin_amdgcn_logf(l)) * LN2 : NEG_BIG);
+}
+
+__global__ __launch_bounds__(512) void attn_serve_kernel(AttnP p, ServeSplits sp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_serve_body<false>(p, sp, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // O = sum_i exp(lse_i - lse) O_i over the NS key splits (the generic combine's arithmetic, every load issued up front).
 // One thread per (b, q, h, 4 d).
-template <int NS>
-__global__ __launch_bounds__(256) void attn_serve_combine_kernel(AttnP p) {
+template <int NS, bool COH>
+__device__ __forceinline__ void attn_serve_combine_body(const AttnP& p, const long long gid) {
   constexpr int HD = 256;
   const int S = p.qlen[1];
   const long long n4 = (long long)p.B * S * p.NH * HD / 4;
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= n4) return;
   const int d0 = (int)(gid % (HD / 4)) * 4;
   long long r = gid / (HD / 4);
@@ -177,10 +219,26 @@ __global__ __launch_bounds__(256) void attn_serve_combine_kernel(AttnP p) {
   const int b = (int)(r / S);
   float li[NS];
   f32x4 oi[NS];
+  if constexpr (COH) {
+    const unsigned nl = (unsigned)((long long)p.nsplit * p.B * p.NH * S * 4), np4 = (unsigned)((long long)p.nsplit * p.B * S * p.NH * HD * 4);
+    const auto rsL = __builtin_amdgcn_make_buffer_rsrc((void*)p.lpart, 0, nl, 0x00020000);
+    const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)p.part, 0, np4, 0x00020000);
 #pragma unroll
-  for (int sp = 0; sp < NS; ++sp) {
-    li[sp] = sp < p.nsplit ? p.lpart[(((long long)sp * p.B + b) * p.NH + h) * S + t] : NEG_BIG;
-    oi[sp] = sp < p.nsplit ? *reinterpret_cast<const f32x4*>(p.part + ((((long long)sp * p.B + b) * S + t) * p.NH + h) * HD + d0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < NS; ++sp) {     // splits past nsplit: out of range, read as zeros and get NEG_BIG below
+      const unsigned lo = sp < p.nsplit ? (unsigned)(((((long long)sp * p.B + b) * p.NH + h) * S + t) * 4) : DMA_OOB;
+      const unsigned po = sp < p.nsplit ? (unsigned)((((((long long)sp * p.B + b) * S + t) * p.NH + h) * HD + d0) * 4) : DMA_OOB;
+      li[sp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, lo, 0, 16));
+      oi[sp] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, po, 0, 16));
+    }
+#pragma unroll
+    for (int sp = 0; sp < NS; ++sp)
+      if (sp >= p.nsplit) li[sp] = NEG_BIG;
+  } else {
+#pragma unroll
+    for (int sp = 0; sp < NS; ++sp) {
+      li[sp] = sp < p.nsplit ? p.lpart[(((long long)sp * p.B + b) * p.NH + h) * S + t] : NEG_BIG;
+      oi[sp] = sp < p.nsplit ? *reinterpret_cast<const f32x4*>(p.part + ((((long long)sp * p.B + b) * S + t) * p.NH + h) * HD + d0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
   float mx = NEG_BIG;
 #pragma unroll
@@ -194,7 +252,22 @@ __global__ __launch_bounds__(256) void attn_serve_combine_kernel(AttnP p) {
     den += wgt;
     acc += oi[sp] * wgt;
   }
-  store4(p.o[1] + (b * (long long)S + t) * p.o_rs[1] + h * HD + d0, acc, den > 0.f ? 1.0f / den : 0.f);
+  bf16* dst = p.o[1] + (b * (long long)S + t) * p.o_rs[1] + h * HD + d0;
+  if constexpr (COH) {
+    const float sc = den > 0.f ? 1.0f / den : 0.f;
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[e] * sc);
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, o);
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(bits) : "memory");
+  } else {
+    store4(dst, acc, den > 0.f ? 1.0f / den : 0.f);
+  }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void attn_serve_combine_kernel(AttnP p) {
+  attn_serve_combine_body<NS, false>(p, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 
 int launch_serve(const AttnP& p, hipStream_t s) {

@@ -53,6 +53,25 @@ class AttnFwdArgs(C.Structure):
     ]
 
 
+CHAIN_MAX_DEPTH = 32    # LAP_CHAIN_MAX_DEPTH (include/lap_hip.h)
+
+
+class ServeChainArgs(C.Structure):
+    _fields_ = [
+        ("depth", _i), ("B", _i), ("S", _i), ("D", _i), ("H", _i), ("NH", _i), ("HD", _i), ("prefix_len", _i),
+        ("x_in", _vp), ("x_out", _vp),
+        ("mod", _vp), ("mod_slot_stride", _i),
+        ("wqkv", _vp * CHAIN_MAX_DEPTH), ("wo", _vp * CHAIN_MAX_DEPTH), ("wgu", _vp * CHAIN_MAX_DEPTH), ("wd", _vp * CHAIN_MAX_DEPTH),
+        ("cache_k", _vp * CHAIN_MAX_DEPTH), ("cache_v", _vp * CHAIN_MAX_DEPTH),
+        ("kv_rs", _i),
+        ("rope_table", _vp), ("qinfo", _vp), ("kinfo", _vp),
+        ("q_scale", _f), ("eps", _f),
+        ("q", _vp), ("k", _vp), ("v", _vp), ("o", _vp), ("xa", _vp), ("act", _vp),
+        ("attn_scratch", _vp), ("attn_scratch_floats", _ll),
+        ("counters", _vp), ("debug_clock", _vp),
+    ]
+
+
 class AttnBwdArgs(C.Structure):
     _fields_ = [
         ("q", _vp * 2), ("o", _vp * 2), ("d_o", _vp * 2), ("k", _vp * 2), ("v", _vp * 2),
@@ -136,6 +155,10 @@ SIGNATURES: dict[str, list] = {
     "lap_serve_proj_residual": [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "lap_serve_set_variant": [_i],
     "lap_serve_embed_actions": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "lap_serve_chain_ok": [_i, _i, _i, _i, _i, _i, _i, _i],
+    "lap_serve_chain_counter_words": [],
+    "lap_serve_chain_status": [_vp, C.POINTER(_i)],
+    "lap_serve_chain": [C.POINTER(ServeChainArgs), _vp],
     "lap_serve_final_euler": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
     "lap_ce_chunk_update": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_ce_chunk_grad": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -846,6 +869,55 @@ def serve_proj_residual(a, w, x, gate, gate_ld, rps):
     N = w.shape[0]
     out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     call("lap_serve_proj_residual", _p(a), _p(w), _p(x), _p(gate), gate_ld, rps, _p(out), M, N, K)
+    return out
+
+
+def serve_chain_ok(B, S, D, H, NH, HD, NKV, prefix_len) -> bool:
+    """Shapes the one-launch denoise step (lap_serve_chain) is built for."""
+    return bool(_fn["lap_serve_chain_ok"](B, S, D, H, NH, HD, NKV, prefix_len))
+
+
+def serve_chain_counters(device) -> torch.Tensor:
+    """The chain's barrier counters: zero before the first launch, left zero by every launch (allocate ONCE, outside stream capture)."""
+    return torch.zeros(_fn["lap_serve_chain_counter_words"](), dtype=torch.int32, device=device)
+
+
+def serve_chain_failed(counters: torch.Tensor) -> bool:
+    """True if a block of some launch gave up waiting at a grid barrier (that launch's results are invalid).  Synchronises."""
+    st = C.c_int(0)
+    _chk(_fn["lap_serve_chain_status"](_p(counters), C.byref(st)), "lap_serve_chain_status")
+    return bool(st.value)
+
+
+def serve_chain(x_in, mod, slot_stride, weights, caches, rope_table, qinfo, kinfo, B, S, NH, HD, H, prefix_len, q_scale, counters,
+                eps=1e-6, debug_clock=None, keep=None):
+    """All action-expert layers of one denoise step in one persistent launch (include/lap_hip.h: lap_serve_chain).
+    weights: per layer (wqkv, wo, wgu, wd); caches: per layer (k, v) of the prefix.  Returns the residual stream [B*S, D]."""
+    M, D = x_in.shape
+    dev = x_in.device
+    depth = len(weights)
+    a = ServeChainArgs()
+    a.depth, a.B, a.S, a.D, a.H, a.NH, a.HD, a.prefix_len = depth, B, S, D, H, NH, HD, prefix_len
+    out = torch.empty_like(x_in)
+    a.x_in, a.x_out, a.mod, a.mod_slot_stride = _p(x_in), _p(out), _p(mod), slot_stride
+    for l, (wqkv, wo, wgu, wd) in enumerate(weights):
+        a.wqkv[l], a.wo[l], a.wgu[l], a.wd[l] = _p(wqkv), _p(wo), _p(wgu), _p(wd)
+        ck, cv = caches[l]
+        a.cache_k[l], a.cache_v[l] = _p(ck), _p(cv)
+    a.kv_rs = 0
+    a.rope_table, a.qinfo, a.kinfo = _p(rope_table), _p(qinfo), _p(kinfo)
+    a.q_scale, a.eps = float(q_scale), float(eps)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    q, k, v, o = torch.empty((M, NH * HD), **bf), torch.empty((M, HD), **bf), torch.empty((M, HD), **bf), torch.empty((M, NH * HD), **bf)
+    xa, act = torch.empty((M, D), **bf), torch.empty((M, H), **bf)
+    ns = _fn["lap_attention_serve_splits"](prefix_len, S)
+    scratch = torch.empty(ns * M * NH * (HD + 1), dtype=torch.float32, device=dev)
+    a.q, a.k, a.v, a.o, a.xa, a.act = _p(q), _p(k), _p(v), _p(o), _p(xa), _p(act)
+    a.attn_scratch, a.attn_scratch_floats, a.counters = _p(scratch), scratch.numel(), _p(counters)
+    a.debug_clock = _p(debug_clock)
+    if keep is not None:      # (tests / debugging: the last layer's intermediates)
+        keep.update(q=q, k=k, v=v, o=o, xa=xa, act=act)
+    _chk(_fn["lap_serve_chain"](C.byref(a), _stream()), "lap_serve_chain")
     return out
 
 

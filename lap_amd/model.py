@@ -90,6 +90,10 @@ class LAP:
         # replay, same box, interleaved: 15.65 -> 16.30 ms per chunk — the step's 110 short kernels take CUs from the prefill's
         # load-bound GEMMs for longer than they save.  Kept as a switch, OFF by default.
         self.serve_overlap = os.environ.get("LAP_SERVE_OVERLAP", "0") != "0"
+        # the 18 action-expert layers of a denoise step as ONE persistent launch (csrc/serve_chain.hpp) instead of 6 launches per
+        # layer; bitwise equal to them.  LAP_SERVE_CHAIN=0: the separate launches (A/B runs, tests).
+        self.serve_chain = os.environ.get("LAP_SERVE_CHAIN", "1") != "0"
+        self._chain_ctr = None
         self._den = None
         ks = os.environ.get("LAP_PREFILL_KS", "4,1,8,5").split(",")    # K splits of the prefill's qkv / out / down projections, down's tile
         self._prefill_ks = tuple(int(k) for k in ks)
@@ -1095,8 +1099,25 @@ class LAP:
         else:
             self._llm_fwd(x0, None, None, ppos, qinfo_p, kinfo_p, B, Pn, 0, False, cache_out=cache)
         nslot = 2 * self.v.depth
+        chain = (fused == "skinny" and self.serve_chain and not overlap and dev.type == "cuda" and self.v.depth <= hip.CHAIN_MAX_DEPTH
+                 and hip.serve_chain_ok(B, S, self.e.width, self.e.mlp_dim, self.v.num_heads, self.v.head_dim, self.v.num_kv_heads, Pn))
+        if chain:
+            if self._chain_ctr is None:
+                self._chain_ctr = hip.serve_chain_counters(dev)
+            for l in range(self.v.depth):
+                self.comm.wait_unit(f"llm{l}")
+            chain_w = [tuple(self.W(f"llm/{l}/{n}") for n in ("wqkv1", "wo1", "wgu1", "wd1")) for l in range(self.v.depth)]
         for step in range(len(times)):
             mod = mods[step:step + 1]
+            if chain:
+                x1 = hip.serve_embed_actions(x_t.view(B * S, ad), self.F("act/in_w"), self.F("act/in_b"))
+                xf1 = hip.serve_chain(x1, mod, 3 * self.e.width, chain_w, cache, rope_tab, qinfo_s, kinfo_all, B, S, self.v.num_heads,
+                                      self.v.head_dim, self.e.mlp_dim, Pn, self.v.head_dim ** -0.5, self._chain_ctr)
+                v_t = torch.empty((B * S, ad), dtype=torch.float32, device=dev) if collect is not None else None
+                hip.serve_final_euler(xf1, self._mod_slot(mod, nslot), 0, S, self.F("act/out_w"), self.F("act/out_b"), x_t.view(B * S, ad), dt, v_t)
+                if collect is not None:
+                    collect[f"v_t/{step}"] = v_t.view(B, S, ad)
+                continue
             if fused == "skinny":
                 side = overlap and step == 0
                 main = torch.cuda.current_stream() if side else None
@@ -1125,6 +1146,16 @@ class LAP:
                 collect[f"v_t/{step}"] = v_t.view(B, S, ad).clone()
             hip.axpy_f32(x_t, v_t, dt)
         return x_t
+
+    def serve_chain_failed(self) -> bool:
+        """True if a launch of the one-launch denoise step gave up at a grid barrier since the last check (synchronises)."""
+        return self._chain_ctr is not None and hip.serve_chain_failed(self._chain_ctr)
+
+    def disable_serve_chain(self):
+        self.serve_chain = False
+        if self._chain_ctr is not None:
+            torch.cuda.synchronize(self.device)
+            self._chain_ctr.zero_()
 
     def _serve_mods(self, nsteps: int, dt: float):
         """adaRMS modulations of the denoise time grid t_k = 1 + k dt (lap.py:655-660 through `_time_mod`), cached per

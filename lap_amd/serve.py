@@ -110,6 +110,13 @@ class Policy:
         else:
             a = self.model.sample_actions(0, o, num_steps=self.num_steps, noise=noise)
         actions = a[0].cpu().numpy()  # device sync
+        if self.model.serve_chain_failed():
+            # A block of the one-launch denoise step (csrc/serve_chain.hpp) was not scheduled within its bounded wait — the GPU is
+            # shared with work that holds compute units — so this chunk is invalid: go back to the separate launches for good.
+            self.model.disable_serve_chain()
+            if self._sampler is not None:
+                self._sampler.graph = None
+            return self.infer(obs, noise=noise.cpu().numpy())
         model_ms = (time.perf_counter() - t0) * 1e3
         if not self._has_transforms:
             return {"actions": actions, "policy_timing": {"infer_ms": model_ms}}

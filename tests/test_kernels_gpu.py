@@ -1122,6 +1122,69 @@ def test_serve_skinny_projections_match_unfused_ops(hip, M, rps, shared):
         hip.serve_proj_residual(rnd(M, 1536), rnd(D, 1536), x, None, 0, rps)
 
 
+@pytest.mark.parametrize("S,Tp,depth,npad", [
+    (50, 816, 3, 0),       # the denoise step of the bench: 6 full key runs + one of 48 | 50 rows
+    (50, 560, 2, 9),       # 4 full runs + a joint one; padded prompt tail (masked keys)
+    (16, 256, 2, 0),       # one token tile; the fresh keys get a run of their own
+    (33, 77, 2, 5),        # ragged token count (3 tiles of 16, 2 of 32), odd prefix length
+])
+def test_serve_chain_equals_the_separate_launches_bitwise(hip, S, Tp, depth, npad):
+    """lap_serve_chain (csrc/serve_chain.hpp: the denoise step's layers as stages of ONE persistent kernel with a software grid
+    barrier) against depth x [lap_serve_qkv_rope, lap_attention_serve, lap_serve_proj_residual, lap_serve_gate_up,
+    lap_serve_proj_residual]: the stages are the same device functions, so the results must be bit-identical — any difference is
+    a stale read across the barrier.  Repeated launches reuse the counters the kernel resets itself."""
+    B, D, NH, HD, H = 1, 1024, 8, 256, 4096
+    M = B * S
+    assert hip.serve_chain_ok(B, S, D, H, NH, HD, 1, Tp)
+    assert not hip.serve_chain_ok(B, 80, D, H, NH, HD, 1, Tp) and not hip.serve_chain_ok(B, S, D, 2048, NH, HD, 1, Tp)
+    x = rnd(M, D, seed=1)
+    nslot = 2 * depth + 1
+    mod = rnd(1, nslot * 3 * D, scale=0.3, seed=2)
+    W = [(rnd((NH + 2) * HD, D, scale=D ** -0.5, seed=10 + 4 * l), rnd(D, NH * HD, scale=(NH * HD) ** -0.5, seed=11 + 4 * l),
+          rnd(2 * H, D, scale=D ** -0.5, seed=12 + 4 * l), rnd(D, H, scale=H ** -0.5, seed=13 + 4 * l)) for l in range(depth)]
+    cache = [(rnd(B * Tp, HD, scale=0.25, seed=100 + l), rnd(B * Tp, HD, seed=200 + l)) for l in range(depth)]
+    pos = (torch.arange(M, device=DEV, dtype=torch.int32) + Tp).view(1, M).contiguous()
+    tab = hip.rope_table(pos, 1, M, M, 0, HD)
+    kinfo = torch.full((B, Tp + S), 3 << 24, dtype=torch.int32, device=DEV)
+    kinfo[:, Tp:] = (4 << 24) | 0x800001
+    if npad:
+        kinfo[0, Tp - npad:Tp] = 0
+    kinfo[0, 3] = 0
+    qinfo = torch.full((B, S), (6 << 24) | 0x800001, dtype=torch.int32, device=DEV)
+    slot = lambda j: mod[:, j * 3 * D:(j + 1) * 3 * D]
+
+    def separate():
+        xx = x
+        for l, (wqkv, wo, wgu, wd) in enumerate(W):
+            q, k, v = hip.serve_qkv_rope(xx, slot(2 * l), 0, S, wqkv, tab, NH, HD, HD ** -0.5)
+            o, _ = hip.attention_fwd([None, q], [cache[l][0], k], [cache[l][1], v], [0, S], [Tp, S], B, NH, 1, HD, qinfo, kinfo, need_lse=False)
+            xa = hip.serve_proj_residual(o[1], wo, xx, slot(2 * l)[:, 2 * D:], 0, S)
+            act = hip.serve_gate_up(xa, slot(2 * l + 1), 0, S, wgu)
+            xx = hip.serve_proj_residual(act, wd, xa, slot(2 * l + 1)[:, 2 * D:], 0, S)
+        return xx
+
+    ref = separate()
+    ctr = hip.serve_chain_counters(DEV)
+    for it in range(4):
+        out = hip.serve_chain(x, mod, 3 * D, W, cache, tab, qinfo, kinfo, B, S, NH, HD, H, Tp, HD ** -0.5, ctr)
+        assert torch.equal(out, ref), (it, (out.float() - ref.float()).abs().max().item())
+    assert not hip.serve_chain_failed(ctr)
+    assert int(ctr.abs().sum()) == 0                  # every launch leaves its counters at zero
+    assert torch.isfinite(ref.float()).all() and ref.float().abs().mean() > 0.1
+    # captured in a hipGraph and replayed: same bits
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g, stream=st):
+            outg = hip.serve_chain(x, mod, 3 * D, W, cache, tab, qinfo, kinfo, B, S, NH, HD, H, Tp, HD ** -0.5, ctr)
+        for _ in range(3):
+            g.replay()
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    assert torch.equal(outg, ref) and not hip.serve_chain_failed(ctr)
+
+
 # ------------------------------------------------------------------ fp8 GEMM path (BASELINE config 5)
 def _e4m3(x, s):
     """torch restatement of the quantiser: e4m3fn(clamp(x * s, +-448)) as f32 (still scaled by s)."""

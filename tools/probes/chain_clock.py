@@ -1,0 +1,49 @@
+"""Where the persistent denoise-layer chain (csrc/serve_chain.hpp) spends its time: blocks 0 and 255 stamp the 100 MHz clock after every
+barrier wait and before every arrival; prints per-stage compute and barrier time (us), averaged over the layers."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from lap_amd import hip
+DEV = "cuda"
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.bfloat16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+B, S, Tp, depth, D, NH, HD, H = 1, 50, 816, 18, 1024, 8, 256, 4096
+M = S
+x = rnd(M, D, seed=1)
+mod = rnd(1, (2 * depth + 1) * 3 * D, scale=0.3, seed=2)
+W = [(rnd((NH + 2) * HD, D, scale=D ** -0.5, seed=10 + 4 * l), rnd(D, NH * HD, scale=(NH * HD) ** -0.5, seed=11 + 4 * l),
+      rnd(2 * H, D, scale=D ** -0.5, seed=12 + 4 * l), rnd(D, H, scale=H ** -0.5, seed=13 + 4 * l)) for l in range(depth)]
+cache = [(rnd(Tp, HD, scale=0.25, seed=100 + l), rnd(Tp, HD, seed=200 + l)) for l in range(depth)]
+pos = (torch.arange(M, device=DEV, dtype=torch.int32) + Tp).view(1, M).contiguous()
+tab = hip.rope_table(pos, 1, M, M, 0, HD)
+kinfo = torch.full((B, Tp + S), 3 << 24, dtype=torch.int32, device=DEV); kinfo[:, Tp:] = (4 << 24) | 0x800001
+qinfo = torch.full((B, S), (6 << 24) | 0x800001, dtype=torch.int32, device=DEV)
+ctr = hip.serve_chain_counters(DEV)
+clk = torch.zeros(8192, dtype=torch.int64, device=DEV)
+run = lambda dbg: hip.serve_chain(x, mod, 3 * D, W, cache, tab, qinfo, kinfo, B, S, NH, HD, H, Tp, HD ** -0.5, ctr, debug_clock=dbg)
+for _ in range(3): run(None)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): run(None)
+e1.record(); torch.cuda.synchronize()
+print(f"chain launch: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us for {depth} layers = {e0.elapsed_time(e1) / 20 * 1e3 / depth:.2f} us per layer; failed={hip.serve_chain_failed(ctr)}")
+run(clk); torch.cuda.synchronize()
+names = ["qkv", "attn", "comb", "out", "gateup", "down"]
+for blk, off in (("block 0", 0), ("block 255", 4096)):
+    t = clk[off:off + 12 * depth + 2].cpu().tolist()
+    # stamps per layer: [stage-end(before arrive), after-wait] x 6  -> sequence: e0 w0 e1 w1 ... ; first stamp of the kernel = end of qkv stage 0
+    comp = [0.0] * 6; bar = [0.0] * 6
+    prev_wait = None
+    n = 0
+    for l in range(depth):
+        for s in range(6):
+            e, w = t[(l * 6 + s) * 2], t[(l * 6 + s) * 2 + 1]
+            if prev_wait is not None and l > 0:
+                comp[s] += (e - prev_wait) * 0.01
+            if l > 0: bar[s] += (w - e) * 0.01
+            prev_wait = w
+        n += l > 0
+    print(blk, "compute us:", " ".join(f"{nm} {c / n:.2f}" for nm, c in zip(names, comp)), "| barrier after:", " ".join(f"{nm} {b / n:.2f}" for nm, b in zip(names, bar)),
+          f"| layer {sum(comp) / n + sum(bar) / n:.2f}")

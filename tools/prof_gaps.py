@@ -55,6 +55,9 @@ if len(sys.argv) > 5:
         if target in name and s - end_prev > thr and shown < 4:
             shown += 1
             print(f"  gap {end_prev % 10**9 / 1e3:.1f} .. {s % 10**9 / 1e3:.1f} us ({(s - end_prev) / 1e3:.1f} us)")
+            for r in main:      # the main queue's own kernels around the gap
+                if r[2] > end_prev - 150e3 and r[1] < s + 5e3:
+                    print(f"     main    : {r[1] % 10**9 / 1e3:10.1f} .. {r[2] % 10**9 / 1e3:10.1f}  {short(r[0])}")
             for q, rs in byq.items():
                 for r in rs:
                     if r[2] > end_prev - 20e3 and r[1] < s + 5e3 and r[3] != main[0][3]:
