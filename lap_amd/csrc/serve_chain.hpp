@@ -10,9 +10,14 @@
 // the device-scope bit (sc1, serve_skinny_body.hpp), so the barrier is "s_waitcnt vmcnt(0)" + a two-level arrival counter
 // (per-XCD group, the group's last arriver bumps the master) + a poll: 2.7 us per round on MI355X, no visibility errors
 // (tools/probes/gridbar_sc1.hip) — against ~4.5 us of fixed cost per dependent launch inside a hipGraph.  And a block knows its
-// NEXT stage's weight rows before the barrier: it issues those loads first and polls while they fly, so the per-CU load path
-// (the real bound of these projections, ~35-48 GB/s per CU) streams weights during what used to be launch latency.
+// NEXT stage's weight rows (and the attention stage its run of the CACHED keys / values) before the barrier: it issues those
+// loads first and polls while they fly, so the per-CU load path (the real bound of these projections, ~35-48 GB/s per CU)
+// streams them during what used to be launch latency.
 // The stage bodies are the stand-alone kernels' device functions: the chain is bitwise equal to the six-launch path.
+// Measured (tools/probes/chain_clock.py, 18 layers, 50 action tokens, 816 cached keys): 49.1 us per layer = 27 us of stage work on
+// the slowest block (qkv 5.3, attention 6.7, combine 1.8, out 2.8, gate|up 5.7, down 4.4) + 22 us in the six barriers (2.6-4.3 us
+// each: the 2.7 us round plus the skew between blocks), against 53 us for the six launches; one chunk (prefill + 10 steps)
+// 15.6 -> 15.4 ms replayed from a hipGraph, 20.0 -> 15.7 ms launched eagerly (1469 -> 399 kernels).
 //
 // Included by attention.hip inside its anonymous namespace, after attention_serve.hpp.
 #pragma once
@@ -49,7 +54,8 @@ struct ChainP {
 // hold the group's last arriver — and with it every block of the chip — until those loads have landed.
 // Two levels: a counter per XCD group (block id % 8), the group's last arriver bumps the master everybody polls.  (Measured
 // alternatives: one flat counter 4.2 us per round instead of 2.7; no master, every block polling the eight group counters: the
-// polls get in the way of the arrivals on the same lines, +4 us per layer.)
+// polls get in the way of the arrivals on the same lines, +4 us per layer; group = the real XCD with the group counter as an
+// atomic of that XCD's own L2: 49.4 vs 49.1 us per layer, nothing.)
 __device__ __forceinline__ void chain_arrive(unsigned* ctrs, unsigned& round, int nb) {
   __builtin_amdgcn_s_waitcnt(0);       // vmcnt(0) expcnt(0) lgkmcnt(0) (a real instruction: the compiler's counter model sees it)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (orders the inline-assembly sc1 stores in front of it as well)

@@ -83,7 +83,11 @@ def test_full_width_sample_actions_matches_oracle(hip, monkeypatch):
     ref16 = O.sample_actions(P, dataclasses.replace(oc, emulate_bf16=True), so, noise, num_steps=10)
     model = _engine(cfg, P)
     o = to_observation(so | {"tokenized_langact_mask": None}, DEV)
-    out = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV))                     # skinny fused projections
+    out = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV))                     # skinny fused projections, one launch per step
+    assert model.serve_chain and model._chain_ctr is not None and not model.serve_chain_failed()
+    model.serve_chain = False                                                               # ... as six launches per layer: same bits
+    assert torch.equal(out, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV)))
+    model.serve_chain = True
     generic = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused=False)
     assert torch.equal(generic, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused="partials"))
     err, base = rel(out, ref), rel(ref16, ref)
@@ -280,6 +284,11 @@ def test_full_depth_lap3b_forward_and_sampler_match_oracle(hip):
     assert rel(col["per_sample_lang"], m32["per_sample_lang"]) < 2e-2 and rel(col["per_sample_action"], m32["per_sample_action"]) < 2e-2
     o = to_observation(so | {"tokenized_langact_mask": None}, DEV)
     out = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV))
+    assert model.serve_chain and model._chain_ctr is not None       # the 18 expert layers of a step ran as ONE launch (serve_chain.hpp) ...
+    model.serve_chain = False
+    assert torch.equal(out, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV)))     # ... bit-equal to 6 launches per layer
+    model.serve_chain = True
+    assert not model.serve_chain_failed()
     generic = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused=False)
     assert torch.equal(generic, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused="partials"))
     err, base = rel(out, ref), rel(ref16, ref)
