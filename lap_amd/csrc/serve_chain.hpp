@@ -1,9 +1,10 @@
 // One launch for the 18 action-expert layers of a denoise step (lap.py:634-667 -> gemma.py:336-387 with only the suffix stream
-// active and a KV cache): the six launches per layer of the stand-alone path (serve_skinny.hip, attention_serve.hpp) become six
+// active and a KV cache): the six launches per layer of the stand-alone path (serve_skinny.hip, attention_serve.hpp) become five
 // STAGES of one persistent kernel — 256 blocks, one per CU, all resident — separated by a software grid barrier:
 //
-//   [adaRMS + qkv + RoPE/split] | attention over [cache | fresh keys], split over key runs | combine of the splits |
-//   [out projection + gated residual] | [adaRMS + gate|up + GeGLU] | [down projection + gated residual]
+//   [adaRMS + qkv + RoPE/split] | attention over [cache | fresh keys], split over key runs, + combine of the splits (the runs
+//   of one head meet at a counter of their own) | [out projection + gated residual] | [adaRMS + gate|up + GeGLU] |
+//   [down projection + gated residual]
 //
 // Why it pays now (it did not in round 2, docs/EXPERIMENTS.md): the barrier used to cost 6.5-11 us because agent-scope release /
 // acquire fences write back and invalidate the XCD's L2.  Here every activation that crosses a stage is stored and loaded with
@@ -27,7 +28,8 @@
 constexpr int CH_MAX_DEPTH = 32;
 constexpr int CH_GROUPS = 8;             // arrival groups = XCDs (block id % 8)
 constexpr int CH_CTR_STRIDE = 64;        // counters 256 B apart
-constexpr int CH_CTR_EXIT = 9, CH_CTR_ERR = 10, CH_CTR_WORDS = 11 * CH_CTR_STRIDE;
+constexpr int CH_CTR_EXIT = 9, CH_CTR_ERR = 10, CH_CTR_HEAD = 11, CH_MAX_HEADS = 64;    // HEAD: one counter per (sample, head), see the attention stage
+constexpr int CH_CTR_WORDS = (CH_CTR_HEAD + CH_MAX_HEADS) * CH_CTR_STRIDE;
 constexpr int CH_BLOCKS = 256;
 
 struct ChainP {
@@ -98,7 +100,6 @@ __global__ __launch_bounds__(512) void serve_chain_kernel(ChainP c) {
   const int fgQ = (c.NH + 2) * c.HD / 32, fgO = c.D / 16, fgG = c.H / 32;
   const int nQ = fgQ * tg32, nO = fgO * tg16, nG = fgG * tg32;
   const int ns = c.sp.nsplit, nA = ns * c.NH * c.attn.B;
-  const int nC = (int)(((long long)c.M * c.NH * c.HD / 4 + 511) / 512);
   const int QKV = c.NH * c.HD;
 
   SkinnyP pq = {}, po = {}, pg = {}, pd = {};
@@ -129,18 +130,41 @@ __global__ __launch_bounds__(512) void serve_chain_kernel(ChainP c) {
     chain_wait(c.ctrs, round);
     CH_STAMP();
     // ---- attention of the action queries over [cached prefix | fresh keys], one key run per block
-    if (vb < nA) attn_serve_body<true, 2>(ap, c.sp, vb % ns, (vb / ns) % c.NH, vb / (ns * c.NH), smem);
+    if (vb < nA) {
+      const int sI = vb % ns, hI = (vb / ns) % c.NH, bI = vb / (ns * c.NH);
+      attn_serve_body<true, 2>(ap, c.sp, sI, hI, bI, smem);
+      // ---- combine of the key runs: only the `ns` blocks of one (sample, head) depend on each other, so they meet at a counter
+      // of their own instead of a grid barrier (7 arrivals instead of 256), and each merges its share of the head's rows
+      __builtin_amdgcn_s_waitcnt(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (threadIdx.x == 0) {
+        unsigned* hc = c.ctrs + CH_CTR_STRIDE * (CH_CTR_HEAD + bI * c.NH + hI);
+        (void)__hip_atomic_fetch_add(hc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (unsigned)(l + 1) * (unsigned)ns;
+        unsigned spins = 0;
+        while (__hip_atomic_load(hc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 21)) {
+            __hip_atomic_fetch_or(c.ctrs + CH_CTR_STRIDE * CH_CTR_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int per_head = c.rps * (c.HD / 4);                       // 4-column items of this (sample, head): row t, columns 4 j ..
+      for (int it = sI * 512 + (int)threadIdx.x; it < per_head; it += ns * 512) {
+        const int t = it / (c.HD / 4), j = it % (c.HD / 4);
+        attn_serve_combine_body<NS, true>(ap, (((long long)bI * c.rps + t) * c.NH + hI) * (c.HD / 4) + j);
+      }
+    }
     CH_STAMP();
     chain_arrive(c.ctrs, round, nb);
-    po.W = c.wo[l];     // the out projection's weights: in flight from here, through the combine stage
+    po.W = c.wo[l];     // the out projection's weights: in flight during the barrier
     skinny_load_w<EPI_RESID, 8, 1, false>(po, vb % fgO, wo);      // (unconditional: a block without work in the stage loads rows it drops)
     __builtin_amdgcn_sched_barrier(0);
-    chain_wait(c.ctrs, round);
-    CH_STAMP();
-    // ---- combine of the key runs
-    if (vb < nC) attn_serve_combine_body<NS, true>(ap, (long long)vb * 512 + threadIdx.x);
-    CH_STAMP();
-    chain_arrive(c.ctrs, round, nb);
     chain_wait(c.ctrs, round);
     CH_STAMP();
     // ---- out projection + gated residual
@@ -179,6 +203,8 @@ __global__ __launch_bounds__(512) void serve_chain_kernel(ChainP c) {
     const unsigned old = __hip_atomic_fetch_add(c.ctrs + CH_CTR_STRIDE * CH_CTR_EXIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == (unsigned)nb - 1) {
       for (int j = 0; j <= CH_GROUPS; ++j) __hip_atomic_store(c.ctrs + CH_CTR_STRIDE * j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int j = 0; j < c.attn.B * c.NH; ++j)
+        __hip_atomic_store(c.ctrs + CH_CTR_STRIDE * (CH_CTR_HEAD + j), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(c.ctrs + CH_CTR_STRIDE * CH_CTR_EXIT, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -190,7 +216,7 @@ inline bool chain_ok(int B, int S, int D, int H, int NH, int HD, int NKV, int pr
   const int M = B * S;
   if (S > 64 || M > 64) return false;
   const ServeSplits sp = serve_splits(prefix_len, S);
-  return sp.nsplit >= 1 && sp.nsplit <= 16 && sp.nsplit * NH * B <= CH_BLOCKS;
+  return sp.nsplit >= 1 && sp.nsplit <= 16 && sp.nsplit * NH * B <= CH_BLOCKS && B * NH <= CH_MAX_HEADS;
 }
 
 int launch_chain(const ChainP& c, hipStream_t s) {

@@ -30,16 +30,17 @@ for _ in range(20): run(None)
 e1.record(); torch.cuda.synchronize()
 print(f"chain launch: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us for {depth} layers = {e0.elapsed_time(e1) / 20 * 1e3 / depth:.2f} us per layer; failed={hip.serve_chain_failed(ctr)}")
 run(clk); torch.cuda.synchronize()
-names = ["qkv", "attn", "comb", "out", "gateup", "down"]
+names = ["qkv", "attn+comb", "out", "gateup", "down"]
+NS = len(names)
 for blk, off in (("block 0", 0), ("block 255", 4096)):
-    t = clk[off:off + 12 * depth + 2].cpu().tolist()
+    t = clk[off:off + 2 * NS * depth + 2].cpu().tolist()
     # stamps per layer: [stage-end(before arrive), after-wait] x 6  -> sequence: e0 w0 e1 w1 ... ; first stamp of the kernel = end of qkv stage 0
-    comp = [0.0] * 6; bar = [0.0] * 6
+    comp = [0.0] * NS; bar = [0.0] * NS
     prev_wait = None
     n = 0
     for l in range(depth):
-        for s in range(6):
-            e, w = t[(l * 6 + s) * 2], t[(l * 6 + s) * 2 + 1]
+        for s in range(NS):
+            e, w = t[(l * NS + s) * 2], t[(l * NS + s) * 2 + 1]
             if prev_wait is not None and l > 0:
                 comp[s] += (e - prev_wait) * 0.01
             if l > 0: bar[s] += (w - e) * 0.01
