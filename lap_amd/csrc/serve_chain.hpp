@@ -15,10 +15,10 @@
 // loads first and polls while they fly, so the per-CU load path (the real bound of these projections, ~35-48 GB/s per CU)
 // streams them during what used to be launch latency.
 // The stage bodies are the stand-alone kernels' device functions: the chain is bitwise equal to the six-launch path.
-// Measured (tools/probes/chain_clock.py, 18 layers, 50 action tokens, 816 cached keys): 49.1 us per layer = 27 us of stage work on
-// the slowest block (qkv 5.3, attention 6.7, combine 1.8, out 2.8, gate|up 5.7, down 4.4) + 22 us in the six barriers (2.6-4.3 us
-// each: the 2.7 us round plus the skew between blocks), against 53 us for the six launches; one chunk (prefill + 10 steps)
-// 15.6 -> 15.4 ms replayed from a hipGraph, 20.0 -> 15.7 ms launched eagerly (1469 -> 399 kernels).
+// Measured (tools/probes/chain_clock.py, 18 layers, 50 action tokens, 816 cached keys): 48.0 us per layer = 29 us of stage work on
+// the slowest block (qkv 5.4, attention + combine 11.0, out 2.7, gate|up 5.6, down 4.4) + 18 us in the five barriers (3.1-4.4 us
+// each: the 2.7 us round plus the skew between blocks), against 50.5 us for the six launches inside a replayed graph; one chunk
+// (prefill + 10 steps) 15.6 -> 15.4-15.5 ms replayed from a hipGraph, 20.0 -> 15.7 ms launched eagerly (1469 -> 399 kernels).
 //
 // Included by attention.hip inside its anonymous namespace, after attention_serve.hpp.
 #pragma once
