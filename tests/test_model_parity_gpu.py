@@ -88,6 +88,13 @@ def test_full_width_sample_actions_matches_oracle(hip, monkeypatch):
     model.serve_chain = False                                                               # ... as six launches per layer: same bits
     assert torch.equal(out, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV)))
     model.serve_chain = True
+    # a barrier that timed out is reported, and the fallback (serve.Policy.infer does this after its device sync) is permanent
+    model._chain_ctr[10 * 64] = 1                                                           # CH_CTR_ERR (csrc/serve_chain.hpp)
+    assert model.serve_chain_failed()
+    model.disable_serve_chain()
+    assert not model.serve_chain and not model.serve_chain_failed()
+    assert torch.equal(out, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV)))
+    model.serve_chain = True
     generic = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused=False)
     assert torch.equal(generic, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV), fused="partials"))
     err, base = rel(out, ref), rel(ref16, ref)
