@@ -1127,6 +1127,8 @@ def test_serve_skinny_projections_match_unfused_ops(hip, M, rps, shared):
     (50, 560, 2, 9),       # 4 full runs + a joint one; padded prompt tail (masked keys)
     (16, 256, 2, 0),       # one token tile; the fresh keys get a run of their own
     (33, 77, 2, 5),        # ragged token count (3 tiles of 16, 2 of 32), odd prefix length
+    (64, 130, 2, 0),       # the largest chunk the chain takes (every stage exactly one round of 256 blocks)
+    (50, 0, 2, 0),         # no cached prefix at all: the fresh keys are the only run
 ])
 def test_serve_chain_equals_the_separate_launches_bitwise(hip, S, Tp, depth, npad):
     """lap_serve_chain (csrc/serve_chain.hpp: the denoise step's layers as stages of ONE persistent kernel with a software grid
