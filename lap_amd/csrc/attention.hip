@@ -796,7 +796,7 @@ extern "C" int lap_attention_serve(const lap_attn_fwd_args* a, void* stream) {
 
 // ---- the denoise step's 18 layers in one persistent launch (serve_chain.hpp)
 extern "C" int lap_serve_chain_ok(int B, int S, int D, int H, int NH, int HD, int NKV, int prefix_len) {
-  return chain_ok(B, S, D, H, NH, HD, NKV, prefix_len) ? 1 : 0;
+  return chain_ok(B, S, D, H, NH, HD, NKV, prefix_len) && chain_device_ok() ? 1 : 0;
 }
 
 extern "C" int lap_serve_chain_counter_words(void) { return CH_CTR_WORDS; }
@@ -814,7 +814,7 @@ extern "C" int lap_serve_chain(const lap_serve_chain_args* a, void* stream) {
   if (!a || a->depth < 1 || a->depth > CH_MAX_DEPTH || a->depth > LAP_CHAIN_MAX_DEPTH) return LAP_ERR_ARG;
   if (!chain_ok(a->B, a->S, a->D, a->H, a->NH, a->HD, 1, a->prefix_len)) return LAP_ERR_ARG;
   if (!a->x_in || !a->x_out || !a->mod || !a->rope_table || !a->q || !a->k || !a->v || !a->o || !a->xa || !a->act || !a->attn_scratch ||
-      !a->counters || (a->mod_slot_stride & 7) || a->mod_slot_stride < 3 * a->D)
+      !a->counters || (a->mod_slot_stride & 7) || a->mod_slot_stride < 3 * a->D || (a->packed && !a->xs))
     return LAP_ERR_ARG;
   if ((a->qinfo == nullptr) != (a->kinfo == nullptr)) return LAP_ERR_ARG;
   const int M = a->B * a->S, kv_rs = a->kv_rs ? a->kv_rs : a->HD;
@@ -840,9 +840,10 @@ extern "C" int lap_serve_chain(const lap_serve_chain_args* a, void* stream) {
   p.part = a->attn_scratch; p.lpart = a->attn_scratch + (long long)c.sp.nsplit * M * a->NH * a->HD;
   c.rope = a->rope_table; c.q_scale = a->q_scale; c.eps = a->eps;
   c.q = (bf16*)a->q; c.k = (bf16*)a->k; c.v = (bf16*)a->v; c.o = (bf16*)a->o; c.xa = (bf16*)a->xa; c.act = (bf16*)a->act;
+  c.xs = (bf16*)a->xs;
   c.ctrs = a->counters;
   c.clk = (unsigned long long*)a->debug_clock;
-  return launch_chain(c, (hipStream_t)stream);
+  return launch_chain(c, a->packed != 0, (hipStream_t)stream);
 }
 
 extern "C" int lap_attention_bwd(const lap_attn_bwd_args* a, void* stream) {

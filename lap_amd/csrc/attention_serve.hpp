@@ -55,7 +55,9 @@ __device__ __forceinline__ void st_f32(float* p, float v) {
 // COH: q / the fresh keys and values were written, and the partial results will be read, by other blocks of the SAME launch.
 // PHASE 0: the whole block.  The chain splits it at its grid barrier: PHASE 1 issues the DMA pieces that read the CACHED prefix
 // only (they do not depend on the launch's own results) and returns; PHASE 2, behind the barrier, issues the fresh rows and goes on.
-template <bool COH, int PHASE = 0>
+// PK (the chain, round 4): q and the combined output o are fragment-packed [row tiles of 16][NH HD / 32][1 KiB] (pk_off,
+// serve_skinny_body.hpp) — the query fragments arrive as whole KiB per wave instruction instead of 16 rows x 64 B.
+template <bool COH, int PHASE = 0, bool PK = false>
 __device__ __forceinline__ void attn_serve_body(const AttnP& p, const ServeSplits& sp, const int s, const int h, const int b, char* smem) {
   using C = DmaCfg<256>;
   constexpr int HD = 256, PITCH = C::PITCH, KS = C::KS;
@@ -114,10 +116,18 @@ __device__ __forceinline__ void attn_serve_body(const AttnP& p, const ServeSplit
   const bool vq = myq < S;
   bf16x8 qf[KS];
   if constexpr (COH) {
+    if constexpr (PK) {
+      const int row = b * S + myq, QK = p.q_rs[1];
+      const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)p.q[1], 0, (unsigned)(((p.B * S + 15) >> 4) * QK * 32), 0x00020000);
+      const unsigned qoff = vq ? (unsigned)((((long long)(row >> 4) * (QK >> 5) + h * (HD >> 5)) * 64 + g * 16 + (row & 15)) * 16) : DMA_OOB;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) qf[kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsQ, qoff + kk * 1024, 0, 16));
+    } else {
     const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)p.q[1], 0, (unsigned)((long long)p.B * S * p.q_rs[1] * 2), 0x00020000);
     const unsigned qoff = vq ? (unsigned)((((long long)b * S + myq) * p.q_rs[1] + h * HD + g * 8) * 2) : DMA_OOB;   // invalid rows read as zeros
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) qf[kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsQ, qoff + kk * 64, 0, 16));
+    }
   } else {
     load_row_frags<HD>(p.q[1] + (b * (long long)S + myq) * p.q_rs[1] + h * HD, vq, lane, qf);
   }
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(512) void attn_serve_kernel(AttnP p, ServeSplits sp
 
 // O = sum_i exp(lse_i - lse) O_i over the NS key splits (the generic combine's arithmetic, every load issued up front).
 // One thread per (b, q, h, 4 d).
-template <int NS, bool COH>
+template <int NS, bool COH, bool PK = false>
 __device__ __forceinline__ void attn_serve_combine_body(const AttnP& p, const long long gid) {
   constexpr int HD = 256;
   const int S = p.qlen[1];
@@ -252,7 +262,7 @@ __device__ __forceinline__ void attn_serve_combine_body(const AttnP& p, const lo
     den += wgt;
     acc += oi[sp] * wgt;
   }
-  bf16* dst = p.o[1] + (b * (long long)S + t) * p.o_rs[1] + h * HD + d0;
+  bf16* dst = PK ? p.o[1] + pk_off((int)(b * (long long)S + t), h * HD + d0, p.o_rs[1]) : p.o[1] + (b * (long long)S + t) * p.o_rs[1] + h * HD + d0;
   if constexpr (COH) {
     const float sc = den > 0.f ? 1.0f / den : 0.f;
     bf16x4 o;

@@ -189,6 +189,12 @@ __device__ __forceinline__ void mc_frag_raw(const char* tile, int m0, int kk, in
   r[1] = ds_read_tr_raw<4 * MW * 2>(a);   // k-row + 4: same swizzle
 }
 
+// Fragment-packed matrix layout of the serving chain (serve_skinny_body.hpp "PK"): a [16 rows x 32 k] tile is 1 KiB, lane
+// 16 g + i of a wave holds row i, k = 8 g .. 8 g + 7; the tiles of one row group are consecutive in k.
+__device__ __forceinline__ long long pk_off(int r, int c, int K) {     // element offset of (row r, column c) of a packed [.., K] matrix
+  return ((long long)(r >> 4) * (K >> 5) + (c >> 5)) * 512 + ((((c & 31) >> 3) << 4) + (r & 15)) * 8 + (c & 7);
+}
+
 // XCD-aware block id remap (bijective for any grid size): consecutive logical
 // ids land on the same XCD (blocks are dispatched round-robin over 8 XCDs), so
 // neighbouring tiles share operand panels in one L2.

@@ -44,6 +44,7 @@ struct ChainP {
   const float* rope;
   float q_scale, eps;
   bf16 *q, *k, *v, *o, *xa, *act;        // activations between the stages
+  bf16* xs;                              // PK: the residual stream between the layers, packed (x_in / x_out stay row-major for the caller)
   unsigned* ctrs;                        // CH_CTR_WORDS words, zero before the first launch (the kernel leaves them zero)
   unsigned long long* clk;               // tuning aid (tools/probes/chain_clock.py): block 0 / block 255 stamp the 100 MHz clock at every stage edge; NULL normally
 };
@@ -71,16 +72,22 @@ __device__ __forceinline__ void chain_arrive(unsigned* ctrs, unsigned& round, in
   }
   asm volatile("" ::: "memory");
 }
+// Never hang the GPU: a wait is bounded (2^21 polls, about a second); the block that gives up raises the error flag
+// (lap_serve_chain_status) and goes on, and from then on EVERY wait of the launch gives up after 1024 polls (~900
+// barriers must not time out one second at a time).  The launch's output is poisoned at its end (chain_poison).
+__device__ __forceinline__ bool chain_give_up(unsigned* ctrs, unsigned spins) {
+  if (spins & 1023u) return false;
+  if (spins <= (1u << 21) && __hip_atomic_load(ctrs + CH_CTR_STRIDE * CH_CTR_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return false;
+  __hip_atomic_fetch_or(ctrs + CH_CTR_STRIDE * CH_CTR_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
 // wait until all blocks have arrived
 __device__ __forceinline__ void chain_wait(unsigned* ctrs, unsigned round) {
   if (threadIdx.x == 0) {
     unsigned spins = 0;
     while (__hip_atomic_load(ctrs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round * CH_GROUPS) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 21)) {     // never hang the GPU: flag it (lap_serve_chain_status) and go on
-        __hip_atomic_fetch_or(ctrs + CH_CTR_STRIDE * CH_CTR_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
+      if (chain_give_up(ctrs, ++spins)) break;
     }
   }
   asm volatile("" ::: "memory");
@@ -88,7 +95,9 @@ __device__ __forceinline__ void chain_wait(unsigned* ctrs, unsigned round) {
   asm volatile("" ::: "memory");
 }
 
-template <int NS>
+// PK: fragment-packed weights and activations (serve_skinny_body.hpp): every operand load of every stage is 1 KiB contiguous per
+// wave instruction.  Same arithmetic in the same order as the row-major form.
+template <int NS, bool PK>
 __global__ __launch_bounds__(512) void serve_chain_kernel(ChainP c) {
   extern __shared__ __attribute__((aligned(16))) char smem[];     // SV_LDS bytes: the attention stage's images; the projections use the front
   float* part = reinterpret_cast<float*>(smem);
@@ -115,24 +124,25 @@ __global__ __launch_bounds__(512) void serve_chain_kernel(ChainP c) {
   // unconditionally — a value carried around the loop, or defined on one side of a branch only, stays allocated / gets spilled)
   bf16x8 wq[2][4];
   pq.W = c.wqkv[0];
-  skinny_load_w<EPI_ROPE, 4, 2, false>(pq, vb % fgQ, wq);
+  skinny_load_w<EPI_ROPE, 4, 2, false, PK>(pq, vb % fgQ, wq);
+  bf16* const xs = PK ? c.xs : c.x_out;      // the stream between the layers
   for (int l = 0; l < c.depth; ++l) {
     bf16x8 wo[1][8], wg[4][4], wd[1][16];
     const bf16* slot_a = c.mod + (long long)(2 * l) * c.slot_ld;
     const bf16* slot_f = slot_a + c.slot_ld;
     // ---- adaRMS + qkv + RoPE / split
-    pq.x = l == 0 ? c.x_in : c.x_out; pq.mod = slot_a;
-    if (vb < nQ) skinny_rest<EPI_ROPE, true, 4, 2, 2, true, true>(pq, vb % fgQ, vb / fgQ, wq, part, red);
+    pq.x = l == 0 ? c.x_in : xs; pq.mod = slot_a; pq.x_rm = l == 0;
+    if (vb < nQ) skinny_rest<EPI_ROPE, true, 4, 2, 2, true, true, PK>(pq, vb % fgQ, vb / fgQ, wq, part, red);
     CH_STAMP();
     chain_arrive(c.ctrs, round, nb);
     ap.k[0] = c.ck[l]; ap.v[0] = c.cv[l];     // the cached keys / values of the block's run: on their way into LDS during the barrier
-    if (vb < nA) attn_serve_body<true, 1>(ap, c.sp, vb % ns, (vb / ns) % c.NH, vb / (ns * c.NH), smem);
+    if (vb < nA) attn_serve_body<true, 1, PK>(ap, c.sp, vb % ns, (vb / ns) % c.NH, vb / (ns * c.NH), smem);
     chain_wait(c.ctrs, round);
     CH_STAMP();
     // ---- attention of the action queries over [cached prefix | fresh keys], one key run per block
     if (vb < nA) {
       const int sI = vb % ns, hI = (vb / ns) % c.NH, bI = vb / (ns * c.NH);
-      attn_serve_body<true, 2>(ap, c.sp, sI, hI, bI, smem);
+      attn_serve_body<true, 2, PK>(ap, c.sp, sI, hI, bI, smem);
       // ---- combine of the key runs: only the `ns` blocks of one (sample, head) depend on each other, so they meet at a counter
       // of their own instead of a grid barrier (7 arrivals instead of 256), and each merges its share of the head's rows
       __builtin_amdgcn_s_waitcnt(0);
@@ -145,10 +155,7 @@ __global__ __launch_bounds__(512) void serve_chain_kernel(ChainP c) {
         unsigned spins = 0;
         while (__hip_atomic_load(hc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 21)) {
-            __hip_atomic_fetch_or(c.ctrs + CH_CTR_STRIDE * CH_CTR_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
+          if (chain_give_up(c.ctrs, ++spins)) break;
         }
       }
       asm volatile("" ::: "memory");
@@ -157,46 +164,53 @@ __global__ __launch_bounds__(512) void serve_chain_kernel(ChainP c) {
       const int per_head = c.rps * (c.HD / 4);                       // 4-column items of this (sample, head): row t, columns 4 j ..
       for (int it = sI * 512 + (int)threadIdx.x; it < per_head; it += ns * 512) {
         const int t = it / (c.HD / 4), j = it % (c.HD / 4);
-        attn_serve_combine_body<NS, true>(ap, (((long long)bI * c.rps + t) * c.NH + hI) * (c.HD / 4) + j);
+        attn_serve_combine_body<NS, true, PK>(ap, (((long long)bI * c.rps + t) * c.NH + hI) * (c.HD / 4) + j);
       }
     }
     CH_STAMP();
     chain_arrive(c.ctrs, round, nb);
     po.W = c.wo[l];     // the out projection's weights: in flight during the barrier
-    skinny_load_w<EPI_RESID, 8, 1, false>(po, vb % fgO, wo);      // (unconditional: a block without work in the stage loads rows it drops)
+    skinny_load_w<EPI_RESID, 8, 1, false, PK>(po, vb % fgO, wo);      // (unconditional: a block without work in the stage loads rows it drops)
     __builtin_amdgcn_sched_barrier(0);
     chain_wait(c.ctrs, round);
     CH_STAMP();
     // ---- out projection + gated residual
-    po.resid = l == 0 ? c.x_in : c.x_out; po.gate = slot_a + 2 * c.D;
-    if (vb < nO) skinny_rest<EPI_RESID, false, 8, 1, 1, false, true>(po, vb % fgO, vb / fgO, wo, part, red);
+    po.resid = l == 0 ? c.x_in : xs; po.gate = slot_a + 2 * c.D; po.resid_rm = l == 0;
+    if (vb < nO) skinny_rest<EPI_RESID, false, 8, 1, 1, false, true, PK>(po, vb % fgO, vb / fgO, wo, part, red);
     CH_STAMP();
     chain_arrive(c.ctrs, round, nb);
     pg.W = c.wgu[l];
-    skinny_load_w<EPI_GEGLU, 4, 4, false>(pg, vb % fgG, wg);
+    skinny_load_w<EPI_GEGLU, 4, 4, false, PK>(pg, vb % fgG, wg);
     __builtin_amdgcn_sched_barrier(0);
     chain_wait(c.ctrs, round);
     CH_STAMP();
     // ---- adaRMS + gate|up + GeGLU
     pg.mod = slot_f;
-    if (vb < nG) skinny_rest<EPI_GEGLU, true, 4, 4, 2, true, true>(pg, vb % fgG, vb / fgG, wg, part, red);
+    if (vb < nG) skinny_rest<EPI_GEGLU, true, 4, 4, 2, true, true, PK>(pg, vb % fgG, vb / fgG, wg, part, red);
     CH_STAMP();
     chain_arrive(c.ctrs, round, nb);
     pd.W = c.wd[l];
-    skinny_load_w<EPI_RESID, 16, 1, false>(pd, vb % fgO, wd);
+    skinny_load_w<EPI_RESID, 16, 1, false, PK>(pd, vb % fgO, wd);
     __builtin_amdgcn_sched_barrier(0);
     chain_wait(c.ctrs, round);
     CH_STAMP();
     // ---- down projection + gated residual
     pd.gate = slot_f + 2 * c.D;
-    if (vb < nO) skinny_rest<EPI_RESID, false, 16, 1, 1, false, true>(pd, vb % fgO, vb / fgO, wd, part, red);
+    pd.o_rm = l + 1 == c.depth; pd.o0 = pd.o_rm ? c.x_out : xs;       // the caller's x_out is row-major
+    if (vb < nO) skinny_rest<EPI_RESID, false, 16, 1, 1, false, true, PK>(pd, vb % fgO, vb / fgO, wd, part, red);
     CH_STAMP();
     chain_arrive(c.ctrs, round, nb);
     pq.W = c.wqkv[l + 1 < c.depth ? l + 1 : l];     // (the last layer re-reads its own: nobody uses them)
-    skinny_load_w<EPI_ROPE, 4, 2, false>(pq, vb % fgQ, wq);
+    skinny_load_w<EPI_ROPE, 4, 2, false, PK>(pq, vb % fgQ, wq);
     __builtin_amdgcn_sched_barrier(0);
     chain_wait(c.ctrs, round);
     CH_STAMP();
+  }
+  // a barrier gave up somewhere in this launch: its results are unsynchronised garbage — make them NaN so that no caller can
+  // mistake them for actions (the flag stays up for lap_serve_chain_status; Policy.infer falls back to the separate launches)
+  if (__hip_atomic_load(c.ctrs + CH_CTR_STRIDE * CH_CTR_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+    unsigned short* xo = reinterpret_cast<unsigned short*>(c.x_out);
+    for (int j = vb * 512 + (int)threadIdx.x; j < c.M * c.D; j += nb * 512) xo[j] = 0x7fc0;     // bf16 NaN
   }
   // the last block out leaves the counters at zero for the next launch (nobody polls any more: every block is past its last wait)
   if (threadIdx.x == 0) {
@@ -219,23 +233,35 @@ inline bool chain_ok(int B, int S, int D, int H, int NH, int HD, int NKV, int pr
   return sp.nsplit >= 1 && sp.nsplit <= 16 && sp.nsplit * NH * B <= CH_BLOCKS && B * NH <= CH_MAX_HEADS;
 }
 
-int launch_chain(const ChainP& c, hipStream_t s) {
-  static int cus = -1;
-  if (cus < 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LAP_ERR_ARG;
-    cus = prop.multiProcessorCount;
+// The CURRENT device can hold the chain's 256 blocks at once (one per CU; the kernel's LDS footprint admits one block per CU).
+// Queried per device and cached per device id (a process-wide static remembered the first device's answer).
+inline bool chain_device_ok() {
+  static int cus_of[64];       // 0 = not asked yet
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (cus_of[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    cus_of[dev] = n > 0 ? n : -1;
   }
-  if (cus < CH_BLOCKS) return LAP_ERR_ARG;       // all 256 blocks must be resident at once: one per CU of an MI355X
+  return cus_of[dev] >= CH_BLOCKS;
+}
+
+int launch_chain(const ChainP& c, bool packed, hipStream_t s) {
+  if (!chain_device_ok()) return LAP_ERR_ARG;       // all 256 blocks must be resident at once: one per CU of an MI355X
   static bool attr = false;
   if (!attr) {
-    if (int e = set_lds(serve_chain_kernel<8>, SV_LDS)) return e;
-    if (int e = set_lds(serve_chain_kernel<16>, SV_LDS)) return e;
+    if (int e = set_lds(serve_chain_kernel<8, false>, SV_LDS)) return e;
+    if (int e = set_lds(serve_chain_kernel<16, false>, SV_LDS)) return e;
+    if (int e = set_lds(serve_chain_kernel<8, true>, SV_LDS)) return e;
+    if (int e = set_lds(serve_chain_kernel<16, true>, SV_LDS)) return e;
     attr = true;
   }
-  if (c.sp.nsplit <= 8) hipLaunchKernelGGL(serve_chain_kernel<8>, dim3(CH_BLOCKS), dim3(512), SV_LDS, s, c);
-  else hipLaunchKernelGGL(serve_chain_kernel<16>, dim3(CH_BLOCKS), dim3(512), SV_LDS, s, c);
+  if (packed) {
+    if (c.sp.nsplit <= 8) hipLaunchKernelGGL((serve_chain_kernel<8, true>), dim3(CH_BLOCKS), dim3(512), SV_LDS, s, c);
+    else hipLaunchKernelGGL((serve_chain_kernel<16, true>), dim3(CH_BLOCKS), dim3(512), SV_LDS, s, c);
+  } else if (c.sp.nsplit <= 8) hipLaunchKernelGGL((serve_chain_kernel<8, false>), dim3(CH_BLOCKS), dim3(512), SV_LDS, s, c);
+  else hipLaunchKernelGGL((serve_chain_kernel<16, false>), dim3(CH_BLOCKS), dim3(512), SV_LDS, s, c);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

@@ -133,9 +133,38 @@ __global__ __launch_bounds__(256) void final_norm_out_euler_kernel(const bf16* _
   }
 }
 
+// one thread per 16-byte chunk of the packed image (serve_skinny_body.hpp PK; the row maps are skinny_load_w's)
+__global__ __launch_bounds__(256) void pack_weight_kernel(const bf16* __restrict__ W, bf16* __restrict__ out, int N, int K, int kind, int HD) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)N * K / 8) return;
+  const int lane = (int)(idx & 63), i = lane & 15, g = lane >> 4;
+  const long long tile = idx >> 6;
+  const int ks = (int)(tile % (K >> 5)), sb = (int)(tile / (K >> 5));
+  int wrow;
+  if (kind == EPI_ROPE) {
+    const int bph = HD / 16, h = sb / bph, j = sb % bph;
+    wrow = h * HD + (i < 8 ? j * 8 + i : HD / 2 + j * 8 + (i - 8));
+  } else if (kind == EPI_GEGLU) {
+    wrow = i < 8 ? sb * 8 + i : N / 2 + sb * 8 + (i - 8);
+  } else {
+    wrow = sb * 16 + i;
+  }
+  *reinterpret_cast<bf16x8*>(out + idx * 8) = *reinterpret_cast<const bf16x8*>(W + (long long)wrow * K + ks * 32 + g * 8);
+}
+
 }  // namespace
 
 #define S_ ((hipStream_t)stream)
+
+extern "C" int lap_serve_pack_weight(const void* w, void* out, int N, int K, int kind, int HD, void* stream) {
+  if (!w || !out || w == out || N <= 0 || K <= 0 || (N & 15) || (K & 31) || kind < EPI_ROPE || kind > EPI_RESID) return LAP_ERR_ARG;
+  if (kind == EPI_ROPE && (HD < 16 || (HD & 15) || N % HD)) return LAP_ERR_ARG;
+  if (kind == EPI_GEGLU && (N & 31)) return LAP_ERR_ARG;
+  const long long n = (long long)N * K / 8;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_, (const bf16*)w, (bf16*)out, N, K, kind, HD);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
 
 extern "C" int lap_serve_qkv_rope(const void* x, const void* mod, int mod_ld, int rows_per_sample, const void* wqkv,
                                   const float* rope_table, void* q, void* k, void* v, int M, int D, int NH, int HD,

@@ -29,7 +29,18 @@ struct SkinnyP {
   const float* rope;    // ROPE: sin / cos f32 [M][HD/2][2] (lap_rope_table)
   int NH, HD;
   float q_scale;
+  // PK only (see pk_off): which of the block input / residual input / output are still row-major (the chain's first and last stage)
+  int x_rm, resid_rm, o_rm;
 };
+
+// ---- PK: fragment-packed layouts (round 4).  tools/probes/cu_pull.hip: a lane that loads its MFMA fragment straight from a
+// row-major matrix makes a wave instruction touch 16 rows x 64 B, and the CU's vector-memory path then delivers 37 GB/s whatever
+// the data's temperature (one tag lookup per 16 B); 1 KiB contiguous per wave instruction gets 130 GB/s out of the L2.  So the
+// chain keeps every operand in the order the MFMA wants it: a [16 rows x 32 k] tile is 64 lanes x 16 B = 1 KiB, lane = 16 g + i
+// holds row i, k = 8 g .. 8 g + 7; tiles of one row group are consecutive in k.  Weights are packed once per parameter version
+// (lap_serve_pack_weight, with the epilogue's row pairing folded in), activations are WRITTEN packed by the producing epilogue.
+// Same values, same summation order: bitwise equal to the row-major path.
+// (pk_off: common.hpp)
 
 __device__ __forceinline__ float sum4groups(float v) {   // over lanes {i, i+16, i+32, i+48}
   v += __shfl_xor(v, 16, 64);
@@ -82,7 +93,7 @@ constexpr int skinny_red_floats(int TT) { return SK_WAVES * TT * SK_TOK; }
 
 // ---- the weight stream of block column bx: which weight row feeds operand row i of feature tile f (sub-block sb = bx * FT + f).
 // Independent of every activation: the chain issues it BEFORE the barrier that guards the block input.
-template <int EPI, int KS, int FT, bool NT>
+template <int EPI, int KS, int FT, bool NT, bool PK = false>
 __device__ __forceinline__ void skinny_load_w(const SkinnyP& p, int bx, bf16x8 (&wf)[FT][KS]) {
   const int tid = opaque_tid();
   const int lane = tid & 63, w = tid >> 6;
@@ -92,6 +103,12 @@ __device__ __forceinline__ void skinny_load_w(const SkinnyP& p, int bx, bf16x8 (
 #pragma unroll
   for (int f = 0; f < FT; ++f) {
     const int sb = bx * FT + f;
+    if constexpr (PK) {      // tile (sb, k-step w KS + s): 1 KiB, this lane's 16 bytes at lane * 16
+      const unsigned woff = (unsigned)((((long long)sb * (p.K >> 5) + w * KS) * 64 + lane) * 16);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) wf[f][s] = ldw8<NT>(rsW, woff + s * 1024);
+      continue;
+    }
     int wrow;
     if (EPI == EPI_ROPE) {
       const int bph = p.HD / 16, h = sb / bph, j = sb % bph;
@@ -117,22 +134,27 @@ __device__ __forceinline__ void skinny_load_w(const SkinnyP& p, int bx, bf16x8 (
 // SHM: every token shares ONE modulation row (mod_ld == 0: the denoise step, where the condition is the step's time) — the
 // prologue then loads scale / shift once per k-slice instead of once per token tile (qkv: 256 -> 132 KB per block).
 // part: skinny_part_floats(FT, TT) floats of LDS, red: skinny_red_floats(TT).
-template <int EPI, bool NORM, int KS, int FT, int TT, bool SHM, bool COH>   // KS: 32-deep k-steps per wave (K = KS * 32 * SK_WAVES)
+template <int EPI, bool NORM, int KS, int FT, int TT, bool SHM, bool COH, bool PK = false>   // KS: 32-deep k-steps per wave (K = KS * 32 * SK_WAVES)
 __device__ __forceinline__ void skinny_rest(const SkinnyP& p, int bx, int by, bf16x8 (&wf)[FT][KS], float* part, float* red) {
   const int tid = opaque_tid();
   const int lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int k0 = w * (KS * 32) + g * 8;
-  const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)(((long long)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
+  const bool xpk = PK && !p.x_rm;       // (wave uniform) packed block input: [row tiles of 16][K / 32 k-steps][1 KiB]
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, xpk ? (unsigned)(((p.M + 15) >> 4) * p.K * 32) : (unsigned)(((long long)(p.M - 1) * p.ldx + p.K) * 2), 0x00020000);
+  const unsigned xstep = xpk ? 1024u : 64u;
   bf16x8 xf[TT][KS];
   constexpr int MT = NORM ? (SHM ? 1 : TT) : 1;
   bf16x8 sc[MT][NORM ? KS : 1], sh[MT][NORM ? KS : 1];
 #pragma unroll
   for (int t = 0; t < TT; ++t) {
     const int r = (by * TT + t) * SK_TOK + i;     // this lane's token row of tile t (MFMA column i)
-    const unsigned xoff = r < p.M ? (unsigned)(((long long)r * p.ldx + k0) * 2) : 0x80000000u;   // rows past M read as zeros
+    // rows past M read as zeros (row-major: out of range offset; packed: tiles past the last one are out of range, the pad rows of
+    // the last tile are never written and belong to columns of the product nobody stores)
+    const unsigned xoff = xpk ? (unsigned)((((long long)(by * TT + t) * (p.K >> 5) + w * KS) * 64 + lane) * 16)
+                              : (r < p.M ? (unsigned)(((long long)r * p.ldx + k0) * 2) : 0x80000000u);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xf[t][s] = ldx8<COH>(rsX, xoff + s * 64);
+    for (int s = 0; s < KS; ++s) xf[t][s] = ldx8<COH>(rsX, xoff + s * xstep);
     if (NORM && (!SHM || t == 0)) {
       const bf16* mrow = p.mod + (SHM ? 0 : (long long)((r < p.M ? r : 0) / p.rps) * p.mod_ld) + k0;
 #pragma unroll
@@ -206,7 +228,8 @@ __device__ __forceinline__ void skinny_rest(const SkinnyP& p, int bx, int by, bf
   if (r >= p.M) return;
   if (EPI == EPI_RESID) {
     const int c = sb * 16 + 4 * g;
-    const bf16x4 xr = ldx4<COH>(p.resid, (long long)r * p.N + c, (unsigned)((long long)p.M * p.N * 2));
+    const long long ro = PK && !p.resid_rm ? pk_off(r, c, p.N) : (long long)r * p.N + c;
+    const bf16x4 xr = ldx4<COH>(p.resid, ro, (unsigned)((long long)(PK && !p.resid_rm ? ((p.M + 15) & ~15) : p.M) * p.N * 2));
     bf16x4 o;
     if (p.gate) {
       const bf16x4 gt = *reinterpret_cast<const bf16x4*>(p.gate + (long long)(r / p.rps) * p.gate_ld + c);
@@ -216,14 +239,14 @@ __device__ __forceinline__ void skinny_rest(const SkinnyP& p, int bx, int by, bf
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = f2bf((float)xr[e] + v[e]);
     }
-    stx4<COH>(p.o0 + (long long)r * p.N + c, o);
+    stx4<COH>(p.o0 + (PK && !p.o_rm ? pk_off(r, c, p.N) : (long long)r * p.N + c), o);
   } else if (EPI == EPI_GEGLU) {
     if (g >= 2) return;        // lanes g = 0, 1 hold gate columns 4g .. 4g+3; their partners the matching up columns
     const int H = p.N / 2, c = sb * 8 + 4 * g;
     bf16x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = f2bf(round_bf16(gelu_tanh_f(v[e])) * pv[e]);
-    stx4<COH>(p.o0 + (long long)r * H + c, o);
+    stx4<COH>(p.o0 + (PK ? pk_off(r, c, H) : (long long)r * H + c), o);
   } else {   // EPI_ROPE
     const int HD = p.HD, half = HD / 2, bph = HD / 16, h = sb / bph, j = sb % bph;
     const int f0 = j * 8 + 4 * (g & 1);             // first of this lane's 4 frequencies
@@ -246,7 +269,9 @@ __device__ __forceinline__ void skinny_rest(const SkinnyP& p, int bx, int by, bf
       for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
     }
     const int d = (g < 2 ? 0 : half) + f0;
-    bf16* dst = h < p.NH ? p.o0 + (long long)r * p.NH * HD + h * HD : (h == p.NH ? p.o1 + (long long)r * HD : p.o2 + (long long)r * HD);
+    // (PK: the queries packed like every other MFMA operand of the chain; k / v stay row-major: they go to LDS as whole rows)
+    bf16* dst = h < p.NH ? (PK ? p.o0 + pk_off(r, h * HD + d, p.NH * HD) - d : p.o0 + (long long)r * p.NH * HD + h * HD)
+                         : (h == p.NH ? p.o1 + (long long)r * HD : p.o2 + (long long)r * HD);
     stx4<COH>(dst + d, o);
   }
 }

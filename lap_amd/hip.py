@@ -69,6 +69,7 @@ class ServeChainArgs(C.Structure):
         ("q", _vp), ("k", _vp), ("v", _vp), ("o", _vp), ("xa", _vp), ("act", _vp),
         ("attn_scratch", _vp), ("attn_scratch_floats", _ll),
         ("counters", _vp), ("debug_clock", _vp),
+        ("packed", _i), ("xs", _vp),
     ]
 
 
@@ -159,6 +160,7 @@ SIGNATURES: dict[str, list] = {
     "lap_serve_chain_counter_words": [],
     "lap_serve_chain_status": [_vp, C.POINTER(_i)],
     "lap_serve_chain": [C.POINTER(ServeChainArgs), _vp],
+    "lap_serve_pack_weight": [_vp, _vp, _i, _i, _i, _i, _vp],
     "lap_serve_final_euler": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
     "lap_ce_chunk_update": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_ce_chunk_grad": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -889,10 +891,34 @@ def serve_chain_failed(counters: torch.Tensor) -> bool:
     return bool(st.value)
 
 
+PACK_QKV, PACK_GATE_UP, PACK_PLAIN = 1, 2, 3     # lap_serve_pack_weight kinds (= the skinny kernels' epilogue ids)
+
+
+def serve_pack_weight(w, kind: int, HD: int = 0, out=None):
+    """Fragment-packed image of a K-contiguous bf16 weight [N, K] for the packed chain (include/lap_hip.h: lap_serve_pack_weight)."""
+    _req(w, torch.bfloat16, "w")
+    N, K = w.shape
+    if not w.is_contiguous():
+        raise ValueError("serve_pack_weight: w must be contiguous")
+    if out is None:
+        out = torch.empty_like(w)
+    call("lap_serve_pack_weight", _p(w), _p(out), N, K, kind, HD)
+    return out
+
+
+def serve_chain_scratch(device, D, H, NH, HD) -> dict:
+    """The packed chain's activation buffers (64 rows each, zero: the pad rows are never written).  Allocate ONCE per sampler,
+    outside stream capture; a launch may be replayed from a graph that holds these addresses."""
+    z = lambda cols: torch.zeros((64, cols), dtype=torch.bfloat16, device=device)
+    return dict(q=z(NH * HD), o=z(NH * HD), xa=z(D), act=z(H), xs=z(D))
+
+
 def serve_chain(x_in, mod, slot_stride, weights, caches, rope_table, qinfo, kinfo, B, S, NH, HD, H, prefix_len, q_scale, counters,
-                eps=1e-6, debug_clock=None, keep=None):
+                eps=1e-6, debug_clock=None, keep=None, packed_scratch=None):
     """All action-expert layers of one denoise step in one persistent launch (include/lap_hip.h: lap_serve_chain).
-    weights: per layer (wqkv, wo, wgu, wd); caches: per layer (k, v) of the prefix.  Returns the residual stream [B*S, D]."""
+    weights: per layer (wqkv, wo, wgu, wd); caches: per layer (k, v) of the prefix.  Returns the residual stream [B*S, D].
+    `packed_scratch` (serve_chain_scratch): the weights are lap_serve_pack_weight images and the activations between the stages are
+    fragment-packed too (same bits, every operand load 1 KiB contiguous per wave instruction)."""
     M, D = x_in.shape
     dev = x_in.device
     depth = len(weights)
@@ -908,8 +934,15 @@ def serve_chain(x_in, mod, slot_stride, weights, caches, rope_table, qinfo, kinf
     a.rope_table, a.qinfo, a.kinfo = _p(rope_table), _p(qinfo), _p(kinfo)
     a.q_scale, a.eps = float(q_scale), float(eps)
     bf = dict(dtype=torch.bfloat16, device=dev)
-    q, k, v, o = torch.empty((M, NH * HD), **bf), torch.empty((M, HD), **bf), torch.empty((M, HD), **bf), torch.empty((M, NH * HD), **bf)
-    xa, act = torch.empty((M, D), **bf), torch.empty((M, H), **bf)
+    k, v = torch.empty((M, HD), **bf), torch.empty((M, HD), **bf)
+    if packed_scratch is not None:
+        ps = packed_scratch
+        q, o, xa, act = ps["q"], ps["o"], ps["xa"], ps["act"]
+        a.packed, a.xs = 1, _p(ps["xs"])
+    else:
+        q, o = torch.empty((M, NH * HD), **bf), torch.empty((M, NH * HD), **bf)
+        xa, act = torch.empty((M, D), **bf), torch.empty((M, H), **bf)
+        a.packed, a.xs = 0, None
     ns = _fn["lap_attention_serve_splits"](prefix_len, S)
     scratch = torch.empty(ns * M * NH * (HD + 1), dtype=torch.float32, device=dev)
     a.q, a.k, a.v, a.o, a.xa, a.act = _p(q), _p(k), _p(v), _p(o), _p(xa), _p(act)

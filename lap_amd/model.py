@@ -93,7 +93,12 @@ class LAP:
         # the 18 action-expert layers of a denoise step as ONE persistent launch (csrc/serve_chain.hpp) instead of 6 launches per
         # layer; bitwise equal to them.  LAP_SERVE_CHAIN=0: the separate launches (A/B runs, tests).
         self.serve_chain = os.environ.get("LAP_SERVE_CHAIN", "1") != "0"
+        # ... on fragment-packed operands (round 4: every operand load 1 KiB contiguous per wave instruction; same bits).
+        # LAP_SERVE_PACKED=0: the row-major chain of round 3 (A/B runs, tests)
+        self.serve_packed = os.environ.get("LAP_SERVE_PACKED", "1") != "0"
         self._chain_ctr = None
+        self._chain_scratch = None
+        self._packed_w = None       # [version, per layer (wqkv, wo, wgu, wd) packed images]
         self._den = None
         ks = os.environ.get("LAP_PREFILL_KS", "4,1,8,5").split(",")    # K splits of the prefill's qkv / out / down projections, down's tile
         self._prefill_ks = tuple(int(k) for k in ks)
@@ -1106,13 +1111,19 @@ class LAP:
                 self._chain_ctr = hip.serve_chain_counters(dev)
             for l in range(self.v.depth):
                 self.comm.wait_unit(f"llm{l}")
-            chain_w = [tuple(self.W(f"llm/{l}/{n}") for n in ("wqkv1", "wo1", "wgu1", "wd1")) for l in range(self.v.depth)]
+            if self.serve_packed:
+                chain_w = self._serve_packed_weights()
+                if self._chain_scratch is None:
+                    self._chain_scratch = hip.serve_chain_scratch(dev, self.e.width, self.e.mlp_dim, self.v.num_heads, self.v.head_dim)
+            else:
+                chain_w = [tuple(self.W(f"llm/{l}/{n}") for n in ("wqkv1", "wo1", "wgu1", "wd1")) for l in range(self.v.depth)]
         for step in range(len(times)):
             mod = mods[step:step + 1]
             if chain:
                 x1 = hip.serve_embed_actions(x_t.view(B * S, ad), self.F("act/in_w"), self.F("act/in_b"))
                 xf1 = hip.serve_chain(x1, mod, 3 * self.e.width, chain_w, cache, rope_tab, qinfo_s, kinfo_all, B, S, self.v.num_heads,
-                                      self.v.head_dim, self.e.mlp_dim, Pn, self.v.head_dim ** -0.5, self._chain_ctr)
+                                      self.v.head_dim, self.e.mlp_dim, Pn, self.v.head_dim ** -0.5, self._chain_ctr,
+                                      packed_scratch=self._chain_scratch if self.serve_packed else None)
                 v_t = torch.empty((B * S, ad), dtype=torch.float32, device=dev) if collect is not None else None
                 hip.serve_final_euler(xf1, self._mod_slot(mod, nslot), 0, S, self.F("act/out_w"), self.F("act/out_b"), x_t.view(B * S, ad), dt, v_t)
                 if collect is not None:
@@ -1158,16 +1169,59 @@ class LAP:
             self._chain_ctr.zero_()
 
     def _serve_mods(self, nsteps: int, dt: float):
-        """adaRMS modulations of the denoise time grid t_k = 1 + k dt (lap.py:655-660 through `_time_mod`), cached per
-        (nsteps, parameter version).  Never filled during stream capture: the tensor must outlive the graph's replays."""
-        key = (nsteps, float(dt), self.ps.version)
+        """adaRMS modulations of the denoise time grid t_k = 1 + k dt (lap.py:655-660 through `_time_mod`), one PERSISTENT tensor
+        per (nsteps, dt), refreshed IN PLACE when the parameters change: a captured sampler holds its address (ADVICE r3 — a
+        cache that dropped the tensor on a version change left a replayed graph reading freed memory and stale modulations).
+        `GraphedSampler.__call__` calls `refresh_serve_caches` before every replay; never refreshed during stream capture."""
+        key = (nsteps, float(dt))
         ent = self.__dict__.setdefault("_mods_cache", {})
-        if key not in ent:
-            ent.clear()
+        rec = ent.get(key)
+        if rec is None or rec[0] != self.ps.version:
+            if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("serving caches are stale inside a stream capture: call refresh_serve_caches() first")
             tvec = 1.0 + dt * torch.arange(nsteps, dtype=torch.float32, device=self.device)
             self.comm.wait_unit("ada")
-            ent[key] = self._time_mod(tvec, False)[0]
-        return ent[key]
+            new = self._time_mod(tvec, False)[0]
+            if rec is None:
+                ent[key] = rec = [self.ps.version, new]
+            else:
+                rec[1].copy_(new)
+                rec[0] = self.ps.version
+        return rec[1]
+
+    def _serve_packed_weights(self):
+        """Fragment-packed images of the action expert's projections for the packed chain (csrc/serve_skinny_body.hpp PK),
+        persistent like `_serve_mods` and re-packed in place per parameter version (+0.62 GB for LAP-3B)."""
+        rec = self._packed_w
+        if rec is not None and rec[0] == self.ps.version:
+            return rec[1]
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("serving caches are stale inside a stream capture: call refresh_serve_caches() first")
+        kinds = (("wqkv1", hip.PACK_QKV), ("wo1", hip.PACK_PLAIN), ("wgu1", hip.PACK_GATE_UP), ("wd1", hip.PACK_PLAIN))
+        old = rec[1] if rec is not None else None
+        out = []
+        for l in range(self.v.depth):
+            self.comm.wait_unit(f"llm{l}")
+            out.append(tuple(hip.serve_pack_weight(self.W(f"llm/{l}/{n}"), kind, self.v.head_dim, out=None if old is None else old[l][j])
+                             for j, (n, kind) in enumerate(kinds)))
+        self._packed_w = [self.ps.version, out]
+        return out
+
+    def _time_grid(self, num_steps: int):
+        dt = -1.0 / num_steps
+        n, t = 0, 1.0
+        while t >= -dt / 2:  # lap.py:669-674 loop condition
+            n += 1
+            t += dt
+        return n, dt
+
+    def refresh_serve_caches(self, num_steps: int = 10):
+        """Bring the sampler's parameter-derived caches (adaRMS modulations, packed expert weights) up to the current parameter
+        version, in place.  Eager `sample_actions` does this itself; a captured graph cannot — call it before a replay."""
+        n, dt = self._time_grid(num_steps)
+        self._serve_mods(n, dt)
+        if self._packed_w is not None:
+            self._serve_packed_weights()
 
     EOS_TOKEN = 1   # PaliGemma <eos> (lap.py: self.EOS_TOKEN)
 

@@ -63,6 +63,9 @@ class GraphedSampler:
     def __call__(self, obs: CoTObservation, noise: torch.Tensor) -> torch.Tensor:
         if self.graph is None:
             self.capture()
+        # parameter-derived caches the graph holds addresses of (adaRMS modulations, packed expert weights) follow the
+        # parameters in place; a no-op unless a train step / restore / reload happened since the last call
+        self.model.refresh_serve_caches(self.num_steps)
         self._load(obs, noise)
         self.graph.replay()
         return self.out

@@ -1185,6 +1185,46 @@ def test_serve_chain_equals_the_separate_launches_bitwise(hip, S, Tp, depth, npa
     torch.cuda.current_stream().wait_stream(st)
     torch.cuda.synchronize()
     assert torch.equal(outg, ref) and not hip.serve_chain_failed(ctr)
+    # the packed form (round 4: weights as lap_serve_pack_weight images, activations between the stages fragment-packed): same
+    # arithmetic in the same order, so the same bits — eagerly (twice: the scratch is reused) and replayed from a graph
+    Wp = [(hip.serve_pack_weight(wqkv, hip.PACK_QKV, HD), hip.serve_pack_weight(wo, hip.PACK_PLAIN), hip.serve_pack_weight(wgu, hip.PACK_GATE_UP),
+           hip.serve_pack_weight(wd, hip.PACK_PLAIN)) for wqkv, wo, wgu, wd in W]
+    sc = hip.serve_chain_scratch(DEV, D, H, NH, HD)
+    for it in range(3):
+        out = hip.serve_chain(x, mod, 3 * D, Wp, cache, tab, qinfo, kinfo, B, S, NH, HD, H, Tp, HD ** -0.5, ctr, packed_scratch=sc)
+        assert torch.equal(out, ref), ("packed", it, (out.float() - ref.float()).abs().max().item())
+    g2 = torch.cuda.CUDAGraph()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g2, stream=st):
+            outp = hip.serve_chain(x, mod, 3 * D, Wp, cache, tab, qinfo, kinfo, B, S, NH, HD, H, Tp, HD ** -0.5, ctr, packed_scratch=sc)
+        for _ in range(3):
+            g2.replay()
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    assert torch.equal(outp, ref) and not hip.serve_chain_failed(ctr) and int(ctr.abs().sum()) == 0
+
+
+def test_serve_pack_weight_layout(hip):
+    """lap_serve_pack_weight against the layout it documents (include/lap_hip.h): tile (sb, ks) is 1 KiB, lane 16 g + i holds
+    k = 32 ks + 8 g .. + 7 of operand row i, with the qkv rotation pairing / gate|up pairing folded into the row map."""
+    HD = 256
+    for kind, N, K in ((hip.PACK_PLAIN, 1024, 2048), (hip.PACK_GATE_UP, 8192, 1024), (hip.PACK_QKV, 2560, 1024)):
+        w = rnd(N, K, seed=kind)
+        got = hip.serve_pack_weight(w, kind, HD).view(N // 16, K // 32, 4, 16, 8)      # [sb][ks][g][i][e]
+        sb = torch.arange(N // 16, device=DEV).view(-1, 1)
+        i = torch.arange(16, device=DEV).view(1, -1)
+        if kind == hip.PACK_PLAIN:
+            rows = sb * 16 + i
+        elif kind == hip.PACK_GATE_UP:
+            rows = torch.where(i < 8, sb * 8 + i, N // 2 + sb * 8 + i - 8)
+        else:
+            h, j = sb // (HD // 16), sb % (HD // 16)
+            rows = h * HD + torch.where(i < 8, j * 8 + i, HD // 2 + j * 8 + i - 8)
+        want = w[rows.reshape(-1)].view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4)
+        assert torch.equal(got, want), kind
+    with pytest.raises(hip.LapHipError):
+        hip.serve_pack_weight(rnd(1000, 1024), hip.PACK_PLAIN)
 
 
 # ------------------------------------------------------------------ fp8 GEMM path (BASELINE config 5)

@@ -8,7 +8,8 @@ DEV = "cuda"
 def rnd(*shape, scale=1.0, seed=0, dtype=torch.bfloat16):
     g = torch.Generator(device="cpu").manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
-B, S, Tp, depth, D, NH, HD, H = 1, 50, 816, 18, 1024, 8, 256, 4096
+B, S, Tp, depth, D, NH, HD, H = 1, 50, int(os.environ.get('TP', 560)), 18, 1024, 8, 256, 4096
+PACKED = os.environ.get('PACKED', '1') != '0'
 M = S
 x = rnd(M, D, seed=1)
 mod = rnd(1, (2 * depth + 1) * 3 * D, scale=0.3, seed=2)
@@ -21,14 +22,18 @@ kinfo = torch.full((B, Tp + S), 3 << 24, dtype=torch.int32, device=DEV); kinfo[:
 qinfo = torch.full((B, S), (6 << 24) | 0x800001, dtype=torch.int32, device=DEV)
 ctr = hip.serve_chain_counters(DEV)
 clk = torch.zeros(8192, dtype=torch.int64, device=DEV)
-run = lambda dbg: hip.serve_chain(x, mod, 3 * D, W, cache, tab, qinfo, kinfo, B, S, NH, HD, H, Tp, HD ** -0.5, ctr, debug_clock=dbg)
+if PACKED:
+    W = [(hip.serve_pack_weight(a, hip.PACK_QKV, HD), hip.serve_pack_weight(b, hip.PACK_PLAIN), hip.serve_pack_weight(c, hip.PACK_GATE_UP),
+          hip.serve_pack_weight(d, hip.PACK_PLAIN)) for a, b, c, d in W]
+sc = hip.serve_chain_scratch(DEV, D, H, NH, HD) if PACKED else None
+run = lambda dbg: hip.serve_chain(x, mod, 3 * D, W, cache, tab, qinfo, kinfo, B, S, NH, HD, H, Tp, HD ** -0.5, ctr, debug_clock=dbg, packed_scratch=sc)
 for _ in range(3): run(None)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(20): run(None)
 e1.record(); torch.cuda.synchronize()
-print(f"chain launch: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us for {depth} layers = {e0.elapsed_time(e1) / 20 * 1e3 / depth:.2f} us per layer; failed={hip.serve_chain_failed(ctr)}")
+print(f"packed={int(PACKED)} Tp={Tp} chain launch: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us for {depth} layers = {e0.elapsed_time(e1) / 20 * 1e3 / depth:.2f} us per layer; failed={hip.serve_chain_failed(ctr)}")
 run(clk); torch.cuda.synchronize()
 names = ["qkv", "attn+comb", "out", "gateup", "down"]
 NS = len(names)
