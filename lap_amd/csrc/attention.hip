@@ -762,9 +762,11 @@ extern "C" int lap_attention_fwd(const lap_attn_fwd_args* a, void* stream) {
   return LAP_ERR_ARG;
 }
 
-extern "C" int lap_attention_serve_splits(int k_len0, int k_len1) {
-  if (k_len0 < 0 || k_len1 < 0 || k_len0 + k_len1 == 0) return 0;
-  return serve_splits(k_len0, k_len1).nsplit;
+extern "C" int lap_attention_serve_splits(int k_len0, int k_len1, int B, int NH, int q_len1) {
+  if (k_len0 < 0 || k_len1 < 0 || k_len0 + k_len1 == 0 || B <= 0 || NH <= 0 || q_len1 <= 0) return 0;
+  int cap = serve_run_cap(B, NH, q_len1);      // the persistent chain's rule: same key runs, same bits
+  if (serve_runs(k_len0, k_len1, cap).nruns < 1) cap = (k_len0 + SV_KEYS - 1) / SV_KEYS + (k_len1 + SV_KEYS - 1) / SV_KEYS;
+  return cap <= SV_MAX_RUNS ? cap : 0;
 }
 
 extern "C" int lap_attention_serve(const lap_attn_fwd_args* a, void* stream) {
@@ -829,15 +831,15 @@ extern "C" int lap_serve_chain(const lap_serve_chain_args* a, void* stream) {
     c.wqkv[l] = (const bf16*)a->wqkv[l]; c.wo[l] = (const bf16*)a->wo[l]; c.wgu[l] = (const bf16*)a->wgu[l]; c.wd[l] = (const bf16*)a->wd[l];
     c.ck[l] = (const bf16*)a->cache_k[l]; c.cv[l] = (const bf16*)a->cache_v[l];
   }
-  c.sp = serve_splits(a->prefix_len, a->S);
-  const long long need = (long long)c.sp.nsplit * M * a->NH * (a->HD + 1);
+  c.sr = serve_runs(a->prefix_len, a->S, serve_run_cap(a->B, a->NH, a->S));
+  const long long need = (long long)c.sr.nruns * M * a->NH * (a->HD + 1);
   if (a->attn_scratch_floats < need) return LAP_ERR_ARG;
   AttnP& p = c.attn;
   p.qlen[0] = 0; p.qlen[1] = a->S; p.klen[0] = a->prefix_len; p.klen[1] = a->S;
   p.q_rs[0] = p.q_rs[1] = a->NH * a->HD; p.o_rs[0] = p.o_rs[1] = a->NH * a->HD; p.kv_rs[0] = kv_rs; p.kv_rs[1] = a->HD;
   p.qinfo = a->qinfo; p.kinfo = a->kinfo; p.scale = 1.0f;       // (q carries head_dim^-0.5 from the qkv stage, gemma.py:216)
-  p.B = a->B; p.NH = a->NH; p.NKV = 1; p.nsplit = c.sp.nsplit; p.hsplit = 1;
-  p.part = a->attn_scratch; p.lpart = a->attn_scratch + (long long)c.sp.nsplit * M * a->NH * a->HD;
+  p.B = a->B; p.NH = a->NH; p.NKV = 1; p.nsplit = c.sr.nruns; p.hsplit = 1;
+  p.part = a->attn_scratch; p.lpart = a->attn_scratch + (long long)c.sr.nruns * M * a->NH * a->HD;
   c.rope = a->rope_table; c.q_scale = a->q_scale; c.eps = a->eps;
   c.q = (bf16*)a->q; c.k = (bf16*)a->k; c.v = (bf16*)a->v; c.o = (bf16*)a->o; c.xa = (bf16*)a->xa; c.act = (bf16*)a->act;
   c.xs = (bf16*)a->xs;

@@ -2,8 +2,8 @@
 // active and a KV cache): the six launches per layer of the stand-alone path (serve_skinny.hip, attention_serve.hpp) become five
 // STAGES of one persistent kernel — 256 blocks, one per CU, all resident — separated by a software grid barrier:
 //
-//   [adaRMS + qkv + RoPE/split] | attention over [cache | fresh keys], split over key runs, + combine of the splits (the runs
-//   of one head meet at a counter of their own) | [out projection + gated residual] | [adaRMS + gate|up + GeGLU] |
+//   [adaRMS + qkv + RoPE/split] | attention over [cache | fresh keys], one (key run, query tile, head) per block, + combine of the
+//   runs (the runs of one (head, query tile) meet at a counter of their own) | [out projection + gated residual] | [adaRMS + gate|up + GeGLU] |
 //   [down projection + gated residual]
 //
 // Why it pays now (it did not in round 2, docs/EXPERIMENTS.md): the barrier used to cost 6.5-11 us because agent-scope release /
@@ -28,7 +28,7 @@
 constexpr int CH_MAX_DEPTH = 32;
 constexpr int CH_GROUPS = 8;             // arrival groups = XCDs (block id % 8)
 constexpr int CH_CTR_STRIDE = 64;        // counters 256 B apart
-constexpr int CH_CTR_EXIT = 9, CH_CTR_ERR = 10, CH_CTR_HEAD = 11, CH_MAX_HEADS = 64;    // HEAD: one counter per (sample, head), see the attention stage
+constexpr int CH_CTR_EXIT = 9, CH_CTR_ERR = 10, CH_CTR_HEAD = 11, CH_MAX_HEADS = 64;    // HEAD: one counter per (sample, head, query tile), see the attention stage
 constexpr int CH_CTR_WORDS = (CH_CTR_HEAD + CH_MAX_HEADS) * CH_CTR_STRIDE;
 constexpr int CH_BLOCKS = 256;
 
@@ -40,7 +40,7 @@ struct ChainP {
   const bf16* wqkv[CH_MAX_DEPTH]; const bf16* wo[CH_MAX_DEPTH]; const bf16* wgu[CH_MAX_DEPTH]; const bf16* wd[CH_MAX_DEPTH];
   const bf16* ck[CH_MAX_DEPTH]; const bf16* cv[CH_MAX_DEPTH];
   AttnP attn;                            // everything but the per-layer cache pointers
-  ServeSplits sp;
+  ServeRuns sr;
   const float* rope;
   float q_scale, eps;
   bf16 *q, *k, *v, *o, *xa, *act;        // activations between the stages
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void serve_chain_kernel(ChainP c) {
   const int tg32 = (c.M + 31) / 32, tg16 = (c.M + 15) / 16;
   const int fgQ = (c.NH + 2) * c.HD / 32, fgO = c.D / 16, fgG = c.H / 32;
   const int nQ = fgQ * tg32, nO = fgO * tg16, nG = fgG * tg32;
-  const int ns = c.sp.nsplit, nA = ns * c.NH * c.attn.B;
+  const int ns = c.sr.nruns, QT = (c.rps + 15) / 16, nA = ns * QT * c.NH * c.attn.B;     // attention blocks: (run, query tile, head, sample)
   const int QKV = c.NH * c.HD;
 
   SkinnyP pq = {}, po = {}, pg = {}, pd = {};
@@ -136,20 +136,23 @@ __global__ __launch_bounds__(512) void serve_chain_kernel(ChainP c) {
     CH_STAMP();
     chain_arrive(c.ctrs, round, nb);
     ap.k[0] = c.ck[l]; ap.v[0] = c.cv[l];     // the cached keys / values of the block's run: on their way into LDS during the barrier
-    if (vb < nA) attn_serve_body<true, 1, PK>(ap, c.sp, vb % ns, (vb / ns) % c.NH, vb / (ns * c.NH), smem);
+    if (vb < nA) attn_run_body<true, 1, PK>(ap, c.sr, vb % ns, (vb / ns) % QT, (vb / (ns * QT)) % c.NH, vb / (ns * QT * c.NH), smem);
     chain_wait(c.ctrs, round);
     CH_STAMP();
     // ---- attention of the action queries over [cached prefix | fresh keys], one key run per block
     if (vb < nA) {
-      const int sI = vb % ns, hI = (vb / ns) % c.NH, bI = vb / (ns * c.NH);
-      attn_serve_body<true, 2, PK>(ap, c.sp, sI, hI, bI, smem);
-      // ---- combine of the key runs: only the `ns` blocks of one (sample, head) depend on each other, so they meet at a counter
-      // of their own instead of a grid barrier (7 arrivals instead of 256), and each merges its share of the head's rows
+      const int sI = vb % ns, qI = (vb / ns) % QT, hI = (vb / (ns * QT)) % c.NH, bI = vb / (ns * QT * c.NH);
+      unsigned long long* tclk = c.clk && (vb == 0 || vb == nb - 1) ? c.clk + (vb ? 6144 : 2048) + 8 * l : nullptr;
+      if (tclk && threadIdx.x == 0) tclk[7] = wall_clock64();
+      attn_run_body<true, 2, PK>(ap, c.sr, sI, qI, hI, bI, smem, tclk);
+      // ---- combine of the key runs: only the `ns` blocks of one (sample, head, query tile) depend on each other, so they meet at
+      // a counter of their own instead of a grid barrier (7 arrivals instead of 256), and each merges its share of the tile's rows
       __builtin_amdgcn_s_waitcnt(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      if (tclk && threadIdx.x == 0) tclk[3] = wall_clock64();
       if (threadIdx.x == 0) {
-        unsigned* hc = c.ctrs + CH_CTR_STRIDE * (CH_CTR_HEAD + bI * c.NH + hI);
+        unsigned* hc = c.ctrs + CH_CTR_STRIDE * (CH_CTR_HEAD + (bI * c.NH + hI) * QT + qI);
         (void)__hip_atomic_fetch_add(hc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = (unsigned)(l + 1) * (unsigned)ns;
         unsigned spins = 0;
@@ -161,10 +164,11 @@ __global__ __launch_bounds__(512) void serve_chain_kernel(ChainP c) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const int per_head = c.rps * (c.HD / 4);                       // 4-column items of this (sample, head): row t, columns 4 j ..
-      for (int it = sI * 512 + (int)threadIdx.x; it < per_head; it += ns * 512) {
-        const int t = it / (c.HD / 4), j = it % (c.HD / 4);
-        attn_serve_combine_body<NS, true, PK>(ap, (((long long)bI * c.rps + t) * c.NH + hI) * (c.HD / 4) + j);
+      if (tclk && threadIdx.x == 0) tclk[4] = wall_clock64();
+      const int per_tile = 16 * (c.HD / 4);                          // 4-column items of this (sample, head, tile): row t, columns 4 j ..
+      for (int it = sI * 512 + (int)threadIdx.x; it < per_tile; it += ns * 512) {
+        const int t = qI * 16 + it / (c.HD / 4), j = it % (c.HD / 4);
+        if (t < c.rps) attn_serve_combine_body<NS, true, PK>(ap, (((long long)bI * c.rps + t) * c.NH + hI) * (c.HD / 4) + j);
       }
     }
     CH_STAMP();
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(512) void serve_chain_kernel(ChainP c) {
     const unsigned old = __hip_atomic_fetch_add(c.ctrs + CH_CTR_STRIDE * CH_CTR_EXIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == (unsigned)nb - 1) {
       for (int j = 0; j <= CH_GROUPS; ++j) __hip_atomic_store(c.ctrs + CH_CTR_STRIDE * j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int j = 0; j < c.attn.B * c.NH; ++j)
+      for (int j = 0; j < c.attn.B * c.NH * QT; ++j)
         __hip_atomic_store(c.ctrs + CH_CTR_STRIDE * (CH_CTR_HEAD + j), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(c.ctrs + CH_CTR_STRIDE * CH_CTR_EXIT, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -229,8 +233,9 @@ inline bool chain_ok(int B, int S, int D, int H, int NH, int HD, int NKV, int pr
   if (B < 1 || S < 1 || D != 1024 || HD != 256 || NH * HD != 2048 || H != 4096 || NKV != 1 || prefix_len < 0) return false;
   const int M = B * S;
   if (S > 64 || M > 64) return false;
-  const ServeSplits sp = serve_splits(prefix_len, S);
-  return sp.nsplit >= 1 && sp.nsplit <= 16 && sp.nsplit * NH * B <= CH_BLOCKS && B * NH <= CH_MAX_HEADS;
+  const int QT = (S + 15) / 16;
+  const ServeRuns sr = serve_runs(prefix_len, S, serve_run_cap(B, NH, S));
+  return sr.nruns >= 1 && sr.nruns <= 8 && sr.nruns * QT * NH * B <= CH_BLOCKS && B * NH * QT <= CH_MAX_HEADS;
 }
 
 // The CURRENT device can hold the chain's 256 blocks at once (one per CU; the kernel's LDS footprint admits one block per CU).
@@ -252,16 +257,12 @@ int launch_chain(const ChainP& c, bool packed, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
     if (int e = set_lds(serve_chain_kernel<8, false>, SV_LDS)) return e;
-    if (int e = set_lds(serve_chain_kernel<16, false>, SV_LDS)) return e;
     if (int e = set_lds(serve_chain_kernel<8, true>, SV_LDS)) return e;
-    if (int e = set_lds(serve_chain_kernel<16, true>, SV_LDS)) return e;
     attr = true;
   }
-  if (packed) {
-    if (c.sp.nsplit <= 8) hipLaunchKernelGGL((serve_chain_kernel<8, true>), dim3(CH_BLOCKS), dim3(512), SV_LDS, s, c);
-    else hipLaunchKernelGGL((serve_chain_kernel<16, true>), dim3(CH_BLOCKS), dim3(512), SV_LDS, s, c);
-  } else if (c.sp.nsplit <= 8) hipLaunchKernelGGL((serve_chain_kernel<8, false>), dim3(CH_BLOCKS), dim3(512), SV_LDS, s, c);
-  else hipLaunchKernelGGL((serve_chain_kernel<16, false>), dim3(CH_BLOCKS), dim3(512), SV_LDS, s, c);
+  if (c.sr.nruns < 1 || c.sr.nruns > 8) return LAP_ERR_ARG;
+  if (packed) hipLaunchKernelGGL((serve_chain_kernel<8, true>), dim3(CH_BLOCKS), dim3(512), SV_LDS, s, c);
+  else hipLaunchKernelGGL((serve_chain_kernel<8, false>), dim3(CH_BLOCKS), dim3(512), SV_LDS, s, c);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

@@ -141,7 +141,7 @@ SIGNATURES: dict[str, list] = {
     "lap_add_posemb_cast": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_add_posemb_cast_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],
-    "lap_attention_serve_splits": [_i, _i],
+    "lap_attention_serve_splits": [_i, _i, _i, _i, _i],
     "lap_attention_serve": [C.POINTER(AttnFwdArgs), _vp],
     "lap_attention_bwd": [C.POINTER(AttnBwdArgs), _vp],
     "lap_attention_set_variant": [_i],
@@ -621,7 +621,7 @@ def attention_fwd(q, k, v, q_len, k_len, B, NH, NKV, HD, qinfo=None, kinfo=None,
     a.B, a.NH, a.NKV, a.HD = B, NH, NKV, HD
     # batch-1 denoise step: a handful of suffix queries against [KV cache | fresh keys] -> the load-everything-up-front kernel
     if _SERVE_ATTN and HD == 256 and a.q_len[0] == 0 and 0 < a.q_len[1] <= 64 and not need_lse and nsplit_hint is None and scale > 0:
-        ns = _fn["lap_attention_serve_splits"](a.k_len[0], a.k_len[1])
+        ns = _fn["lap_attention_serve_splits"](a.k_len[0], a.k_len[1], B, NH, a.q_len[1])
         if 0 < ns <= 16:
             a.nsplit = ns
             scratch = torch.empty(ns * B * Tq * NH * (HD + 1), dtype=torch.float32, device=dev)
@@ -943,7 +943,7 @@ def serve_chain(x_in, mod, slot_stride, weights, caches, rope_table, qinfo, kinf
         q, o = torch.empty((M, NH * HD), **bf), torch.empty((M, NH * HD), **bf)
         xa, act = torch.empty((M, D), **bf), torch.empty((M, H), **bf)
         a.packed, a.xs = 0, None
-    ns = _fn["lap_attention_serve_splits"](prefix_len, S)
+    ns = _fn["lap_attention_serve_splits"](prefix_len, S, B, NH, S)
     scratch = torch.empty(ns * M * NH * (HD + 1), dtype=torch.float32, device=dev)
     a.q, a.k, a.v, a.o, a.xa, a.act = _p(q), _p(k), _p(v), _p(o), _p(xa), _p(act)
     a.attn_scratch, a.attn_scratch_floats, a.counters = _p(scratch), scratch.numel(), _p(counters)

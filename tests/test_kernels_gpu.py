@@ -904,11 +904,11 @@ def test_attention_suffix_only_queries(hip):
 
 
 @pytest.mark.parametrize("B,NH,NKV,Tp,S,npad", [
-    (1, 8, 1, 560, 50, 0),      # the denoise step: 4 full splits + one of 48 | 50 rows
+    (1, 8, 1, 560, 50, 0),      # the denoise step: 7 prefix runs of 80 keys + the fresh keys, 4 query tiles
     (1, 8, 1, 560, 50, 9),      # ... with a padded prompt tail (masked keys inside the last prefix run)
-    (2, 8, 1, 256, 16, 3),      # prefix = whole splits: the fresh keys get a split of their own
-    (2, 4, 2, 100, 40, 0),      # 100 + 40 rows do not fit one split: [100] [40]; grouped kv heads
-    (3, 8, 1, 77, 1, 5),        # single-token decode (odd prefix length: the fresh key starts at the next even row)
+    (2, 8, 1, 256, 16, 3),      # two samples: 7 prefix runs of 48 keys (the last one short)
+    (2, 4, 2, 100, 40, 0),      # grouped kv heads, three query tiles
+    (3, 8, 1, 77, 1, 5),        # single-token decode (odd prefix length, runs of 16 keys)
     (1, 8, 8, 130, 64, 0),      # 64 queries, one kv head per query head
 ])
 def test_attention_serve_kernel_matches_reference_and_generic_path(hip, monkeypatch, B, NH, NKV, Tp, S, npad):
@@ -946,6 +946,34 @@ def test_attention_serve_kernel_matches_reference_and_generic_path(hip, monkeypa
     (_, o4), _ = hip.attention_fwd([None, q1], [k0s, k1], [v0s, v1], [0, S], [Tp, S], B, NH, NKV, HD, qinfo, kinfo, need_lse=False,
                                    kv_rs=(2 * NKV * HD, 0))
     assert torch.equal(o4, o1)
+
+
+@pytest.mark.parametrize("B,NH,Tp,Sq,Sk", [
+    (2, 8, 77, 1, 5),        # single-token decode, a few generated keys (lap.py:734-752 through LAP._vlm_decode_step)
+    (1, 8, 300, 1, 200),     # ... many of them: the fresh keys need two runs
+    (2, 8, 0, 3, 40),        # no cached prefix
+    (1, 8, 560, 50, 50),     # the denoise step for reference
+])
+def test_attention_serve_fresh_keys_need_not_match_queries(hip, monkeypatch, B, NH, Tp, Sq, Sk):
+    """lap_attention_serve with k_len[1] != q_len[1]: every fresh key is visible (the round-3 kernel took q_len[1] for the number
+    of fresh keys: a decode step saw only the first generated key).  Against the f32 restatement and the generic kernel."""
+    HD = 256
+    q1 = rnd(B, Sq, NH * HD, scale=0.25); k0 = rnd(B, max(Tp, 1), HD, scale=0.25, seed=1)[:, :Tp]; k1 = rnd(B, Sk, HD, scale=0.25, seed=2)
+    v0 = rnd(B, max(Tp, 1), HD, seed=3)[:, :Tp]; v1 = rnd(B, Sk, HD, seed=4)
+    kinfo = torch.full((B, Tp + Sk), 1 << 24, dtype=torch.int32, device=DEV)
+    kinfo[:, Tp + Sk - 1] = (1 << 24) | 7
+    qinfo = torch.full((B, Sq), (1 << 24) | 7, dtype=torch.int32, device=DEV)
+    k0a, v0a = (k0.contiguous(), v0.contiguous()) if Tp else (None, None)
+    args = ([None, q1], [k0a, k1], [v0a, v1], [0, Sq], [Tp, Sk], B, NH, 1, HD, qinfo, kinfo)
+    (_, o1), _ = hip.attention_fwd(*args, need_lse=False)
+    monkeypatch.setattr(hip, "_SERVE_ATTN", False)
+    (_, og), _ = hip.attention_fwd(*args, need_lse=False)
+    monkeypatch.setattr(hip, "_SERVE_ATTN", True)
+    mask = _mask_from_info(qinfo, kinfo)
+    kk = torch.cat([k0, k1], 1).float().view(B, Tp + Sk, 1, HD); vv = torch.cat([v0, v1], 1).float().view(B, Tp + Sk, 1, HD)
+    ref = _attn_ref(q1.float().view(B, Sq, NH, HD), kk, vv, mask, NH, 1)
+    assert rel_err(o1.view(B, Sq, NH, HD), ref) < 1e-2 and rel_err(og.view(B, Sq, NH, HD), ref) < 1e-2
+    assert rel_err(o1, og) < 6e-3
 
 
 # ------------------------------------------------------------------ loss / optimizer / misc
@@ -1123,9 +1151,9 @@ def test_serve_skinny_projections_match_unfused_ops(hip, M, rps, shared):
 
 
 @pytest.mark.parametrize("S,Tp,depth,npad", [
-    (50, 816, 3, 0),       # the denoise step of the bench: 6 full key runs + one of 48 | 50 rows
-    (50, 560, 2, 9),       # 4 full runs + a joint one; padded prompt tail (masked keys)
-    (16, 256, 2, 0),       # one token tile; the fresh keys get a run of their own
+    (50, 816, 3, 0),       # three images: 7 prefix runs of 128 keys (the last one 48) + the fresh keys
+    (50, 560, 2, 9),       # the denoise step of the bench: 7 prefix runs of 80 keys + the fresh keys; padded prompt tail (masked keys)
+    (16, 256, 2, 0),       # one token tile
     (33, 77, 2, 5),        # ragged token count (3 tiles of 16, 2 of 32), odd prefix length
     (64, 130, 2, 0),       # the largest chunk the chain takes (every stage exactly one round of 256 blocks)
     (50, 0, 2, 0),         # no cached prefix at all: the fresh keys are the only run

@@ -53,3 +53,10 @@ for blk, off in (("block 0", 0), ("block 255", 4096)):
         n += l > 0
     print(blk, "compute us:", " ".join(f"{nm} {c / n:.2f}" for nm, c in zip(names, comp)), "| barrier after:", " ".join(f"{nm} {b / n:.2f}" for nm, b in zip(names, bar)),
           f"| layer {sum(comp) / n + sum(bar) / n:.2f}")
+
+# attention sub-stamps (serve_chain.hpp): [7] stage start (behind the grid barrier), [0] loads landed, [1] behind the block barrier,
+# [2] scores + softmax + P.V done, [3] partial stores performed, [4] runs of the (head, tile) all arrived
+for blk, off in (("block 0", 2048), ("block 255", 6144)):
+    t = clk[off:off + 8 * depth].view(depth, 8)[1:].cpu().double() * 0.01
+    seg = lambda a, b: float((t[:, b] - t[:, a]).mean())
+    print(blk, f"attention: loads {seg(7, 0):.2f} | block barrier {seg(0, 1):.2f} | S, softmax, PV {seg(1, 2):.2f} | partial stores {seg(2, 3):.2f} | wait for the runs {seg(3, 4):.2f}")
