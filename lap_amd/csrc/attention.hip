@@ -610,6 +610,7 @@ int set_lds(K kernel, int bytes) {
 
 #include "attention_serve.hpp"
 #include "serve_chain.hpp"
+#include "serve_chain_tp.hpp"
 
 // Tuning / test knob (lap_attention_set_variant): -1 = automatic; 0 = generic kernels also for HD = 256;
 // 1 = the HD = 256 LDS-DMA kernels (what automatic picks whenever their LDS info table fits).
@@ -801,6 +802,10 @@ extern "C" int lap_serve_chain_ok(int B, int S, int D, int H, int NH, int HD, in
   return chain_ok(B, S, D, H, NH, HD, NKV, prefix_len) && chain_device_ok() ? 1 : 0;
 }
 
+extern "C" int lap_serve_chain_tp_ok(int B, int S, int D, int H, int NH, int HD, int NKV, int prefix_len) {
+  return chain_tp_ok(B, S, D, H, NH, HD, NKV, prefix_len) && chain_device_ok() ? 1 : 0;
+}
+
 extern "C" int lap_serve_chain_counter_words(void) { return CH_CTR_WORDS; }
 
 // 0: every barrier of every launch so far completed; 1: a block gave up waiting (the results of that launch are invalid)
@@ -845,6 +850,15 @@ extern "C" int lap_serve_chain(const lap_serve_chain_args* a, void* stream) {
   c.xs = (bf16*)a->xs;
   c.ctrs = a->counters;
   c.clk = (unsigned long long*)a->debug_clock;
+  if (a->packed == 2) {      // tensor parallel over the XCDs (serve_chain_tp.hpp)
+    if (!chain_tp_ok(a->B, a->S, a->D, a->H, a->NH, a->HD, 1, a->prefix_len) || !a->tp_slabs || !a->tp_xs || !a->tp_xn || !a->tp_k || !a->tp_v)
+      return LAP_ERR_ARG;
+    TpP t;
+    t.c = c;
+    t.slab_o = a->tp_slabs; t.slab_d = a->tp_slabs + (long long)TP_X * 64 * a->D;
+    t.xs8 = (bf16*)a->tp_xs; t.xn8 = (bf16*)a->tp_xn; t.k8 = (bf16*)a->tp_k; t.v8 = (bf16*)a->tp_v;
+    return launch_chain_tp(t, (hipStream_t)stream);
+  }
   return launch_chain(c, a->packed != 0, (hipStream_t)stream);
 }
 

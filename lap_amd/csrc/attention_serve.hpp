@@ -69,7 +69,8 @@ __device__ __forceinline__ void st_f32(float* p, float v) {
 // the query fragments arrive as whole KiB per wave instruction instead of 16 rows x 64 B.
 // PHASE 0: the whole block.  The chain splits it at its grid barrier: PHASE 1 issues the DMA pieces of a run of the CACHED prefix
 // (they do not depend on the launch's own results) and returns; PHASE 2, behind the barrier, issues the rest and goes on.
-template <bool COH, int PHASE = 0, bool PK = false>
+// LST (the tensor-parallel chain, serve_chain_tp.hpp): the run's partial results are read by blocks of the SAME XCD: plain stores.
+template <bool COH, int PHASE = 0, bool PK = false, bool LST = false>
 __device__ __forceinline__ void attn_run_body(const AttnP& p, const ServeRuns& sr, const int run, const int qt, const int h, const int b, char* smem,
                                               unsigned long long* tclk = nullptr) {      // tclk: tuning aid (thread 0 stamps the 100 MHz clock)
   using C = DmaCfg<256>;
@@ -247,8 +248,8 @@ __device__ __forceinline__ void attn_run_body(const AttnP& p, const ServeRuns& s
   const long long row = ((long long)run * p.B + b) * Sq + myq;
   float* op = p.part + (row * p.NH + h) * HD + w * 32;
 #pragma unroll
-  for (int d = 0; d < 2; ++d) st_f32x4<COH>(op + d * 16 + 4 * g, acc[d] * inv);
-  if (w == 0 && g == 0) st_f32<COH>(p.lpart + (((long long)run * p.B + b) * p.NH + h) * Sq + myq, l > 0.f ? (m + __builtin_amdgcn_logf(l)) * LN2 : NEG_BIG);
+  for (int d = 0; d < 2; ++d) st_f32x4<COH && !LST>(op + d * 16 + 4 * g, acc[d] * inv);
+  if (w == 0 && g == 0) st_f32<COH && !LST>(p.lpart + (((long long)run * p.B + b) * p.NH + h) * Sq + myq, l > 0.f ? (m + __builtin_amdgcn_logf(l)) * LN2 : NEG_BIG);
 }
 
 // grid = (runs, query tiles, heads x samples)
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(512) void attn_serve_kernel(AttnP p, ServeRuns sr) 
 
 // O = sum_i exp(lse_i - lse) O_i over the NS key splits (the generic combine's arithmetic, every load issued up front).
 // One thread per (b, q, h, 4 d).
-template <int NS, bool COH, bool PK = false>
+template <int NS, bool COH, bool PK = false, bool LST = false>
 __device__ __forceinline__ void attn_serve_combine_body(const AttnP& p, const long long gid) {
   constexpr int HD = 256;
   const int S = p.qlen[1];
@@ -306,7 +307,7 @@ __device__ __forceinline__ void attn_serve_combine_body(const AttnP& p, const lo
     acc += oi[sp] * wgt;
   }
   bf16* dst = PK ? p.o[1] + pk_off((int)(b * (long long)S + t), h * HD + d0, p.o_rs[1]) : p.o[1] + (b * (long long)S + t) * p.o_rs[1] + h * HD + d0;
-  if constexpr (COH) {
+  if constexpr (COH && !LST) {
     const float sc = den > 0.f ? 1.0f / den : 0.f;
     bf16x4 o;
 #pragma unroll

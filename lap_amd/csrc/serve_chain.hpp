@@ -29,7 +29,8 @@ constexpr int CH_MAX_DEPTH = 32;
 constexpr int CH_GROUPS = 8;             // arrival groups = XCDs (block id % 8)
 constexpr int CH_CTR_STRIDE = 64;        // counters 256 B apart
 constexpr int CH_CTR_EXIT = 9, CH_CTR_ERR = 10, CH_CTR_HEAD = 11, CH_MAX_HEADS = 64;    // HEAD: one counter per (sample, head, query tile), see the attention stage
-constexpr int CH_CTR_WORDS = (CH_CTR_HEAD + CH_MAX_HEADS) * CH_CTR_STRIDE;
+constexpr int CH_CTR_LOCAL = CH_CTR_HEAD + CH_MAX_HEADS, CH_CTR_RANK = CH_CTR_LOCAL + 8;     // the tensor-parallel chain (serve_chain_tp.hpp): per-XCD barrier counters, rank tickets
+constexpr int CH_CTR_WORDS = (CH_CTR_RANK + 8) * CH_CTR_STRIDE;
 constexpr int CH_BLOCKS = 256;
 
 struct ChainP {

@@ -11,7 +11,7 @@
 constexpr int SK_WAVES = 8;
 constexpr int SK_TOK = 16;      // tokens per block (one MFMA column tile)
 
-enum { EPI_ROPE = 1, EPI_GEGLU = 2, EPI_RESID = 3 };
+enum { EPI_ROPE = 1, EPI_GEGLU = 2, EPI_RESID = 3, EPI_PARTIAL = 4 };     // PARTIAL: f32 partial sums of a K slice (serve_chain_tp.hpp)
 
 struct SkinnyP {
   const bf16* x;        // [M][ldx] block input (K columns used)
@@ -31,6 +31,12 @@ struct SkinnyP {
   float q_scale;
   // PK only (see pk_off): which of the block input / residual input / output are still row-major (the chain's first and last stage)
   int x_rm, resid_rm, o_rm;
+  // PK only, the tensor-parallel chain (serve_chain_tp.hpp): the block contracts over the K slice that starts at k-step ks0 (a wave's
+  // steps are ks0 + w KS + s; K stays the full row length of the packed operands); sbv != NULL: the feature tiles of the block are
+  // sbv[0 .. FT) instead of bx FT + f; PARTIAL: f32 sums [M][N] at `pout`
+  int ks0;
+  const int* sbv;
+  float* pout;
 };
 
 // ---- PK: fragment-packed layouts (round 4).  tools/probes/cu_pull.hip: a lane that loads its MFMA fragment straight from a
@@ -102,9 +108,9 @@ __device__ __forceinline__ void skinny_load_w(const SkinnyP& p, int bx, bf16x8 (
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((long long)p.N * p.K * 2), 0x00020000);
 #pragma unroll
   for (int f = 0; f < FT; ++f) {
-    const int sb = bx * FT + f;
-    if constexpr (PK) {      // tile (sb, k-step w KS + s): 1 KiB, this lane's 16 bytes at lane * 16
-      const unsigned woff = (unsigned)((((long long)sb * (p.K >> 5) + w * KS) * 64 + lane) * 16);
+    const int sb = PK && p.sbv ? p.sbv[f] : bx * FT + f;
+    if constexpr (PK) {      // tile (sb, k-step ks0 + w KS + s): 1 KiB, this lane's 16 bytes at lane * 16
+      const unsigned woff = (unsigned)((((long long)sb * (p.K >> 5) + p.ks0 + w * KS) * 64 + lane) * 16);
 #pragma unroll
       for (int s = 0; s < KS; ++s) wf[f][s] = ldw8<NT>(rsW, woff + s * 1024);
       continue;
@@ -134,7 +140,9 @@ __device__ __forceinline__ void skinny_load_w(const SkinnyP& p, int bx, bf16x8 (
 // SHM: every token shares ONE modulation row (mod_ld == 0: the denoise step, where the condition is the step's time) — the
 // prologue then loads scale / shift once per k-slice instead of once per token tile (qkv: 256 -> 132 KB per block).
 // part: skinny_part_floats(FT, TT) floats of LDS, red: skinny_red_floats(TT).
-template <int EPI, bool NORM, int KS, int FT, int TT, bool SHM, bool COH, bool PK = false>   // KS: 32-deep k-steps per wave (K = KS * 32 * SK_WAVES)
+// LST (the tensor-parallel chain): outputs go to consumers of the SAME XCD — plain stores (they stay in that XCD's L2) where COH alone
+// would write through with the device-scope bit; loads keep it (L1 bypass, served by the L2).
+template <int EPI, bool NORM, int KS, int FT, int TT, bool SHM, bool COH, bool PK = false, bool LST = false>   // KS: 32-deep k-steps per wave (K slice = KS * 32 * SK_WAVES)
 __device__ __forceinline__ void skinny_rest(const SkinnyP& p, int bx, int by, bf16x8 (&wf)[FT][KS], float* part, float* red) {
   const int tid = opaque_tid();
   const int lane = tid & 63, w = tid >> 6;
@@ -151,7 +159,7 @@ __device__ __forceinline__ void skinny_rest(const SkinnyP& p, int bx, int by, bf
     const int r = (by * TT + t) * SK_TOK + i;     // this lane's token row of tile t (MFMA column i)
     // rows past M read as zeros (row-major: out of range offset; packed: tiles past the last one are out of range, the pad rows of
     // the last tile are never written and belong to columns of the product nobody stores)
-    const unsigned xoff = xpk ? (unsigned)((((long long)(by * TT + t) * (p.K >> 5) + w * KS) * 64 + lane) * 16)
+    const unsigned xoff = xpk ? (unsigned)((((long long)(by * TT + t) * (p.K >> 5) + p.ks0 + w * KS) * 64 + lane) * 16)
                               : (r < p.M ? (unsigned)(((long long)r * p.ldx + k0) * 2) : 0x80000000u);
 #pragma unroll
     for (int s = 0; s < KS; ++s) xf[t][s] = ldx8<COH>(rsX, xoff + s * xstep);
@@ -213,11 +221,18 @@ __device__ __forceinline__ void skinny_rest(const SkinnyP& p, int bx, int by, bf
     for (int t = 0; t < TT; ++t) *reinterpret_cast<f32x4*>(part + ((w * (FT * TT) + f * TT + t) * 64 + lane) * 4) = acc[f][t];
   __syncthreads();
   if (w >= FT * TT) return;          // wave (f, t) finishes output tile (f, t)
-  const int f = w / TT, t = w % TT, sb = bx * FT + f;
+  const int f = w / TT, t = w % TT, sb = PK && p.sbv ? p.sbv[f] : bx * FT + f;
   const int r = (by * TT + t) * SK_TOK + i;
   f32x4 y = *reinterpret_cast<const f32x4*>(part + (w * 64 + lane) * 4);
 #pragma unroll
   for (int ww = 1; ww < SK_WAVES; ++ww) y += *reinterpret_cast<const f32x4*>(part + ((ww * (FT * TT) + w) * 64 + lane) * 4);
+  if constexpr (EPI == EPI_PARTIAL) {     // f32 partial sums of this block's K slice: features 4 g .. 4 g + 3 of token row r
+    if (r < p.M) {
+      float* dst = p.pout + (long long)r * p.N + sb * 16 + 4 * g;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(y) : "memory");     // (read by every XCD behind the grid barrier)
+    }
+    return;
+  }
   float v[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = round_bf16(y[e]);      // the projection's bf16 output
@@ -246,7 +261,7 @@ __device__ __forceinline__ void skinny_rest(const SkinnyP& p, int bx, int by, bf
     bf16x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = f2bf(round_bf16(gelu_tanh_f(v[e])) * pv[e]);
-    stx4<COH>(p.o0 + (PK ? pk_off(r, c, H) : (long long)r * H + c), o);
+    stx4<COH && !LST>(p.o0 + (PK ? pk_off(r, c, H) : (long long)r * H + c), o);
   } else {   // EPI_ROPE
     const int HD = p.HD, half = HD / 2, bph = HD / 16, h = sb / bph, j = sb % bph;
     const int f0 = j * 8 + 4 * (g & 1);             // first of this lane's 4 frequencies
@@ -272,6 +287,6 @@ __device__ __forceinline__ void skinny_rest(const SkinnyP& p, int bx, int by, bf
     // (PK: the queries packed like every other MFMA operand of the chain; k / v stay row-major: they go to LDS as whole rows)
     bf16* dst = h < p.NH ? (PK ? p.o0 + pk_off(r, h * HD + d, p.NH * HD) - d : p.o0 + (long long)r * p.NH * HD + h * HD)
                          : (h == p.NH ? p.o1 + (long long)r * HD : p.o2 + (long long)r * HD);
-    stx4<COH>(dst + d, o);
+    stx4<COH && !LST>(dst + d, o);
   }
 }

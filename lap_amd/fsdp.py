@@ -72,6 +72,7 @@ class UnitPipeline:
         # REDUCED gradient and stays a pass over the shard.  LAP_FOLD_SUMSQ=0: off (A/B)
         self.fold_sumsq = self.is_cuda and self.world_size == 1 and os.environ.get("LAP_FOLD_SUMSQ", "1") != "0"
         self.folded = set()
+        self._bwd_open = False      # a backward has added to `sumsq` and no optimizer pass has consumed it yet (before_backward)
         # release order = the order in which the forward first needs the units: the store's order, except that the adaRMS
         # bank (built last) is needed second — the model issues embed_suffix (on its second stream) ahead of the SigLIP tower
         sched = [u for u in store.units if u.name != "ada"]
@@ -106,6 +107,18 @@ class UnitPipeline:
         if self.is_cuda and self._opt_done is not None:
             torch.cuda.current_stream().wait_event(self._opt_done)
             self._opt_done = None
+        if self._bwd_open:
+            # The previous backward was not followed by an optimizer pass (`LAP.loss_and_grad` used directly: gradient checks, an
+            # exception mid-step, a future accumulation loop): its partial sums of squares would inflate the next global norm and
+            # clip factor.  run_optimizer is the only place that clears them on the normal path; do it here, ordered
+            # behind that backward's last partial on the side stream and in front of this backward's first.
+            if self.is_cuda:
+                torch.cuda.current_stream().wait_stream(self.side)
+            self.sumsq.zero_()
+            if self.is_cuda:
+                self.side.wait_stream(torch.cuda.current_stream())
+            self.folded = set()
+        self._bwd_open = True
 
     def wait_unit(self, name: str, also=None):
         """The current stream (and `also`, the model's second stream) waits until the unit's parameters are the updated ones."""
@@ -193,6 +206,7 @@ class UnitPipeline:
             # any stream that has waited for one of this pass's units (all of them do, in the next forward) is ordered behind the
             # clearing — the weight-gradient GEMMs add their share from the compute / weight-gradient streams (fold_sumsq)
             self.sumsq.zero_()
+            self._bwd_open = False
             gnorm = self.scal[0].sqrt()      # a fresh tensor per step: callers keep the infos of many steps
             self.gnorm = gnorm
             if self.is_cuda:

@@ -70,6 +70,7 @@ class ServeChainArgs(C.Structure):
         ("attn_scratch", _vp), ("attn_scratch_floats", _ll),
         ("counters", _vp), ("debug_clock", _vp),
         ("packed", _i), ("xs", _vp),
+        ("tp_slabs", _vp), ("tp_xs", _vp), ("tp_xn", _vp), ("tp_k", _vp), ("tp_v", _vp),
     ]
 
 
@@ -94,6 +95,7 @@ SIGNATURES: dict[str, list] = {
     "lap_gemm_set_debug": [_i],
     "lap_gemm_asm": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_asm_ok": [_i, _i, _i, _i, _i, _i, _i, _i, _i],
+    "lap_gemm_asm_launch_counts": [C.POINTER(C.c_longlong), _i],
     "lap_gemm_asm_bias": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_asm_bias_ok": [_i, _i, _i, _i, _i, _i],
     "lap_gemm_asm_res": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -157,6 +159,7 @@ SIGNATURES: dict[str, list] = {
     "lap_serve_set_variant": [_i],
     "lap_serve_embed_actions": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_serve_chain_ok": [_i, _i, _i, _i, _i, _i, _i, _i],
+    "lap_serve_chain_tp_ok": [_i, _i, _i, _i, _i, _i, _i, _i],
     "lap_serve_chain_counter_words": [],
     "lap_serve_chain_status": [_vp, C.POINTER(_i)],
     "lap_serve_chain": [C.POINTER(ServeChainArgs), _vp],
@@ -288,6 +291,16 @@ def linear_wgrad(dy, x, out, *, accum=False, ksplit=0, tile=-1):
     Kin = x.shape[1]
     return gemm(dy, x, out, M=Nout, N=Kin, K=Mrows, lda=dy.stride(0), ldb=x.stride(0), ldc=out.stride(0), a_kc=False,
                 b_kc=False, accum=accum, ksplit=ksplit, tile=tile)
+
+
+ASM_KERNELS = ("nt", "nn", "tn", "nt_bias", "tn_t", "nt_res", "nt_bias_res", "nn_geglu_bwd", "nt_geglu", "nn_gelu_bwd", "nt_bias_gelu")
+
+
+def gemm_asm_launch_counts() -> dict:
+    """Launches of each assembly GEMM kernel since the library was loaded (include/lap_hip.h: lap_gemm_asm_launch_counts)."""
+    buf = (C.c_longlong * len(ASM_KERNELS))()
+    _chk(_fn["lap_gemm_asm_launch_counts"](buf, len(ASM_KERNELS)), "lap_gemm_asm_launch_counts")
+    return dict(zip(ASM_KERNELS, (int(v) for v in buf)))
 
 
 def linear_wgrad_sumsq(dy, x, out, sumsq):
@@ -906,19 +919,30 @@ def serve_pack_weight(w, kind: int, HD: int = 0, out=None):
     return out
 
 
-def serve_chain_scratch(device, D, H, NH, HD) -> dict:
+def serve_chain_tp_ok(B, S, D, H, NH, HD, NKV, prefix_len) -> bool:
+    """Shapes (and device) the tensor-parallel form of the packed chain takes (lap_serve_chain with packed = 2)."""
+    return bool(_fn["lap_serve_chain_tp_ok"](B, S, D, H, NH, HD, NKV, prefix_len))
+
+
+def serve_chain_scratch(device, D, H, NH, HD, tp: bool = False) -> dict:
     """The packed chain's activation buffers (64 rows each, zero: the pad rows are never written).  Allocate ONCE per sampler,
-    outside stream capture; a launch may be replayed from a graph that holds these addresses."""
+    outside stream capture; a launch may be replayed from a graph that holds these addresses.  tp: also the tensor-parallel
+    form's per-XCD buffers and partial-sum slabs."""
     z = lambda cols: torch.zeros((64, cols), dtype=torch.bfloat16, device=device)
-    return dict(q=z(NH * HD), o=z(NH * HD), xa=z(D), act=z(H), xs=z(D))
+    d = dict(q=z(NH * HD), o=z(NH * HD), xa=z(D), act=z(H), xs=z(D))
+    if tp:
+        z8 = lambda cols: torch.zeros((8, 64, cols), dtype=torch.bfloat16, device=device)
+        d.update(tp_slabs=torch.zeros((2, 8, 64, D), dtype=torch.float32, device=device), tp_xs=z8(D), tp_xn=z8(D), tp_k=z8(HD), tp_v=z8(HD))
+    return d
 
 
 def serve_chain(x_in, mod, slot_stride, weights, caches, rope_table, qinfo, kinfo, B, S, NH, HD, H, prefix_len, q_scale, counters,
-                eps=1e-6, debug_clock=None, keep=None, packed_scratch=None):
+                eps=1e-6, debug_clock=None, keep=None, packed_scratch=None, tp: bool = False):
     """All action-expert layers of one denoise step in one persistent launch (include/lap_hip.h: lap_serve_chain).
     weights: per layer (wqkv, wo, wgu, wd); caches: per layer (k, v) of the prefix.  Returns the residual stream [B*S, D].
     `packed_scratch` (serve_chain_scratch): the weights are lap_serve_pack_weight images and the activations between the stages are
-    fragment-packed too (same bits, every operand load 1 KiB contiguous per wave instruction)."""
+    fragment-packed too (same bits, every operand load 1 KiB contiguous per wave instruction).  `tp` (with a scratch made with
+    tp=True): the tensor-parallel form, lap_serve_chain packed = 2."""
     M, D = x_in.shape
     dev = x_in.device
     depth = len(weights)
@@ -939,6 +963,9 @@ def serve_chain(x_in, mod, slot_stride, weights, caches, rope_table, qinfo, kinf
         ps = packed_scratch
         q, o, xa, act = ps["q"], ps["o"], ps["xa"], ps["act"]
         a.packed, a.xs = 1, _p(ps["xs"])
+        if tp:
+            a.packed = 2
+            a.tp_slabs, a.tp_xs, a.tp_xn, a.tp_k, a.tp_v = (_p(ps[n]) for n in ("tp_slabs", "tp_xs", "tp_xn", "tp_k", "tp_v"))
     else:
         q, o = torch.empty((M, NH * HD), **bf), torch.empty((M, NH * HD), **bf)
         xa, act = torch.empty((M, D), **bf), torch.empty((M, H), **bf)

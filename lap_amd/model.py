@@ -96,6 +96,9 @@ class LAP:
         # ... on fragment-packed operands (round 4: every operand load 1 KiB contiguous per wave instruction; same bits).
         # LAP_SERVE_PACKED=0: the row-major chain of round 3 (A/B runs, tests)
         self.serve_packed = os.environ.get("LAP_SERVE_PACKED", "1") != "0"
+        # ... mapped onto the chip as 8-way tensor parallelism over the XCDs (csrc/serve_chain_tp.hpp: two chip-wide seams per layer
+        # instead of five; bf16-rounding-noise equal to the flat chain, not bitwise).  LAP_SERVE_TP=0: the flat packed chain
+        self.serve_tp = os.environ.get("LAP_SERVE_TP", "0") != "0"
         self._chain_ctr = None
         self._chain_scratch = None
         self._packed_w = None       # [version, per layer (wqkv, wo, wgu, wd) packed images]
@@ -1111,10 +1114,12 @@ class LAP:
                 self._chain_ctr = hip.serve_chain_counters(dev)
             for l in range(self.v.depth):
                 self.comm.wait_unit(f"llm{l}")
+            tp = (self.serve_packed and self.serve_tp
+                  and hip.serve_chain_tp_ok(B, S, self.e.width, self.e.mlp_dim, self.v.num_heads, self.v.head_dim, self.v.num_kv_heads, Pn))
             if self.serve_packed:
                 chain_w = self._serve_packed_weights()
-                if self._chain_scratch is None:
-                    self._chain_scratch = hip.serve_chain_scratch(dev, self.e.width, self.e.mlp_dim, self.v.num_heads, self.v.head_dim)
+                if self._chain_scratch is None or (tp and "tp_slabs" not in self._chain_scratch):
+                    self._chain_scratch = hip.serve_chain_scratch(dev, self.e.width, self.e.mlp_dim, self.v.num_heads, self.v.head_dim, tp=tp)
             else:
                 chain_w = [tuple(self.W(f"llm/{l}/{n}") for n in ("wqkv1", "wo1", "wgu1", "wd1")) for l in range(self.v.depth)]
         for step in range(len(times)):
@@ -1123,7 +1128,7 @@ class LAP:
                 x1 = hip.serve_embed_actions(x_t.view(B * S, ad), self.F("act/in_w"), self.F("act/in_b"))
                 xf1 = hip.serve_chain(x1, mod, 3 * self.e.width, chain_w, cache, rope_tab, qinfo_s, kinfo_all, B, S, self.v.num_heads,
                                       self.v.head_dim, self.e.mlp_dim, Pn, self.v.head_dim ** -0.5, self._chain_ctr,
-                                      packed_scratch=self._chain_scratch if self.serve_packed else None)
+                                      packed_scratch=self._chain_scratch if self.serve_packed else None, tp=tp)
                 v_t = torch.empty((B * S, ad), dtype=torch.float32, device=dev) if collect is not None else None
                 hip.serve_final_euler(xf1, self._mod_slot(mod, nslot), 0, S, self.F("act/out_w"), self.F("act/out_b"), x_t.view(B * S, ad), dt, v_t)
                 if collect is not None:
@@ -1163,7 +1168,12 @@ class LAP:
         return self._chain_ctr is not None and hip.serve_chain_failed(self._chain_ctr)
 
     def disable_serve_chain(self):
-        self.serve_chain = False
+        """After a launch that gave up at a barrier: one step back — the tensor-parallel chain (which needs 32 blocks on each of 8
+        XCDs) falls back to the flat chain, the flat chain to the separate launches."""
+        if self.serve_chain and self.serve_packed and self.serve_tp:
+            self.serve_tp = False
+        else:
+            self.serve_chain = False
         if self._chain_ctr is not None:
             torch.cuda.synchronize(self.device)
             self._chain_ctr.zero_()

@@ -71,6 +71,37 @@ def test_full_width_reference_config_shapes_match_oracle(hip, monkeypatch, name,
     _check_loss_activations_and_grads(_full_width_cfg(monkeypatch, **kw), B=2, ragged=True)
 
 
+def test_full_width_b16_benchmark_gemm_route_matches_oracle(hip, monkeypatch):
+    """The route that runs the benchmark step, under the oracle.  At B = 2 the prefix stream has 1120 rows:
+    not a multiple of 256, so gate|up + GeGLU, the down projection's data gradient + GeGLU backward, the residual-epilogue kernels,
+    the M cut and the ring weight-gradient kernels all fall back to the HIP tiles there.  B = 16 at the LAP-3B widths (2 layers per
+    tower, benchmark shapes) gives the prefix stream 8960 = 35 x 256 rows and SigLIP 8192: every assembly kernel of the B = 32 step
+    takes its products, and loss, every layer (free running and teacher forced) and every gradient are held to the bounds of the
+    B = 2 slices against the f32 oracle's autograd.  The test asserts that the kernels really ran."""
+    import collections
+
+    cfg = _full_width_cfg(monkeypatch, max_token_len=48, action_horizon=50, action_dim=7, language_loss_weight=0.4)
+    calls = collections.Counter()
+    for name in ("linear_geglu_train", "linear_dgrad_geglu_bwd", "linear_bias_gelu_train", "linear_dgrad_gelu_bwd"):
+        def wrap(fn, name):
+            def counted(*a, **k):
+                calls[name] += 1
+                return fn(*a, **k)
+            return counted
+        monkeypatch.setattr(hip, name, wrap(getattr(hip, name), name))
+    before = hip.gemm_asm_launch_counts()
+    _check_loss_activations_and_grads(cfg, B=16, ragged=True)
+    ran = {k: v - before[k] for k, v in hip.gemm_asm_launch_counts().items()}
+    L = 2       # layers per tower (free-running pass; the teacher-forced sweeps add forward launches on top)
+    assert calls["linear_geglu_train"] >= L and ran["nt_geglu"] >= L, (calls, ran)              # gate|up + GeGLU, one launch
+    assert calls["linear_dgrad_geglu_bwd"] >= L and ran["nn_geglu_bwd"] >= L, (calls, ran)      # down dgrad + GeGLU backward
+    assert calls["linear_bias_gelu_train"] >= L and ran["nt_bias_gelu"] >= L, (calls, ran)      # SigLIP fc1 + bias + GELU
+    assert calls["linear_dgrad_gelu_bwd"] >= L and ran["nn_gelu_bwd"] >= L, (calls, ran)        # SigLIP fc2 dgrad + GELU backward
+    assert ran["nt_res"] + ran["nt_bias_res"] >= 4 * L, ran       # out / down (+ residual) of both towers: whole products or the M cut's full rounds
+    assert ran["tn"] >= L and ran["tn_t"] >= L, ran               # ring weight-gradient kernels of gate|up and down (K = 8960 rows)
+    assert ran["nt"] >= 2 * L and ran["nn"] >= 2 * L, ran         # plain forward / data-gradient products (qkv, out, gate|up dgrad)
+
+
 def test_full_width_sample_actions_matches_oracle(hip, monkeypatch):
     """Batch-1 serving at the LAP-3B widths: prefill + 10 denoise steps through the fused split-K consumers, the hoisted
     sin / cos table and the key-split attention, against the oracle and against the generic layer path (bit for bit)."""

@@ -104,6 +104,29 @@ def test_train_step_with_image_augmentation(hip):
     assert torch.isfinite(l1) and float(l1) == float(l2) and float(l1) != float(l3) and float(l1) != float(l0)
 
 
+def test_backward_without_optimizer_pass_does_not_inflate_the_next_gradient_norm(hip):
+    """the per-step sum of squares is cleared by `run_optimizer`; a backward that is NOT followed by an optimizer pass
+    (`LAP.loss_and_grad` used directly: gradient checks, an exception mid-step) used to leave its partial sums behind, and the next
+    train step's global norm — and clip factor — contained them."""
+    from lap_amd.config import get_config
+    from lap_amd.train import TrainingStepRunner, init_train_state
+    from tests.common import make_inputs, to_observation
+
+    tc = get_config("debug")
+    obs, actions, noise, time = make_inputs(tc.model, B=2, ragged=True)
+    batch = (to_observation(obs, "cuda"), actions.cuda())
+    kw = dict(noise=noise.cuda(), time=time.cuda())
+    runner = TrainingStepRunner(tc)
+    _, ref = runner(0, init_train_state(tc, seed=3, device="cuda"), batch, 0, **kw)
+    state = init_train_state(tc, seed=3, device="cuda")
+    for _ in range(2):                                          # two backward passes nobody consumes
+        state.model.loss_and_grad(0, *batch, **kw)
+    _, info = runner(0, state, batch, 0, **kw)
+    torch.cuda.synchronize()
+    assert float(info["loss"]) == float(ref["loss"])
+    assert abs(float(info["grad_norm"]) - float(ref["grad_norm"])) <= 1e-5 * float(ref["grad_norm"]), (float(info["grad_norm"]), float(ref["grad_norm"]))
+
+
 def test_frozen_vlm_trains_only_the_action_expert(hip):
     """openpi freeze_filter semantics (scripts/train.py:225-240,358-363) with LAPConfig.get_vlm_freeze_filter: frozen
     parameters keep their (bf16-rounded) values and stay out of the gradient norm; trainable ones move exactly as in an

@@ -10,6 +10,7 @@ def rnd(*shape, scale=1.0, seed=0, dtype=torch.bfloat16):
     return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
 B, S, Tp, depth, D, NH, HD, H = 1, 50, int(os.environ.get('TP', 560)), 18, 1024, 8, 256, 4096
 PACKED = os.environ.get('PACKED', '1') != '0'
+TPAR = os.environ.get('TPAR', '0') != '0'
 M = S
 x = rnd(M, D, seed=1)
 mod = rnd(1, (2 * depth + 1) * 3 * D, scale=0.3, seed=2)
@@ -25,15 +26,16 @@ clk = torch.zeros(8192, dtype=torch.int64, device=DEV)
 if PACKED:
     W = [(hip.serve_pack_weight(a, hip.PACK_QKV, HD), hip.serve_pack_weight(b, hip.PACK_PLAIN), hip.serve_pack_weight(c, hip.PACK_GATE_UP),
           hip.serve_pack_weight(d, hip.PACK_PLAIN)) for a, b, c, d in W]
-sc = hip.serve_chain_scratch(DEV, D, H, NH, HD) if PACKED else None
-run = lambda dbg: hip.serve_chain(x, mod, 3 * D, W, cache, tab, qinfo, kinfo, B, S, NH, HD, H, Tp, HD ** -0.5, ctr, debug_clock=dbg, packed_scratch=sc)
+sc = hip.serve_chain_scratch(DEV, D, H, NH, HD, tp=TPAR) if PACKED else None
+run = lambda dbg: hip.serve_chain(x, mod, 3 * D, W, cache, tab, qinfo, kinfo, B, S, NH, HD, H, Tp, HD ** -0.5, ctr, debug_clock=dbg, packed_scratch=sc, tp=TPAR)
 for _ in range(3): run(None)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(20): run(None)
 e1.record(); torch.cuda.synchronize()
-print(f"packed={int(PACKED)} Tp={Tp} chain launch: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us for {depth} layers = {e0.elapsed_time(e1) / 20 * 1e3 / depth:.2f} us per layer; failed={hip.serve_chain_failed(ctr)}")
+print(f"packed={int(PACKED)} tp={int(TPAR)} Tp={Tp} chain launch: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us for {depth} layers = {e0.elapsed_time(e1) / 20 * 1e3 / depth:.2f} us per layer; failed={hip.serve_chain_failed(ctr)}")
+if TPAR: sys.exit(0)
 run(clk); torch.cuda.synchronize()
 names = ["qkv", "attn+comb", "out", "gateup", "down"]
 NS = len(names)
