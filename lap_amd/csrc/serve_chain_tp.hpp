@@ -31,7 +31,7 @@ constexpr int TP_X = 8, TP_CU = 32;
 
 struct TpP {
   ChainP c;                        // shapes, packed weights, caches, modulation slots, RoPE table, counters; q / o / act packed, global
-  float* slab_o; float* slab_d;    // [8][64][D] f32: the XCDs' partial sums of the out / down projection
+  float* slab_o; float* slab_d;    // [64][8][D] f32: the XCDs' partial sums of the out / down projection, row major over (row, XCD)
   bf16* xs8; bf16* xn8;            // [8][64 x D] packed: each XCD's copy of the residual stream / of the adaRMS-normed operand
   bf16* k8; bf16* v8;              // [8][64][HD] row-major: each XCD's copy of the fresh keys / values
 };
@@ -86,7 +86,7 @@ __device__ __forceinline__ void tp_reduce(const ChainP& c, const float* slab, co
       f32x4 part[TP_X];
 #pragma unroll
       for (int j = 0; j < TP_X; ++j)
-        part[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, (unsigned)((((j * 64 + r) * D) + col) * 4), 0, 16));
+        part[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, (unsigned)((((r * TP_X + j) * D) + col) * 4), 0, 16));
       const bf16x4 xo = ldx4<true>(xs, pk_off(r, col, D), (unsigned)(64 * D * 2));
       const bf16x4 gt = *reinterpret_cast<const bf16x4*>(gate + col);
       f32x4 y = part[0];
@@ -134,6 +134,9 @@ __global__ __launch_bounds__(512) void serve_chain_tp_kernel(TpP t) {
   float* red = reinterpret_cast<float*>(smem + 65536);
   const int nb = gridDim.x;
   unsigned round = 0, lround = 0;
+  int nstamp = 0;
+  const int vb = blockIdx.x;
+#define TP_STAMP() do { if (c.clk && threadIdx.x == 0 && (vb == 0 || vb == nb - 1)) c.clk[(vb ? 4096 : 0) + nstamp++] = wall_clock64(); } while (0)
   // ---- who am I inside my XCD
   __shared__ int s_rank;
   const int xcd = tp_xcc_id() & (TP_X - 1);
@@ -149,8 +152,10 @@ __global__ __launch_bounds__(512) void serve_chain_tp_kernel(TpP t) {
   bf16* xn = t.xn8 + (long long)xcd * 64 * D;
   bf16* kx = t.k8 + (long long)xcd * 64 * HD;
   bf16* vx = t.v8 + (long long)xcd * 64 * HD;
-  float* so = t.slab_o + (long long)xcd * 64 * D;
-  float* sd = t.slab_d + (long long)xcd * 64 * D;
+  // slabs are [row][XCD][D]: a row's eight partial sums are one contiguous 32 KiB.  ([XCD][row][D] put the eight loads of a thread
+  // 256 KiB apart — the same memory channel — and the reduction took 4.0 us per seam instead of ...: tools/probes/chain_clock.py)
+  float* so = t.slab_o + (long long)xcd * D;
+  float* sd = t.slab_d + (long long)xcd * D;
   const int ns = c.sr.nruns, QT = (c.rps + 15) / 16, nA = ns * QT;          // attention blocks of one head: (run, query tile)
 
   int sbq[3];                                                               // this block's three feature tiles of [q_h | k | v]
@@ -162,9 +167,9 @@ __global__ __launch_bounds__(512) void serve_chain_tp_kernel(TpP t) {
   SkinnyP pq = {}, po = {}, pg = {}, pd = {};
   pq.x = xn; pq.M = c.M; pq.N = (NH + 2) * HD; pq.K = D; pq.ldx = D; pq.rps = c.rps; pq.eps = c.eps; pq.sbv = sbq;
   pq.o0 = c.q; pq.o1 = kx; pq.o2 = vx; pq.rope = c.rope; pq.NH = NH; pq.HD = HD; pq.q_scale = c.q_scale;
-  po.x = c.o; po.M = c.M; po.N = D; po.K = QKV; po.ldx = QKV; po.rps = c.rps; po.ks0 = (QKV / 32 / TP_X) * xcd; po.pout = so;
+  po.x = c.o; po.M = c.M; po.N = D; po.K = QKV; po.ldx = QKV; po.rps = c.rps; po.ks0 = (QKV / 32 / TP_X) * xcd; po.pout = so; po.pld = TP_X * D;
   pg.x = xn; pg.M = c.M; pg.N = 2 * H; pg.K = D; pg.ldx = D; pg.rps = c.rps; pg.eps = c.eps; pg.o0 = c.act;
-  pd.x = c.act; pd.M = c.M; pd.N = D; pd.K = H; pd.ldx = H; pd.rps = c.rps; pd.ks0 = (H / 32 / TP_X) * xcd; pd.pout = sd;
+  pd.x = c.act; pd.M = c.M; pd.N = D; pd.K = H; pd.ldx = H; pd.rps = c.rps; pd.ks0 = (H / 32 / TP_X) * xcd; pd.pout = sd; pd.pld = TP_X * D;
   AttnP ap = c.attn;
   ap.q[1] = c.q; ap.k[1] = kx; ap.v[1] = vx; ap.o[1] = c.o;
   const int bxg = 16 * xcd + (cu & 15), byg = cu >> 4;                      // gate | up: 4 paired tiles x 32 tokens per block
@@ -179,14 +184,18 @@ __global__ __launch_bounds__(512) void serve_chain_tp_kernel(TpP t) {
     // ---- chip-wide seam (behind the grid barrier of the previous layer's down projection): residual + adaRMS of the attention block
     if (l == 0) tp_reduce<0>(c, nullptr, nullptr, slot_a, xs, xn, cu, xcd, red);
     else tp_reduce<1>(c, t.slab_d, slot_a - c.slot_ld + 2 * D, slot_a, xs, xn, cu, xcd, red);     // (the gate of the previous layer's MLP block)
+    TP_STAMP();
     tp_arrive(c.ctrs, xcd, lround);
     tp_wait(c.ctrs, xcd, lround);
+    TP_STAMP();
     // ---- q_h | k | v + RoPE / split
     skinny_rest<EPI_ROPE, false, 4, 3, 2, false, true, true, true>(pq, 0, cu >> 4, wq, part, red);
+    TP_STAMP();
     tp_arrive(c.ctrs, xcd, lround);
     ap.k[0] = c.ck[l]; ap.v[0] = c.cv[l];     // the cached keys / values of the block's run: on their way into LDS during the barrier
     if (cu < nA) attn_run_body<true, 1, true, true>(ap, c.sr, cu % ns, cu / ns, xcd, 0, smem);
     tp_wait(c.ctrs, xcd, lround);
+    TP_STAMP();
     // ---- attention of head `xcd`: one (key run, query tile) per block, then the combine of the runs of a tile
     if (cu < nA) {
       const int sI = cu % ns, qI = cu / ns;
@@ -213,36 +222,46 @@ __global__ __launch_bounds__(512) void serve_chain_tp_kernel(TpP t) {
         if (tq < c.rps) attn_serve_combine_body<8, true, true, true>(ap, ((long long)tq * NH + xcd) * (HD / 4) + j);
       }
     }
+    TP_STAMP();
     tp_arrive(c.ctrs, xcd, lround);
     po.W = c.wo[l];
     skinny_load_w<EPI_PARTIAL, 1, 2, false, true>(po, cu, wo);
     __builtin_amdgcn_sched_barrier(0);
     tp_wait(c.ctrs, xcd, lround);
+    TP_STAMP();
     // ---- out projection, K slice of head `xcd`: f32 partial sums for every XCD
     skinny_rest<EPI_PARTIAL, false, 1, 2, 4, false, true, true, true>(po, cu, 0, wo, part, red);
+    TP_STAMP();
     chain_arrive(c.ctrs, round, nb);
     pg.W = c.wgu[l];
     skinny_load_w<EPI_GEGLU, 4, 4, false, true>(pg, bxg, wg);     // (two stages ahead: in flight through the seam and the reduction)
     __builtin_amdgcn_sched_barrier(0);
     chain_wait(c.ctrs, round);
+    TP_STAMP();
     // ---- chip-wide seam: residual of the attention block + adaRMS of the MLP block
     tp_reduce<1>(c, t.slab_o, slot_a + 2 * D, slot_f, xs, xn, cu, xcd, red);
+    TP_STAMP();
     tp_arrive(c.ctrs, xcd, lround);
     tp_wait(c.ctrs, xcd, lround);
+    TP_STAMP();
     // ---- gate | up of hidden columns 512 xcd .. + GeGLU
     skinny_rest<EPI_GEGLU, false, 4, 4, 2, false, true, true, true>(pg, bxg, byg, wg, part, red);
+    TP_STAMP();
     tp_arrive(c.ctrs, xcd, lround);
     pd.W = c.wd[l];
     skinny_load_w<EPI_PARTIAL, 2, 2, false, true>(pd, cu, wd);
     __builtin_amdgcn_sched_barrier(0);
     tp_wait(c.ctrs, xcd, lround);
+    TP_STAMP();
     // ---- down projection, K slice over those columns
     skinny_rest<EPI_PARTIAL, false, 2, 2, 4, false, true, true, true>(pd, cu, 0, wd, part, red);
+    TP_STAMP();
     chain_arrive(c.ctrs, round, nb);
     pq.W = c.wqkv[l + 1 < c.depth ? l + 1 : l];     // (the last layer re-reads its own: nobody uses them)
     skinny_load_w<EPI_ROPE, 4, 3, false, true>(pq, 0, wq);
     __builtin_amdgcn_sched_barrier(0);
     chain_wait(c.ctrs, round);
+    TP_STAMP();
   }
   // ---- the last layer's MLP residual: the caller's row-major x_out
   tp_reduce<2>(c, t.slab_d, c.mod + (long long)(2 * c.depth - 1) * c.slot_ld + 2 * D, nullptr, xs, xn, cu, xcd, red);

@@ -37,6 +37,7 @@ struct SkinnyP {
   int ks0;
   const int* sbv;
   float* pout;
+  int pld;              // PARTIAL: row stride of pout in floats
 };
 
 // ---- PK: fragment-packed layouts (round 4).  tools/probes/cu_pull.hip: a lane that loads its MFMA fragment straight from a
@@ -228,7 +229,7 @@ __device__ __forceinline__ void skinny_rest(const SkinnyP& p, int bx, int by, bf
   for (int ww = 1; ww < SK_WAVES; ++ww) y += *reinterpret_cast<const f32x4*>(part + ((ww * (FT * TT) + w) * 64 + lane) * 4);
   if constexpr (EPI == EPI_PARTIAL) {     // f32 partial sums of this block's K slice: features 4 g .. 4 g + 3 of token row r
     if (r < p.M) {
-      float* dst = p.pout + (long long)r * p.N + sb * 16 + 4 * g;
+      float* dst = p.pout + (long long)r * p.pld + sb * 16 + 4 * g;
       asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(y) : "memory");     // (read by every XCD behind the grid barrier)
     }
     return;

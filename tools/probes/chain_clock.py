@@ -35,8 +35,17 @@ e0.record()
 for _ in range(20): run(None)
 e1.record(); torch.cuda.synchronize()
 print(f"packed={int(PACKED)} tp={int(TPAR)} Tp={Tp} chain launch: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us for {depth} layers = {e0.elapsed_time(e1) / 20 * 1e3 / depth:.2f} us per layer; failed={hip.serve_chain_failed(ctr)}")
-if TPAR: sys.exit(0)
 run(clk); torch.cuda.synchronize()
+if TPAR:
+    names = ["reduceA", "qkv", "attn+comb", "out", "reduceF", "gateup", "down"]
+    NS = len(names)
+    for blk, off in (("block 0", 0), ("block 255", 4096)):
+        t = clk[off:off + 2 * NS * depth].view(depth, NS, 2)[1:].cpu().double() * 0.01
+        prev = torch.cat([clk[off:off + 2 * NS * depth].view(depth, NS, 2)[:-1, -1:, 1].cpu().double() * 0.01, t[:, :-1, 1]], 1)     # wait-exit stamp in front of each stage
+        comp = (t[:, :, 0] - prev).mean(0); bar = (t[:, :, 1] - t[:, :, 0]).mean(0)
+        print(blk, "compute us:", " ".join(f"{n} {v:.2f}" for n, v in zip(names, comp.tolist())), "| barrier after:", " ".join(f"{n} {v:.2f}" for n, v in zip(names, bar.tolist())),
+              f"| layer {float(comp.sum() + bar.sum()):.2f}")
+    sys.exit(0)
 names = ["qkv", "attn+comb", "out", "gateup", "down"]
 NS = len(names)
 for blk, off in (("block 0", 0), ("block 255", 4096)):
