@@ -39,7 +39,8 @@ def _worker(rank, world, port, ret):
         assert rows.shape[1] == D and (hi - lo) * D == rows.numel() and lo == rank * (hi - lo)
         # gradients: rank r contributes (r+1) * g  ->  reduce-scatter gives 3 g on every shard
         g = torch.Generator().manual_seed(0)
-        gfull = {u.name: torch.randn(ps.padded(u), generator=g) for u in ps.units}
+        # (bf16-representable values: (rank + 1) * g and their sum over up to 8 ranks are exact in f32 in ANY summation order)
+        gfull = {u.name: torch.randn(ps.padded(u), generator=g).bfloat16().float() for u in ps.units}
         for u in ps.units:
             ps.grad[u.name].copy_(gfull[u.name] * (rank + 1))
             comm.grads_ready(u.name)
@@ -74,16 +75,19 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_fsdp_world2_gloo():
-    world = 2
-    port = 29500 + os.getpid() % 500
+@pytest.mark.parametrize("world", [2, 8])
+def test_fsdp_step_protocol_gloo(world):
+    """The whole FsdpComm step at debug size — shard geometry, gradient reduce-scatter (+ the replicated unit's all-reduce), the
+    per-shard update, the in-place parameter all-gather, the scalar all-reduce — at world size 2 and at 8, the size of the node the
+    benchmark's FSDP configuration runs on (BASELINE.json config 3; mh_sharding.py:14-100)."""
+    port = 29500 + os.getpid() % 500 + 7 * world
     mgr = mp.get_context("spawn").Manager()   # (a forked manager next to an initialised HIP runtime is not safe)
     ret = mgr.dict()
     procs = [mp.get_context("spawn").Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(300)
     assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
 
 

@@ -166,3 +166,24 @@ def test_rccl_backend_executes_with_world_size_one(hip):
     if p.is_alive():
         p.kill()
     assert ret.get("r") == "ok", ret.get("r", "worker timed out")
+
+
+def test_bench_self_launch_two_ranks_gloo_flow():
+    """`bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (rendezvous on 127.0.0.1) exactly as the
+    driver's multi-GPU bench does; with `--backend gloo` both ranks share this box's one GPU, so the whole N > 1 flow — rank
+    environment, FSDP train state, barrier + max-over-ranks timing, rank 0's single JSON line — runs here (VERDICT r3 next #7a)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "debug", "--steps", "2",
+                        "--warmup", "1", "--batch", "2", "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["parallelism"] == "fsdp2" and d["config"]["global_batch"] == 4
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["ms_per_step"] > 0 and "serve" not in d and "NON-HEADLINE" in d["config"]["workload"]
+    assert d["final_loss"] == d["final_loss"]           # finite, not NaN

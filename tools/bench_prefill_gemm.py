@@ -17,6 +17,8 @@ SHAPES = {   # name: (M, N, K, bias, gelu, residual)
 }
 CANDS = {"sig_qkv": [-1, 16, 18, 6], "sig_out": [-1, 17, 16, 18], "sig_fc1": [-1, 16, 18, 6], "sig_fc2": [-1, 17, 16], "sig_head": [-1, 16, 17, 18],
          "gem_qkv": [-1, 16, 18, 6], "gem_out": [-1, 16, 17, 18], "gem_gu": [-1, 15, 10, 6], "gem_down": [-1, 15, 16]}
+# (round 4: the same tiles with 5 - 8 LDS stages instead of 3 - 4 were measured too — 12.1 vs 12.4 us, 17.2 vs 17.2 us ...: these
+#  launches are not bound by k-tiles in flight; profiles/r04_prefill_gemm_ring_depth.txt)
 
 
 def timed(fn, n=20, reps=10):
