@@ -243,4 +243,138 @@ def test_rlds_export_libero_and_droid_record_to_episode():
     b = R.binarize_gripper_actions(np.array([0.5, 0.5, 0.99, 0.5, 0.01, 0.5]))                                  # default threshold 0.95
     assert np.allclose(b, [1, 1, 1, 0, 0, 0.5])                                                                # the tail keeps the last raw value
     with pytest.raises(KeyError):
-        R.episode_from_rlds("bridge_v2_oxe", traj)
+        R.episode_from_rlds("kuka", traj)
+
+
+def test_rlds_export_helpers_of_the_oxe_transforms():
+    """transform_helpers.py:57-82,165-189, rotation_utils.py:382-450,504-518 and tensorflow_graphics' quaternion -> euler, restated
+    in numpy: against scipy and hand-computed cases."""
+    from scipy.spatial.transform import Rotation
+
+    from lap_amd import rlds_export as R
+
+    g = np.random.default_rng(2)
+    eul = np.stack([g.uniform(-3, 3, 32), g.uniform(-1.4, 1.4, 32), g.uniform(-3, 3, 32)], -1)
+    rot = Rotation.from_euler("xyz", eul)
+    assert np.allclose(R.quaternion_xyzw_to_euler(rot.as_quat()), eul, atol=1e-9)                      # scipy quaternions are xyzw
+    # column-major 4 x 4 pose -> [xyz, rpy, gripper / 0.079 clipped]
+    T = np.tile(np.eye(4), (32, 1, 1)); T[:, :3, :3] = rot.as_matrix(); T[:, :3, 3] = g.normal(size=(32, 3))
+    flat = np.swapaxes(T, 1, 2).reshape(32, 16)                                                          # column-major flattening
+    st = R.extract_state_from_matrix(flat, np.linspace(-0.01, 0.1, 32)[:, None])
+    assert np.allclose(st[:, :3], T[:, :3, 3]) and np.allclose(st[:, 3:6], eul, atol=1e-9)
+    assert st[0, 6] == 0.0 and st[-1, 6] == 1.0 and np.isclose(st[16, 6], np.linspace(-0.01, 0.1, 32)[16] / 0.079)
+    # relative -> absolute gripper: holds between commands, starts as the opposite of the first command, open without any
+    assert np.allclose(R.rel2abs_gripper_actions([0, 0, 0.5, 0, 0, -0.7, 0.05, 0]), [1, 1, 0, 0, 0, 1, 1, 1])
+    assert np.allclose(R.rel2abs_gripper_actions([0, -1, 0, 1]), [0, 1, 1, 0])
+    assert np.allclose(R.rel2abs_gripper_actions([0.05, -0.05, 0]), [1, 1, 1])
+    # a frame change acts on the translation as C t and on the rotation as C R C^T
+    for C in (R.TRANSFORM_BCZ, R.TRANSFORM_JACO):
+        m = np.concatenate([g.normal(size=(8, 3)), eul[:8]], 1)
+        out = R.apply_coordinate_transform(m, C)
+        assert np.allclose(out[:, :3], m[:, :3] @ C.T)
+        assert np.allclose(Rotation.from_euler("xyz", out[:, 3:]).as_matrix(), C @ rot[:8].as_matrix() @ C.T, atol=1e-9)
+    assert np.allclose(R.apply_coordinate_transform(np.array([[1.0, 2.0, 3.0, 0, 0, 0]]), R.TRANSFORM_JACO)[0, :3], [-2.0, 1.0, 3.0])
+    assert np.allclose(R.apply_coordinate_transform(np.array([[1.0, 2.0, 3.0, 0, 0, 0]]), R.TRANSFORM_BCZ)[0, :3], [-2.0, -1.0, -3.0])
+    # fallback instruction: only for blank instructions; deterministic needs the injected hash, random draws from the 18 phrases
+    assert R.fill_empty_language_instruction("pick up", 0.0) == "pick up" and len(R.FALLBACK_INSTRUCTIONS) == 18
+    assert R.fill_empty_language_instruction("  ", 1.5, hash_bucket=lambda v, n: 3) == "Carry out the objective."
+    with pytest.raises(ValueError):
+        R.fill_empty_language_instruction("", 1.5)
+    assert R.fill_empty_language_instruction("", 0.0, deterministic=False, rng=np.random.default_rng(0)) in R.FALLBACK_INSTRUCTIONS
+
+
+def test_rlds_export_covers_the_training_mixture_of_the_lap_config():
+    """Every dataset of `oxe_magic_soup` (mixtures.py:2-22, the `lap` config's data_mix) has its standardisation transform
+    (transforms.py) restated: hand-built raw trajectories in each dataset's own schema come out with one convention — state =
+    [xyz, extrinsic-XYZ euler, gripper (1 = open)], per-step language action = pose delta (zero at the last step) + gripper command."""
+    from scipy.spatial.transform import Rotation
+
+    from lap_amd import data as D, rlds_export as R
+
+    assert set(D.NAMED_MIXTURES["oxe_magic_soup"] if isinstance(D.NAMED_MIXTURES["oxe_magic_soup"], dict) else dict(D.NAMED_MIXTURES["oxe_magic_soup"])) <= set(R.STANDARDIZE)
+    T = 5
+    g = np.random.default_rng(3)
+    img = g.integers(0, 255, (T, 4, 4, 3), dtype=np.uint8)
+    xyz = np.cumsum(g.normal(size=(T, 3)) * 0.01, 0)
+    eul = np.stack([np.linspace(0.1, 0.3, T), np.linspace(-0.2, 0.1, T), np.linspace(1.0, 1.4, T)], -1)
+    rot = Rotation.from_euler("xyz", eul)
+    quat = rot.as_quat()                                                                                  # xyzw
+    Tm = np.tile(np.eye(4), (T, 1, 1)); Tm[:, :3, :3] = rot.as_matrix(); Tm[:, :3, 3] = xyz
+    flat = np.swapaxes(Tm, 1, 2).reshape(T, 16)
+    lang = np.array([b"stack the cups"] * T)
+    pose = np.concatenate([xyz, eul], 1)
+    mov = R.compute_padded_movement_actions(pose)
+    assert np.allclose(mov[-1], 0) and np.allclose(mov[:-1, :3], np.diff(xyz, axis=0))
+    closed = np.array([0.0, 0.0, 1.0, 1.0, 0.0])[:, None]           # 1 = closed in most raw schemas
+
+    def check(name, traj, want_state_grip, want_cmd, want_pose=pose, want_mov=mov, prompt="stack the cups", **kw):
+        ep = R.episode_from_rlds(name, traj, **kw)
+        assert ep is not None and ep["prompt"] == prompt and ep["dataset_name"] == name, name
+        assert ep["state"].shape == (len(want_pose), 7) and ep["actions"].shape == (len(want_pose), 7), name
+        assert np.allclose(ep["state"][:, :6], want_pose, atol=1e-6), name
+        assert np.allclose(ep["state"][:, 6], np.ravel(want_state_grip), atol=1e-6), name
+        assert np.allclose(ep["actions"][:, :6], want_mov, atol=1e-6), name
+        assert np.allclose(ep["actions"][:, 6], np.ravel(want_cmd), atol=1e-6), name
+        b, w = R.IMAGE_KEYS[name]
+        assert ep["base_0_rgb"].shape[0] == len(want_pose) and (("left_wrist_0_rgb" in ep) == (w is not None)), name
+        return ep
+
+    nli = {"natural_language_instruction": lang}
+    # RT-1: quaternion pose, gripper_closed state, relative gripper command (+ close / - open)
+    check("fractal20220817_data", {"observation": {"image": img, "base_pose_tool_reached": np.concatenate([xyz, quat], 1), "gripper_closed": closed, **nli},
+                                   "action": {"gripper_closedness_action": np.array([0, 1.0, 0, -1.0, 0])[:, None], "world_vector": xyz, "rotation_delta": eul}},
+          1 - closed, [1, 0, 0, 1, 1])
+    # Bridge V2 (website version): first step dropped, 7-dim state, gripper command binarised
+    st7 = np.concatenate([pose, np.array([0.2, 1.3, -0.1, 0.5, 0.9])[:, None]], 1)
+    act7 = np.concatenate([g.normal(size=(T, 6)), np.array([1.0, 1.0, 0.5, 0.0, 0.0])[:, None]], 1)
+    check("bridge_v2_oxe", {"observation": {"image_0": img, "state": st7}, "action": act7, "language_instruction": lang, "traj_metadata": {"episode_id": 7}},
+          np.clip(st7[1:, 6], 0, 1), [1, 0, 0, 0], want_pose=pose[1:], want_mov=R.compute_padded_movement_actions(pose[1:]))
+    # taco_play: robot_obs = [pose, gripper width ...]; command in -1 .. 1
+    ro = np.concatenate([pose, np.array([0.0, 0.04, 0.0807, 0.1, -0.01])[:, None], np.zeros((T, 8))], 1)
+    check("taco_play", {"observation": {"rgb_static": img, "rgb_gripper": img, "robot_obs": ro, **nli}, "action": {"rel_actions_world": np.concatenate([np.zeros((T, 6)), np.array([-1, -1, 1, 0.5, 3.0])[:, None]], 1)}},
+          np.clip(12.3903 * ro[:, 6], 0, 1), [0, 0, 1, 0.75, 1])
+    # jaco_play: pose rotated into x' = -y, y' = x
+    jp = R.apply_coordinate_transform(pose, R.TRANSFORM_JACO)
+    check("jaco_play", {"observation": {"image": img, "image_wrist": img, "end_effector_cartesian_pos": np.concatenate([pose, np.array([0.0, 0.1, 0.2, 0.3, 0.15])[:, None]], 1), **nli},
+                        "action": {"gripper_closedness_action": np.array([0, 0, 1.0, 0, -1.0])[:, None], "world_vector": xyz}},
+          np.clip(np.array([0.0, 0.1, 0.2, 0.3, 0.15]) * 4.33, 0, 1), [1, 1, 0, 0, 1], want_pose=jp, want_mov=R.compute_padded_movement_actions(jp))
+    # viola / mutex / austin_*: column-major pose matrices
+    width = np.array([0.0, 0.0395, 0.079, 0.1, 0.02])[:, None]
+    check("viola", {"observation": {"agentview_rgb": img, "eye_in_hand_rgb": img, "ee_states": flat, "gripper_states": width, **nli},
+                    "action": {"gripper_closedness_action": np.array([-1.0, 0.0, 1.0, 0.5, 2.0])}}, np.clip(width / 0.079, 0, 1), [1, 1, 0, 0.5, 0])
+    st24 = np.concatenate([np.zeros((T, 7)), width, flat], 1)                                            # [7 joints, gripper, 16 pose]
+    a7 = np.concatenate([np.zeros((T, 6)), np.array([-1.0, 0.0, 1.0, 0.3, 1.0])[:, None]], 1)
+    check("utaustin_mutex", {"observation": {"image": img, "wrist_image": img, "state": st24}, "action": a7, "language_instruction": lang},
+          np.clip(width / 0.079, 0, 1), [1, 1, 0, 0.7, 0])
+    blank = np.array([b""] * T)
+    ep = check("austin_buds_dataset_converted_externally_to_rlds", {"observation": {"image": img, "wrist_image": img, "state": st24}, "action": a7, "language_instruction": blank},
+               np.clip(width / 0.079, 0, 1), [1, 1, 0, 0.7, 0], prompt=R.FALLBACK_INSTRUCTIONS[5], hash_bucket=lambda v, n: 5)
+    st8 = np.concatenate([np.zeros((T, 7)), width], 1)
+    for name, kw in (("austin_sailor_dataset_converted_externally_to_rlds", dict(hash_bucket=lambda v, n: 0)), ("austin_sirius_dataset_converted_externally_to_rlds", dict(rng=np.random.default_rng(1)))):
+        e2 = R.episode_from_rlds(name, {"observation": {"image": img, "wrist_image": img, "state": st8, "state_ee": flat}, "action": a7, "language_instruction": blank}, **kw)
+        assert e2["prompt"] in R.FALLBACK_INSTRUCTIONS and np.allclose(e2["state"][:, :6], pose, atol=1e-6) and np.allclose(e2["actions"][:, 6], [1, 1, 0, 0.7, 0])
+    # quaternion-pose datasets
+    check("furniture_bench_dataset_converted_externally_to_rlds", {"observation": {"image": img, "wrist_image": img, "state": np.concatenate([xyz, quat, width], 1)}, "action": a7, "language_instruction": lang},
+          np.clip(width / 0.079, 0, 1), [1, 1, 0, 0.7, 0])
+    check("fmb", {"observation": {"image_side_1": img, "image_wrist_2": img, "eef_pose": np.concatenate([xyz, quat], 1), "state_gripper_pose": closed[:, 0]}, "action": np.concatenate([np.zeros((T, 6)), closed], 1), "language_instruction": lang},
+          1 - closed, 1 - closed)
+    rs = np.concatenate([np.zeros((T, 6)), xyz, quat, closed, np.zeros((T, 1))], 1)
+    check("berkeley_autolab_ur5", {"observation": {"image": img, "hand_image": img, "image_with_depth": img[..., :1], "robot_state": rs, **nli},
+                                   "action": {"gripper_closedness_action": np.array([0, 0, 1.0, 0, -1.0]), "world_vector": xyz, "rotation_delta": eul}}, 1 - closed, [1, 1, 0, 0, 1])
+    # fanuc: the stored action is the movement part of the language action, the gripper STATE stands in for the command
+    fa = g.normal(size=(T, 6))
+    check("berkeley_fanuc_manipulation", {"observation": {"image": img, "wrist_image": img, "state": np.concatenate([np.zeros((T, 6)), closed], 1), "end_effector_state": np.concatenate([xyz, quat], 1)},
+                                          "action": fa, "language_instruction": lang}, 1 - closed, 1 - closed, want_mov=fa)
+    # molmoact: the stored action IS the language action; gripper conventions inverted
+    ma = np.concatenate([g.normal(size=(T, 6)), closed], 1)
+    check("molmoact_dataset", {"observation": {"first_view_image": img, "wrist_image": img, "state": np.concatenate([pose, closed], 1)}, "action": ma, "language_instruction": lang},
+          1 - closed, 1 - closed, want_mov=ma[:, :6])
+    # bc_z: axis-angle pose in the frame x' = -y, y' = -x, z' = -z; sensed_close scaled by 0.8
+    bp = R.apply_coordinate_transform(pose, R.TRANSFORM_BCZ)
+    sensed = np.array([0.0, 0.2, 0.6, 1.0, 0.5])[:, None]
+    check("bc_z", {"observation": {"image": img, "present/xyz": xyz, "present/axis_angle": rot.as_rotvec(), "present/sensed_close": sensed, **nli},
+                   "action": {"future/xyz_residual": np.zeros((T, 30)), "future/axis_angle_residual": np.zeros((T, 30)), "future/target_close": np.tile(closed, (1, 10)).astype(np.int64)}},
+          np.clip((1 - sensed) / 0.8, 0, 1), 1 - closed, want_pose=bp, want_mov=R.compute_padded_movement_actions(bp))
+    # an instruction-free trajectory of a dataset without a fallback is dropped
+    assert R.episode_from_rlds("fmb", {"observation": {"image_side_1": img, "image_wrist_2": img, "eef_pose": np.concatenate([xyz, quat], 1), "state_gripper_pose": closed[:, 0]},
+                                       "action": np.concatenate([np.zeros((T, 6)), closed], 1), "language_instruction": blank}) is None

@@ -46,11 +46,17 @@ def main():
     builder = tfds.builder(args.dataset, data_dir=args.data_dir)
     ds = tfds.as_numpy(builder.as_dataset(split=args.split))
     kept = dropped = 0
+    rng = np.random.default_rng(0)
+
+    def tf_hash_bucket(value, n):   # transform_helpers.py:110-114: the reference's own hash of the decimal string of sum(state[0])
+        import tensorflow as tf
+        return int(tf.strings.to_hash_bucket_fast(tf.strings.as_string(tf.constant(value, tf.float32)), n))
+
     for i, episode in enumerate(ds):
         if args.max_episodes is not None and kept >= args.max_episodes:
             break
         traj = stack_steps(list(episode["steps"]))
-        ep = R.episode_from_rlds(args.dataset, traj)
+        ep = R.episode_from_rlds(args.dataset, traj, hash_bucket=tf_hash_bucket, rng=rng)
         if ep is None:
             dropped += 1
             continue
