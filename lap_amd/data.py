@@ -78,6 +78,51 @@ class EpisodeDataset:
                 "has_wrist_image": "left_wrist_0_rgb" in e}
 
 
+class VqaDataset:
+    """Vision-language samples in a mixture (datasets/vqa/vqa_base.py:53-265 through output_schema.py:78-133): one frame per
+    sample, a prompt and a caption, a zero state, zero actions, `is_vqa_sample`, the dataset's id.  Items are the dicts of
+    `lap_amd.vqa_export.sample_from_record` — a list of them, or a directory of `.npz` files written by
+    `tools/export_vqa_samples.py` (an encoded image is decoded with PIL on access).  Indexable like `EpisodeDataset`, carries no
+    episodes (VQA sets are left out of the normalisation statistics, dataset_mixer.py:166-214)."""
+
+    def __init__(self, samples: Sequence[dict] | str | pathlib.Path, *, action_horizon: int, action_dim: int = 7, state_dim: int = 7):
+        if isinstance(samples, (str, pathlib.Path)):
+            files = sorted(pathlib.Path(samples).glob("*.npz"))
+            if not files:
+                raise FileNotFoundError(f"no sample files (*.npz) under {samples}")
+            samples = [dict(np.load(f, allow_pickle=False)) for f in files]
+        for i, e in enumerate(samples):
+            for k in ("image", "prompt", "caption", "dataset_name", "vqa_dataset_id"):
+                if k not in e:
+                    raise KeyError(f"VQA sample {i} has no '{k}'")
+        self.samples = list(samples)
+        self.action_horizon, self.action_dim, self.state_dim = action_horizon, action_dim, state_dim
+        self.episodes: list = []
+
+    def __len__(self) -> int:
+        return len(self.samples)
+
+    @staticmethod
+    def _image(e: dict) -> np.ndarray:
+        img = np.asarray(e["image"])
+        if bool(np.asarray(e.get("image_encoded", False))):
+            import io
+
+            from PIL import Image
+            img = np.asarray(Image.open(io.BytesIO(img.tobytes())).convert("RGB"))
+        return img
+
+    def __getitem__(self, index: int) -> dict:
+        e = self.samples[int(index)]
+        txt = lambda v: str(np.asarray(v).item()) if not isinstance(v, str) else v
+        return {"observation": {"base_0_rgb": self._image(e), "state": np.zeros(self.state_dim, dtype=np.float32)},
+                "prompt": txt(e["prompt"]), "caption": txt(e["caption"]), "dataset_name": txt(e["dataset_name"]),
+                "is_vqa_sample": True, "is_prediction_sample": False, "vqa_dataset_id": int(np.asarray(e["vqa_dataset_id"])),
+                "time_horizon_seconds": 1.0, "actions": np.zeros((self.action_horizon, self.action_dim), dtype=np.float32),
+                "language_actions": np.zeros(7, dtype=np.float32), "raw_state": np.zeros(self.state_dim, dtype=np.float32),
+                "has_wrist_image": False}
+
+
 def compute_norm_stats(dataset: EpisodeDataset, *, action_pad_to: int | None = None) -> dict:
     """scripts/compute_norm_stats.py equivalent over the whole store: mean / std / q01 / q99 / min / max of `state` and of the
     per-step `actions` (norm_stats.json layout, openpi NormStats fields).  The reference computes them AFTER the data
@@ -229,6 +274,8 @@ def compute_mixture_norm_stats(mixture: MixtureDataset, *, action_pad_to: int, s
     (dataset_mixer.py:166-214)."""
     per = {}
     for name, ds in zip(mixture.names, mixture.datasets):
+        if isinstance(ds, VqaDataset):       # no robot state / actions to normalise (dataset_mixer.py:166-214 skips VQA sets)
+            continue
         st = compute_norm_stats(ds, action_pad_to=action_pad_to)
         n_tr, n_ep = len(ds), len(ds.episodes)
         per[name] = {k: {**{f: np.asarray(v[f], dtype=np.float32) for f in v}, "num_transitions": n_tr, "num_trajectories": n_ep} for k, v in st.items()}
@@ -333,6 +380,8 @@ def create_data_loader(config, dataset: "EpisodeDataset | MixtureDataset", token
     stack = pio.compose([
         pio.CoTInputs(action_dim=mc.action_dim, random_base_prob=getattr(config.data, "random_base_prob", 0.0),
                       enable_langact_training=mc.enable_langact_training),
+        # (mixtures: cameras of different resolutions must batch — the reference's decode step resizes every frame, image_utils.py:192-267)
+        *([pio.ResizeImages(mc.image_size, mc.image_size)] if isinstance(dataset, MixtureDataset) else []),
         pio.Normalize(norm_stats, normalization_type=ntype),
         pio.TokenizePromptAndReasoning(tokenizer, discrete_state_input=mc.discrete_state_input, verbose_mode=mc.verbose_mode,
                                        state_dropout=mc.state_dropout if split == "train" else 0.0),

@@ -233,6 +233,46 @@ class PadStatesAndActions:
         return data
 
 
+def dataset_resize_with_pad(image: np.ndarray, height: int, width: int) -> np.ndarray:
+    """datasets/utils/image_utils.py:192-228 (`make_decode_images_fn(resize_to=(224, 224))`): what the reference's DATA pipeline does
+    to every decoded frame so that a mixture of datasets with different camera resolutions batches — aspect-preserving bilinear
+    resize to floor(h / r) x floor(w / r), r = max(w / width, h / height) (tf.image.resize: half-pixel centres, NO anti-aliasing,
+    unlike the model-side `observation.resize_with_pad`), rounded to uint8, centred zero padding (the odd pixel goes after)."""
+    import torch
+
+    img = np.asarray(image)
+    h, w = img.shape[:2]
+    if (h, w) == (height, width):
+        return img
+    ratio = np.float32(max(np.float32(w) / np.float32(width), np.float32(h) / np.float32(height)))
+    rh, rw = int(np.floor(np.float32(h) / ratio)), int(np.floor(np.float32(w) / ratio))
+    x = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1)[None].to(torch.float32)
+    x = torch.nn.functional.interpolate(x, size=(rh, rw), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0)
+    if img.dtype == np.uint8:
+        res, fill = x.round().clamp(0, 255).to(torch.uint8).numpy(), 0
+    else:
+        res, fill = x.clamp(-1.0, 1.0).numpy().astype(img.dtype), -1.0
+    out = np.full((height, width, img.shape[2]), fill, dtype=res.dtype)
+    ph0, pw0 = (height - rh) // 2, (width - rw) // 2
+    out[ph0:ph0 + rh, pw0:pw0 + rw] = res
+    return out
+
+
+@dataclasses.dataclass(frozen=True)
+class ResizeImages:
+    """The loader-side use of `dataset_resize_with_pad`: every image of the sample to (height, width); a no-op for frames that have
+    the size already (stores exported at the model's resolution)."""
+    height: int
+    width: int
+
+    def __call__(self, data: dict) -> dict:
+        if "image" not in data:
+            return data
+        data = dict(data)
+        data["image"] = {k: dataset_resize_with_pad(v, self.height, self.width) for k, v in data["image"].items()}
+        return data
+
+
 def parse_image(image):
     """image_utils.py:7-17: float images are [0, 1] -> uint8 (truncating), CHW / TCHW -> channels last."""
     if image is None:

@@ -378,3 +378,96 @@ def test_rlds_export_covers_the_training_mixture_of_the_lap_config():
     # an instruction-free trajectory of a dataset without a fallback is dropped
     assert R.episode_from_rlds("fmb", {"observation": {"image_side_1": img, "image_wrist_2": img, "eef_pose": np.concatenate([xyz, quat], 1), "state_gripper_pose": closed[:, 0]},
                                        "action": np.concatenate([np.zeros((T, 6)), closed], 1), "language_instruction": blank}) is None
+
+
+# ------------------------------------------------------------------------------ VQA readers (lap_amd/vqa_export.py)
+def test_vqa_tables_and_geometry_match_the_reference_fixture():
+    """Every prompt table of datasets/vqa/*.py and bbox/prompts.py, the loc-token text of 186 boxes and the direction words of 486
+    (box, slope) cases, against tests/golden/vqa_v1.json — produced from the reference's own sources by make_vqa_golden.py."""
+    import json
+    import pathlib
+
+    from lap_amd import vqa_export as V
+
+    d = json.loads((pathlib.Path(__file__).parent / "golden" / "vqa_v1.json").read_text())
+    for k in ("COCO_CAPTION_PROMPTS", "PIXMO_CAP_PROMPTS"):
+        assert list(getattr(V, k)) == d[k], k
+    for k in ("PIXMO_POINT_PROMPT_PARTS", "GENERAL_BBOX_PROMPT_PARTS", "ROBOT_BBOX_PROMPT_PARTS", "ROBOT_BBOX_PROMPT_PARTS_OXE", "ROBOT_BBOX_PROMPT_PARTS_EE",
+              "DIRECTION_PROMPT_PARTS", "ROBOT_DIRECTION_PROMPT_PARTS_OXE", "ROBOT_DIRECTION_PROMPT_PARTS_EE"):
+        assert [list(p) for p in getattr(V, k)] == d[k], k
+    assert V.MAX_POINTS == d["MAX_POINTS"]
+    for c in d["loc_cases"]:
+        assert V.bbox_to_text(*c["box"], num_bins=c.get("bins", 1024)) == c["expected"], c
+    for c in d["direction_cases"]:
+        assert V.direction_from_bbox(*c["box"], slope=c["slope"]) == c["expected"], c
+        assert V.direction_from_bbox(*c["box"], slope=c["slope"], add_move_prefix=True) == "move " + c["expected"]
+
+
+def test_vqa_records_become_samples_and_join_a_mixture(setup):
+    """Hand-built records in each dataset's TFDS schema -> (trajectory id, prompt, caption) by the rules of the six reader classes, with the
+    random draws injected; then a VqaDataset next to an episode store in one mixture, through the loader's transform stack."""
+    from lap_amd import vqa_export as V
+
+    first = lambda seed_pair, n: 0
+    last = lambda seed_pair, n: n - 1
+    hb = lambda text, n: len(text) % n
+    img = np.full((6, 8, 3), 7, dtype=np.uint8)
+    # VQAv2: the record's own question / answer
+    r = {"image": img, "question_id": 42, "image/id": 9, "question_text": b"what color is the cup?", "top_answer": b"red"}
+    assert V.prompt_and_caption("vqa", r) == ("what color is the cup?", "red") and V.trajectory_id("vqa", r) == "vqa_42_9"
+    assert V.sample_from_record("vqa", dict(r, top_answer=b"")) is None                       # empty answers are filtered
+    # COCO: one of the captions, one of the 20 prompts, seeded by the image id
+    r = {"image": img, "image/filename": b"a.jpg", "image/id": 3, "captions": {"text": np.array([b"two dogs", b"dogs playing"])}}
+    assert V.prompt_and_caption("coco_captions", r, choose=first) == (V.COCO_CAPTION_PROMPTS[0], "two dogs")
+    assert V.prompt_and_caption("coco_captions", r, choose=last) == (V.COCO_CAPTION_PROMPTS[-1], "dogs playing")
+    assert V.trajectory_id("coco_captions", r) == "coco_a.jpg_3"
+    seeds = []
+    V.prompt_and_caption("coco_captions", r, seed=11, choose=lambda sp, n: seeds.append(tuple(sp)) or 0)
+    assert seeds == [(11, 3), (12, 3)]                                                        # [seed, id] for the caption, [seed + 1, id] for the prompt
+    # PixMo-Cap: the caption as it is; id and seed from the FarmHash of the file name
+    r = {"image": img, "image_filename": b"xy.png", "caption": b"a long caption"}
+    assert V.prompt_and_caption("pixmo_cap", r, choose=last, hash_bucket=hb) == (V.PIXMO_CAP_PROMPTS[-1], "a long caption")
+    assert V.trajectory_id("pixmo_cap", r, hb) == f"pixmo_cap_xy.png_{len('xy.png_a long caption') % 2147483647}"
+    # PixMo-Points: points on a 0-100 scale, sorted by x then y, as <locY><locX> pairs; at most 20
+    r = {"image": img, "image_sha256": b"ab12", "label": b"mugs", "count": 2, "points": {"x": np.array([50.0, 10.04]), "y": np.array([25.0, 99.96])}}
+    p, c = V.prompt_and_caption("pixmo_point", r, scale=1.0 * 1, choose=first, hash_bucket=hb)
+    assert p == "How many mugs are in the image? Point them out."
+    want = lambda x, y: f"<loc{int(round(y / 100 * 1023)):04d}><loc{int(round(x / 100 * 1023)):04d}>"
+    assert V.points_to_text(np.array([[50.0, 25.0], [10.0, 100.0]])) == want(10.0, 100.0) + want(50.0, 25.0)
+    many = {"x": np.linspace(1, 99, 30), "y": np.linspace(99, 1, 30)}
+    assert V.prompt_and_caption("pixmo_point", dict(r, points=many), scale=100.0 / 100.0, choose=first, hash_bucket=hb)[1].count("<loc") == 2 * V.MAX_POINTS
+    # LVIS / PACO: a category and its box -> an OXE bbox prompt + loc tokens, or (directional / with direction_prob) a direction
+    r = {"image": img, "image_id": b"000123", "annotations": {"category_name": np.array([b"spoon"]), "bbox": np.array([[[0.1, 0.6], [0.3, 0.9]]], dtype=np.float32)}}
+    p, c = V.prompt_and_caption("lvis", r, choose=first, hash_bucket=hb, uniform=lambda sp: 0.9)
+    assert p == "Pick up the spoon, predict where it is in the image." and c == V.bbox_to_text(np.float32(0.1), np.float32(0.6), np.float32(0.3), np.float32(0.9))
+    assert c == "<loc0614><loc0102><loc0921><loc0307>"
+    p, c = V.prompt_and_caption("paco_lvis", r, direction_prob=0.5, choose=last, hash_bucket=hb, uniform=lambda sp: 0.2)
+    assert p == "".join([V.GENERAL_BBOX_PROMPT_PARTS[-1][0], "spoon", V.GENERAL_BBOX_PROMPT_PARTS[-1][1]]) and c == "move left"
+    p, c = V.prompt_and_caption("lvis", r, directional=True, choose=first, hash_bucket=hb)
+    assert p.startswith("From the image center") and "spoon" in p and c == "move left"
+    assert V.trajectory_id("lvis", r, hb).startswith("lvis_000123_") and V.trajectory_id("paco_ego4d", r, hb).startswith("paco_000123_")
+    assert V.is_validation("vqa", {"question_id": 1, "image/id": 2}, 0, 1.0, hb) and not V.is_validation("vqa", {"question_id": 1, "image/id": 2}, 0, 0.0, hb)
+    assert V.VQA_DATASET_IDS == {"coco_captions": 1, "lvis": 2, "paco_lvis": 3, "paco_ego4d": 4, "pixmo_cap": 5, "pixmo_point": 6, "vqa": 7}
+    # the stand-in draws are pure functions of the seed pair
+    assert V.numpy_choices((3, 4), 20) == V.numpy_choices((3, 4), 20) and 0 <= V.numpy_uniform((1, 2)) < 1
+    # ---- into a mixture with robot episodes, through the loader
+    cfg, tok, eps_ds = setup
+    recs = [{"image": np.full((30, 44, 3), 10 * i + 5, dtype=np.uint8), "question_id": i, "image/id": i, "question_text": f"what is item {i}?".encode(), "top_answer": f"thing {i}".encode()}
+            for i in range(6)]
+    vqa = D.VqaDataset([V.sample_from_record("vqa", r) for r in recs], action_horizon=cfg.model.action_horizon, action_dim=7, state_dim=10)
+    s = vqa[2]
+    assert s["is_vqa_sample"] and s["vqa_dataset_id"] == 7 and s["caption"] == "thing 2" and s["observation"]["base_0_rgb"].shape == (30, 44, 3)
+    mix = D.MixtureDataset({"droid": eps_ds, "vqa": vqa}, [("droid", 1.0), ("vqa", 1.0)], balance_weights=False, seed=0)
+    loader = D.create_data_loader(cfg, mix, tok, shuffle=True, seed=1, num_batches=6, split="val")
+    n_vqa = n = 0
+    for obs, actions in loader:
+        isv = np.asarray(obs.is_vqa_sample.cpu()) if hasattr(obs, "is_vqa_sample") and obs.is_vqa_sample is not None else None
+        assert isv is not None, "the observation carries the VQA flag compute_loss mixes by"
+        n_vqa += int(isv.sum()); n += len(isv)
+        assert torch.isfinite(actions).all()        # (a VQA sample's dummy actions are masked out of the action loss, lap.py:560-569)
+    assert 0 < n_vqa < n
+    # frames of different native sizes were brought to the model's resolution the way the reference's decode step does it
+    small = np.zeros((30, 60, 3), dtype=np.uint8); small[:, :30] = 200
+    out = pio.dataset_resize_with_pad(small, 56, 56)                       # ratio 60 / 56: 28 x 56 rows, 14 rows of padding above and below
+    assert out.shape == (56, 56, 3) and (out[:14] == 0).all() and (out[42:] == 0).all() and out[14:42, :20].min() == 200 and out[14:42, 36:].max() == 0
+    assert pio.dataset_resize_with_pad(out, 56, 56) is out
