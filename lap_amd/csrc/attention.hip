@@ -32,6 +32,7 @@ struct AttnP {
   int q_rs[2], kv_rs[2], o_rs[2];   // row strides (elements) of q/dq, k/v/dk/dv, o/dO
   const int32_t* qinfo; const int32_t* kinfo;
   float* lse; float* delta;
+  int fuse_delta;   // backward, LDS-DMA kernels: the dQ launch computes delta itself and runs FIRST (no attn_delta_kernel)
   float scale;                      // logits = scale * q.k
   int B, NH, NKV, stop;
   int hsplit;                       // dK/dV: query heads of one kv head are split over hsplit blocks ...
@@ -613,7 +614,8 @@ int set_lds(K kernel, int bytes) {
 #include "serve_chain_tp.hpp"
 
 // Tuning / test knob (lap_attention_set_variant): -1 = automatic; 0 = generic kernels also for HD = 256;
-// 1 = the HD = 256 LDS-DMA kernels (what automatic picks whenever their LDS info table fits).
+// 1 = the HD = 256 LDS-DMA kernels (what automatic picks whenever their LDS info table fits); 2 = as 1 with the backward's
+// delta as a separate pass in front (the arrangement before round 4; A/B measurements).
 int g_attn_variant = -1;
 int attn_variant() { return g_attn_variant; }
 
@@ -666,44 +668,50 @@ int launch_fwd(const AttnP& p, hipStream_t s) {
 template <int HD>
 int launch_bwd(const AttnP& p, hipStream_t s) {
   const int Tq = p.qlen[0] + p.qlen[1];
-  const int lds = 2 * Cfg<HD>::TILE + 1024;   // + staged info words / lse / delta
-  const long long items = (long long)p.B * Tq * p.NH;
-  hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, s, p);
-  LAP_CHECK_LAUNCH();
   const int ntk = (p.klen[0] + 63) / 64 + (p.klen[1] + 63) / 64;
-  bool kv_dma = false;
-  if constexpr (HD == 256 || HD == 72) kv_dma = dma_path_ok(p);
-  if (kv_dma) {
-    if constexpr (HD == 256 || HD == 72) {
-      const int ntq32 = (p.qlen[0] + 31) / 32 + (p.qlen[1] + 31) / 32;
-      const int lds2 = 4 * DmaCfg<HD>::TILE + 1024 + ntq32 * 144;
-      auto kern = attn_dma_kv_kernel<HD>;
-      if (int e = set_lds(kern, lds2)) return e;
-      hipLaunchKernelGGL(kern, dim3(p.B * p.NKV * p.hsplit * ntk), dim3(256), lds2, s, p);
+  auto reduce = [&]() -> int {
+    if (p.hsplit > 1) {
+      const long long n4 = (long long)p.B * (p.klen[0] + p.klen[1]) * p.NKV * HD / 4;
+      hipLaunchKernelGGL(attn_dkdv_reduce_kernel<HD>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
       LAP_CHECK_LAUNCH();
     }
-  } else {
-    if (int e = set_lds(attn_bwd_dkdv_kernel<HD>, lds)) return e;
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HD>, dim3(p.B * p.NKV * p.hsplit * ntk), dim3(256), lds, s, p);
+    return LAP_OK;
+  };
+  auto delta = [&]() -> int {
+    const long long items = (long long)p.B * Tq * p.NH;
+    hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, s, p);
     LAP_CHECK_LAUNCH();
-  }
-  if (p.hsplit > 1) {
-    const long long n4 = (long long)p.B * (p.klen[0] + p.klen[1]) * p.NKV * HD / 4;
-    hipLaunchKernelGGL(attn_dkdv_reduce_kernel<HD>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
-    LAP_CHECK_LAUNCH();
-  }
+    return LAP_OK;
+  };
   if constexpr (HD == 256 || HD == 72) {
     if (dma_path_ok(p)) {
-      const int nt = (p.qlen[0] + p.qlen[1] + 63) / 64;
+      // dQ first: it computes delta = rowsum(dO o O) for its own rows and publishes it for the dK / dV launch behind it
+      // (variant 2: the separate delta pass in front, for A/B measurements)
+      AttnP q = p;
+      q.fuse_delta = attn_variant() != 2;
+      if (!q.fuse_delta) { if (int e = delta()) return e; }
+      const int nt = (Tq + 63) / 64;
       const int ntk32 = (p.klen[0] + 31) / 32 + (p.klen[1] + 31) / 32;
-      const int lds2 = 4 * DmaCfg<HD>::TILE + ntk32 * 144;
-      auto kern = attn_dma_q_kernel<HD, 1>;
-      if (int e = set_lds(kern, lds2)) return e;
-      hipLaunchKernelGGL(kern, dim3(p.B * p.NH * nt, 1), dim3(256), lds2, s, p);
+      const int lds_q = 4 * DmaCfg<HD>::TILE + ntk32 * 144;
+      auto kq = attn_dma_q_kernel<HD, 1>;
+      if (int e = set_lds(kq, lds_q)) return e;
+      hipLaunchKernelGGL(kq, dim3(p.B * p.NH * nt, 1), dim3(256), lds_q, s, q);
       LAP_CHECK_LAUNCH();
-      return LAP_OK;
+      const int ntq32 = (p.qlen[0] + 31) / 32 + (p.qlen[1] + 31) / 32;
+      const int lds_kv = 4 * DmaCfg<HD>::TILE + 1024 + ntq32 * 144;
+      auto kkv = attn_dma_kv_kernel<HD>;
+      if (int e = set_lds(kkv, lds_kv)) return e;
+      hipLaunchKernelGGL(kkv, dim3(p.B * p.NKV * p.hsplit * ntk), dim3(256), lds_kv, s, p);
+      LAP_CHECK_LAUNCH();
+      return reduce();
     }
   }
+  const int lds = 2 * Cfg<HD>::TILE + 1024;   // + staged info words / lse / delta
+  if (int e = delta()) return e;
+  if (int e = set_lds(attn_bwd_dkdv_kernel<HD>, lds)) return e;
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HD>, dim3(p.B * p.NKV * p.hsplit * ntk), dim3(256), lds, s, p);
+  LAP_CHECK_LAUNCH();
+  if (int e = reduce()) return e;
   const int ntq = (p.qlen[0] + 63) / 64 + (p.qlen[1] + 63) / 64;
   if (int e = set_lds(attn_bwd_dq_kernel<HD>, lds)) return e;
   hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, dim3(p.B * p.NH * ntq), dim3(256), lds, s, p);
@@ -722,7 +730,7 @@ bool check_common(int B, int NH, int NKV, int HD, const int* qlen, const int* kl
 }  // namespace
 
 extern "C" int lap_attention_set_variant(int variant) {
-  if (variant < -1 || variant > 1) return LAP_ERR_ARG;
+  if (variant < -1 || variant > 2) return LAP_ERR_ARG;
   g_attn_variant = variant;
   return LAP_OK;
 }

@@ -22,7 +22,7 @@ constexpr int T32_TILE = 32 * 512;         // bytes of one 32 x 256 bf16 tile (h
 // (d >= 72) are fetched with an out-of-range offset, i.e. as zeros.
 template <int HD> struct DmaCfg;
 template <> struct DmaCfg<256> {
-  static constexpr int KS = 8, DF = 16, PITCH = 512, REAL_CHUNKS = 32, TILE = 32 * 512, PIECES = 4, KREGS = 4, VREGS = 8, BLOCKS = 2, KV_BLOCKS = 2;
+  static constexpr int KS = 8, DF = 16, PITCH = 512, REAL_CHUNKS = 32, TILE = 32 * 512, PIECES = 4, KREGS = 4, VREGS = 8, BLOCKS = 2, KV_BLOCKS = 1;
   __device__ static __forceinline__ int swz(int row) { return (row & 7) << 1; }
 };
 template <> struct DmaCfg<72> {
@@ -107,6 +107,17 @@ __device__ __forceinline__ float sum_over_groups(float v) {
 }
 
 template <int V> struct IC { static constexpr int value = V; };
+// K-contiguous fragment through a raw ds_read_b128 (see ds_read_tr_raw: valid only behind lds_wait4x / lds_wait_all + lds_tie)
+template <int OFFSET>
+__device__ __forceinline__ bf16x8 ds_read_b128_raw(unsigned lds_addr) {
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFFSET));
+  return r;
+}
+template <int LEFT>
+__device__ __forceinline__ void lds_wait4x(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(LEFT));
+}
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 // Streamed-side cursor: the 32-row tiles of the two segments form one list.  `rs*` are buffer descriptors whose
@@ -173,7 +184,21 @@ __global__ __launch_bounds__(256, DmaCfg<HD>::BLOCKS) void attn_dma_q_kernel(Att
   if constexpr (MODE == 1) {
     load_row_frags<HD>(p.d_o[qsg] + (b * (long long)p.qlen[qsg] + qloc) * p.o_rs[qsg] + h * HD, vq, lane, dof);
     lse2 = (vq ? p.lse[((long long)b * p.NH + h) * Tq + myq] : LSE_EMPTY) * LOG2E;
-    dl_q = vq ? p.delta[((long long)b * p.NH + h) * Tq + myq] : 0.f;
+    if (p.fuse_delta) {
+      // delta = rowsum(dO o O) of my row, computed here (the dO fragments are in registers anyway) and published for the dK / dV
+      // launch BEHIND this one: no separate pass over O and dO.  Lane (i, g) holds 8 of every 32 d; the four g sum up.
+      bf16x8 of[KS];
+      load_row_frags<HD>(p.o[qsg] + (b * (long long)p.qlen[qsg] + qloc) * p.o_rs[qsg] + h * HD, vq, lane, of);
+      float a = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += (float)dof[kk][e] * (float)of[kk][e];
+      dl_q = sum_over_groups(a);
+      if (vq && g == 0) p.delta[((long long)b * p.NH + h) * Tq + myq] = dl_q;
+    } else {
+      dl_q = vq ? p.delta[((long long)b * p.NH + h) * Tq + myq] : 0.f;
+    }
   }
 
   // ---- stage the info words + tile summaries of my share of the key tiles (once per block); all loads of a
@@ -364,6 +389,9 @@ __global__ __launch_bounds__(256, DmaCfg<HD>::BLOCKS) void attn_dma_q_kernel(Att
 
     if constexpr (HD == 256) {
     // O^T += V^T P^T: V fragments through raw transposing reads, software pipelined in groups of 4 d-fragments
+    // (measured, round 4: all 16 K fragments of the S product in flight ahead of their MFMAs and the first V groups issued before
+    // the softmax change nothing here, 166.9 -> 164.3 us; neither does dropping the DMA wait, 152 us, or the barrier, 138 us —
+    // two waves per SIMD already cover each other's LDS latency; docs/EXPERIMENTS.md H)
     bf16x4 vr[2][8];
 #define LAP_ISSUE_V(GRP, R)                                                               \
   _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
@@ -529,6 +557,9 @@ __global__ __launch_bounds__(256, DmaCfg<HD>::KV_BLOCKS) void attn_dma_kv_kernel
   const char* kp[C::KREGS];
   unsigned va[C::VREGS];
   dma_frag_bases<HD>(smem, lane, kp, va);
+  unsigned ka[C::KREGS];
+#pragma unroll
+  for (int c = 0; c < C::KREGS; ++c) ka[c] = lds_addr_of(kp[c]);
 
   const float c2 = p.scale * LOG2E;
   f32x4 acc_dk[DF], acc_dv[DF];
@@ -546,6 +577,37 @@ __global__ __launch_bounds__(256, DmaCfg<HD>::KV_BLOCKS) void attn_dma_kv_kernel
     const bool fast = (fastmask >> qt) & 1;
 
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    // lane: key column i, query rows 16 f + 4 g + r
+    const float* ld = sLD + ST * 128;
+    f32x4 l0 = *reinterpret_cast<const f32x4*>(ld + 4 * g) * LOG2E, l1 = *reinterpret_cast<const f32x4*>(ld + 16 + 4 * g) * LOG2E;
+    f32x4 x0 = *reinterpret_cast<const f32x4*>(ld + 64 + 4 * g), x1 = *reinterpret_cast<const f32x4*>(ld + 80 + 4 * g);
+    if constexpr (HD == 256) { lds_tie(l0); lds_tie(l1); lds_tie(x0); lds_tie(x1); }     // the compiler's own lgkmcnt(0) for these goes HERE, not behind the raw reads below
+    if constexpr (HD == 256) {
+      // One block per CU = one wave per SIMD: K, V (64 registers), the dK / dV accumulators (128) and the fragment buffers do not
+      // fit 256 registers (two blocks per CU spilled 66 dwords to scratch, reloaded per tile: 458 us; one block without
+      // spills: 352 us).  With nobody else on the SIMD to hide the LDS latency, the K-contiguous fragment reads run in a sliding
+      // window of 12 ahead of their MFMAs (lgkmcnt is a 4-bit counter) instead of read, wait, MFMA, read, ...: 300 us.  Same
+      // operands, same order of accumulation: bitwise equal.
+      bf16x8 fr[32];
+#define LAP_RQ(KK) \
+      fr[4 * KK] = ds_read_b128_raw<QOFF + kimm<HD>(KK)>(ka[kreg<HD>(KK)]); \
+      fr[4 * KK + 1] = ds_read_b128_raw<QOFF + 16 * PITCH + kimm<HD>(KK)>(ka[kreg<HD>(KK)]); \
+      fr[4 * KK + 2] = ds_read_b128_raw<DOFF + kimm<HD>(KK)>(ka[kreg<HD>(KK)]); \
+      fr[4 * KK + 3] = ds_read_b128_raw<DOFF + 16 * PITCH + kimm<HD>(KK)>(ka[kreg<HD>(KK)]);
+#define LAP_SQ(KK, LEFT) \
+      lds_wait4x<LEFT>(fr[4 * KK], fr[4 * KK + 1], fr[4 * KK + 2], fr[4 * KK + 3]); \
+      s0 = mfma16(fr[4 * KK], kf[KK], s0); s1 = mfma16(fr[4 * KK + 1], kf[KK], s1); \
+      d0 = mfma16(fr[4 * KK + 2], vf[KK], d0); d1 = mfma16(fr[4 * KK + 3], vf[KK], d1);
+      LAP_RQ(0) LAP_RQ(1) LAP_RQ(2)
+      LAP_SQ(0, 8) LAP_RQ(3)
+      LAP_SQ(1, 8) LAP_RQ(4)
+      LAP_SQ(2, 8) LAP_RQ(5)
+      LAP_SQ(3, 8) LAP_RQ(6)
+      LAP_SQ(4, 8) LAP_RQ(7)
+      LAP_SQ(5, 8) LAP_SQ(6, 4) LAP_SQ(7, 0)
+#undef LAP_RQ
+#undef LAP_SQ
+    } else {
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(kp[kreg<HD>(kk)] + QOFF + kimm<HD>(kk));
@@ -557,10 +619,7 @@ __global__ __launch_bounds__(256, DmaCfg<HD>::KV_BLOCKS) void attn_dma_kv_kernel
       d0 = mfma16(o0, vf[kk], d0);      // dP[q][key]
       d1 = mfma16(o1, vf[kk], d1);
     }
-    // lane: key column i, query rows 16 f + 4 g + r
-    const float* ld = sLD + ST * 128;
-    const f32x4 l0 = *reinterpret_cast<const f32x4*>(ld + 4 * g) * LOG2E, l1 = *reinterpret_cast<const f32x4*>(ld + 16 + 4 * g) * LOG2E;
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(ld + 64 + 4 * g), x1 = *reinterpret_cast<const f32x4*>(ld + 80 + 4 * g);
+    }
     if (fast) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
