@@ -4,7 +4,7 @@ The reference reads RLDS / TFDS shards through TensorFlow (`src/lap/datasets/**`
 the per-sample transform stack to every element of a TF batch and yields `CoTObservation.from_dict(batch), batch["actions"]`
 (`data_loader.py:286-326`).  TensorFlow and the RLDS corpora do not exist here, so the STORAGE format is our own (one `.npz`
 per episode, below); everything after a raw sample dict exists is the reference's pipeline: `CoTInputs` (label text, frame,
-idle mask) -> `Normalize` (per-dataset q01/q99) -> `TokenizePromptAndReasoning` -> `PadStatesAndActions` -> stack ->
+idle mask) -> `NormalizeActionAndProprio` (the mixer's: clipped q01/q99 bounds) -> `TokenizePromptAndReasoning` -> `PadStatesAndActions` -> stack ->
 `CoTObservation`.  The loader keeps the contract the train loop and the checkpoint code rely on: endless iteration for
 `split="train"`, one pass for `"val"`, `get_state` / `set_state` resume with the batches the interrupted run would have seen
 (the reference skips `batches_seen` batches of the host's shard, data_loader.py:289-306), per-rank shards of every epoch's
@@ -382,7 +382,9 @@ def create_data_loader(config, dataset: "EpisodeDataset | MixtureDataset", token
                       enable_langact_training=mc.enable_langact_training),
         # (mixtures: cameras of different resolutions must batch — the reference's decode step resizes every frame, image_utils.py:192-267)
         *([pio.ResizeImages(mc.image_size, mc.image_size)] if isinstance(dataset, MixtureDataset) else []),
-        pio.Normalize(norm_stats, normalization_type=ntype),
+        # the training side's normalisation is the mixer's `NormalizeActionAndProprio` (clipped bounds, float32), not the policy
+        # side's `Normalize` (dataset_mixer.py:334-359; the train-time transform group carries none, training/config.py:195-207)
+        pio.NormalizeActionAndProprio(norm_stats, normalization_type=ntype),
         pio.TokenizePromptAndReasoning(tokenizer, discrete_state_input=mc.discrete_state_input, verbose_mode=mc.verbose_mode,
                                        state_dropout=mc.state_dropout if split == "train" else 0.0),
         pio.PadStatesAndActions(mc.action_dim),

@@ -208,6 +208,65 @@ class Unnormalize:
         return (x + 1.0) / 2.0 * (s.q99 - s.q01 + 1e-6) + s.q01
 
 
+@dataclasses.dataclass(frozen=True)
+class NormalizeActionAndProprio:
+    """transforms.py:292-444, numpy branch: the normalisation of the TRAINING data path — the mixer maps it over every robot
+    dataset with the mixture's global statistics (dataset_mixer.py:334-359; VQA sets are skipped), and the train-time transform
+    group has no `Normalize` (training/config.py:195-207).  It is NOT `Normalize`: float32 arithmetic; `bounds` and `bounds_q99`
+    share one formula, 2 (x - lo) / (hi - lo + 1e-8) - 1 CLIPPED to [-1, 1] (q01 / q99 or min / max), constant dimensions -> 0,
+    where the policy-side `Normalize` leaves quantile-normalised values unclipped with 1e-6.  Statistics: `{"actions" | "action":
+    {...}, "state": {...}}` of dicts or objects; a missing group or field leaves that entry as it is (cast to float32).
+    Here the sample is flat (`data[action_key]`, `data[state_key]`); the reference's trajectory keeps the state under
+    `observation`."""
+    norm_stats: Any
+    normalization_type: Any = "normal"
+    action_key: str = "actions"
+    state_key: str = "state"
+
+    def __post_init__(self):
+        object.__setattr__(self, "normalization_type", _norm_type(self.normalization_type))
+
+    @staticmethod
+    def _group(root, name):
+        if not isinstance(root, dict):
+            return None
+        g = root.get(name)
+        return root.get(name[:-1]) if g is None and name.endswith("s") else g
+
+    @staticmethod
+    def _value(group, key):
+        if group is None:
+            return None
+        v = group.get(key) if isinstance(group, dict) else getattr(group, key, None)
+        return None if v is None else np.asarray(v, dtype=np.float32)
+
+    def _one(self, x, group):
+        x = np.asarray(x, dtype=np.float32)
+        if group is not None and not isinstance(group, dict):
+            group = {k: getattr(group, k, None) for k in ("mean", "std", "q01", "q99", "min", "max")}
+        if group is not None:     # statistics wider than the data (a mixture's pooled state width) are cut like `Normalize` cuts them
+            group = {k: (None if v is None else np.asarray(v, dtype=np.float32)[..., :x.shape[-1]]) for k, v in group.items()
+                     if k in ("mean", "std", "q01", "q99", "min", "max")}
+        if self.normalization_type == "normal":
+            mean, std = self._value(group, "mean"), self._value(group, "std")
+            return x if mean is None or std is None else (x - mean) / (std + 1e-6)
+        lo_k, hi_k = ("min", "max") if self.normalization_type == "bounds" else ("q01", "q99")
+        lo, hi = self._value(group, lo_k), self._value(group, hi_k)
+        if lo is None or hi is None:
+            return x
+        y = np.clip(2.0 * (x - lo) / (hi - lo + 1e-8) - 1.0, -1.0, 1.0)
+        return np.where(np.equal(lo, hi), 0.0, y)
+
+    def __call__(self, data: dict) -> dict:
+        if self.norm_stats is None:
+            return data
+        out = dict(data)
+        out[self.action_key] = self._one(data[self.action_key], self._group(self.norm_stats, "actions"))
+        if data.get(self.state_key) is not None:
+            out[self.state_key] = self._one(data[self.state_key], self._group(self.norm_stats, "state"))
+        return out
+
+
 # ------------------------------------------------------------------------------------------------ inputs
 @dataclasses.dataclass(frozen=True)
 class InjectDefaultPrompt:

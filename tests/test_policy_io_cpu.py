@@ -351,3 +351,32 @@ def test_action_processor_and_training_inputs(tiny_tokenizer):
     dropped = pio.CoTInputs(action_dim=32, wrist_image_dropout_prob=1.0)(sample)
     assert not dropped["image"]["left_wrist_0_rgb"].any() and not dropped["image_mask"]["left_wrist_0_rgb"]
     assert pio.CoTInputs(action_dim=32, wrist_image_dropout_prob=1.0, random_mask_prob=1.0)(sample)["image_mask"]["left_wrist_0_rgb"]
+
+
+def test_normalisation_transforms_match_reference_generated_fixture():
+    """tests/golden/normalize_v1.json (make_normalize_golden.py: the reference's `Normalize`, `Unnormalize` and the training side's
+    `NormalizeActionAndProprio`, compiled from its own source and run on a seeded grid with a constant dimension, rows far outside the
+    quantiles, 32-wide model outputs, a trajectory without state and the singular "action" group name)."""
+    import json
+    import pathlib
+
+    fx = json.loads((pathlib.Path(__file__).parent / "golden" / "normalize_v1.json").read_text())
+    stats = fx["stats"]
+    xa, xs, wide = np.asarray(fx["x_actions"]), np.asarray(fx["x_state"]), np.asarray(fx["wide_actions"])
+    for case in fx["cases"]:
+        t = case["type"]
+        n = pio.Normalize(stats, t)({"actions": xa.copy(), "state": xs.copy(), "other": np.ones(2)})
+        for k, ref in case["normalize"].items():
+            np.testing.assert_allclose(n[k], np.asarray(ref), rtol=1e-12, atol=1e-12, err_msg=f"Normalize {t} {k}")
+        u = pio.Unnormalize(stats, t)({"actions": wide.copy(), "state": xs.copy()})
+        for k, ref in case["unnormalize"].items():
+            np.testing.assert_allclose(u[k], np.asarray(ref), rtol=1e-12, atol=1e-12, err_msg=f"Unnormalize {t} {k}")
+        tr = pio.NormalizeActionAndProprio(stats, t)({"actions": xa.copy(), "state": xs.copy()})
+        assert str(tr["actions"].dtype) == case["traj"]["dtype"] == "float32"
+        np.testing.assert_array_equal(tr["actions"], np.asarray(case["traj"]["actions"], dtype=np.float32), err_msg=f"train-side {t} actions")
+        np.testing.assert_array_equal(tr["state"], np.asarray(case["traj"]["state"], dtype=np.float32), err_msg=f"train-side {t} state")
+        tr2 = pio.NormalizeActionAndProprio({"action": stats["actions"]}, t)({"actions": xa.copy()})
+        np.testing.assert_array_equal(tr2["actions"], np.asarray(case["traj_no_state"]["actions"], dtype=np.float32))
+    q = next(c for c in fx["cases"] if c["type"] == "bounds_q99")
+    # the two sides differ exactly where it matters: beyond the quantiles the policy side extrapolates, the training side clips
+    assert np.abs(np.asarray(q["normalize"]["actions"])).max() > 5.0 and np.abs(np.asarray(q["traj"]["actions"])).max() == 1.0
