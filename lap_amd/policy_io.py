@@ -92,6 +92,8 @@ def as_norm_stats(tree) -> dict[str, NormStats] | None:
         elif isinstance(v, dict):
             for kk, vv in as_norm_stats(v).items():
                 flat[f"{k}/{kk}"] = vv
+        elif hasattr(v, "mean") and hasattr(v, "std"):     # any record with the fields as attributes (openpi's NormStats, ExtendedNormStats)
+            flat[k] = NormStats.from_dict({f: getattr(v, f, None) for f in ("mean", "std", "q01", "q99", "min", "max")})
         else:
             raise TypeError(f"norm stats entry {k!r} is neither a stats record nor a sub-tree")
     return flat

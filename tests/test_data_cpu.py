@@ -471,3 +471,21 @@ def test_vqa_records_become_samples_and_join_a_mixture(setup):
     out = pio.dataset_resize_with_pad(small, 56, 56)                       # ratio 60 / 56: 28 x 56 rows, 14 rows of padding above and below
     assert out.shape == (56, 56, 3) and (out[:14] == 0).all() and (out[42:] == 0).all() and out[14:42, :20].min() == 200 and out[14:42, 36:].max() == 0
     assert pio.dataset_resize_with_pad(out, 56, 56) is out
+
+
+def test_global_norm_stats_match_reference_generated_fixture():
+    """tests/golden/global_stats_v1.json (make_global_stats_golden.py): the reference's `GlobalStatisticsBuilder` on five datasets of
+    different widths and sizes — pooled mean / variance weighted by transitions, bracketing quantiles, states pooled per state type,
+    the stateless and the VQA set left out."""
+    import json
+    import pathlib
+
+    from lap_amd.data import global_norm_stats
+
+    fx = json.loads((pathlib.Path(__file__).parent / "golden" / "global_stats_v1.json").read_text())
+    g = global_norm_stats(fx["per_dataset"], action_dim=fx["action_dim"], state_dim=fx["state_dim"], state_types=fx["state_types"], exclude=fx["vqa"])
+    assert sorted(g) == sorted(fx["global"])
+    for key, ref in fx["global"].items():
+        for f in ("mean", "std", "q01", "q99", "min", "max"):
+            np.testing.assert_allclose(np.asarray(g[key][f], dtype=np.float64), np.asarray(ref[f]), rtol=2e-6, atol=2e-6, err_msg=f"{key}.{f}")
+        assert int(g[key]["num_transitions"]) == ref["num_transitions"] and int(g[key]["num_trajectories"]) == ref["num_trajectories"]

@@ -380,3 +380,118 @@ def test_normalisation_transforms_match_reference_generated_fixture():
     q = next(c for c in fx["cases"] if c["type"] == "bounds_q99")
     # the two sides differ exactly where it matters: beyond the quantiles the policy side extrapolates, the training side clips
     assert np.abs(np.asarray(q["normalize"]["actions"])).max() > 5.0 and np.abs(np.asarray(q["traj"]["actions"])).max() == 1.0
+
+
+def test_tokenizer_and_tokenize_transform_match_reference_generated_fixture():
+    """tests/golden/tokenize_v1.json (make_tokenize_golden.py): the reference's `PaligemmaTokenizer.tokenize` and its
+    `TokenizePromptAndReasoning`, run unmodified on the tiny SentencePiece model the fixture carries — ids, all five masks, truncation,
+    VQA / prediction formats, frame description, seeded reasoning dropout (np.random) and state dropout, the left-padded dataset name."""
+    import base64
+    import json
+    import pathlib
+    import random
+    import zlib
+
+    fx = json.loads((pathlib.Path(__file__).parent / "golden" / "tokenize_v1.json").read_text())
+    proto = zlib.decompress(base64.b64decode(fx["sentencepiece_model_zlib_b64"]))
+    ib = lambda a: None if a is None else np.asarray(a, dtype=bool)
+    for c in fx["tokenize"]:
+        a = dict(c["args"])
+        tk = pio.PaligemmaTokenizer(model_proto=proto, max_len=a.pop("max_len"), reasoning_mask_prob=a.pop("p"))
+        seed = a.pop("seed")
+        if seed is not None:
+            np.random.seed(seed); random.seed(seed)
+        st = None if a["state"] is None else np.asarray(a.pop("state"))
+        a.pop("state", None)
+        toks, attn, reason, num, direc, loss = tk.tokenize(a.pop("prompt"), a.pop("reasoning"), st, **a)
+        assert toks.dtype == np.int32 and toks.tolist() == c["tokens"], c["args"]
+        for got, key in ((attn, "attn"), (reason, "reason"), (num, "number"), (direc, "direction"), (loss, "loss")):
+            if c[key] is None:
+                assert got is None, (key, c["args"])
+            else:
+                np.testing.assert_array_equal(np.asarray(got, dtype=bool), ib(c[key]), err_msg=f"{key} {c['args']}")
+    for c in fx["transform"]:
+        sample = {k: (np.asarray(v) if isinstance(v, list) else v) for k, v in c["sample"].items()}
+        tf = pio.TokenizePromptAndReasoning(pio.PaligemmaTokenizer(model_proto=proto, max_len=96), discrete_state_input=True, dataset_name_pad_len=20,
+                                            verbose_mode=c["verbose"])
+        out = tf(sample)
+        assert sorted(out) == c["out_keys"]
+        for k, ref in c["out"].items():
+            got = out[k]
+            if isinstance(ref, list):
+                np.testing.assert_array_equal(np.asarray(got).astype(int), np.asarray(ref), err_msg=k)
+            else:
+                assert (got is None and ref is None) or got == ref, (k, got, ref)
+
+
+def test_cot_inputs_match_reference_generated_fixture():
+    """tests/golden/cot_inputs_v1.json (make_cot_inputs_golden.py): the reference's `CoTInputs`, imported unmodified, end to end — an
+    inference request (CHW float image, byte prompt, frame description), training samples (label text in the end-effector / base frame, idle
+    -> sample_mask False, rough scale, random base frame through python's `random`, language-action training off, wrist dropout + random
+    un-masking through np.random), a VQA sample and a prediction sample.  Every key and every value of the output must agree."""
+    import json
+    import pathlib
+    import random
+
+    def load(v):
+        if isinstance(v, dict):
+            if "__nd__" in v:
+                return np.asarray(v["__nd__"], dtype=v["dtype"])
+            if "__bytes__" in v:
+                return v["__bytes__"].encode()
+            return {k: load(x) for k, x in v.items()}
+        return v
+
+    def same(got, ref, path):
+        if isinstance(ref, dict):
+            assert isinstance(got, dict) and sorted(got) == sorted(ref), (path, sorted(got) if isinstance(got, dict) else got, sorted(ref))
+            for k in ref:
+                same(got[k], ref[k], f"{path}.{k}")
+        elif isinstance(ref, np.ndarray):
+            g = np.asarray(got)
+            assert g.dtype == ref.dtype and g.shape == ref.shape, (path, g.dtype, ref.dtype, g.shape, ref.shape)
+            np.testing.assert_array_equal(g, ref, err_msg=path)
+        elif isinstance(ref, (bool, type(None))):
+            assert (got is None) == (ref is None) and bool(got) == bool(ref), (path, got, ref)
+        elif isinstance(ref, float):
+            assert float(got) == ref, (path, got, ref)
+        else:
+            assert got == ref, (path, got, ref)
+
+    cases = json.loads((pathlib.Path(__file__).parent / "golden" / "cot_inputs_v1.json").read_text())
+    assert len(cases) >= 10 and not any("error" in c for c in cases)
+    for c in cases:
+        np.random.seed(5); random.seed(5)
+        out = pio.CoTInputs(**c["config"])(load(c["data"]))
+        same(out, load(c["out"]), c["title"])
+
+
+def test_cot_outputs_match_reference_generated_fixture():
+    """tests/golden/cot_outputs_v1.json (make_cot_outputs_golden.py): the reference's `CoTOutputs`, imported unmodified — pass-through,
+    text -> deltas in base / end-effector frame with and without the request's raw state, texts without a gripper command or without
+    anything parseable, and the VLA-0 grid with its three un-normalisations (and an unknown type: untouched)."""
+    import json
+    import pathlib
+    import types
+
+    fx = json.loads((pathlib.Path(__file__).parent / "golden" / "cot_outputs_v1.json").read_text())
+    state = np.asarray(fx["state"])
+    st = types.SimpleNamespace(**{k: np.asarray(v) for k, v in fx["stats"].items()})
+    n = {"flow": 0, "text": 0, "vla0": 0}
+    for c in fx["cases"]:
+        n[c["kind"]] += 1
+        if c["kind"] == "flow":
+            r = pio.CoTOutputs("verbose_eef_with_rotation")({"actions": np.asarray(c["actions"])})
+            assert r["reasoning"] is None
+            np.testing.assert_array_equal(r["actions"], np.asarray(c["out"]["actions"]))
+            continue
+        if c["kind"] == "text":
+            data = {"actions": np.zeros((1, 7)), "reasoning": fx["texts"][c["text"]], **({"raw_state": state} if c["with_state"] else {})}
+            r = pio.CoTOutputs(c["format"])(data)
+        else:
+            from lap_amd import lang_actions as la
+            kw = {} if c["ntype"] is None else {"norm_stats": {"actions": st}, "normalization_type": c["ntype"]}
+            r = pio.CoTOutputs(la.VLA0_CHUNKED_FORMAT, transform_strategy="vla0", **kw)({"actions": np.zeros((1, 7)), "reasoning": c["text"]})
+        assert r["reasoning"] == c["out"]["reasoning"]
+        np.testing.assert_allclose(np.asarray(r["actions"], dtype=np.float64), np.asarray(c["out"]["actions"]), rtol=1e-12, atol=1e-12, err_msg=str(c)[:120])
+    assert n["flow"] == 1 and n["text"] >= 20 and n["vla0"] == 5
