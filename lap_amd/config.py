@@ -305,8 +305,8 @@ class EmaScheduleChoice:
 # ------------------------------------------------------------------------------ data / weights (carried, not executed)
 @dataclasses.dataclass(frozen=True)
 class RLDSDataConfig:
-    repo_id: str | None = None
-    asset_id: str | None = None
+    repo_id: str | None = "oxe"        # config.py:317-319: the defaults are set for OXE training
+    asset_id: str | None = "oxe"
     data_mix: str | None = None
     rlds_data_dir: str | None = None
     shuffle_buffer_size: int = 1_000_000
@@ -343,7 +343,7 @@ class TrainConfig:
     name: str = "lap"
     project_name: str = "lap"
     exp_name: str = ""
-    model: LAPConfig = dataclasses.field(default_factory=LAPConfig)
+    model: LAPConfig = dataclasses.field(default_factory=lambda: LAPConfig(action_horizon=32, max_token_len=110))   # build_lap_model, config.py:53-66
     weight_loader: WeightLoaderChoice = dataclasses.field(default_factory=WeightLoaderChoice)
     data: RLDSDataConfig = dataclasses.field(default_factory=RLDSDataConfig)
     lr_schedule: CosineDecaySchedule = dataclasses.field(default_factory=build_cosine_lr)
@@ -441,6 +441,17 @@ _CONFIGS = [
         weight_loader=WeightLoaderChoice(kind="checkpoint", params_path="checkpoints/lap/params"),
         save_interval=2000, keep_period=2000, num_train_steps=40_001, batch_size=256,
         ema_schedule_choice=EmaScheduleChoice(kind="constant"),
+    ),
+    TrainConfig(  # config.py:632-642 (named after pi0; pi05 keeps its default: flow matching only, no language-action loss)
+        name="pi0_replicated",
+        model=LAPConfig(action_dim=7, action_horizon=16, max_token_len=220, enable_action_training=True, enable_langact_training=False),
+        batch_size=2048,
+    ),
+    TrainConfig(  # config.py:786-797
+        name="lap_cotrain",
+        model=LAPConfig(action_dim=7, action_horizon=16, max_token_len=220, enable_action_training=True, enable_prediction_training=True,
+                        stop_action_to_vlm_grad=True),
+        batch_size=2048,
     ),
     TrainConfig(  # BASELINE.json synthetic shapes: 48-token prompt, 50-step chunk
         name="lap_bench",

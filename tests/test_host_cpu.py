@@ -160,3 +160,44 @@ def test_sample_tokens_right_alignment_is_a_relabelling(hole):
     mask = torch.cat([in_range, torch.ones(B, 1, dtype=torch.bool)], 1)[:, None, :]
     (pre1, _), _ = O.gemma_forward(P, oc, [emb, None], plen[:, None], mask, [None, None], kv_cache=cache)
     assert ((pre1 @ table.t())[:, 0] - c["logit/1"]).abs().max() < 1e-4
+
+
+def test_config_registry_and_defaults_match_reference_source_fixture():
+    """tests/golden/train_configs_v1.json (make_train_configs_golden.py: keyword literals of the reference's `_CONFIGS` and `LAPConfig`
+    field defaults, read from the parsed source).  Every named config built here must carry exactly the reference's overrides; the
+    names not built are the Gemma-3 / FAST-tokenizer / VLA-0 variants (out of scope) and nothing else."""
+    import dataclasses
+    import json
+    import pathlib
+
+    from lap_amd import config as C
+
+    fx = json.loads((pathlib.Path(__file__).parent / "golden" / "train_configs_v1.json").read_text())
+    mine = {f.name: (f.default if f.default is not dataclasses.MISSING else None) for f in dataclasses.fields(C.LAPConfig)}
+    for k, v in fx["lap_config_defaults"].items():
+        assert k in mine and mine[k] == v, (k, v, mine.get(k))
+
+    def check(name, ref, obj, path=""):
+        for k, v in ref.items():
+            if k in ("__call__", "name"):
+                continue
+            assert hasattr(obj, k), f"{name}{path}.{k} missing here"
+            m = getattr(obj, k)
+            if isinstance(v, dict) and "__call__" in v:
+                check(name, v, m, f"{path}.{k}")
+            else:
+                assert getattr(m, "value", m) == v, (name, path, k, v, m)
+
+    built, absent = [], []
+    for name, ref in fx["registry"].items():
+        try:
+            obj = C.get_config(name)
+        except ValueError:
+            absent.append(name)
+            continue
+        built.append(name)
+        check(name, ref, obj)
+    assert sorted(built) == ["lap", "lap_cotrain", "lap_libero", "pi0_replicated"]
+    for name in absent:
+        m = fx["registry"][name].get("model", {})
+        assert "gemma3" in str(m.get("paligemma_variant", "")) or m.get("use_fast") or m.get("prompt_format") == "vla0_chunked", name
