@@ -305,15 +305,38 @@ class EmaScheduleChoice:
 # ------------------------------------------------------------------------------ data / weights (carried, not executed)
 @dataclasses.dataclass(frozen=True)
 class RLDSDataConfig:
+    """training/config.py:85-148 (`DataConfig`) + 310-319 (`RLDSDataConfig`): the fields the data path here consumes, with the
+    reference's defaults (held to them by tests/golden/train_configs_v1.json).  Not carried: TensorFlow pipeline knobs (thread counts,
+    determinism), the Gemma-3 / DROID-variant fields."""
     repo_id: str | None = "oxe"        # config.py:317-319: the defaults are set for OXE training
     asset_id: str | None = "oxe"
-    data_mix: str | None = None
-    rlds_data_dir: str | None = None
+    data_mix: str | None = "oxe_magic_soup"
+    balance_weights: bool = True
+    rlds_data_dir: str | None = "./data"
     shuffle_buffer_size: int = 1_000_000
-    val_fraction: float = 0.02
-    random_base_prob: float = 0.0
     max_samples: int | None = None
+    val_max_samples: int | None = None
+    val_fraction: float | None = 0.025
+    use_wrist_image: bool = True
+    wrist_image_dropout_prob: float = 0.1
     action_proprio_normalization_type: str = "bounds_q99"   # config.py:98-99 (normal | bounds | bounds_q99)
+    resize_resolution: tuple = (224, 224)
+    # augmentation (CoTInputs, config.py:336-352)
+    aug_wrist_image: bool = True
+    random_base_prob: float = 0.0
+    random_mask_prob: float = 0.2
+    use_rough_scale: bool = False
+    language_action_format_name: str = "verbose_eef_with_rotation"
+    transform_strategy: str = "standard"                    # "vla0": labels from the normalised action chunk (config.py:715,737)
+    # prediction samples and their questions
+    max_prediction_horizon: int = 30
+    pred_prob: float = 0.3
+    primary_pred_prob: float = 0.8
+    enable_diverse_questions: bool = True
+    question_type_weights: dict | None = None
+    delta_motion_format_weights: dict | None = None
+    use_diverse_prompts: bool = True
+    direction_prob: float = 0.0
 
 
 @dataclasses.dataclass(frozen=True)
@@ -452,6 +475,23 @@ _CONFIGS = [
         model=LAPConfig(action_dim=7, action_horizon=16, max_token_len=220, enable_action_training=True, enable_prediction_training=True,
                         stop_action_to_vlm_grad=True),
         batch_size=2048,
+    ),
+    TrainConfig(  # config.py:701-717 ("VLA-0": actions as text, no action expert)
+        name="vla0_replicated",
+        model=LAPConfig(action_dim=7, action_horizon=10, max_token_len=390, pi05=True, discrete_state_input=True, enable_action_training=False,
+                        enable_langact_training=True, paligemma_variant="gemma_2b", action_expert_variant="gemma_300m", prompt_format="vla0_chunked"),
+        data=RLDSDataConfig(language_action_format_name="vla0_chunked", transform_strategy="vla0"),
+        batch_size=2048,
+    ),
+    TrainConfig(  # config.py:718-751
+        name="vla0_replicated_libero",
+        model=LAPConfig(action_dim=7, action_horizon=10, max_token_len=390, enable_action_training=False, enable_langact_training=True,
+                        paligemma_variant="gemma_2b", action_expert_variant="gemma_300m", prompt_format="vla0_chunked", reasoning_mask_prob=0.2),
+        data=RLDSDataConfig(shuffle_buffer_size=100000, repo_id="libero", asset_id="libero", data_mix="libero_finetune", val_fraction=0.0,
+                            language_action_format_name="vla0_chunked", transform_strategy="vla0"),
+        lr_schedule=CosineDecaySchedule(warmup_steps=1000, peak_lr=5e-5, decay_steps=40_000, decay_lr=5e-5),
+        save_interval=2000, keep_period=2000, num_train_steps=40_001, batch_size=256,
+        ema_schedule_choice=EmaScheduleChoice(kind="cosine_delayed", start_step=1000),
     ),
     TrainConfig(  # BASELINE.json synthetic shapes: 48-token prompt, 50-step chunk
         name="lap_bench",

@@ -376,15 +376,40 @@ def create_data_loader(config, dataset: "EpisodeDataset | MixtureDataset", token
             norm_stats = compute_mixture_norm_stats(dataset, action_pad_to=mc.action_dim, state_dim=state_dim)
         else:
             norm_stats = compute_norm_stats(dataset, action_pad_to=mc.action_dim)
-    ntype = getattr(config.data, "action_proprio_normalization_type", "bounds_q99")
+    dc = config.data
+    ntype = getattr(dc, "action_proprio_normalization_type", "bounds_q99")
+    question_config = None
+    if getattr(dc, "enable_diverse_questions", False):      # training/config.py:325-334
+        from lap_amd.questions import QuestionConfig
+        question_config = QuestionConfig(type_weights=getattr(dc, "question_type_weights", None),
+                                         delta_motion_format_weights=getattr(dc, "delta_motion_format_weights", None),
+                                         use_diverse_prompts=getattr(dc, "use_diverse_prompts", True))
+    cot = pio.CoTInputs(    # every field the reference's data-transform group passes (training/config.py:336-352)
+        action_dim=mc.action_dim, wrist_image_dropout_prob=getattr(dc, "wrist_image_dropout_prob", 0.0),
+        language_action_format=getattr(dc, "language_action_format_name", "verbose_eef_with_rotation"),
+        random_mask_prob=getattr(dc, "random_mask_prob", 0.0), random_base_prob=getattr(dc, "random_base_prob", 0.0),
+        use_rough_scale=getattr(dc, "use_rough_scale", False), transform_strategy=getattr(dc, "transform_strategy", "standard"),
+        enable_langact_training=mc.enable_langact_training, enable_diverse_questions=getattr(dc, "enable_diverse_questions", False),
+        question_config=question_config)
+    # the training side's normalisation is the mixer's `NormalizeActionAndProprio` (clipped bounds, float32), not the policy side's
+    # `Normalize` (dataset_mixer.py:334-359; the train-time transform group carries none, training/config.py:195-207).  The mixer runs
+    # it on the raw trajectory, i.e. BEFORE `CoTInputs`; elementwise, so the order only matters to the VLA-0 strategy, whose label text
+    # is made from the normalised chunk: there the sample's actions / state are normalised first.
+    norm = pio.NormalizeActionAndProprio(norm_stats, normalization_type=ntype)
+    vla0 = getattr(dc, "transform_strategy", "standard") == "vla0"
+
+    def norm_raw(sample: dict) -> dict:
+        obs = dict(sample["observation"])
+        flat = norm({"actions": sample["actions"], "state": obs.get("state")}) if "actions" in sample else {"state": norm({"actions": np.zeros(1), "state": obs.get("state")})["state"]}
+        obs["state"] = flat["state"]
+        return {**sample, "observation": obs, **({"actions": flat["actions"]} if "actions" in flat else {})}
+
     stack = pio.compose([
-        pio.CoTInputs(action_dim=mc.action_dim, random_base_prob=getattr(config.data, "random_base_prob", 0.0),
-                      enable_langact_training=mc.enable_langact_training),
+        *([norm_raw] if vla0 else []),
+        cot,
         # (mixtures: cameras of different resolutions must batch — the reference's decode step resizes every frame, image_utils.py:192-267)
         *([pio.ResizeImages(mc.image_size, mc.image_size)] if isinstance(dataset, MixtureDataset) else []),
-        # the training side's normalisation is the mixer's `NormalizeActionAndProprio` (clipped bounds, float32), not the policy
-        # side's `Normalize` (dataset_mixer.py:334-359; the train-time transform group carries none, training/config.py:195-207)
-        pio.NormalizeActionAndProprio(norm_stats, normalization_type=ntype),
+        *([] if vla0 else [norm]),
         pio.TokenizePromptAndReasoning(tokenizer, discrete_state_input=mc.discrete_state_input, verbose_mode=mc.verbose_mode,
                                        state_dropout=mc.state_dropout if split == "train" else 0.0),
         pio.PadStatesAndActions(mc.action_dim),

@@ -378,6 +378,7 @@ class CoTInputs:
     enable_diverse_questions: bool = False
     question_config: Any = None
     image_keys: tuple[str, ...] = IMAGE_KEYS
+    transform_strategy: str = "standard"     # "vla0" (sample_handlers.py:434-457): the label is the grid of the (normalised) action chunk
 
     def __post_init__(self):
         from lap_amd import lang_actions as la
@@ -450,6 +451,11 @@ class CoTInputs:
                 proc = la.ActionProcessor(language_action_format=self.language_action_format, random_base_prob=self.random_base_prob)
                 return PredictionSampleHandler(self.question_config, proc).process(data, out, dataset_name, data.get("rotation_applied", False))
         fmt = self.language_action_format
+        if self.transform_strategy == "vla0":     # VLA-0: the text IS the normalised, padded action chunk as integers; never masked out
+            out["language_actions"] = fmt.summarize_actions(out["actions"]) if "actions" in out else ""
+            out["frame_description"] = "normalized"
+            out["sample_mask"] = True
+            return out
         if "language_actions" in data and self.enable_langact_training:
             proc = la.ActionProcessor(language_action_format=fmt, random_base_prob=self.random_base_prob)
             text, frame = proc.summarize_language_actions(data, "language_actions", np.asarray(data["raw_state"]), dataset_name,

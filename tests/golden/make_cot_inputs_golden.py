@@ -94,6 +94,11 @@ cases = [
     ("VQA sample: caption as label", dict(action_dim=32),
      {"observation": {"base_0_rgb": img(), "state": np.zeros(8)}, "prompt": "what is in the image", "caption": "a red block", "dataset_name": "coco_captions",
       "is_vqa_sample": True, "vqa_dataset_id": 3, "actions": np.zeros((4, 7))}),
+    ("VLA-0 strategy: label text = the (normalised) action chunk as integers", dict(action_dim=7, transform_strategy="vla0", language_action_format="vla0_chunked"),
+     {"observation": {"base_0_rgb": img(), "state": state9.copy()}, "prompt": "pick up the block", "dataset_name": "libero_10_no_noops",
+      "actions": np.clip(rng.normal(size=(10, 7)) * 0.6, -1, 1), "language_actions": chunk.copy(), "raw_state": state9.copy()}),
+    ("VLA-0 strategy: inference request (no actions)", dict(action_dim=7, transform_strategy="vla0", language_action_format="vla0_chunked"),
+     {"observation": {"base_0_rgb": img(), "state": state9.copy()}, "prompt": "pick up the block"}),
     ("prediction sample: default prompt", dict(action_dim=32),
      {"observation": {"base_0_rgb": img(), "left_wrist_0_rgb": img(), "state": state9.copy()}, "prompt": "ignored", "dataset_name": "droid",
       "is_prediction_sample": True, "time_horizon_seconds": 1.5, "actions": np.zeros((4, 7)), "language_actions": chunk.copy(), "raw_state": state9.copy()}),

@@ -27,5 +27,13 @@ for e in cfgs.elts:
         registry[d["name"]] = d
 cls = next(n for n in ast.parse((REF / "models/lap_config.py").read_text()).body if isinstance(n, ast.ClassDef) and n.name == "LAPConfig")
 defaults = {n.target.id: conv(n.value) for n in cls.body if isinstance(n, ast.AnnAssign) and n.value is not None and isinstance(n.target, ast.Name)}
-pathlib.Path(__file__).with_name("train_configs_v1.json").write_text(json.dumps({"registry": registry, "lap_config_defaults": defaults}, indent=1))
+def class_defaults(t, name):
+    c = next(n for n in t.body if isinstance(n, ast.ClassDef) and n.name == name)
+    return {n.target.id: conv(n.value) for n in c.body if isinstance(n, ast.AnnAssign) and n.value is not None and isinstance(n.target, ast.Name)}
+
+
+data_defaults = {**class_defaults(tree, "DataConfig"), **class_defaults(tree, "RLDSDataConfig")}
+train_defaults = class_defaults(tree, "TrainConfig")
+pathlib.Path(__file__).with_name("train_configs_v1.json").write_text(json.dumps(
+    {"registry": registry, "lap_config_defaults": defaults, "data_config_defaults": data_defaults, "train_config_defaults": train_defaults}, indent=1))
 print("wrote train_configs_v1.json:", sorted(registry))

@@ -489,3 +489,27 @@ def test_global_norm_stats_match_reference_generated_fixture():
         for f in ("mean", "std", "q01", "q99", "min", "max"):
             np.testing.assert_allclose(np.asarray(g[key][f], dtype=np.float64), np.asarray(ref[f]), rtol=2e-6, atol=2e-6, err_msg=f"{key}.{f}")
         assert int(g[key]["num_transitions"]) == ref["num_transitions"] and int(g[key]["num_trajectories"]) == ref["num_trajectories"]
+
+
+def test_vla0_strategy_labels_come_from_the_normalised_chunk():
+    """`transform_strategy="vla0"` (training/config.py:701-751): the reference's mixer normalises the trajectory BEFORE `CoTInputs`, and the
+    VLA-0 handler writes the normalised, padded chunk as integers (sample_handlers.py:434-457).  The loader therefore normalises first for
+    this strategy: the label text of a batch row must be the format's own summary of that row's normalised actions."""
+    import dataclasses
+
+    from lap_amd import lang_actions as la
+
+    base = get_config("debug")
+    cfg = dataclasses.replace(base, model=dataclasses.replace(base.model, action_dim=7, max_token_len=400, prompt_format="vla0_chunked"),
+                              data=dataclasses.replace(base.data, transform_strategy="vla0", language_action_format_name="vla0_chunked",
+                                                       wrist_image_dropout_prob=0.0, random_mask_prob=0.0, enable_diverse_questions=False))
+    tok = pio.PaligemmaTokenizer(model_proto=tiny_sentencepiece_proto(), max_len=400, prompt_format="vla0_chunked")
+    ds = D.EpisodeDataset(_episodes(), action_horizon=cfg.model.action_horizon)
+    loader = D.create_data_loader(cfg, ds, tok, shuffle=False, num_batches=2)
+    obs, actions = next(iter(loader))
+    assert float(actions.abs().max()) <= 1.0                      # the training side clips
+    for b in range(actions.shape[0]):
+        want = la.VLA0_CHUNKED_FORMAT.summarize_actions(actions[b].numpy())
+        ids = obs.tokenized_prompt[b][obs.tokenized_langact_mask[b]].tolist()
+        assert ids == tok._tokenizer.encode(want, add_eos=True), (b, want[:60])     # (ids: the tiny vocabulary has no piece for every digit)
+        assert bool(obs.sample_mask[b])

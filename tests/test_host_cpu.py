@@ -197,7 +197,17 @@ def test_config_registry_and_defaults_match_reference_source_fixture():
             continue
         built.append(name)
         check(name, ref, obj)
-    assert sorted(built) == ["lap", "lap_cotrain", "lap_libero", "pi0_replicated"]
+    assert sorted(built) == ["lap", "lap_cotrain", "lap_libero", "pi0_replicated", "vla0_replicated", "vla0_replicated_libero"]
     for name in absent:
         m = fx["registry"][name].get("model", {})
-        assert "gemma3" in str(m.get("paligemma_variant", "")) or m.get("use_fast") or m.get("prompt_format") == "vla0_chunked", name
+        assert "gemma3" in str(m.get("paligemma_variant", "")) or m.get("use_fast"), name
+    # field defaults of the data config and of TrainConfig: every field carried here has the reference's default
+    for cls, ref in ((C.RLDSDataConfig, fx["data_config_defaults"]), (C.TrainConfig, fx["train_config_defaults"])):
+        for f in dataclasses.fields(cls):
+            if f.name in ref and not isinstance(ref[f.name], dict):
+                want = tuple(ref[f.name]) if isinstance(f.default, tuple) else ref[f.name]
+                assert getattr(f.default, "value", f.default) == want, (cls.__name__, f.name, f.default, ref[f.name])
+    carried = {f.name for f in dataclasses.fields(C.RLDSDataConfig)}
+    for must in ("wrist_image_dropout_prob", "random_mask_prob", "random_base_prob", "use_rough_scale", "language_action_format_name",
+                 "transform_strategy", "enable_diverse_questions", "val_fraction", "data_mix", "action_proprio_normalization_type"):
+        assert must in carried and must in fx["data_config_defaults"]
