@@ -30,7 +30,10 @@ def _episodes(n=3, T=12, seed=0, hw=(40, 48)):
 def setup():
     import dataclasses
     cfg = get_config("debug")
-    cfg = dataclasses.replace(cfg, model=dataclasses.replace(cfg.model, action_dim=16))   # room for the 10-value [xyz, rot6d, grip] state
+    cfg = dataclasses.replace(cfg, model=dataclasses.replace(cfg.model, action_dim=16),   # room for the 10-value [xyz, rot6d, grip] state
+                              # (the reference's training-time image randomness — wrist dropout 0.1, random un-masking 0.2, drawn from np.random —
+                              # is off here: these tests assert exact masks; test_training_time_image_randomness_follows_the_data_config turns it on)
+                              data=dataclasses.replace(cfg.data, wrist_image_dropout_prob=0.0, random_mask_prob=0.0))
     tok = pio.PaligemmaTokenizer(model_proto=tiny_sentencepiece_proto(), max_len=cfg.model.max_token_len)
     ds = D.EpisodeDataset(_episodes(), action_horizon=cfg.model.action_horizon)
     return cfg, tok, ds
@@ -513,3 +516,27 @@ def test_vla0_strategy_labels_come_from_the_normalised_chunk():
         ids = obs.tokenized_prompt[b][obs.tokenized_langact_mask[b]].tolist()
         assert ids == tok._tokenizer.encode(want, add_eos=True), (b, want[:60])     # (ids: the tiny vocabulary has no piece for every digit)
         assert bool(obs.sample_mask[b])
+
+
+def test_training_time_image_randomness_follows_the_data_config(setup):
+    """training/config.py:336-352: the data config's `wrist_image_dropout_prob` / `random_mask_prob` reach `CoTInputs`.  With both at 1 every
+    wrist image is dropped (zeros) and every all-zero image is un-masked; with the defaults (0.1 / 0.2) the rates over many samples are the
+    configured ones."""
+    import dataclasses
+    cfg, tok, _ = setup
+    eps = _episodes(2, 12, seed=4)
+    for e in eps:
+        e["left_wrist_0_rgb"] = np.full_like(e["base_0_rgb"], 7)
+    ds = D.EpisodeDataset(eps, action_horizon=cfg.model.action_horizon)
+    on = dataclasses.replace(cfg, data=dataclasses.replace(cfg.data, wrist_image_dropout_prob=1.0, random_mask_prob=1.0))
+    obs, _ = next(iter(D.create_data_loader(on, ds, tok, shuffle=False, num_batches=1)))
+    assert float(obs.images["left_wrist_0_rgb"].abs().max()) == 1.0 and bool((obs.images["left_wrist_0_rgb"] == -1.0).all())     # zeros, scaled to [-1, 1]
+    assert bool(obs.image_masks["left_wrist_0_rgb"].all())
+    dflt = dataclasses.replace(cfg, batch_size=8, data=dataclasses.replace(cfg.data, wrist_image_dropout_prob=0.1, random_mask_prob=0.2))
+    np.random.seed(0)
+    dropped = masked_on = total = 0
+    for obs, _ in D.create_data_loader(dflt, ds, tok, shuffle=True, seed=2, num_batches=60):
+        gone = (obs.images["left_wrist_0_rgb"] == -1.0).flatten(1).all(1)
+        dropped += int(gone.sum()); total += gone.numel()
+        masked_on += int((obs.image_masks["left_wrist_0_rgb"] & gone).sum())
+    assert 0.05 < dropped / total < 0.16 and 0.08 < masked_on / max(dropped, 1) < 0.4, (dropped, masked_on, total)
