@@ -328,6 +328,7 @@ class RLDSDataConfig:
     use_rough_scale: bool = False
     language_action_format_name: str = "verbose_eef_with_rotation"
     transform_strategy: str = "standard"                    # "vla0": labels from the normalised action chunk (config.py:715,737)
+    horizon_seconds: tuple = (1.0,)                         # label window(s) in seconds, one drawn per frame (base_dataset.py:493-531)
     # prediction samples and their questions
     max_prediction_horizon: int = 30
     pred_prob: float = 0.3

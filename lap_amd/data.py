@@ -31,10 +31,47 @@ from lap_amd.observation import CoTObservation
 IMAGE_KEYS = pio.IMAGE_KEYS
 
 
-class EpisodeDataset:
-    """Random access over (episode, step) pairs of a list of episode dicts or of `*.npz` files in a directory."""
+def sum_language_actions(window: np.ndarray) -> np.ndarray:
+    """base_dataset.py:722-776 (`sum_actions`, one window of per-step language actions [dx, dy, dz, droll, dpitch, dyaw, tail...]):
+    translations add, rotations COMPOSE in order (R = R_1 R_2 ..., extrinsic XYZ angles of the product: not the sum of the angles), the
+    tail (gripper ...) is the last row's."""
+    from lap_amd.rlds_export import euler_to_rotation_matrix
+    w = np.asarray(window, dtype=np.float64)
+    if w.shape[-1] < 6:
+        w = np.pad(w, [(0, 0), (0, 6 - w.shape[-1])])
+    R = np.eye(3)
+    for rpy in w[:, 3:6]:
+        R = R @ euler_to_rotation_matrix(rpy)
+    sy = np.sqrt(max(R[0, 0] * R[0, 0] + R[1, 0] * R[1, 0], 1e-12))        # _matrix_to_euler_xyz_extrinsic (base_dataset.py:702-719)
+    if sy < 1e-6:
+        rpy = [np.arctan2(-R[1, 2], R[1, 1]), np.arctan2(-R[2, 0], sy), 0.0]
+    else:
+        rpy = [np.arctan2(R[2, 1], R[2, 2]), np.arctan2(-R[2, 0], sy), np.arctan2(R[1, 0], R[0, 0])]
+    return np.concatenate([w[:, :3].sum(0), rpy, w[-1, 6:]]).astype(np.float32)
 
-    def __init__(self, episodes: Sequence[dict] | str | pathlib.Path, *, action_horizon: int, summation_steps: int | None = None):
+
+class EpisodeDataset:
+    """Random access over (episode, step) pairs of a list of episode dicts or of `*.npz` files in a directory; a sample is what the
+    reference's trajectory-level transforms leave per frame (`datasets/base_dataset.py:428-590,603-697`):
+
+    * state: an episode marked `state_encoding = "pos_euler"` (the exporter's) stores [xyz, euler, gripper]; it becomes
+      [xyz, rot6d, gripper] (`state_euler_to_rot6d`, :437-456) — what the model sees and what the end-effector-frame labels rotate with;
+    * action chunk (`chunk_mode`): "relative" — over a last-value-padded window of `target_actions` (absolute pose + gripper command),
+      row k = [pose[t+1+k] - pose[t] (translation), euler_diff(pose[t+1+k], pose[t]), gripper[t+k]] (:387-427: every end-effector dataset
+      incl. DROID); "window_zero" — rows t .. t+H-1 of `target_actions`, zeros past the end (LIBERO, oxe_datasets.py:259-269); absent —
+      "steps": rows of `actions` (per-step deltas), motion zeroed and gripper held past the end (hand-built stores);
+    * raw language action: `sum_language_actions` over the next round(horizon_seconds x control_frequency) steps (one of
+      `horizon_seconds` drawn per frame), cut at the episode's end, and `time_horizon_seconds` = steps used / frequency (:493-531).
+      Without a control frequency (episode field or argument) the window is `summation_steps` (default: the action horizon);
+    * prediction samples (`enable_prediction_training`): with probability `pred_prob` a frame becomes (frame t, frame min(t + m, T-1)),
+      m = clamp(int(2.5 x frequency), 1, T-1), of the base camera (probability `primary_pred_prob`, or always without a wrist camera) or of
+      the wrist camera, in the base / wrist slots; the label is the summed movement over those m steps (ZERO-padded window: past the end the
+      tail, i.e. the gripper, reads 0 as in the reference), the horizon m / frequency (:534-590,603-697).
+    Draws are a pure function of (seed, episode, step) (the reference keys TensorFlow's stateless generator with hashes of the trajectory id)."""
+
+    def __init__(self, episodes: Sequence[dict] | str | pathlib.Path, *, action_horizon: int, summation_steps: int | None = None,
+                 control_frequency: float | None = None, horizon_seconds: Sequence[float] = (1.0,), enable_prediction_training: bool = False,
+                 pred_prob: float = 0.3, primary_pred_prob: float = 0.8, seed: int = 0):
         if isinstance(episodes, (str, pathlib.Path)):
             files = sorted(pathlib.Path(episodes).glob("*.npz"))
             if not files:
@@ -43,20 +80,64 @@ class EpisodeDataset:
         self.episodes = [self._check(e, i) for i, e in enumerate(episodes)]
         self.action_horizon = action_horizon
         self.summation_steps = summation_steps or action_horizon
+        self.control_frequency, self.horizon_seconds = control_frequency, tuple(float(h) for h in horizon_seconds)
+        self.enable_prediction_training, self.pred_prob, self.primary_pred_prob, self.seed = enable_prediction_training, pred_prob, primary_pred_prob, seed
         self._starts = np.cumsum([0] + [len(e["actions"]) for e in self.episodes])
 
     @staticmethod
-    def _check(e: dict, i: int) -> dict:
+    def _text(v, default: str = "") -> str:
+        if v is None:
+            return default
+        return v if isinstance(v, str) else str(np.asarray(v).item())
+
+    @classmethod
+    def _check(cls, e: dict, i: int) -> dict:
         for k in ("base_0_rgb", "state", "actions", "prompt"):
             if k not in e:
                 raise KeyError(f"episode {i} has no '{k}'")
         T = len(e["actions"])
         if len(e["state"]) != T or len(e["base_0_rgb"]) != T or np.asarray(e["actions"]).shape[-1] < 7:
             raise ValueError(f"episode {i}: state / images / actions must share T and actions need >= 7 columns")
+        mode = cls._text(e.get("chunk_mode"), "steps")
+        if mode not in ("steps", "relative", "window_zero"):
+            raise ValueError(f"episode {i}: unknown chunk_mode {mode!r}")
+        if mode != "steps" and ("target_actions" not in e or len(e["target_actions"]) != T):
+            raise ValueError(f"episode {i}: chunk_mode {mode!r} needs target_actions [T, A]")
+        if cls._text(e.get("state_encoding")) == "pos_euler":        # base_dataset.py:437-456
+            from lap_amd.rlds_export import euler_to_r6
+            st = np.asarray(e["state"], dtype=np.float64)
+            e = dict(e, state=np.concatenate([st[:, :3], euler_to_r6(st[:, 3:6]), st[:, 6:]], -1).astype(np.float32), state_encoding="pos_r6")
         return e
 
     def __len__(self) -> int:
         return int(self._starts[-1])
+
+    def _frequency(self, e: dict):
+        f = e.get("control_frequency")
+        return float(np.asarray(f)) if f is not None else self.control_frequency
+
+    def chunk(self, e: dict, t: int) -> np.ndarray:
+        """The action chunk of frame t, [action_horizon, A] (see the class docstring)."""
+        H, T = self.action_horizon, len(e["actions"])
+        mode = self._text(e.get("chunk_mode"), "steps")
+        if mode == "steps":
+            acts = np.asarray(e["actions"], dtype=np.float32)
+            idx = np.arange(t, t + H)
+            chunk = acts[np.minimum(idx, T - 1)].copy()
+            chunk[idx >= T, :6] = 0.0          # past the end: hold still, keep the gripper
+            return chunk
+        tgt = np.asarray(e["target_actions"], dtype=np.float64)
+        if mode == "window_zero":
+            idx = np.arange(t, t + H)
+            chunk = tgt[np.minimum(idx, T - 1)].copy()
+            chunk[idx >= T] = 0.0
+            return chunk.astype(np.float32)
+        from lap_amd.rlds_export import euler_diff
+        w = tgt[np.minimum(np.arange(t, t + H + 1), T - 1)]        # last-value padding
+        return np.concatenate([w[1:, :3] - w[0:1, :3], euler_diff(w[1:, 3:6], np.broadcast_to(w[0:1, 3:6], w[1:, 3:6].shape)), w[:-1, 6:7]], -1).astype(np.float32)
+
+    def _draws(self, ep: int, t: int) -> np.ndarray:
+        return np.random.Generator(np.random.Philox(key=self.seed, counter=[1, 0, ep, t])).random(3)
 
     def __getitem__(self, index: int) -> dict:
         ep = int(np.searchsorted(self._starts, index, side="right") - 1)
@@ -64,18 +145,48 @@ class EpisodeDataset:
         e = self.episodes[ep]
         acts = np.asarray(e["actions"], dtype=np.float32)
         T = len(acts)
-        rows = np.minimum(np.arange(t, t + self.action_horizon), T - 1)
-        chunk = acts[rows].copy()
-        chunk[np.arange(t, t + self.action_horizon) >= T, :6] = 0.0          # past the end: hold still, keep the gripper
-        window = acts[t:min(T, t + self.summation_steps)]
-        lang = np.concatenate([window[:, :6].sum(0), window[-1:, 6]]).astype(np.float32)
-        obs = {"base_0_rgb": e["base_0_rgb"][t], "state": np.asarray(e["state"][t], dtype=np.float32)}
-        if "left_wrist_0_rgb" in e:
+        u = self._draws(ep, t)
+        freq = self._frequency(e)
+        if freq:
+            steps = max(int(round(self.horizon_seconds[min(int(u[0] * len(self.horizon_seconds)), len(self.horizon_seconds) - 1)] * freq)), 1)
+        else:
+            steps = self.summation_steps
+        used = max(min(steps, T - t), 1)
+        lang = sum_language_actions(acts[t:t + used])
+        horizon = used / freq if freq else None
+        state = np.asarray(e["state"][t], dtype=np.float32)
+        obs = {"base_0_rgb": e["base_0_rgb"][t], "state": state}
+        has_wrist = "left_wrist_0_rgb" in e
+        if has_wrist:
             obs["left_wrist_0_rgb"] = e["left_wrist_0_rgb"][t]
-        return {"observation": obs, "prompt": str(np.asarray(e["prompt"]).item()) if not isinstance(e["prompt"], str) else e["prompt"],
-                "dataset_name": str(np.asarray(e.get("dataset_name", "")).item()) if not isinstance(e.get("dataset_name", ""), str) else e.get("dataset_name", ""),
-                "actions": chunk, "language_actions": lang, "raw_state": np.asarray(e["state"][t], dtype=np.float32),
-                "has_wrist_image": "left_wrist_0_rgb" in e}
+        sample = {"observation": obs, "prompt": self._text(e["prompt"]), "dataset_name": self._text(e.get("dataset_name")),
+                  "actions": self.chunk(e, t), "language_actions": lang, "raw_state": state.copy(), "has_wrist_image": has_wrist,
+                  "is_prediction_sample": False, "pred_use_primary": False}
+        if horizon is not None:
+            sample["time_horizon_seconds"] = float(horizon)
+        if self.enable_prediction_training and u[1] < self.pred_prob:
+            f = freq or float(self.summation_steps)            # (no clock: the summation window stands in for 1 s)
+            m = max(min(int(2.5 * f), T - 1), 1)
+            fut = min(t + m, T - 1)
+            primary = (not has_wrist) or u[2] < self.primary_pred_prob
+            cam = e["base_0_rgb"] if primary else e["left_wrist_0_rgb"]
+            obs["base_0_rgb"], obs["left_wrist_0_rgb"] = cam[t], cam[fut]
+            window = np.zeros((m, acts.shape[-1]), dtype=np.float32)          # zero-padded, NOT cut (sum_actions(window, deltas))
+            window[:max(min(m, T - t), 0)] = acts[t:t + m]
+            sample.update(is_prediction_sample=True, pred_use_primary=bool(primary), language_actions=sum_language_actions(window),
+                          time_horizon_seconds=float(m / f))
+        return sample
+
+
+def episode_dataset_from_config(config, episodes, *, seed: int | None = None) -> EpisodeDataset:
+    """An `EpisodeDataset` with the knobs the reference's dataset classes take from the train config (dataset_mixer.py:262-290,
+    base_dataset.py:240-283): action horizon and prediction co-training from the model config; label windows, prediction probabilities
+    from the data config."""
+    dc, mc = config.data, config.model
+    return EpisodeDataset(episodes, action_horizon=mc.action_horizon, horizon_seconds=tuple(getattr(dc, "horizon_seconds", (1.0,))),
+                          enable_prediction_training=bool(getattr(mc, "enable_prediction_training", False)),
+                          pred_prob=getattr(dc, "pred_prob", 0.3), primary_pred_prob=getattr(dc, "primary_pred_prob", 0.8),
+                          seed=config.seed if seed is None else seed)
 
 
 class VqaDataset:
@@ -124,15 +235,18 @@ class VqaDataset:
 
 
 def compute_norm_stats(dataset: EpisodeDataset, *, action_pad_to: int | None = None) -> dict:
-    """scripts/compute_norm_stats.py equivalent over the whole store: mean / std / q01 / q99 / min / max of `state` and of the
-    per-step `actions` (norm_stats.json layout, openpi NormStats fields).  The reference computes them AFTER the data
-    transforms, i.e. on actions already zero-padded to the model's action_dim (`action_pad_to`): `Normalize` cuts statistics
-    to the data's width but cannot widen them, and all-zero columns normalise to 0 by the q01 == q99 rule."""
+    """shared/normalize_adapter.py `get_dataset_statistics` as the reference runs it (base_dataset.py:297-312): AFTER the trajectory
+    transforms, i.e. over the action CHUNKS of every frame flattened to rows (mean / std / q01 / q99 / min / max, openpi NormStats
+    fields; num_transitions counts those rows) and over the per-frame state as the model sees it ([xyz, rot6d, gripper] for end-effector
+    states).  The mixer pads to the model's widths later (`global_norm_stats`); `action_pad_to` zero-pads here for single datasets:
+    all-zero columns normalise to 0 by the q01 == q99 rule."""
+    chunks = np.concatenate([dataset.chunk(e, t).astype(np.float64) for e in dataset.episodes for t in range(len(e["actions"]))], 0)
+    chunks = chunks[np.isfinite(chunks).all(1)]
+    if action_pad_to is not None:
+        chunks = pio.pad_to_dim(chunks, action_pad_to, axis=-1)
+    states = np.concatenate([np.asarray(e["state"], dtype=np.float64).reshape(len(e["actions"]), -1) for e in dataset.episodes], 0)
     out = {}
-    for key in ("state", "actions"):
-        x = np.concatenate([np.asarray(e[key], dtype=np.float64).reshape(len(e["actions"]), -1) for e in dataset.episodes], 0)
-        if key == "actions" and action_pad_to is not None:
-            x = pio.pad_to_dim(x, action_pad_to, axis=-1)
+    for key, x in (("state", states), ("actions", chunks)):
         out[key] = {"mean": x.mean(0).tolist(), "std": x.std(0).tolist(), "q01": np.quantile(x, 0.01, axis=0).tolist(),
                     "q99": np.quantile(x, 0.99, axis=0).tolist(), "min": x.min(0).tolist(), "max": x.max(0).tolist()}
     return out

@@ -65,6 +65,31 @@ def rotation_matrix_to_euler(R: np.ndarray, eps: float = 1e-6) -> np.ndarray:
     return np.stack([roll, pitch, yaw], -1)
 
 
+def euler_to_r6(euler: np.ndarray) -> np.ndarray:
+    """rotation_utils.py:303-315,351-361: the first two COLUMNS of R(euler): [r11, r21, r31, r12, r22, r32]."""
+    R = euler_to_rotation_matrix(euler)
+    return np.concatenate([R[..., :, 0], R[..., :, 1]], -1)
+
+
+# configs.py:335-521 (OXE_DATASET_METADATA): control frequency in Hz of the datasets standardised here (held to the reference's table by
+# tests/golden/dataset_configs_v1.json).  It sets the summation window of the label text (horizon_seconds x frequency steps,
+# base_dataset.py:493-531) and the look-ahead of prediction samples (2.5 s, base_dataset.py:542-551).
+CONTROL_FREQUENCY: dict[str, int] = {
+    "austin_buds_dataset_converted_externally_to_rlds": 20, "austin_sailor_dataset_converted_externally_to_rlds": 20,
+    "austin_sirius_dataset_converted_externally_to_rlds": 20, "bc_z": 30, "berkeley_autolab_ur5": 5, "berkeley_fanuc_manipulation": 10,
+    "bridge_v2_oxe": 5, "droid": 15, "fmb": 10, "fractal20220817_data": 3, "furniture_bench_dataset_converted_externally_to_rlds": 10,
+    "jaco_play": 10, "libero_10_no_noops": 15, "libero_goal_no_noops": 15, "libero_object_no_noops": 15, "libero_spatial_no_noops": 15,
+    "molmoact_dataset": 15, "taco_play": 15, "utaustin_mutex": 20, "viola": 20,
+}
+
+
+def chunk_mode_of(dataset_name: str) -> str:
+    """Which `chunk_actions` the reference's dataset class runs: LIBERO a zero-padded window of the raw controller actions
+    (oxe_datasets.py:259-269), every other end-effector dataset incl. DROID the displacement from the CURRENT pose over a last-value-padded
+    window of absolute poses (base_dataset.py:387-427)."""
+    return "window_zero" if dataset_name.startswith("libero") else "relative"
+
+
 def euler_diff(angles1: np.ndarray, angles2: np.ndarray) -> np.ndarray:
     """rotation_utils.py:453-471: angles_rel with R(angles2) R(angles_rel) = R(angles1)."""
     R1, R2 = euler_to_rotation_matrix(angles1), euler_to_rotation_matrix(angles2)
@@ -412,8 +437,8 @@ def episode_from_rlds(dataset_name: str, traj: dict, *, hash_bucket=None, rng=No
     """One raw RLDS trajectory (dict of numpy arrays stacked over steps: `observation`, `action` [, `action_dict`],
     `language_instruction`) -> the episode-store dict of `lap_amd/data.py`, or None when the reference's filters drop it
     (empty instruction, zero length: oxe_datasets.py SingleOXEDataset "standard filtering").  `actions` are the per-step
-    language actions [dx, dy, dz, droll, dpitch, dyaw, gripper] the label text is summed from; `state` keeps
-    [xyz, euler, gripper].  `hash_bucket` / `rng`: see fill_empty_language_instruction (the Austin datasets only)."""
+    language actions [dx, dy, dz, droll, dpitch, dyaw, gripper] the label text is summed from; `target_actions` the reference's
+    `action` field (what its `chunk_actions` turns into the training target); `state` keeps [xyz, euler, gripper].  `hash_bucket` / `rng`: see fill_empty_language_instruction (the Austin datasets only)."""
     if dataset_name not in STANDARDIZE:
         raise KeyError(f"no standardisation transform for {dataset_name!r} (built: {sorted(STANDARDIZE)})")
     kw = dict(hash_bucket=hash_bucket, rng=rng) if dataset_name in NEEDS_FALLBACK else {}
@@ -425,7 +450,13 @@ def episode_from_rlds(dataset_name: str, traj: dict, *, hash_bucket=None, rng=No
     obs = std["observation"]
     state = std["state"] if "state" in std else obs["state"]
     ep = {"base_0_rgb": np.asarray(obs[base_key], dtype=np.uint8), "state": np.asarray(state, dtype=np.float32),
-          "actions": np.asarray(std["language_action"], dtype=np.float32), "prompt": prompt, "dataset_name": dataset_name}
+          "actions": np.asarray(std["language_action"], dtype=np.float32), "prompt": prompt, "dataset_name": dataset_name,
+          # what the reference CHUNKS into the flow-matching target (its `action`: absolute pose + gripper command, LIBERO: the raw
+          # controller action), how, and the clock the label window / prediction look-ahead are measured on; the state is
+          # [xyz, euler, gripper]: the loader converts it to [xyz, rot6d, gripper] as base_dataset.py:437-456 does
+          "target_actions": np.asarray(std["action"], dtype=np.float32), "chunk_mode": chunk_mode_of(dataset_name), "state_encoding": "pos_euler"}
+    if dataset_name in CONTROL_FREQUENCY:
+        ep["control_frequency"] = np.int32(CONTROL_FREQUENCY[dataset_name])
     if wrist_key and wrist_key in obs and np.asarray(obs[wrist_key]).size:
         ep["left_wrist_0_rgb"] = np.asarray(obs[wrist_key], dtype=np.uint8)
     return ep

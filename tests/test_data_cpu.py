@@ -47,7 +47,12 @@ def test_samples_and_batches(setup):
     e = ds.episodes[1]
     assert s["actions"].shape == (mc.action_horizon, 7) and np.array_equal(s["actions"][:3], e["actions"][9:12])
     assert not s["actions"][3:, :6].any() and np.all(s["actions"][3:, 6] == e["actions"][11, 6])
-    np.testing.assert_allclose(s["language_actions"][:6], e["actions"][9:12, :6].sum(0), rtol=1e-6)
+    np.testing.assert_allclose(s["language_actions"][:3], e["actions"][9:12, :3].sum(0), rtol=1e-6)
+    from scipy.spatial.transform import Rotation
+    rot = Rotation.identity()
+    for rpy in e["actions"][9:12, 3:6]:                                  # rotations compose (base_dataset.py:756-766), they do not add
+        rot = rot * Rotation.from_euler("xyz", rpy)
+    np.testing.assert_allclose(s["language_actions"][3:6], rot.as_euler("xyz"), atol=1e-6)
     assert s["language_actions"][6] == e["actions"][11, 6] and "left_wrist_0_rgb" not in s["observation"] and not s["has_wrist_image"]
     dl = D.create_data_loader(cfg, ds, tok, shuffle=True, seed=3)
     obs, actions = next(iter(dl))
@@ -231,10 +236,22 @@ def test_rlds_export_libero_and_droid_record_to_episode():
     assert np.allclose(ep["actions"][:-1, :3], [[0.01, 0.0, -0.02]] * (T - 1), atol=1e-7) and np.allclose(ep["actions"][:-1, 3:6], [[0, 0, 0.1]] * (T - 1), atol=1e-6)
     assert np.allclose(ep["actions"][-1, :6], 0.0)                                                             # zero-padded last step
     assert R.episode_from_rlds("libero_10_no_noops", dict(traj, language_instruction=np.array([b""] * T))) is None
+    # what the exporter adds for the loader's trajectory transforms: the reference's `action` (LIBERO: the raw controller action with the
+    # gripper flipped), how it is chunked, the dataset's clock, the state's encoding
+    assert np.allclose(ep["target_actions"], np.concatenate([act[:, :6], want_grip[:, None]], 1), atol=1e-6)
+    assert ep["chunk_mode"] == "window_zero" and int(ep["control_frequency"]) == 15 and ep["state_encoding"] == "pos_euler"
     ds = D.EpisodeDataset([ep], action_horizon=4)
     s = ds[1]
-    assert s["actions"].shape == (4, 7) and np.allclose(s["language_actions"][:3], 4 * np.array([0.01, 0.0, -0.02]), atol=1e-6)   # steps 1..4
-    assert np.isclose(s["language_actions"][5], 0.4, atol=1e-5) and s["language_actions"][6] == 0.0 and s["has_wrist_image"]     # gripper of step 4: closed
+    # label window: 1 s x 15 Hz = 15 steps, cut at the episode's end (steps 1..5; the last step's movement is the zero padding)
+    assert np.allclose(s["language_actions"][:3], 4 * np.array([0.01, 0.0, -0.02]), atol=1e-6) and np.isclose(s["language_actions"][5], 0.4, atol=1e-5)
+    assert s["language_actions"][6] == want_grip[5] and s["has_wrist_image"] and np.isclose(s["time_horizon_seconds"], 5 / 15)
+    # LIBERO chunk: rows 1..4 of the raw action; from step 4 on the window runs past the end and reads zeros (oxe_datasets.py:259-269)
+    assert s["actions"].shape == (4, 7) and np.allclose(s["actions"], ep["target_actions"][1:5], atol=1e-6)
+    assert np.allclose(ds[4]["actions"][:2], ep["target_actions"][4:6], atol=1e-6) and not ds[4]["actions"][2:].any()
+    # the model-side state: [xyz, rot6d, gripper] (base_dataset.py:437-456); pure yaw psi: first two columns of Rz(psi)
+    psi = 0.1
+    assert s["observation"]["state"].shape == (10,) and np.allclose(s["observation"]["state"][3:9], [np.cos(psi), np.sin(psi), 0, -np.sin(psi), np.cos(psi), 0], atol=1e-6)
+    assert np.array_equal(s["raw_state"], s["observation"]["state"]) and np.isclose(s["observation"]["state"][9], 0.5)
     # DROID: gripper_position 0 open .. 1 closed, rank-1; in-between values take the next decided step
     cart = np.concatenate([np.arange(T)[:, None] * np.array([[0.0, 0.02, 0.0]]), np.zeros((T, 3))], 1)
     gp = np.array([0.0, 0.1, 0.45, 0.55, 0.9, 1.0])
@@ -243,6 +260,15 @@ def test_rlds_export_libero_and_droid_record_to_episode():
     de = R.episode_from_rlds("droid", dtraj)
     assert np.allclose(de["state"][:, 6], [1, 1, 1, 0, 0, 0]) and np.allclose(de["actions"][:, 6], [1, 1, 1, 0, 0, 0])
     assert np.allclose(de["actions"][:-1, 1], 0.02) and np.allclose(de["actions"][-1, :6], 0)
+    # DROID chunk (base_dataset.py:387-427): displacement from the CURRENT pose over a last-value-padded window of absolute poses, the
+    # gripper command of the step itself
+    assert de["chunk_mode"] == "relative" and int(de["control_frequency"]) == 15 and np.allclose(de["target_actions"][:, :6], cart)
+    dd = D.EpisodeDataset([de], action_horizon=4)
+    c3 = dd[3]["actions"]
+    assert np.allclose(c3[:, 1], [0.02, 0.04, 0.04, 0.04], atol=1e-6) and not c3[:, [0, 2, 3, 4, 5]].any() and np.allclose(c3[:, 6], [0, 0, 0, 0])
+    assert np.allclose(dd[0]["actions"][:, 1], [0.02, 0.04, 0.06, 0.08], atol=1e-6) and np.allclose(dd[0]["actions"][:, 6], [1, 1, 1, 0])
+    st = D.compute_norm_stats(dd)                    # statistics over the CHUNKS of every frame (base_dataset.py:297-312), 6 x 4 rows
+    assert np.isclose(st["actions"]["max"][1], 0.08) and np.isclose(st["actions"]["min"][1], 0.0) and len(st["state"]["mean"]) == 10
     b = R.binarize_gripper_actions(np.array([0.5, 0.5, 0.99, 0.5, 0.01, 0.5]))                                  # default threshold 0.95
     assert np.allclose(b, [1, 1, 1, 0, 0, 0.5])                                                                # the tail keeps the last raw value
     with pytest.raises(KeyError):
@@ -540,3 +566,65 @@ def test_training_time_image_randomness_follows_the_data_config(setup):
         dropped += int(gone.sum()); total += gone.numel()
         masked_on += int((obs.image_masks["left_wrist_0_rgb"] & gone).sum())
     assert 0.05 < dropped / total < 0.16 and 0.08 < masked_on / max(dropped, 1) < 0.4, (dropped, masked_on, total)
+
+
+def test_prediction_samples_and_label_windows_follow_the_reference_rules():
+    """base_dataset.py:493-590,603-697 restated (data.EpisodeDataset): the label window is horizon_seconds x control_frequency steps cut at
+    the episode's end, with `time_horizon_seconds` = steps used / frequency; with prediction co-training a frame becomes a (now, future)
+    pair of ONE camera with probability `pred_prob`, the future m = clamp(int(2.5 f), 1, T - 1) steps ahead, labelled with the movement over
+    those m steps (zero-padded: past the end the gripper reads 0), horizon m / f; without a wrist camera the base camera is always used."""
+    import dataclasses
+    T, f = 40, 5
+    eps = _episodes(2, T, seed=3)
+    for e in eps:
+        e["left_wrist_0_rgb"] = (255 - e["base_0_rgb"]).astype(np.uint8)
+        e["control_frequency"] = np.int32(f)
+    plain = D.EpisodeDataset(eps, action_horizon=10)
+    s = plain[7]
+    assert np.isclose(s["time_horizon_seconds"], 1.0) and not s["is_prediction_sample"]
+    np.testing.assert_allclose(s["language_actions"][:3], eps[0]["actions"][7:12, :3].sum(0), rtol=1e-5)      # 1 s x 5 Hz = 5 steps
+    assert np.isclose(plain[T - 2]["time_horizon_seconds"], 2 / f) and plain[T - 2]["language_actions"][6] == eps[0]["actions"][T - 1, 6]
+    two = D.EpisodeDataset(eps, action_horizon=10, horizon_seconds=(1.0, 2.0))
+    assert sorted({round(two[i]["time_horizon_seconds"], 3) for i in range(25)}) == [1.0, 2.0]
+    cfg = get_config("lap_cotrain")
+    ds = D.episode_dataset_from_config(dataclasses.replace(cfg, model=dataclasses.replace(cfg.model, action_horizon=10)), eps, seed=1)
+    assert ds.enable_prediction_training and ds.pred_prob == 0.3 and ds.primary_pred_prob == 0.8
+    m = int(2.5 * f)
+    pred = [ds[i] for i in range(len(ds)) if ds[i]["is_prediction_sample"]]
+    assert 0.2 < len(pred) / len(ds) < 0.42 and 0.6 < np.mean([p["pred_use_primary"] for p in pred]) < 0.95
+    for i in range(len(ds)):
+        p = ds[i]
+        if not p["is_prediction_sample"]:
+            continue
+        ep, t = divmod(i, T)
+        e = eps[ep]
+        cam = e["base_0_rgb"] if p["pred_use_primary"] else e["left_wrist_0_rgb"]
+        assert np.array_equal(p["observation"]["base_0_rgb"], cam[t]) and np.array_equal(p["observation"]["left_wrist_0_rgb"], cam[min(t + m, T - 1)])
+        assert np.isclose(p["time_horizon_seconds"], m / f)
+        np.testing.assert_allclose(p["language_actions"][:3], e["actions"][t:t + m, :3].sum(0), rtol=1e-4, atol=1e-6)
+        assert p["language_actions"][6] == (e["actions"][t + m - 1, 6] if t + m <= T else 0.0)
+        assert np.array_equal(p["actions"], plain[i]["actions"])                      # the action chunk is the frame's own either way
+    again = D.episode_dataset_from_config(dataclasses.replace(cfg, model=dataclasses.replace(cfg.model, action_horizon=10)), eps, seed=1)
+    assert [ds[i]["is_prediction_sample"] for i in range(20)] == [again[i]["is_prediction_sample"] for i in range(20)]      # a function of (seed, episode, step)
+    no_wrist = D.EpisodeDataset([{k: v for k, v in eps[0].items() if k != "left_wrist_0_rgb"}], action_horizon=10, enable_prediction_training=True, pred_prob=1.0)
+    q = no_wrist[3]
+    assert q["pred_use_primary"] and np.array_equal(q["observation"]["left_wrist_0_rgb"], eps[0]["base_0_rgb"][3 + m])
+    # through the loader: a prediction sample keeps both frames and gets the prediction prompt / question
+    tok = pio.PaligemmaTokenizer(model_proto=tiny_sentencepiece_proto(), max_len=200)
+    small = dataclasses.replace(get_config("debug"), batch_size=4, model=dataclasses.replace(get_config("debug").model, action_dim=16, max_token_len=200, enable_prediction_training=True))
+    pds = D.episode_dataset_from_config(dataclasses.replace(small, data=dataclasses.replace(small.data, pred_prob=1.0, wrist_image_dropout_prob=0.0, random_mask_prob=0.0)), eps)
+    obs, _ = next(iter(D.create_data_loader(small, pds, tok, shuffle=False, num_batches=1)))
+    assert bool(obs.is_prediction_sample.all()) and bool(obs.image_masks["left_wrist_0_rgb"].all())
+
+
+def test_control_frequencies_match_the_reference_table():
+    """tests/golden/dataset_configs_v1.json (make_dataset_configs_golden.py: `OXE_DATASET_METADATA` of datasets/utils/configs.py read with
+    ast.literal_eval): the control frequency of every dataset the exporter standardises."""
+    import json
+    import pathlib
+
+    from lap_amd import rlds_export as R
+    ref = json.loads((pathlib.Path(__file__).parent / "golden" / "dataset_configs_v1.json").read_text())["control_frequency"]
+    for name, f in R.CONTROL_FREQUENCY.items():
+        assert ref[name] == f, (name, f, ref[name])
+    assert set(R.STANDARDIZE) - set(R.CONTROL_FREQUENCY) == {"libero_combined"} and "libero_combined" not in ref
