@@ -325,6 +325,7 @@ class RLDSDataConfig:
     aug_wrist_image: bool = True
     random_base_prob: float = 0.0
     random_mask_prob: float = 0.2
+    not_rotate_wrist_prob: float = 0.0
     use_rough_scale: bool = False
     language_action_format_name: str = "verbose_eef_with_rotation"
     transform_strategy: str = "standard"                    # "vla0": labels from the normalised action chunk (config.py:715,737)

@@ -31,6 +31,16 @@ from lap_amd.observation import CoTObservation
 IMAGE_KEYS = pio.IMAGE_KEYS
 
 
+# datasets/registry.py:104-163,402-407: datasets whose wrist camera is mounted upside down — the frame is rotated by 180 degrees, and the
+# end-effector-frame label text is told so (`rotation_applied`, frame_transforms.py:52-54)
+WRIST_ROTATION_PATTERNS = ("droid", "aloha", "mobile_aloha", "furniture_bench_dataset_converted_externally_to_rlds",
+                           "berkeley_fanuc_manipulation", "berkeley_autolab_ur5", "fmb")
+
+
+def needs_wrist_rotation(dataset_name: str) -> bool:
+    return any(p in dataset_name for p in WRIST_ROTATION_PATTERNS)
+
+
 def sum_language_actions(window: np.ndarray) -> np.ndarray:
     """base_dataset.py:722-776 (`sum_actions`, one window of per-step language actions [dx, dy, dz, droll, dpitch, dyaw, tail...]):
     translations add, rotations COMPOSE in order (R = R_1 R_2 ..., extrinsic XYZ angles of the product: not the sum of the angles), the
@@ -66,23 +76,45 @@ class EpisodeDataset:
     * prediction samples (`enable_prediction_training`): with probability `pred_prob` a frame becomes (frame t, frame min(t + m, T-1)),
       m = clamp(int(2.5 x frequency), 1, T-1), of the base camera (probability `primary_pred_prob`, or always without a wrist camera) or of
       the wrist camera, in the base / wrist slots; the label is the summed movement over those m steps (ZERO-padded window: past the end the
-      tail, i.e. the gripper, reads 0 as in the reference), the horizon m / frequency (:534-590,603-697).
+      tail, i.e. the gripper, reads 0 as in the reference), the horizon m / frequency (:534-590,603-697);
+    * images (datasets/utils/image_utils.py:192-380): with `resize_to` every frame is resized with padding first; the wrist frame of a
+      dataset in `WRIST_ROTATION_PATTERNS` is then rotated by 180 degrees (skipped with probability `not_rotate_wrist_prob`), for a
+      prediction pair of the wrist camera both frames, for one of the base camera none; `rotation_applied` says what happened.
     Draws are a pure function of (seed, episode, step) (the reference keys TensorFlow's stateless generator with hashes of the trajectory id)."""
 
     def __init__(self, episodes: Sequence[dict] | str | pathlib.Path, *, action_horizon: int, summation_steps: int | None = None,
                  control_frequency: float | None = None, horizon_seconds: Sequence[float] = (1.0,), enable_prediction_training: bool = False,
-                 pred_prob: float = 0.3, primary_pred_prob: float = 0.8, seed: int = 0):
+                 pred_prob: float = 0.3, primary_pred_prob: float = 0.8, seed: int = 0, split: str | None = None,
+                 val_fraction: float | None = None, resize_to: tuple | None = None, not_rotate_wrist_prob: float = 0.0):
         if isinstance(episodes, (str, pathlib.Path)):
             files = sorted(pathlib.Path(episodes).glob("*.npz"))
             if not files:
                 raise FileNotFoundError(f"no episode files (*.npz) under {episodes}")
             episodes = [dict(np.load(f, allow_pickle=False)) for f in files]
         self.episodes = [self._check(e, i) for i, e in enumerate(episodes)]
+        if split is not None:          # base_dataset.py:375-385: whole trajectories go to one side, by a salted hash of their id
+            if split not in ("train", "val"):
+                raise ValueError(f"split must be 'train', 'val' or None, got {split!r}")
+            val = [self.is_val_episode(e, i, seed, val_fraction or 0.0) for i, e in enumerate(self.episodes)]
+            self.episodes = [e for e, v in zip(self.episodes, val) if v == (split == "val")]
+            if not self.episodes:
+                raise ValueError(f"the {split} split of this store is empty (val_fraction = {val_fraction})")
         self.action_horizon = action_horizon
         self.summation_steps = summation_steps or action_horizon
         self.control_frequency, self.horizon_seconds = control_frequency, tuple(float(h) for h in horizon_seconds)
         self.enable_prediction_training, self.pred_prob, self.primary_pred_prob, self.seed = enable_prediction_training, pred_prob, primary_pred_prob, seed
+        self.resize_to, self.not_rotate_wrist_prob = (tuple(resize_to) if resize_to else None), not_rotate_wrist_prob
         self._starts = np.cumsum([0] + [len(e["actions"]) for e in self.episodes])
+
+    @classmethod
+    def is_val_episode(cls, e: dict, index: int, seed: int, val_fraction: float) -> bool:
+        """bucket(salt + trajectory id) < int(val_fraction x 1000) of 1000 buckets, the salt being the split seed (base_dataset.py:375-385).
+        The reference hashes with TensorFlow's FarmHash, which does not exist here: the same rule with BLAKE2 picks other trajectories, the
+        same share of them.  Id: the episode's `trajectory_id`, else `<dataset name>-<position in the store>`."""
+        import hashlib
+        tid = cls._text(e.get("trajectory_id")) or f"{cls._text(e.get('dataset_name'))}-{index}"
+        bucket = int.from_bytes(hashlib.blake2b(f"{seed}{tid}".encode(), digest_size=8).digest(), "little") % 1000
+        return bucket < int(val_fraction * 1000)
 
     @staticmethod
     def _text(v, default: str = "") -> str:
@@ -137,7 +169,7 @@ class EpisodeDataset:
         return np.concatenate([w[1:, :3] - w[0:1, :3], euler_diff(w[1:, 3:6], np.broadcast_to(w[0:1, 3:6], w[1:, 3:6].shape)), w[:-1, 6:7]], -1).astype(np.float32)
 
     def _draws(self, ep: int, t: int) -> np.ndarray:
-        return np.random.Generator(np.random.Philox(key=self.seed, counter=[1, 0, ep, t])).random(3)
+        return np.random.Generator(np.random.Philox(key=self.seed, counter=[1, 0, ep, t])).random(4)
 
     def __getitem__(self, index: int) -> dict:
         ep = int(np.searchsorted(self._starts, index, side="right") - 1)
@@ -175,10 +207,22 @@ class EpisodeDataset:
             window[:max(min(m, T - t), 0)] = acts[t:t + m]
             sample.update(is_prediction_sample=True, pred_use_primary=bool(primary), language_actions=sum_language_actions(window),
                           time_horizon_seconds=float(m / f))
+        if self.resize_to is not None:
+            for k in list(obs):
+                if k != "state":
+                    obs[k] = pio.dataset_resize_with_pad(np.asarray(obs[k]), *self.resize_to)
+        rotated = False
+        if needs_wrist_rotation(sample["dataset_name"]) and "left_wrist_0_rgb" in obs and not (sample["is_prediction_sample"] and sample["pred_use_primary"]):
+            if not (self.not_rotate_wrist_prob > 0.0 and u[3] < self.not_rotate_wrist_prob):
+                rotated = True
+                obs["left_wrist_0_rgb"] = np.ascontiguousarray(np.asarray(obs["left_wrist_0_rgb"])[::-1, ::-1])
+                if sample["is_prediction_sample"]:          # a pair of the wrist camera: both frames
+                    obs["base_0_rgb"] = np.ascontiguousarray(np.asarray(obs["base_0_rgb"])[::-1, ::-1])
+        sample["rotation_applied"] = rotated
         return sample
 
 
-def episode_dataset_from_config(config, episodes, *, seed: int | None = None) -> EpisodeDataset:
+def episode_dataset_from_config(config, episodes, *, seed: int | None = None, split: str | None = None) -> EpisodeDataset:
     """An `EpisodeDataset` with the knobs the reference's dataset classes take from the train config (dataset_mixer.py:262-290,
     base_dataset.py:240-283): action horizon and prediction co-training from the model config; label windows, prediction probabilities
     from the data config."""
@@ -186,7 +230,8 @@ def episode_dataset_from_config(config, episodes, *, seed: int | None = None) ->
     return EpisodeDataset(episodes, action_horizon=mc.action_horizon, horizon_seconds=tuple(getattr(dc, "horizon_seconds", (1.0,))),
                           enable_prediction_training=bool(getattr(mc, "enable_prediction_training", False)),
                           pred_prob=getattr(dc, "pred_prob", 0.3), primary_pred_prob=getattr(dc, "primary_pred_prob", 0.8),
-                          seed=config.seed if seed is None else seed)
+                          seed=config.seed if seed is None else seed, split=split, val_fraction=getattr(dc, "val_fraction", None),
+                          resize_to=getattr(dc, "resize_resolution", None), not_rotate_wrist_prob=getattr(dc, "not_rotate_wrist_prob", 0.0))
 
 
 class VqaDataset:

@@ -579,6 +579,7 @@ def test_prediction_samples_and_label_windows_follow_the_reference_rules():
     for e in eps:
         e["left_wrist_0_rgb"] = (255 - e["base_0_rgb"]).astype(np.uint8)
         e["control_frequency"] = np.int32(f)
+        e["dataset_name"] = "bridge_v2_oxe"            # (no upside-down wrist camera: frames compare as stored)
     plain = D.EpisodeDataset(eps, action_horizon=10)
     s = plain[7]
     assert np.isclose(s["time_horizon_seconds"], 1.0) and not s["is_prediction_sample"]
@@ -587,6 +588,7 @@ def test_prediction_samples_and_label_windows_follow_the_reference_rules():
     two = D.EpisodeDataset(eps, action_horizon=10, horizon_seconds=(1.0, 2.0))
     assert sorted({round(two[i]["time_horizon_seconds"], 3) for i in range(25)}) == [1.0, 2.0]
     cfg = get_config("lap_cotrain")
+    cfg = dataclasses.replace(cfg, data=dataclasses.replace(cfg.data, resize_resolution=None))
     ds = D.episode_dataset_from_config(dataclasses.replace(cfg, model=dataclasses.replace(cfg.model, action_horizon=10)), eps, seed=1)
     assert ds.enable_prediction_training and ds.pred_prob == 0.3 and ds.primary_pred_prob == 0.8
     m = int(2.5 * f)
@@ -628,3 +630,43 @@ def test_control_frequencies_match_the_reference_table():
     for name, f in R.CONTROL_FREQUENCY.items():
         assert ref[name] == f, (name, f, ref[name])
     assert set(R.STANDARDIZE) - set(R.CONTROL_FREQUENCY) == {"libero_combined"} and "libero_combined" not in ref
+
+
+def test_train_val_split_is_per_trajectory_and_salted():
+    """base_dataset.py:375-385: a trajectory is a validation trajectory when the bucket of (seed, trajectory id) falls below
+    val_fraction x 1000; train and val are complementary, a function of the seed, and whole episodes."""
+    eps = _episodes(60, 3, seed=9)
+    tr = D.EpisodeDataset(eps, action_horizon=4, split="train", val_fraction=0.25, seed=3)
+    va = D.EpisodeDataset(eps, action_horizon=4, split="val", val_fraction=0.25, seed=3)
+    assert len(tr.episodes) + len(va.episodes) == 60 and 5 <= len(va.episodes) <= 25
+    ids = lambda d: {e["prompt"] for e in d.episodes}
+    assert not ids(tr) & ids(va)
+    assert ids(va) != ids(D.EpisodeDataset(eps, action_horizon=4, split="val", val_fraction=0.25, seed=4))
+    assert len(D.EpisodeDataset(eps, action_horizon=4, split="train", val_fraction=0.0).episodes) == 60
+    with pytest.raises(ValueError, match="empty"):
+        D.EpisodeDataset(eps, action_horizon=4, split="val", val_fraction=0.0)
+    cfg = get_config("lap_libero")          # val_fraction 0.0: everything trains
+    assert len(D.episode_dataset_from_config(cfg, eps, split="train").episodes) == 60
+
+
+def test_wrist_rotation_and_resize_follow_the_dataset_rules():
+    """datasets/registry.py:155-163 + image_utils.py:289-377: DROID's wrist camera is upside down — the wrist frame is rotated by 180 degrees
+    (after the resize with padding), `rotation_applied` reaches the label code; a prediction pair of the wrist camera rotates both frames, one
+    of the base camera none; other datasets are left alone."""
+    eps = _episodes(1, 8, seed=2, hw=(20, 32))
+    eps[0]["left_wrist_0_rgb"] = np.random.default_rng(0).integers(0, 255, eps[0]["base_0_rgb"].shape, dtype=np.uint8)
+    eps[0]["dataset_name"] = "droid"
+    ds = D.EpisodeDataset(eps, action_horizon=4, resize_to=(24, 24))
+    s = ds[2]
+    want = pio.dataset_resize_with_pad(eps[0]["left_wrist_0_rgb"][2], 24, 24)[::-1, ::-1]
+    assert s["rotation_applied"] and s["observation"]["left_wrist_0_rgb"].shape == (24, 24, 3) and np.array_equal(s["observation"]["left_wrist_0_rgb"], want)
+    assert np.array_equal(s["observation"]["base_0_rgb"], pio.dataset_resize_with_pad(eps[0]["base_0_rgb"][2], 24, 24))
+    assert not D.EpisodeDataset(eps, action_horizon=4, not_rotate_wrist_prob=1.0)[2]["rotation_applied"]
+    other = D.EpisodeDataset([dict(eps[0], dataset_name="bridge_v2_oxe")], action_horizon=4)[2]
+    assert not other["rotation_applied"] and np.array_equal(other["observation"]["left_wrist_0_rgb"], eps[0]["left_wrist_0_rgb"][2])
+    pw = D.EpisodeDataset(eps, action_horizon=4, enable_prediction_training=True, pred_prob=1.0, primary_pred_prob=0.0)[1]
+    assert pw["is_prediction_sample"] and not pw["pred_use_primary"] and pw["rotation_applied"]
+    assert np.array_equal(pw["observation"]["base_0_rgb"], eps[0]["left_wrist_0_rgb"][1][::-1, ::-1])
+    pp = D.EpisodeDataset(eps, action_horizon=4, enable_prediction_training=True, pred_prob=1.0, primary_pred_prob=1.0)[1]
+    assert pp["pred_use_primary"] and not pp["rotation_applied"] and np.array_equal(pp["observation"]["base_0_rgb"], eps[0]["base_0_rgb"][1])
+    assert D.needs_wrist_rotation("berkeley_fanuc_manipulation") and not D.needs_wrist_rotation("taco_play")
