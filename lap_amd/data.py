@@ -79,7 +79,10 @@ class EpisodeDataset:
       tail, i.e. the gripper, reads 0 as in the reference), the horizon m / frequency (:534-590,603-697);
     * images (datasets/utils/image_utils.py:192-380): with `resize_to` every frame is resized with padding first; the wrist frame of a
       dataset in `WRIST_ROTATION_PATTERNS` is then rotated by 180 degrees (skipped with probability `not_rotate_wrist_prob`), for a
-      prediction pair of the wrist camera both frames, for one of the base camera none; `rotation_applied` says what happened.
+      prediction pair of the wrist camera both frames, for one of the base camera none; `rotation_applied` says what happened;
+    * DROID (droid_dataset.py:104-232): an episode with `prompt_alternatives` / `base_0_rgb_alt` gets one of its instructions and one
+      of its two exterior cameras per (seed, episode); frames whose `frame_mask` is False (the reference's idle-range filter, read from
+      a table next to the shards) are not samples — they still belong to their neighbours' chunks and windows.
     Draws are a pure function of (seed, episode, step) (the reference keys TensorFlow's stateless generator with hashes of the trajectory id)."""
 
     def __init__(self, episodes: Sequence[dict] | str | pathlib.Path, *, action_horizon: int, summation_steps: int | None = None,
@@ -104,7 +107,8 @@ class EpisodeDataset:
         self.control_frequency, self.horizon_seconds = control_frequency, tuple(float(h) for h in horizon_seconds)
         self.enable_prediction_training, self.pred_prob, self.primary_pred_prob, self.seed = enable_prediction_training, pred_prob, primary_pred_prob, seed
         self.resize_to, self.not_rotate_wrist_prob = (tuple(resize_to) if resize_to else None), not_rotate_wrist_prob
-        self._starts = np.cumsum([0] + [len(e["actions"]) for e in self.episodes])
+        self._frames = [np.flatnonzero(np.asarray(e["frame_mask"], dtype=bool)) if "frame_mask" in e else np.arange(len(e["actions"])) for e in self.episodes]
+        self._starts = np.cumsum([0] + [len(f) for f in self._frames])
 
     @classmethod
     def is_val_episode(cls, e: dict, index: int, seed: int, val_fraction: float) -> bool:
@@ -173,11 +177,17 @@ class EpisodeDataset:
 
     def __getitem__(self, index: int) -> dict:
         ep = int(np.searchsorted(self._starts, index, side="right") - 1)
-        t = int(index - self._starts[ep])
+        t = int(self._frames[ep][int(index - self._starts[ep])])
         e = self.episodes[ep]
         acts = np.asarray(e["actions"], dtype=np.float32)
         T = len(acts)
         u = self._draws(ep, t)
+        ue = np.random.Generator(np.random.Philox(key=self.seed, counter=[2, 0, ep, 0])).random(2)      # per-episode draws
+        if "base_0_rgb_alt" in e and not ue[0] > 0.5:          # random_val > 0.5: the first camera, else the second
+            e = dict(e, base_0_rgb=e["base_0_rgb_alt"])
+        if "prompt_alternatives" in e:
+            alts = [self._text(a) for a in np.asarray(e["prompt_alternatives"]).reshape(-1)]
+            e = dict(e, prompt=alts[min(int(ue[1] * len(alts)), len(alts) - 1)])
         freq = self._frequency(e)
         if freq:
             steps = max(int(round(self.horizon_seconds[min(int(u[0] * len(self.horizon_seconds)), len(self.horizon_seconds) - 1)] * freq)), 1)

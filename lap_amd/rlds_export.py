@@ -433,7 +433,19 @@ def decode_instruction(x) -> str:
     return v.decode("utf-8") if isinstance(v, bytes) else str(v)
 
 
-def episode_from_rlds(dataset_name: str, traj: dict, *, hash_bucket=None, rng=None) -> dict | None:
+def droid_keep_mask(filter_dict: dict, traj: dict) -> np.ndarray:
+    """droid_mixins.py:113-143 + droid_dataset.py:131-140: frame t of a DROID episode passes when the keep-ranges file lists
+    `<recording_folderpath>--<file_path>` with a [start, end) range containing t; an episode the file does not list keeps nothing."""
+    meta = traj["traj_metadata"]["episode_metadata"]
+    key = decode_instruction(meta["recording_folderpath"]) + "--" + decode_instruction(meta["file_path"])
+    T = len(np.asarray(traj["observation"]["cartesian_position"]))
+    mask = np.zeros(T, dtype=bool)
+    for start, end in filter_dict.get(key, []):
+        mask[max(int(start), 0):max(min(int(end), T), 0)] = True
+    return mask
+
+
+def episode_from_rlds(dataset_name: str, traj: dict, *, hash_bucket=None, rng=None, keep_mask=None) -> dict | None:
     """One raw RLDS trajectory (dict of numpy arrays stacked over steps: `observation`, `action` [, `action_dict`],
     `language_instruction`) -> the episode-store dict of `lap_amd/data.py`, or None when the reference's filters drop it
     (empty instruction, zero length: oxe_datasets.py SingleOXEDataset "standard filtering").  `actions` are the per-step
@@ -457,6 +469,23 @@ def episode_from_rlds(dataset_name: str, traj: dict, *, hash_bucket=None, rng=No
           "target_actions": np.asarray(std["action"], dtype=np.float32), "chunk_mode": chunk_mode_of(dataset_name), "state_encoding": "pos_euler"}
     if dataset_name in CONTROL_FREQUENCY:
         ep["control_frequency"] = np.int32(CONTROL_FREQUENCY[dataset_name])
+    if dataset_name == "droid":      # droid_dataset.py:104-232
+        # one of three instructions and one of two exterior cameras is drawn per episode: all of them travel; the loader draws
+        alts = [decode_instruction(std[k]) for k in ("language_instruction", "language_instruction_2", "language_instruction_3") if k in std]
+        alts = [a for a in alts if a.strip()]
+        if len(alts) > 1:
+            ep["prompt_alternatives"] = np.asarray(alts)
+        if "exterior_image_2_left" in obs and np.asarray(obs["exterior_image_2_left"]).size:
+            ep["base_0_rgb_alt"] = np.asarray(obs["exterior_image_2_left"], dtype=np.uint8)
+        # only successful recordings with an instruction of more than 10 characters train (:215-229); the per-frame keep ranges of the
+        # reference's idle filter come from a table outside the RLDS shards: `keep_mask` [T] when the caller has it
+        meta = traj.get("traj_metadata", {}).get("episode_metadata", {}) if isinstance(traj.get("traj_metadata"), dict) else {}
+        if "file_path" in meta and "success" not in decode_instruction(meta["file_path"]):
+            return None
+        if len(prompt) <= 10:
+            return None
+        if keep_mask is not None:
+            ep["frame_mask"] = np.asarray(keep_mask, dtype=bool)
     if wrist_key and wrist_key in obs and np.asarray(obs[wrist_key]).size:
         ep["left_wrist_0_rgb"] = np.asarray(obs[wrist_key], dtype=np.uint8)
     return ep

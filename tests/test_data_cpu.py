@@ -670,3 +670,39 @@ def test_wrist_rotation_and_resize_follow_the_dataset_rules():
     pp = D.EpisodeDataset(eps, action_horizon=4, enable_prediction_training=True, pred_prob=1.0, primary_pred_prob=1.0)[1]
     assert pp["pred_use_primary"] and not pp["rotation_applied"] and np.array_equal(pp["observation"]["base_0_rgb"], eps[0]["base_0_rgb"][1])
     assert D.needs_wrist_rotation("berkeley_fanuc_manipulation") and not D.needs_wrist_rotation("taco_play")
+
+
+def test_droid_episode_options():
+    """droid_dataset.py:104-232: three instructions / two exterior cameras drawn per episode, unsuccessful or instruction-less recordings
+    dropped, frames outside the keep ranges are not samples."""
+    from lap_amd import rlds_export as R
+    T = 6
+    g = np.random.default_rng(2)
+    im = lambda: g.integers(0, 255, (T, 8, 8, 3), dtype=np.uint8)
+    cart = np.concatenate([np.arange(T)[:, None] * np.array([[0.0, 0.02, 0.0]]), np.zeros((T, 3))], 1)
+    gp = np.linspace(0, 1, T)
+    base = {"observation": {"exterior_image_1_left": im(), "exterior_image_2_left": im(), "wrist_image_left": im(), "cartesian_position": cart,
+                            "gripper_position": gp},
+            "action_dict": {"gripper_position": gp[:, None]}, "language_instruction": b"open the top drawer", "language_instruction_2": b"pull the drawer open",
+            "language_instruction_3": b"", "traj_metadata": {"episode_metadata": {"file_path": np.array([b"/x/success/2023/traj.h5"] * T)}}}
+    ep = R.episode_from_rlds("droid", base, keep_mask=[1, 1, 0, 0, 1, 1])
+    assert list(ep["prompt_alternatives"]) == ["open the top drawer", "pull the drawer open"] and ep["base_0_rgb_alt"].shape == (T, 8, 8, 3)
+    assert R.episode_from_rlds("droid", dict(base, traj_metadata={"episode_metadata": {"file_path": np.array([b"/x/failure/traj.h5"] * T)}})) is None
+    assert R.episode_from_rlds("droid", dict(base, language_instruction=b"open it")) is None          # <= 10 characters
+    ds = D.EpisodeDataset([ep], action_horizon=3)
+    assert len(ds) == 4 and np.allclose(ds[2]["actions"][:, 1], [0.02, 0.02, 0.02])                  # frame 4: last-value padding after frame 5
+    seen_p, seen_c = set(), set()
+    for seed in range(12):
+        s = D.EpisodeDataset([ep], action_horizon=3, seed=seed)[0]
+        seen_p.add(s["prompt"]); seen_c.add(bool(np.array_equal(s["observation"]["base_0_rgb"], ep["base_0_rgb"][0])))
+    assert seen_p == {"open the top drawer", "pull the drawer open"} and seen_c == {True, False}
+    a = D.EpisodeDataset([ep], action_horizon=3, seed=5)
+    assert a[0]["prompt"] == a[3]["prompt"]                                                             # one draw per episode
+
+
+def test_droid_keep_mask_from_ranges():
+    from lap_amd import rlds_export as R
+    traj = {"observation": {"cartesian_position": np.zeros((8, 6))},
+            "traj_metadata": {"episode_metadata": {"recording_folderpath": b"gs://x/rec", "file_path": np.array([b"gs://x/success/t.h5"] * 8)}}}
+    m = R.droid_keep_mask({"gs://x/rec--gs://x/success/t.h5": [[1, 3], [5, 20]]}, traj)
+    assert m.tolist() == [False, True, True, False, False, True, True, True] and not R.droid_keep_mask({}, traj).any()

@@ -36,7 +36,12 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--split", default="train")
     ap.add_argument("--max-episodes", type=int, default=None)
+    ap.add_argument("--droid-keep-ranges", default=None, help="DROID only: the keep-ranges JSON of the reference's idle-frame filter (droid_mixins.py:113-143)")
     args = ap.parse_args()
+    keep_ranges = None
+    if args.droid_keep_ranges:
+        import json
+        keep_ranges = json.loads(pathlib.Path(args.droid_keep_ranges).read_text())
     try:
         import tensorflow_datasets as tfds
     except ImportError as e:   # pragma: no cover - the build image has no TensorFlow
@@ -56,7 +61,10 @@ def main():
         if args.max_episodes is not None and kept >= args.max_episodes:
             break
         traj = stack_steps(list(episode["steps"]))
-        ep = R.episode_from_rlds(args.dataset, traj, hash_bucket=tf_hash_bucket, rng=rng)
+        if "episode_metadata" in episode:          # (DROID: success filter, keep ranges)
+            traj["traj_metadata"] = {"episode_metadata": {k: np.asarray(v) for k, v in episode["episode_metadata"].items()}}
+        mask = R.droid_keep_mask(keep_ranges, traj) if (keep_ranges is not None and args.dataset == "droid") else None
+        ep = R.episode_from_rlds(args.dataset, traj, hash_bucket=tf_hash_bucket, rng=rng, keep_mask=mask)
         if ep is None:
             dropped += 1
             continue
