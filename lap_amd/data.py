@@ -534,6 +534,24 @@ class DataLoader:
             yield CoTObservation.from_dict(batch, device=self.device), actions
 
 
+def data_transform_inputs(dc, mc) -> "pio.CoTInputs":
+    """`RLDSDataConfig._create_data_transforms` (training/config.py:321-352), inputs side: the ONE `CoTInputs` both the train loader and
+    `create_trained_policy` use, with every field the reference passes from the data / model config."""
+    question_config = None
+    if getattr(dc, "enable_diverse_questions", False):      # :325-334
+        from lap_amd.questions import QuestionConfig
+        question_config = QuestionConfig(type_weights=getattr(dc, "question_type_weights", None),
+                                         delta_motion_format_weights=getattr(dc, "delta_motion_format_weights", None),
+                                         use_diverse_prompts=getattr(dc, "use_diverse_prompts", True))
+    return pio.CoTInputs(
+        action_dim=mc.action_dim, wrist_image_dropout_prob=getattr(dc, "wrist_image_dropout_prob", 0.0),
+        language_action_format=getattr(dc, "language_action_format_name", "verbose_eef_with_rotation"),
+        random_mask_prob=getattr(dc, "random_mask_prob", 0.0), random_base_prob=getattr(dc, "random_base_prob", 0.0),
+        use_rough_scale=getattr(dc, "use_rough_scale", False), transform_strategy=getattr(dc, "transform_strategy", "standard"),
+        enable_langact_training=mc.enable_langact_training, enable_diverse_questions=getattr(dc, "enable_diverse_questions", False),
+        question_config=question_config)
+
+
 def create_data_loader(config, dataset: "EpisodeDataset | MixtureDataset", tokenizer, *, norm_stats: dict | None = None, shuffle: bool = True, seed: int = 0,
                        rank: int = 0, world_size: int = 1, num_batches: int | None = None, split: str = "train", device=None) -> DataLoader:
     """datasets/data_loader.py:126-198: per-rank batch = config.batch_size // world_size; the transform stack of
@@ -547,19 +565,7 @@ def create_data_loader(config, dataset: "EpisodeDataset | MixtureDataset", token
             norm_stats = compute_norm_stats(dataset, action_pad_to=mc.action_dim)
     dc = config.data
     ntype = getattr(dc, "action_proprio_normalization_type", "bounds_q99")
-    question_config = None
-    if getattr(dc, "enable_diverse_questions", False):      # training/config.py:325-334
-        from lap_amd.questions import QuestionConfig
-        question_config = QuestionConfig(type_weights=getattr(dc, "question_type_weights", None),
-                                         delta_motion_format_weights=getattr(dc, "delta_motion_format_weights", None),
-                                         use_diverse_prompts=getattr(dc, "use_diverse_prompts", True))
-    cot = pio.CoTInputs(    # every field the reference's data-transform group passes (training/config.py:336-352)
-        action_dim=mc.action_dim, wrist_image_dropout_prob=getattr(dc, "wrist_image_dropout_prob", 0.0),
-        language_action_format=getattr(dc, "language_action_format_name", "verbose_eef_with_rotation"),
-        random_mask_prob=getattr(dc, "random_mask_prob", 0.0), random_base_prob=getattr(dc, "random_base_prob", 0.0),
-        use_rough_scale=getattr(dc, "use_rough_scale", False), transform_strategy=getattr(dc, "transform_strategy", "standard"),
-        enable_langact_training=mc.enable_langact_training, enable_diverse_questions=getattr(dc, "enable_diverse_questions", False),
-        question_config=question_config)
+    cot = data_transform_inputs(dc, mc)
     # the training side's normalisation is the mixer's `NormalizeActionAndProprio` (clipped bounds, float32), not the policy side's
     # `Normalize` (dataset_mixer.py:334-359; the train-time transform group carries none, training/config.py:195-207).  The mixer runs
     # it on the raw trajectory, i.e. BEFORE `CoTInputs`; elementwise, so the order only matters to the VLA-0 strategy, whose label text

@@ -139,8 +139,8 @@ def create_trained_policy(train_config, checkpoint_dir, *, tokenizer_model_path=
                           device="cuda", use_graph: bool = True) -> Policy:
     """policies/policy_config_adapter.py:85-154: model from `<checkpoint_dir>/params`, norm stats from
     `<checkpoint_dir>/assets/<asset_id>/norm_stats.json`, and the standard transform stack
-        [repack.inputs, InjectDefaultPrompt, CoTInputs, Normalize, InjectDefaultPrompt, Tokenize, PadStatesAndActions]
-        -> model -> [Unnormalize, CoTOutputs, repack.outputs].
+        [repack.inputs, InjectDefaultPrompt, CoTInputs (the data config's), Normalize, InjectDefaultPrompt, Tokenize, PadStatesAndActions]
+        -> model -> [DetokenizeReasoning, Unnormalize, CoTOutputs, repack.outputs]  (VLA-0: [DetokenizeReasoning, CoTOutputs(norm stats)]).
     `repack_transforms` = (inputs, outputs) lists.  The PaliGemma SentencePiece model cannot be downloaded here: pass
     `tokenizer_model_path` (or a ready `tokenizer`)."""
     import pathlib
@@ -160,12 +160,25 @@ def create_trained_policy(train_config, checkpoint_dir, *, tokenizer_model_path=
         tokenizer = pio.PaligemmaTokenizer(tokenizer_model_path, mc.max_token_len, prompt_format=mc.prompt_format,
                                            reasoning_mask_prob=0.0)
     rin, rout = (list(repack_transforms[0]), list(repack_transforms[1])) if repack_transforms else ([], [])
-    transforms = [*rin, pio.InjectDefaultPrompt(default_prompt), pio.CoTInputs(action_dim=mc.action_dim),
+    from lap_amd.data import data_transform_inputs
+    dc = train_config.data
+    strategy = getattr(dc, "transform_strategy", "standard")
+    fmt_name = getattr(dc, "language_action_format_name", "verbose_eef_with_rotation")
+    # policy_config_adapter.py:137-150: the data config's OWN data-transform group serves too — the same `CoTInputs` as in training,
+    # training-time image randomness included (wrist dropout / random un-masking are whatever the data config says: the reference has no
+    # serving override; set them to 0 in the config a server is started with) — then Normalize, then the model transforms
+    # (training/config.py:195-207: default prompt, tokenizer with the model's state dropout, padding).
+    transforms = [*rin, pio.InjectDefaultPrompt(default_prompt), data_transform_inputs(dc, mc),
                   pio.Normalize(norm_stats, normalization_type=ntype), pio.InjectDefaultPrompt(None),
                   pio.TokenizePromptAndReasoning(tokenizer, discrete_state_input=mc.discrete_state_input, verbose_mode=mc.verbose_mode,
-                                                 state_dropout=0.0),
+                                                 state_dropout=getattr(mc, "state_dropout", 0.0)),
                   pio.PadStatesAndActions(mc.action_dim)]
-    outputs = [pio.Unnormalize(norm_stats, normalization_type=ntype), pio.CoTOutputs(), *rout]
+    detok = pio.DetokenizeReasoning(tokenizer)      # model_transforms.outputs (include_outputs, training/config.py:192-194)
+    if strategy == "vla0":      # OutputTransformAssembler._build_vla0_outputs (:44-66): the decoder un-normalises, no Unnormalize
+        outputs = [detok, pio.CoTOutputs(language_action_format=fmt_name, norm_stats=norm_stats, normalization_type=ntype, transform_strategy="vla0"), *rout]
+    else:                       # _build_standard_outputs (:68-82)
+        outputs = [detok, pio.Unnormalize(norm_stats, normalization_type=ntype),
+                   pio.CoTOutputs(language_action_format=fmt_name, transform_strategy=strategy), *rout]
     return Policy(model, transforms=transforms, output_transforms=outputs, sample_kwargs=sample_kwargs, use_graph=use_graph,
                   metadata=getattr(train_config, "policy_metadata", None))
 

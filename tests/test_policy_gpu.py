@@ -31,7 +31,9 @@ def _checkpoint(tmp_path, cfg, model):
 
 def test_policy_from_checkpoint_serves_raw_requests(hip, tmp_path):
     tc = get_config("debug")
-    tc = dataclasses.replace(tc, data=dataclasses.replace(tc.data, asset_id="debug"))
+    # (the policy serves with the data config's own CoTInputs, policy_config_adapter.py:137-150: a serving config switches the
+    # training-time image randomness off)
+    tc = dataclasses.replace(tc, data=dataclasses.replace(tc.data, asset_id="debug", wrist_image_dropout_prob=0.0, random_mask_prob=0.0))
     cfg = tc.model
     model = LAP(cfg, seed=5, device=DEV, with_grads=False)
     stats = _checkpoint(tmp_path, cfg, model)
