@@ -152,25 +152,29 @@ class EpisodeDataset:
         f = e.get("control_frequency")
         return float(np.asarray(f)) if f is not None else self.control_frequency
 
-    def chunk(self, e: dict, t: int) -> np.ndarray:
-        """The action chunk of frame t, [action_horizon, A] (see the class docstring)."""
+    def chunks(self, e: dict, ts=None) -> np.ndarray:
+        """The action chunks of frames `ts` (default: every frame) of one episode, [len(ts), action_horizon, A] (class docstring)."""
         H, T = self.action_horizon, len(e["actions"])
+        ts = np.arange(T) if ts is None else np.asarray(ts, dtype=np.int64).reshape(-1)
         mode = self._text(e.get("chunk_mode"), "steps")
+        idx = ts[:, None] + np.arange(H)[None]                      # [n, H]
         if mode == "steps":
             acts = np.asarray(e["actions"], dtype=np.float32)
-            idx = np.arange(t, t + H)
-            chunk = acts[np.minimum(idx, T - 1)].copy()
-            chunk[idx >= T, :6] = 0.0          # past the end: hold still, keep the gripper
-            return chunk
+            out = acts[np.minimum(idx, T - 1)].copy()
+            out[..., :6] = np.where((idx >= T)[..., None], 0.0, out[..., :6])      # past the end: hold still, keep the gripper
+            return out
         tgt = np.asarray(e["target_actions"], dtype=np.float64)
         if mode == "window_zero":
-            idx = np.arange(t, t + H)
-            chunk = tgt[np.minimum(idx, T - 1)].copy()
-            chunk[idx >= T] = 0.0
-            return chunk.astype(np.float32)
+            out = tgt[np.minimum(idx, T - 1)].copy()
+            out[idx >= T] = 0.0
+            return out.astype(np.float32)
         from lap_amd.rlds_export import euler_diff
-        w = tgt[np.minimum(np.arange(t, t + H + 1), T - 1)]        # last-value padding
-        return np.concatenate([w[1:, :3] - w[0:1, :3], euler_diff(w[1:, 3:6], np.broadcast_to(w[0:1, 3:6], w[1:, 3:6].shape)), w[:-1, 6:7]], -1).astype(np.float32)
+        w = tgt[np.minimum(ts[:, None] + np.arange(H + 1)[None], T - 1)]          # [n, H + 1, A]: last-value padding
+        rot = euler_diff(w[:, 1:, 3:6], np.broadcast_to(w[:, 0:1, 3:6], w[:, 1:, 3:6].shape))
+        return np.concatenate([w[:, 1:, :3] - w[:, 0:1, :3], rot, w[:, :-1, 6:7]], -1).astype(np.float32)
+
+    def chunk(self, e: dict, t: int) -> np.ndarray:
+        return self.chunks(e, [t])[0]
 
     def _draws(self, ep: int, t: int) -> np.ndarray:
         return np.random.Generator(np.random.Philox(key=self.seed, counter=[1, 0, ep, t])).random(4)
@@ -295,7 +299,7 @@ def compute_norm_stats(dataset: EpisodeDataset, *, action_pad_to: int | None = N
     fields; num_transitions counts those rows) and over the per-frame state as the model sees it ([xyz, rot6d, gripper] for end-effector
     states).  The mixer pads to the model's widths later (`global_norm_stats`); `action_pad_to` zero-pads here for single datasets:
     all-zero columns normalise to 0 by the q01 == q99 rule."""
-    chunks = np.concatenate([dataset.chunk(e, t).astype(np.float64) for e in dataset.episodes for t in range(len(e["actions"]))], 0)
+    chunks = np.concatenate([dataset.chunks(e).astype(np.float64).reshape(-1, dataset.chunks(e, [0]).shape[-1]) for e in dataset.episodes], 0)
     chunks = chunks[np.isfinite(chunks).all(1)]
     if action_pad_to is not None:
         chunks = pio.pad_to_dim(chunks, action_pad_to, axis=-1)
