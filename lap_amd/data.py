@@ -148,6 +148,12 @@ class EpisodeDataset:
     def __len__(self) -> int:
         return int(self._starts[-1])
 
+    @property
+    def num_transitions(self) -> int:
+        """The size this dataset enters the mixture weights with (dataset_mixer.py:141): the reference takes it from the statistics,
+        which count the rows of the flattened action CHUNKS of every frame — frames x action horizon (normalize_adapter.py:108-113)."""
+        return int(sum(len(e["actions"]) for e in self.episodes) * self.action_horizon)
+
     def _frequency(self, e: dict):
         f = e.get("control_frequency")
         return float(np.asarray(f)) if f is not None else self.control_frequency
@@ -271,6 +277,15 @@ class VqaDataset:
 
     def __len__(self) -> int:
         return len(self.samples)
+
+    @property
+    def num_transitions(self) -> int:
+        """The reference's constant for the set (vqa_export.VQA_NUM_TRANSITIONS), whatever the store holds; an unknown set: its length."""
+        from lap_amd.vqa_export import VQA_NUM_TRANSITIONS
+        e = self.samples[0] if self.samples else {}
+        name = e.get("dataset_name", "")
+        name = name if isinstance(name, str) else str(np.asarray(name).item())
+        return int(VQA_NUM_TRANSITIONS.get(name, len(self.samples)))
 
     @staticmethod
     def _image(e: dict) -> np.ndarray:
@@ -408,7 +423,10 @@ class MixtureDataset:
         self.names = [n for n, _ in spec]
         self.datasets = [datasets[n] for n in self.names]
         self.sizes = [len(d) for d in self.datasets]
-        self.sample_weights, self.length = mixture_weights(self.sizes, [w for _, w in spec], balance_weights=balance_weights)
+        # the sizes the reference weights with are the statistics' transition counts (dataset_mixer.py:134-156): chunk rows for robot sets
+        # (frames x action horizon), a per-set constant for VQA sets — not the number of samples
+        self.weight_sizes = [int(getattr(d, "num_transitions", len(d))) for d in self.datasets]
+        self.sample_weights, self.length = mixture_weights(self.weight_sizes, [w for _, w in spec], balance_weights=balance_weights)
         self._cdf = np.cumsum(self.sample_weights)
         self.seed = int(seed)
         horizons = {d.action_horizon for d in self.datasets}

@@ -22,6 +22,11 @@ import numpy as np
 # Registration order of the reference's VQA classes = their ids (registry.py:288-303 assigns 1, 2, ... as the modules of
 # datasets/vqa/__init__.py:10-18 are imported; 0 = not a VQA sample)
 VQA_DATASET_IDS = {"coco_captions": 1, "lvis": 2, "paco_lvis": 3, "paco_ego4d": 4, "pixmo_cap": 5, "pixmo_point": 6, "vqa": 7}
+# `get_num_transitions` of the seven readers (coco_caption_dataset.py:52-54, lvis_dataset.py:41-43, paco_dataset.py:40-41,136-137,
+# pixmo_cap_dataset.py:63-65, pixmo_point_dataset.py:100-102, vqav2_dataset.py:31): the SIZE a VQA set enters the mixture weights with —
+# constants of the reference, not counts of what a store holds
+VQA_NUM_TRANSITIONS = {"coco_captions": 80340, "lvis": 1231766, "paco_lvis": 612188, "paco_ego4d": 116356, "pixmo_cap": 620032,
+                       "pixmo_point": 1702160, "vqa": 443800}
 NUM_TRANSITIONS = {"coco_captions": 80340, "lvis": 1231766, "paco_lvis": 612188, "paco_ego4d": 116356, "pixmo_cap": 620032,
                    "pixmo_point": 1702160, "vqa": 443800}          # get_num_transitions() of each class (dummy statistics)
 MAX_POINTS = 20                                                    # pixmo_point_dataset.py:10

@@ -57,6 +57,18 @@ names = {"GENERAL_BBOX_PROMPT_PARTS", "ROBOT_BBOX_PROMPT_PARTS", "ROBOT_BBOX_PRO
 for k, v in exec_assignments(module("bbox/prompts.py"), names).items():
     out[k] = [list(p) for p in v]
 
+# the size constants the VQA sets enter the mixture weights with: `return <int>` of every reader's get_num_transitions, by registered name
+sizes = {}
+for f in sorted(REF.glob("*_dataset.py")):
+    for c in [n for n in ast.walk(ast.parse(f.read_text())) if isinstance(n, ast.ClassDef)]:
+        name = next((ast.literal_eval(k.value) for d in c.decorator_list if isinstance(d, ast.Call) for k in d.keywords if k.arg == "name"), None)
+        for fn in c.body:
+            if isinstance(fn, ast.FunctionDef) and fn.name == "get_num_transitions" and name:
+                ret = [n for n in ast.walk(fn) if isinstance(n, ast.Return)]
+                if ret:
+                    sizes[name] = ast.literal_eval(ret[0].value)
+out["NUM_TRANSITIONS"] = sizes
+
 loc = function(module("bbox/coord_utils.py"), "bbox_to_loc_tokens")
 direction = function(module("bbox/direction.py"), "compute_direction_from_bbox")
 grid = [0.0, 0.03, 0.12, 0.25, 0.333, 0.4995, 0.5, 0.5005, 0.62, 0.75, 0.9, 0.999, 1.0]

@@ -140,7 +140,8 @@ def test_mixture_dataset_draws_by_weight_and_is_a_pure_function_of_seed_and_inde
     for e in b.episodes:
         e["dataset_name"] = "bridge_v2_oxe"
     mix = D.MixtureDataset({"droid": a, "bridge_v2_oxe": b}, [("droid", 1.0), ("bridge_v2_oxe", 3.0)], balance_weights=False, seed=5)
-    assert np.allclose(mix.sample_weights, [0.25, 0.75]) and len(mix) == int(max(80 / 0.25, 20 / 0.75))
+    # sizes in the weights / the effective length are the statistics' transition counts: frames x action horizon (dataset_mixer.py:134-156)
+    assert a.num_transitions == 80 * H and np.allclose(mix.sample_weights, [0.25, 0.75]) and len(mix) == int(max(80 * H / 0.25, 20 * H / 0.75))
     picks = np.array([mix.locate(i) for i in range(4000)])
     assert abs((picks[:, 0] == 1).mean() - 0.75) < 0.03                         # dataset frequencies = mixture weights
     inner = picks[picks[:, 0] == 1, 1]
@@ -156,7 +157,7 @@ def test_mixture_dataset_draws_by_weight_and_is_a_pure_function_of_seed_and_inde
         D.MixtureDataset({"droid": a}, "libero_finetune")
     # balanced: weight x size -> every transition of the pool is equally likely
     bal = D.MixtureDataset({"droid": a, "bridge_v2_oxe": b}, [("droid", 1.0), ("bridge_v2_oxe", 1.0)], balance_weights=True)
-    assert np.allclose(bal.sample_weights, [0.8, 0.2]) and len(bal) == 100
+    assert np.allclose(bal.sample_weights, [0.8, 0.2]) and len(bal) == 100 * H
     # and it feeds the loader like a single dataset (global statistics, resume protocol)
     loader = D.create_data_loader(cfg, mix, tok, seed=0, num_batches=2)
     obs, actions = next(iter(loader))
@@ -430,6 +431,15 @@ def test_vqa_tables_and_geometry_match_the_reference_fixture():
     for c in d["direction_cases"]:
         assert V.direction_from_bbox(*c["box"], slope=c["slope"]) == c["expected"], c
         assert V.direction_from_bbox(*c["box"], slope=c["slope"], add_move_prefix=True) == "move " + c["expected"]
+
+
+def test_vqa_mixture_sizes_are_the_reference_constants():
+    import json
+    import pathlib
+
+    from lap_amd import vqa_export as V
+    fx = json.loads((pathlib.Path(__file__).parent / "golden" / "vqa_v1.json").read_text())
+    assert V.VQA_NUM_TRANSITIONS == fx["NUM_TRANSITIONS"] and set(V.VQA_NUM_TRANSITIONS) == set(V.VQA_DATASET_IDS)
 
 
 def test_vqa_records_become_samples_and_join_a_mixture(setup):
