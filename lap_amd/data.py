@@ -261,7 +261,8 @@ class VqaDataset:
     `tools/export_vqa_samples.py` (an encoded image is decoded with PIL on access).  Indexable like `EpisodeDataset`, carries no
     episodes (VQA sets are left out of the normalisation statistics, dataset_mixer.py:166-214)."""
 
-    def __init__(self, samples: Sequence[dict] | str | pathlib.Path, *, action_horizon: int, action_dim: int = 7, state_dim: int = 7):
+    def __init__(self, samples: Sequence[dict] | str | pathlib.Path, *, action_horizon: int, action_dim: int = 7, state_dim: int = 7,
+                 split: str | None = None, val_fraction: float | None = None, seed: int = 0):
         if isinstance(samples, (str, pathlib.Path)):
             files = sorted(pathlib.Path(samples).glob("*.npz"))
             if not files:
@@ -272,6 +273,13 @@ class VqaDataset:
                 if k not in e:
                     raise KeyError(f"VQA sample {i} has no '{k}'")
         self.samples = list(samples)
+        if split is not None:      # vqa_base.py:190-202: the same salted-hash rule as the robot sets, one sample = one trajectory
+            if split not in ("train", "val"):
+                raise ValueError(f"split must be 'train', 'val' or None, got {split!r}")
+            val = [EpisodeDataset.is_val_episode(e, i, seed, val_fraction or 0.0) for i, e in enumerate(self.samples)]
+            self.samples = [e for e, v in zip(self.samples, val) if v == (split == "val")]
+            if not self.samples:
+                raise ValueError(f"the {split} split of this VQA store is empty (val_fraction = {val_fraction})")
         self.action_horizon, self.action_dim, self.state_dim = action_horizon, action_dim, state_dim
         self.episodes: list = []
 

@@ -716,3 +716,12 @@ def test_droid_keep_mask_from_ranges():
             "traj_metadata": {"episode_metadata": {"recording_folderpath": b"gs://x/rec", "file_path": np.array([b"gs://x/success/t.h5"] * 8)}}}
     m = R.droid_keep_mask({"gs://x/rec--gs://x/success/t.h5": [[1, 3], [5, 20]]}, traj)
     assert m.tolist() == [False, True, True, False, False, True, True, True] and not R.droid_keep_mask({}, traj).any()
+
+
+def test_vqa_store_split_follows_the_same_rule():
+    """vqa_base.py:190-202: VQA samples split train / val by the salted hash of their id, like robot trajectories."""
+    samples = [{"image": np.zeros((4, 4, 3), np.uint8), "prompt": f"q{i}", "caption": "a", "dataset_name": "coco_captions", "vqa_dataset_id": 1} for i in range(80)]
+    tr = D.VqaDataset(samples, action_horizon=4, split="train", val_fraction=0.25, seed=1)
+    va = D.VqaDataset(samples, action_horizon=4, split="val", val_fraction=0.25, seed=1)
+    assert len(tr) + len(va) == 80 and 8 <= len(va) <= 32 and not {s["prompt"] for s in tr.samples} & {s["prompt"] for s in va.samples}
+    assert va.num_transitions == 80340          # the mixture weight stays the reference's constant
