@@ -476,7 +476,7 @@ def compute_mixture_norm_stats(mixture: MixtureDataset, *, action_pad_to: int, s
         if isinstance(ds, VqaDataset):       # no robot state / actions to normalise (dataset_mixer.py:166-214 skips VQA sets)
             continue
         st = compute_norm_stats(ds, action_pad_to=action_pad_to)
-        n_tr, n_ep = len(ds), len(ds.episodes)
+        n_tr, n_ep = int(getattr(ds, "num_transitions", len(ds))), len(ds.episodes)      # (chunk rows, as the reference's statistics count)
         per[name] = {k: {**{f: np.asarray(v[f], dtype=np.float32) for f in v}, "num_transitions": n_tr, "num_trajectories": n_ep} for k, v in st.items()}
     g = global_norm_stats(per, action_dim=action_pad_to, state_dim=state_dim, state_types=state_types)
     state = next((g[k] for k in sorted(g) if k.startswith("state_")), None)
