@@ -725,3 +725,36 @@ def test_vqa_store_split_follows_the_same_rule():
     va = D.VqaDataset(samples, action_horizon=4, split="val", val_fraction=0.25, seed=1)
     assert len(tr) + len(va) == 80 and 8 <= len(va) <= 32 and not {s["prompt"] for s in tr.samples} & {s["prompt"] for s in va.samples}
     assert va.num_transitions == 80340          # the mixture weight stays the reference's constant
+
+
+def test_exported_droid_episode_runs_through_the_train_loader_with_eef_labels():
+    """Exporter -> episode store -> config-driven dataset -> train loader, end to end on a DROID-shaped trajectory: the rot6d state the
+    loader derives feeds the end-effector-frame label text (with `rotation_applied` from the rotated wrist camera), the chunk is the
+    displacement from the current pose, statistics are over chunks, tokens carry a language-action span."""
+    import dataclasses
+
+    from lap_amd import rlds_export as R
+    T = 24
+    g = np.random.default_rng(5)
+    im = lambda: g.integers(1, 255, (T, 30, 40, 3), dtype=np.uint8)
+    cart = np.concatenate([np.cumsum(g.normal(scale=0.004, size=(T, 3)), 0) + 0.3, np.cumsum(g.normal(scale=0.01, size=(T, 3)), 0)], 1)
+    gp = (np.arange(T) > 12).astype(np.float64)
+    traj = {"observation": {"exterior_image_1_left": im(), "wrist_image_left": im(), "cartesian_position": cart, "gripper_position": gp},
+            "action_dict": {"gripper_position": gp[:, None]}, "language_instruction": b"put the marker in the cup"}
+    ep = R.episode_from_rlds("droid", traj)
+    base = get_config("debug")
+    cfg = dataclasses.replace(base, batch_size=4, model=dataclasses.replace(base.model, action_dim=16, max_token_len=160),
+                              data=dataclasses.replace(base.data, resize_resolution=(56, 56), wrist_image_dropout_prob=0.0, random_mask_prob=0.0))
+    ds = D.episode_dataset_from_config(cfg, [ep])
+    s = ds[3]
+    assert s["rotation_applied"] and s["raw_state"].shape == (10,) and s["observation"]["base_0_rgb"].shape == (56, 56, 3)
+    np.testing.assert_allclose(s["actions"][:, :3], cart[4:4 + cfg.model.action_horizon, :3] - cart[3, :3], atol=1e-6)
+    out = pio.CoTInputs(action_dim=16)(dict(s))
+    assert out["frame_description"] == "end-effector frame" and isinstance(out["language_actions"], str) and out["language_actions"]
+    tok = pio.PaligemmaTokenizer(model_proto=tiny_sentencepiece_proto(), max_len=160)
+    loader = D.create_data_loader(cfg, ds, tok, shuffle=False, num_batches=2)
+    obs, actions = next(iter(loader))
+    assert actions.shape == (4, cfg.model.action_horizon, 16) and float(actions.abs().max()) <= 1.0 and bool(obs.tokenized_langact_mask.any())
+    assert obs.state.shape == (4, 16) and bool(obs.image_masks["left_wrist_0_rgb"].all())
+    stats, kind = loader.get_norm_stats_for_checkpoint()
+    assert len(stats["actions"]["q99"]) == 16 and len(stats["state"]["q99"]) == 10
