@@ -34,12 +34,36 @@ import torch
 
 SERVE_BYTES = 4.79e9 + 10 * 0.86e9 + 10 * 10.3e6   # prefix weights once + 10 x (expert weights + KV)
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
-# profiles/r03_gemm_pmc_counters.txt: gate-up forward GEMM M=17920 N=32768 K=2048 (the largest launch of the step, assembly NT kernel),
-# separate --pmc passes: FETCH_SIZE 1,745,372 KB raw x 2 (gfx950 half-count correction for wide coalesced reads,
-# MI355X_MICROARCH.md §HBM) + WRITE_SIZE 1,147,751 KB; algorithmic bytes of that launch: 0.207 GB read + 1.174 GB written.
-# A STATIC figure copied from the committed profile (rocprofv3 cannot run inside this process): `traffic_measured_in_run` is false.
-GEMM_TRAFFIC = {"bytes_per_launch": 2 * 1745371.8e3 + 1147751.3e3, "algorithmic_bytes_per_launch": 73.4e6 + 134.2e6 + 1174.4e6,
-                "shape": "gate-up fwd M=17920 N=32768 K=2048 (lap_gemm_asm_nt)", "source": "profiles/r03_gemm_pmc_counters.txt"}
+def gemm_traffic():
+    """`roofline.traffic`: L2-to-fabric bytes of ONE launch of the step's largest GEMM (gate|up forward, M = 17920, N = 32768,
+    K = 2048) from the NEWEST committed rocprofv3 --pmc pass (profiles/rNN_gemm_pmc_counters.txt, written by tools/pmc_traffic.sh:
+    FETCH_SIZE and WRITE_SIZE in separate passes, raw counter unit KB): FETCH_SIZE x 2 (gfx950 half-count of wide coalesced reads,
+    MI355X_MICROARCH.md section HBM) + WRITE_SIZE.  rocprofv3 cannot run inside this process: the figure is static per commit
+    (`traffic_measured_in_run` false) and names its source file.  These are requests the L2s send to the fabric; the Infinity
+    Cache serves part of them (the guide: hits are counted, not excluded), so it is an upper bound of the HBM bytes."""
+    import glob
+    import re
+
+    alg = {"plain": 73.4e6 + 134.2e6 + 1174.4e6,           # A 17920 x 2048 + B 32768 x 2048 read, C 17920 x 32768 written (bf16)
+           "geglu": 73.4e6 + 134.2e6 + 1174.4e6 + 587.2e6}  # ... + act = gelu(gate) * up, 17920 x 16384, written by the same launch
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_pmc_counters.txt")):
+        m = re.match(r"r(\d+)([a-z]?)_", os.path.basename(f))
+        txt = open(f).read()
+        fe = re.findall(r"FETCH_SIZE per launch \(raw counter units, KB\): ([0-9.eE+]+)", txt)
+        wr = re.findall(r"WRITE_SIZE per launch \(raw counter units, KB\): ([0-9.eE+]+)", txt)
+        if m and fe and wr:
+            key = (int(m.group(1)), m.group(2))
+            if best is None or key > best[0]:
+                kind = "geglu" if "traffic kernel: lap_gemm_asm_nt_geglu" in txt else "plain"
+                best = (key, float(fe[0]) * 1e3, float(wr[0]) * 1e3, os.path.relpath(f, ROOT), kind)
+    if best is None:
+        return {"bytes_per_launch": None, "algorithmic_bytes_per_launch": alg["plain"], "shape": "gate-up fwd M=17920 N=32768 K=2048", "source": None}
+    _, fetch, write, src, kind = best
+    return {"bytes_per_launch": 2 * fetch + write, "algorithmic_bytes_per_launch": alg[kind], "source": src,
+            "shape": "gate-up fwd M=17920 N=32768 K=2048 (" + ("lap_gemm_asm_nt_geglu: gate|up + GeGLU, writes gu and act" if kind == "geglu" else "lap_gemm_asm_nt") + ")"}
+
+
 TRAIN_FLOP_PER_SAMPLE = 8.375e12  # SURVEY.md §8(d): 3 x forward (2.792 TFLOP), recompute not credited
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA
 
@@ -260,29 +284,45 @@ def cpu_baseline(cores: int):
         t0 = time.perf_counter()
         loss, _ = O.compute_loss(Pg, oc, obs, actions, noise, t)
         loss.backward()
-        return time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        # the serving half of the metric on the same host cores: one batch-1 action chunk (prefix prefill + KV cache + 10 Euler
+        # steps of the action expert, lap.py:605-675) on the oracle, f32, no autograd
+        for v in Pg.values():
+            v.grad = None
+        so = {k: ({kk: vv[:1] for kk, vv in v.items()} if isinstance(v, dict) else v[:1]) for k, v in obs.items() if k != "tokenized_langact_mask"}
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            O.sample_actions(P, oc, so, noise[:1], num_steps=10)
+            dts = time.perf_counter() - t0
+        return dt, dts
 
     if free_gb >= 96:
         oc = O.OracleCfg(paligemma_variant="gemma_2b", action_expert_variant="gemma_300m", siglip_variant="So400m/14",
                          action_horizon=50, max_token_len=L, vocab_size=257152, language_loss_weight=0.4)
-        dt = run(oc, 1, 257152)
+        dt, dts = run(oc, 1, 257152)
         return {"value": round(1.0 / dt, 6), "unit": "samples/s", "cores": cores, "kind": "port",
                 "sample": f"oracle f32 forward + backward (torch CPU autograd) of the full LAP-3B at batch 1, benchmark shapes: one sample in {dt:.1f} s on "
                           f"{cores} threads (optimizer update not included: < 1 % of the step's FLOPs); stand-in for the reference's JAX-CPU path, "
-                          f"which cannot be installed offline"}
+                          f"which cannot be installed offline"}, \
+               {"value": round(dts * 1e3, 1), "unit": "ms per batch-1 action chunk", "cores": cores, "kind": "port",
+                "sample": f"oracle f32 sample_actions of the full LAP-3B at batch 1 (SigLIP + prefix prefill + 10 denoise steps against the cached "
+                          f"prefix keys / values): one chunk in {dts:.2f} s on {cores} threads; stand-in for the reference's JAX-CPU path"}
     NL, B, V = 6, 2, 16384
     O.GEMMA["gemma_2b_slice"] = O.GemmaCfg(2048, NL, 16384, 8, 1, 256)
     O.GEMMA["gemma_300m_slice"] = O.GemmaCfg(1024, NL, 4096, 8, 1, 256)
     O.SIGLIP["So400m/14_slice"] = O.SiglipCfg(1152, NL, 4304, 16)
     oc = O.OracleCfg(paligemma_variant="gemma_2b_slice", action_expert_variant="gemma_300m_slice", siglip_variant="So400m/14_slice",
                      action_horizon=50, max_token_len=L, vocab_size=V, language_loss_weight=0.4)
-    dt = run(oc, B, V)
+    dt, dts = run(oc, B, V)
     f_slice = 2 * (2 * 256 * NL * w_sig_l + NL * 4 * 256 ** 2 * 1152) + 2 * Tp * NL * w_vlm_l + NL * 4 * Tp ** 2 * 2048 \
         + 2 * S * NL * w_exp_l + NL * 4 * S * (Tp + S) * 2048 + 2 * 47 * 2048 * V
     return {"value": round(B / (dt * f_full / f_slice), 6), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"host has {free_gb:.0f} GB free (< 96): oracle f32 fwd+bwd, batch {B}, LAP-3B widths, {NL}/18 Gemma layers + {NL}/27 SigLIP blocks "
                       f"+ 16k-row vocab slice ({dt:.1f} s), extrapolated by forward-FLOP ratio {f_full / f_slice:.1f}x; stand-in for the reference's "
-                      f"JAX-CPU path, which cannot be installed offline"}
+                      f"JAX-CPU path, which cannot be installed offline"}, \
+           {"value": round(dts * f_full / f_slice * 1e3, 1), "unit": "ms per batch-1 action chunk", "cores": cores, "kind": "port",
+            "sample": f"host has {free_gb:.0f} GB free (< 96): oracle f32 sample_actions at batch 1 on the {NL}-layer slice ({dts:.2f} s), extrapolated by the "
+                      f"forward-FLOP ratio {f_full / f_slice:.1f}x"}
 
 
 def serve_latency(cfg, dev, reps: int = 20):
@@ -435,6 +475,7 @@ def main():
     loss = info["loss"].item()
     if rank == 0:
         n_launch, t_gemm, fl_gemm = meter.summary()
+        GEMM_TRAFFIC = gemm_traffic()
         samples = args.batch * world * args.steps
         value = samples / dt
         in_situ = fl_gemm / t_gemm / 1e12 if t_gemm > 0 else 0.0
@@ -459,26 +500,27 @@ def main():
                         else f"NON-HEADLINE flow test: config {args.config}"),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": 610,
                        "parallelism": f"fsdp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "kernel": "lap_gemm_asm_* (csrc/gemm_asm_kernels.s) / gemm_pq_kernel / gemm_sp_kernel / gemm_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", "achieved": round(achieved, 1),
-                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                         "definition": "sum over the step's GEMM call signatures (compute stream) of count x 2MNK / count x isolated launch "
-                                       "duration, each signature re-run alone in this process with HIP events on the launch stream; "
-                                       "GEMMs with a fused GeGLU / GELU epilogue count 2MNK and carry their epilogue in the duration",
-                         "isolated_gemm_ms_per_step": round(iso_t / msteps * 1e3, 2),
+            "roofline": {"bound": "mfma", "kernel": "lap_gemm_asm_* (csrc/gemm_asm_kernels.s) / gemm_pq_kernel / gemm_sp_kernel / gemm_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", "achieved": round(in_situ, 1),
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(in_situ / MFMA_PEAK_TFLOPS, 4),
+                         "definition": "IN THE STEP: sum of 2MNK over the compute stream's GEMM launches / sum of their durations, HIP events on the "
+                                       "launch stream around every launch of a separate 2-step pass behind the timed steps (the timed steps carry no "
+                                       "events); includes what the co-running optimizer / action-expert / weight-gradient streams cost each launch; "
+                                       "GEMMs with a fused GeGLU / GELU epilogue count 2MNK and carry their epilogue in the duration.  This is the "
+                                       "figure profiles/*_per_queue_step_breakdown.txt reproduces.",
+                         "gemm_ms_per_step": round(t_gemm / msteps * 1e3, 2),
+                         "isolated": {"achieved": round(achieved, 1), "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                                      "gemm_ms_per_step": round(iso_t / msteps * 1e3, 2),
+                                      "note": "side figure: every distinct call signature of the step re-run ALONE in this process (fresh operands, HIP events), "
+                                              "the step's mix priced with those durations: sum count x 2MNK / sum count x t_isolated"},
                          "distinct_shapes": len(iso_rows),
                          "plain_signatures_only": (lambda pl: {"achieved": round(sum(r * tt_ for tt_, _, _, _, r in pl) / max(sum(tt_ for tt_, *_ in pl), 1e-12), 1),
                                                                "ms_per_step": round(sum(tt_ for tt_, *_ in pl) / msteps * 1e3, 2),
-                                                               "note": "the same sum without the four fused-epilogue signatures (gate|up + GeGLU, down dgrad + GeGLU "
+                                                               "note": "the ISOLATED sum without the four fused-epilogue signatures (gate|up + GeGLU, down dgrad + GeGLU "
                                                                        "backward, SigLIP fc1 + GELU, fc2 dgrad + GELU backward), whose durations contain elementwise work "
                                                                        "that used to be separate HBM-bound kernels"})([x for x in iso_rows if "+" not in x[1]]),
-                         "top_shapes": [{"shape": nm, "launches_per_step": c // msteps, "us": round(t * 1e6, 1), "TFLOPs": round(r, 0)}
+                         "top_shapes_isolated": [{"shape": nm, "launches_per_step": c // msteps, "us": round(t * 1e6, 1), "TFLOPs": round(r, 0)}
                                         for _, nm, c, t, r in iso_rows[:8]],
-                         "in_situ_event_timed": {"achieved": round(in_situ, 1), "frac": round(in_situ / MFMA_PEAK_TFLOPS, 4),
-                                                 "gemm_ms_per_step": round(t_gemm / msteps * 1e3, 2),
-                                                 "note": "HIP events around every compute-stream launch of a separate 2-step pass behind the timed steps (the timed "
-                                                         "steps themselves carry no events): includes what the co-running optimizer / action-expert / weight-gradient "
-                                                         "streams cost each launch"},
-                         "traffic": GEMM_TRAFFIC["bytes_per_launch"], "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE)",
+                         "traffic": GEMM_TRAFFIC["bytes_per_launch"], "traffic_unit": "L2-to-fabric bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits included)",
                          "traffic_shape": GEMM_TRAFFIC["shape"], "traffic_algorithmic_bytes": GEMM_TRAFFIC["algorithmic_bytes_per_launch"],
                          "traffic_source": GEMM_TRAFFIC["source"], "traffic_measured_in_run": False,
                          "launches_per_step": n_launch // msteps,
@@ -499,7 +541,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             # 32 host threads: torch-CPU matmuls of this size stop scaling (and get slower) well beyond that (256 threads on
             # the GPU box took 166 s for a 6-layer slice that 16 threads finish in 9 s)
-            out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))
+            out["cpu_baseline"], serve_cpu = cpu_baseline(min(os.cpu_count() or 1, 32))
+            if "serve" in out:
+                out["serve"]["cpu_baseline"] = serve_cpu
+        if world > 1:
+            try:
+                ver = torch.cuda.nccl.version()
+            except Exception:   # noqa: BLE001
+                ver = None
+            out["rccl"] = {"ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                           "version": ".".join(str(v) for v in ver) if isinstance(ver, tuple) else ver}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

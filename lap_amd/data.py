@@ -600,10 +600,17 @@ def create_data_loader(config, dataset: "EpisodeDataset | MixtureDataset", token
     # `Normalize` (dataset_mixer.py:334-359; the train-time transform group carries none, training/config.py:195-207).  The mixer runs
     # it on the raw trajectory, i.e. BEFORE `CoTInputs`; elementwise, so the order only matters to the VLA-0 strategy, whose label text
     # is made from the normalised chunk: there the sample's actions / state are normalised first.
-    norm = pio.NormalizeActionAndProprio(norm_stats, normalization_type=ntype)
+    norm_robot = pio.NormalizeActionAndProprio(norm_stats, normalization_type=ntype)
     vla0 = getattr(dc, "transform_strategy", "standard") == "vla0"
 
+    def norm(sample: dict) -> dict:
+        # the mixer maps the normaliser over the ROBOT datasets only (dataset_mixer.py:338-341): a VQA sample keeps its all-zero
+        # state and actions (2 * (0 - q01) / (q99 - q01) - 1 would make them non-zero)
+        return sample if bool(sample.get("is_vqa_sample", False)) else norm_robot(sample)
+
     def norm_raw(sample: dict) -> dict:
+        if bool(sample.get("is_vqa_sample", False)):
+            return sample
         obs = dict(sample["observation"])
         flat = norm({"actions": sample["actions"], "state": obs.get("state")}) if "actions" in sample else {"state": norm({"actions": np.zeros(1), "state": obs.get("state")})["state"]}
         obs["state"] = flat["state"]

@@ -726,7 +726,8 @@ class LAP:
         v, e = self.v, self.e
         NH, HD, KV = v.num_heads, v.head_dim, v.num_kv_heads
         Ttot = pos.shape[1]
-        ldm = mod.stride(0)
+        has_sfx = dx1 is not None         # False: prefix-only backward (enable_action_training=False, lap.py:449-455)
+        ldm = mod.stride(0) if has_sfx else 0
         zero_do0 = None
         sfx = self._suffix_stream(dx1, dmod, mod)
         main = torch.cuda.current_stream() if sfx is not None else None
@@ -737,21 +738,22 @@ class LAP:
             d_o = [None, None]
             # ---- FFN + attention output, suffix stream: xn = xa + y1f * gate_f  (on the second HIP stream, see the module doc)
             slot_f, slot_a = 2 * l + 1, 2 * l
-            with on_sfx():
-                gate_f = self._mod_slot(mod, slot_f)[:, 2 * e.width:]
-                dy1f = hip.gated_residual_bwd(dx1, c["y1f"], gate_f, n1, ldm, self._mod_slot(dmod, slot_f)[:, 2 * e.width:], dmod.stride(0))
-                self._wgrad(dy1f, c["act"][1], p + "wd1")
-                dact = hip.linear_dgrad(dy1f, self.W(p + "wd1"))
-                dgu = hip.geglu_bwd(c["gu"][1], dact)
-                self._wgrad(dgu, c["hf"][1], p + "wgu1")
-                dhf = hip.linear_dgrad(dgu, self.W(p + "wgu1"))
-                hip.rmsnorm_bwd(c["xa"][1], dhf, c["rstd_f"][1], mod=self._mod_slot(mod, slot_f), rows_per_sample=n1, dx=dx1,
-                                dmod=self._mod_slot(dmod, slot_f), accum_dx=True)
-                gate_a = self._mod_slot(mod, slot_a)[:, 2 * e.width:]
-                dy1 = hip.gated_residual_bwd(dx1, c["y1"], gate_a, n1, ldm, self._mod_slot(dmod, slot_a)[:, 2 * e.width:], dmod.stride(0))
-                self._wgrad(dy1, c["o"][1], p + "wo1")
-                d_o[1] = hip.linear_dgrad(dy1, self.W(p + "wo1"))
-                del dy1f, dact, dgu, dhf, dy1
+            if has_sfx:
+                with on_sfx():
+                    gate_f = self._mod_slot(mod, slot_f)[:, 2 * e.width:]
+                    dy1f = hip.gated_residual_bwd(dx1, c["y1f"], gate_f, n1, ldm, self._mod_slot(dmod, slot_f)[:, 2 * e.width:], dmod.stride(0))
+                    self._wgrad(dy1f, c["act"][1], p + "wd1")
+                    dact = hip.linear_dgrad(dy1f, self.W(p + "wd1"))
+                    dgu = hip.geglu_bwd(c["gu"][1], dact)
+                    self._wgrad(dgu, c["hf"][1], p + "wgu1")
+                    dhf = hip.linear_dgrad(dgu, self.W(p + "wgu1"))
+                    hip.rmsnorm_bwd(c["xa"][1], dhf, c["rstd_f"][1], mod=self._mod_slot(mod, slot_f), rows_per_sample=n1, dx=dx1,
+                                    dmod=self._mod_slot(dmod, slot_f), accum_dx=True)
+                    gate_a = self._mod_slot(mod, slot_a)[:, 2 * e.width:]
+                    dy1 = hip.gated_residual_bwd(dx1, c["y1"], gate_a, n1, ldm, self._mod_slot(dmod, slot_a)[:, 2 * e.width:], dmod.stride(0))
+                    self._wgrad(dy1, c["o"][1], p + "wo1")
+                    d_o[1] = hip.linear_dgrad(dy1, self.W(p + "wo1"))
+                    del dy1f, dact, dgu, dhf, dy1
             # ---- FFN, prefix stream: xn = xa + act @ wd^T   (dx0 is None: the whole prefix side is frozen)
             if dx0 is not None:
                 self._wgrad(dx0, c["act"][0], p + "wd0")
@@ -779,13 +781,14 @@ class LAP:
             dq, dk, dv = hip.attention_bwd(c["q"], c["k"], c["v"], c["o"], d_o, c["lse"], [n0, n1], [n0, n1], B, NH, KV, HD, qinfo, kinfo,
                                            stop_q1_to_k0=self.config.stop_action_to_vlm_grad)
             self._handoff(main, sfx, dq[1], dk[1], dv[1])
-            with on_sfx():
-                dqkv = hip.rope_split_bwd(dq[1], dk[1], dv[1], pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
-                self._wgrad(dqkv, c["h"][1], p + "wqkv1")
-                dh = hip.linear_dgrad(dqkv, self.W(p + "wqkv1"))
-                hip.rmsnorm_bwd(c["x"][1], dh, c["rstd_a"][1], mod=self._mod_slot(mod, slot_a), rows_per_sample=n1, dx=dx1,
-                                dmod=self._mod_slot(dmod, slot_a), accum_dx=True)
-                del dqkv, dh
+            if has_sfx:
+                with on_sfx():
+                    dqkv = hip.rope_split_bwd(dq[1], dk[1], dv[1], pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
+                    self._wgrad(dqkv, c["h"][1], p + "wqkv1")
+                    dh = hip.linear_dgrad(dqkv, self.W(p + "wqkv1"))
+                    hip.rmsnorm_bwd(c["x"][1], dh, c["rstd_a"][1], mod=self._mod_slot(mod, slot_a), rows_per_sample=n1, dx=dx1,
+                                    dmod=self._mod_slot(dmod, slot_a), accum_dx=True)
+                    del dqkv, dh
             if dx0 is not None:
                 dqkv = hip.rope_split_bwd(dq[0], dk[0], dv[0], pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5)
                 self._wgrad(dqkv, c["h"][0], p + "wqkv0")
@@ -855,8 +858,11 @@ class LAP:
     def _loss_impl(self, rng, observation: CoTObservation, actions: torch.Tensor, *, train: bool, noise=None, time=None,
                    backward: bool, collect: dict | None = None):
         cfg = self.config
-        if not (cfg.enable_action_training and cfg.enable_langact_training):
-            raise NotImplementedError("lap_amd implements the LAP-3B training path: action + langact losses enabled")
+        # lap.py:426-462,557-596: three branches — both losses (LAP-3B); enable_action_training=False: `llm([prefix])` and the
+        # cross entropy only (VLA-0 style configs); enable_langact_training=False: both streams, flow matching only (pi0 style)
+        act_on, lang_on = cfg.enable_action_training, cfg.enable_langact_training
+        if not (act_on or lang_on):
+            raise ValueError("LAPConfig with neither enable_action_training nor enable_langact_training has no loss")
         dev = self.device
         self.comm.wait_unit("small")
         g = _gen(rng, dev)
@@ -866,86 +872,95 @@ class LAP:
         B, S, ad = actions.shape
         if S != self.action_horizon:
             raise ValueError(f"actions horizon {S} != action_horizon {self.action_horizon}")
-        # lap.py:185-207 prepare_suffix — noise ~ N(0,1), time ~ Beta(1.5, 1) * 0.999 + 0.001
-        if noise is None:
-            noise = torch.randn(actions.shape, generator=g, device=dev, dtype=torch.float32)
-        if time is None:
-            u1 = torch.rand(B, generator=g, device=dev, dtype=torch.float32)
-            time = u1.pow(1.0 / 1.5) * 0.999 + 0.001  # Beta(a, 1) by inverse CDF
-        noise = noise.to(dev, torch.float32).contiguous(); time = time.to(dev, torch.float32).contiguous()
-        x_t, u_t = hip.fm_mix(noise, actions, time)
-        # suffix first: its small kernels go to the second HIP stream and run under the SigLIP tower issued next
-        x1, mod, sctx = self._embed_suffix(x_t, time, backward, overlap=True)
+        x1 = mod = sctx = u_t = None
+        if act_on:
+            # lap.py:185-207 prepare_suffix — noise ~ N(0,1), time ~ Beta(1.5, 1) * 0.999 + 0.001
+            if noise is None:
+                noise = torch.randn(actions.shape, generator=g, device=dev, dtype=torch.float32)
+            if time is None:
+                u1 = torch.rand(B, generator=g, device=dev, dtype=torch.float32)
+                time = u1.pow(1.0 / 1.5) * 0.999 + 0.001  # Beta(a, 1) by inverse CDF
+            noise = noise.to(dev, torch.float32).contiguous(); time = time.to(dev, torch.float32).contiguous()
+            x_t, u_t = hip.fm_mix(noise, actions, time)
+            # suffix first: its small kernels go to the second HIP stream and run under the SigLIP tower issued next
+            x1, mod, sctx = self._embed_suffix(x_t, time, backward, overlap=True)
+        Sx = S if act_on else 0      # suffix rows in the joint sequence (none without the action expert: lap.py:449-455)
         x0, Pn, pctx = self._embed_prefix(obs, backward, collect)
-        qinfo, kinfo, pos = self._train_infos(obs, S)
+        qinfo, kinfo, pos = self._train_infos(obs, Sx)
         if collect is not None:
             collect["x0_in"], collect["x1_in"], collect["pos"], collect["mod"] = x0, x1, pos, mod
-        xf0, xf1, lctx = self._llm_fwd(x0, x1, mod, pos, qinfo, kinfo, B, Pn, S, backward, collect=collect)
+        xf0, xf1, lctx = self._llm_fwd(x0, x1, mod, pos, qinfo, kinfo, B, Pn, Sx, backward, collect=collect)
         if collect is not None:
             collect["x0_out"], collect["x1_out"] = xf0, xf1
 
-        # ---- language loss (lap.py:209-289): rows Pn-Lt .. Pn-2 predict tokens 1 .. Lt-1
-        Lt = obs.tokenized_prompt.shape[1]
-        Dv, V = self.v.width, cfg.vocab_size
-        loss_mask = obs.tokenized_langact_mask[:, 1:] & obs.tokenized_prompt_mask[:, 1:]
-        if obs.token_loss_mask is not None:
-            loss_mask = loss_mask & obs.token_loss_mask[:, 1:]
-        lm_bool = loss_mask if obs.sample_mask is None else loss_mask & obs.sample_mask[:, None]
-        lm = lm_bool.to(torch.float32)
-        cnt = torch.clamp(lm.sum(-1), min=1.0)
-        # Only rows whose loss mask is set matter (the reference multiplies the other rows' cross entropy by 0): with the host
-        # hint `loss_rows_max` the head runs on that many rows per sample — the masked ones first (stable order), padded with
-        # rows of weight 0 — instead of all Lt - 1 (BASELINE shapes: 16 of 47).  A hint smaller than a sample's count would drop
-        # tokens silently, so the device-side check turns the loss into NaN instead (no host sync).
-        n_sel = observation.loss_rows_max if observation.loss_rows_max is not None else obs.loss_rows_max
-        sel = None
-        if n_sel is not None and 0 < n_sel < Lt - 1 and os.environ.get("LAP_LM_ALL_ROWS", "0") != "1":
-            sel = torch.sort((~lm_bool).to(torch.uint8), dim=1, stable=True).indices[:, :n_sel]          # [B, n_sel] in 0 .. Lt-2
-            hint_too_small = (lm.sum(-1) > n_sel).any()
-            Ls = n_sel
-            rowid = (torch.arange(B, device=dev) * Pn + (Pn - Lt))[:, None] + sel
-            rows = xf0.index_select(0, rowid.view(-1))
-            targets = obs.tokenized_prompt[:, 1:].gather(1, sel).to(torch.int32).contiguous().view(-1)
-            lm_s = lm.gather(1, sel)
-        else:
-            Ls = Lt - 1
-            rows = torch.empty((B * Ls, Dv), dtype=torch.bfloat16, device=dev)
-            hip.copy_rows_bf16(xf0, rows, B * Ls, Ls, Dv, Pn, Pn - Lt, Ls, 0)
-            targets = obs.tokenized_prompt[:, 1:].to(torch.int32).contiguous().view(-1)
-            lm_s = lm
-        R = B * Ls
-        pl, rstd_pl = hip.rmsnorm_fwd(rows, scale=self.F("llm/final_norm"), save_rstd=backward)
-        # Embedder.decode (gemma.py:153-154) multiplies the bf16 pre-logits by the F32 table: table = hi + lo, two bf16 planes
-        # (16 mantissa bits; the products are exact in the f32 accumulator) -> logits to ~2^-17 of the f32 product
-        table16, table_lo = self.W("llm/embed"), self.ps.w16lo("llm/embed")
-        if os.environ.get("LAP_LM_NO_LO", "0") == "1":       # A/B switch: the bf16 mirror alone (the pre-round-3 dtype flow)
-            table_lo = None
-        # vocab chunks: one when [R, V] bf16 stays below the 2 GiB buffer-descriptor range of the GEMM (B <= 32 here)
-        vc_max = max(1024, (int(1.5e9) // (2 * R)) // 1024 * 1024)
-        chunks = [(v0, min(vc_max, V - v0)) for v0 in range(0, V, vc_max)]
-        m = torch.full((R,), -3.0e38, dtype=torch.float32, device=dev)
-        lsum = torch.zeros(R, dtype=torch.float32, device=dev); tl = torch.zeros(R, dtype=torch.float32, device=dev)
-        logit_chunks = []
-        for v0, vc in chunks:
-            lg = torch.empty((R, vc), dtype=torch.float32, device=dev)
-            hip.gemm(pl, table16[v0:v0 + vc], lg, M=R, N=vc, K=Dv, lda=Dv, ldb=Dv, ldc=vc)
-            if table_lo is not None:
-                hip.gemm(pl, table_lo[v0:v0 + vc], lg, M=R, N=vc, K=Dv, lda=Dv, ldb=Dv, ldc=vc, accum=True)
-            hip.ce_chunk_update(lg, targets, m, lsum, tl, v0)
-            logit_chunks.append(lg if backward else None)
-        nll = (m + torch.log(lsum) - tl).view(B, Ls)
-        lang_loss = (nll * lm_s).sum(-1) / cnt
-        if sel is not None:
-            lang_loss = torch.where(hint_too_small, torch.full_like(lang_loss, float("nan")), lang_loss)
-        # ---- action loss (lap.py:291-301)
-        pre1, rstd_p1 = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=backward)
-        pre1f = hip.cast_bf16_to_f32(pre1)
-        v_t = self._lin32(pre1f, "act/out_w", "act/out_b")  # [B*S, ad]
-        # ---- combination (lap.py:472-596).  Per-sample weights: language loss x {language, VQA (optionally per dataset),
-        # prediction} weight by sample kind; action loss only on samples that are neither VQA nor prediction samples.
         fb = lambda t: t.to(torch.float32)
         sm = obs.sample_mask if obs.sample_mask is not None else torch.ones(B, dtype=torch.bool, device=dev)
-        mixing = cfg.enable_vqa_training or cfg.enable_prediction_training
+        lang_loss = torch.zeros(B, dtype=torch.float32, device=dev)
+        sel = pl = None
+        Dv, V = self.v.width, cfg.vocab_size
+        if lang_on:
+            # ---- language loss (lap.py:209-289): rows Pn-Lt .. Pn-2 predict tokens 1 .. Lt-1
+            Lt = obs.tokenized_prompt.shape[1]
+            loss_mask = obs.tokenized_langact_mask[:, 1:] & obs.tokenized_prompt_mask[:, 1:]
+            if obs.token_loss_mask is not None:
+                loss_mask = loss_mask & obs.token_loss_mask[:, 1:]
+            lm_bool = loss_mask if obs.sample_mask is None else loss_mask & obs.sample_mask[:, None]
+            lm = lm_bool.to(torch.float32)
+            cnt = torch.clamp(lm.sum(-1), min=1.0)
+            # Only rows whose loss mask is set matter (the reference multiplies the other rows' cross entropy by 0): with the host
+            # hint `loss_rows_max` the head runs on that many rows per sample — the masked ones first (stable order), padded with
+            # rows of weight 0 — instead of all Lt - 1 (BASELINE shapes: 16 of 47).  A hint smaller than a sample's count would drop
+            # tokens silently, so the device-side check turns the loss into NaN instead (no host sync).
+            n_sel = observation.loss_rows_max if observation.loss_rows_max is not None else obs.loss_rows_max
+            sel = None
+            if n_sel is not None and 0 < n_sel < Lt - 1 and os.environ.get("LAP_LM_ALL_ROWS", "0") != "1":
+                sel = torch.sort((~lm_bool).to(torch.uint8), dim=1, stable=True).indices[:, :n_sel]          # [B, n_sel] in 0 .. Lt-2
+                hint_too_small = (lm.sum(-1) > n_sel).any()
+                Ls = n_sel
+                rowid = (torch.arange(B, device=dev) * Pn + (Pn - Lt))[:, None] + sel
+                rows = xf0.index_select(0, rowid.view(-1))
+                targets = obs.tokenized_prompt[:, 1:].gather(1, sel).to(torch.int32).contiguous().view(-1)
+                lm_s = lm.gather(1, sel)
+            else:
+                Ls = Lt - 1
+                rows = torch.empty((B * Ls, Dv), dtype=torch.bfloat16, device=dev)
+                hip.copy_rows_bf16(xf0, rows, B * Ls, Ls, Dv, Pn, Pn - Lt, Ls, 0)
+                targets = obs.tokenized_prompt[:, 1:].to(torch.int32).contiguous().view(-1)
+                lm_s = lm
+            R = B * Ls
+            pl, rstd_pl = hip.rmsnorm_fwd(rows, scale=self.F("llm/final_norm"), save_rstd=backward)
+            # Embedder.decode (gemma.py:153-154) multiplies the bf16 pre-logits by the F32 table: table = hi + lo, two bf16 planes
+            # (16 mantissa bits; the products are exact in the f32 accumulator) -> logits to ~2^-17 of the f32 product
+            table16, table_lo = self.W("llm/embed"), self.ps.w16lo("llm/embed")
+            if os.environ.get("LAP_LM_NO_LO", "0") == "1":       # A/B switch: the bf16 mirror alone (the pre-round-3 dtype flow)
+                table_lo = None
+            # vocab chunks: one when [R, V] bf16 stays below the 2 GiB buffer-descriptor range of the GEMM (B <= 32 here)
+            vc_max = max(1024, (int(1.5e9) // (2 * R)) // 1024 * 1024)
+            chunks = [(v0, min(vc_max, V - v0)) for v0 in range(0, V, vc_max)]
+            m = torch.full((R,), -3.0e38, dtype=torch.float32, device=dev)
+            lsum = torch.zeros(R, dtype=torch.float32, device=dev); tl = torch.zeros(R, dtype=torch.float32, device=dev)
+            logit_chunks = []
+            for v0, vc in chunks:
+                lg = torch.empty((R, vc), dtype=torch.float32, device=dev)
+                hip.gemm(pl, table16[v0:v0 + vc], lg, M=R, N=vc, K=Dv, lda=Dv, ldb=Dv, ldc=vc)
+                if table_lo is not None:
+                    hip.gemm(pl, table_lo[v0:v0 + vc], lg, M=R, N=vc, K=Dv, lda=Dv, ldb=Dv, ldc=vc, accum=True)
+                hip.ce_chunk_update(lg, targets, m, lsum, tl, v0)
+                logit_chunks.append(lg if backward else None)
+            nll = (m + torch.log(lsum) - tl).view(B, Ls)
+            lang_loss = (nll * lm_s).sum(-1) / cnt
+            if sel is not None:
+                lang_loss = torch.where(hint_too_small, torch.full_like(lang_loss, float("nan")), lang_loss)
+
+        # ---- action loss (lap.py:291-301)
+        pre1 = v_t = None
+        if act_on:
+            pre1, rstd_p1 = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=backward)
+            pre1f = hip.cast_bf16_to_f32(pre1)
+            v_t = self._lin32(pre1f, "act/out_w", "act/out_b")  # [B*S, ad]
+        # ---- combination (lap.py:472-596).  Per-sample weights: language loss x {language, VQA (optionally per dataset),
+        # prediction} weight by sample kind; action loss only on samples that are neither VQA nor prediction samples.
+        mixing = lang_on and (cfg.enable_vqa_training or cfg.enable_prediction_training)
         vqa = obs.is_vqa_sample.to(dev, torch.bool) if (cfg.enable_vqa_training and obs.is_vqa_sample is not None) else None
         pred = obs.is_prediction_sample.to(dev, torch.bool) if (cfg.enable_prediction_training and obs.is_prediction_sample is not None) else None
         extra_metrics = {}
@@ -972,8 +987,8 @@ class LAP:
                 extra_metrics[pfx + "sample_portion"] = fb(msk).sum() / torch.clamp(n_act_loc, min=1.0)
             extra_metrics["active_num_samples"] = n_act_loc
             extra_metrics["active_sample_portion"] = n_act_loc / max(B, 1)
-        else:
-            wl = torch.full((B,), cfg.language_loss_weight, dtype=torch.float32, device=dev)
+        else:   # (also the langact-off branch: the VQA / prediction masks reach the action loss as they came, lap.py:557-566)
+            wl = torch.full((B,), cfg.language_loss_weight if lang_on else 0.0, dtype=torch.float32, device=dev)
             act_mask = torch.ones(B, dtype=torch.bool, device=dev)
             if vqa is not None:
                 act_mask = act_mask & ~vqa
@@ -981,17 +996,24 @@ class LAP:
                 act_mask = act_mask & ~pred
         n_active = torch.clamp(self.comm.all_reduce_sum(fb(sm).sum().view(1)), min=1.0) if obs.sample_mask is not None else \
             self.comm.all_reduce_sum(torch.tensor([float(B)], device=dev))
-        n_action = torch.clamp(self.comm.all_reduce_sum(fb(act_mask).sum().view(1)), min=1.0)
-        coef = cfg.action_loss_weight * fb(act_mask) / n_action
-        act_loss, dv = hip.mse_fwd_bwd(v_t.view(B, S * ad), u_t.view(B, S * ad), coef, need_grad=backward)
+        # lang_term: sum / active samples, or the batch mean without a sample mask (lap.py:579-596; the action-off branch's
+        # `final_loss` is the same expression)
         lang_term = (wl * lang_loss).sum() / n_active
-        action_term = (cfg.action_loss_weight * act_loss * fb(act_mask)).sum() / n_action
+        act_loss = torch.zeros(B, dtype=torch.float32, device=dev)
+        action_term = 0.0
+        dv = None
+        if act_on:
+            n_action = torch.clamp(self.comm.all_reduce_sum(fb(act_mask).sum().view(1)), min=1.0)
+            coef = cfg.action_loss_weight * fb(act_mask) / n_action
+            act_loss, dv = hip.mse_fwd_bwd(v_t.view(B, S * ad), u_t.view(B, S * ad), coef, need_grad=backward)
+            action_term = (cfg.action_loss_weight * act_loss * fb(act_mask)).sum() / n_action
         loss = self.comm.all_reduce_sum((lang_term + action_term).view(1)).view(())
         metrics = {"lang_loss": lang_loss.mean(), "action_loss": (act_loss * fb(act_mask)).sum() / torch.clamp(fb(act_mask).sum(), min=1.0),
                    "langact_loss": (lang_loss * fb(sm)).sum() / torch.clamp(fb(sm).sum(), min=1.0) if not mixing else extra_metrics["langact_loss"],
                    **{k: v for k, v in extra_metrics.items() if k != "langact_loss"}}
         if collect is not None:
-            collect.update(pl=pl, pre1=pre1, v_t=v_t.view(B, S, ad), u_t=u_t, per_sample_lang=lang_loss, per_sample_action=act_loss)
+            collect.update(pl=pl, pre1=pre1, v_t=v_t.view(B, S, ad) if v_t is not None else None, u_t=u_t, per_sample_lang=lang_loss,
+                           per_sample_action=act_loss)
         if not backward:
             return loss, metrics
 
@@ -999,14 +1021,18 @@ class LAP:
         self.comm.before_backward()
         self._wg_begin()
         We = self.e.width
-        dmod = torch.zeros(mod.shape, dtype=torch.float32, device=dev)
-        # action head
-        dpre1f = self._lin32_bwd(pre1f, dv.view(B * S, ad), "act/out_w", "act/out_b")
-        dx1 = hip.rmsnorm_bwd(xf1, hip.cast_f32_to_bf16(dpre1f), rstd_p1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S,
-                              dmod=self._mod_slot(dmod, 2 * self.v.depth))
+        dmod = dx1 = None
+        if act_on:      # action head
+            dmod = torch.zeros(mod.shape, dtype=torch.float32, device=dev)
+            dpre1f = self._lin32_bwd(pre1f, dv.view(B * S, ad), "act/out_w", "act/out_b")
+            dx1 = hip.rmsnorm_bwd(xf1, hip.cast_f32_to_bf16(dpre1f), rstd_p1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S,
+                                  dmod=self._mod_slot(dmod, 2 * self.v.depth))
         skip_prefix = self._prefix_frozen()
         dx0 = None
-        if not skip_prefix:
+        if not skip_prefix and not lang_on:
+            # no language loss: the prefix stream's only cotangents are those of its keys / values under the action queries
+            dx0 = torch.zeros((B * Pn, Dv), dtype=torch.bfloat16, device=dev)
+        elif not skip_prefix:
             # language head: dlogits = w * (softmax - onehot); w = d loss / d nll.  The cotangent of the f32 logits stays f32 in the
             # reference (d pre_logits = dlogits . table, d table = dlogits^T . pre_logits in f32): dlogits = dh + dl (two bf16
             # planes), table = hi + lo -> dh.hi + dl.hi + dh.lo (dl.lo is 2^-16 of the sum) and (dh + dl)^T . pre_logits
@@ -1040,8 +1066,12 @@ class LAP:
                 dx0.index_copy_(0, rowid.view(-1), drows)
             else:
                 hip.copy_rows_bf16(drows, dx0, R, Lt - 1, Dv, Lt - 1, 0, Pn, Pn - Lt)
-        dx0, dx1 = self._llm_bwd(lctx, dx0, dx1, mod, dmod, pos, qinfo, kinfo, B, Pn, S)
-        sfx = self._embed_suffix_bwd(sctx, dx1, dmod)
+        dx0, dx1 = self._llm_bwd(lctx, dx0, dx1, mod, dmod, pos, qinfo, kinfo, B, Pn, Sx)
+        sfx = None
+        if act_on:
+            sfx = self._embed_suffix_bwd(sctx, dx1, dmod)
+        else:       # the action expert's units saw no gradient (zeros): still declared complete for the optimizer's pipeline
+            self.comm.grads_ready("ada")
         if not skip_prefix:
             self._embed_prefix_bwd(pctx, dx0, B, Pn)
         self._handoff(sfx, torch.cuda.current_stream() if sfx is not None else None)

@@ -136,13 +136,16 @@ class Policy:
 
 def create_trained_policy(train_config, checkpoint_dir, *, tokenizer_model_path=None, tokenizer=None, repack_transforms=(),
                           sample_kwargs: dict | None = None, default_prompt: str | None = None, norm_stats: dict | None = None,
-                          device="cuda", use_graph: bool = True) -> Policy:
+                          device="cuda", use_graph: bool = True, deterministic: bool = False) -> Policy:
     """policies/policy_config_adapter.py:85-154: model from `<checkpoint_dir>/params`, norm stats from
     `<checkpoint_dir>/assets/<asset_id>/norm_stats.json`, and the standard transform stack
         [repack.inputs, InjectDefaultPrompt, CoTInputs (the data config's), Normalize, InjectDefaultPrompt, Tokenize, PadStatesAndActions]
         -> model -> [DetokenizeReasoning, Unnormalize, CoTOutputs, repack.outputs]  (VLA-0: [DetokenizeReasoning, CoTOutputs(norm stats)]).
     `repack_transforms` = (inputs, outputs) lists.  The PaliGemma SentencePiece model cannot be downloaded here: pass
-    `tokenizer_model_path` (or a ready `tokenizer`)."""
+    `tokenizer_model_path` (or a ready `tokenizer`).
+    `deterministic` (not in the reference, which has no serving override): True switches off the training-time randomness the data /
+    model config carries into the serving stack — wrist-image dropout, random un-masking of missing cameras, state dropout — so that
+    equal requests give equal prompts and masks.  False keeps the reference's wiring and warns when any of the three is non-zero."""
     import pathlib
 
     from lap_amd import checkpoints as _ckpt
@@ -160,8 +163,22 @@ def create_trained_policy(train_config, checkpoint_dir, *, tokenizer_model_path=
         tokenizer = pio.PaligemmaTokenizer(tokenizer_model_path, mc.max_token_len, prompt_format=mc.prompt_format,
                                            reasoning_mask_prob=0.0)
     rin, rout = (list(repack_transforms[0]), list(repack_transforms[1])) if repack_transforms else ([], [])
+    import dataclasses as _dc
+    import warnings
+
     from lap_amd.data import data_transform_inputs
     dc = train_config.data
+    state_dropout = getattr(mc, "state_dropout", 0.0)
+    noisy = {k: v for k, v in (("data.wrist_image_dropout_prob", getattr(dc, "wrist_image_dropout_prob", 0.0)),
+                               ("data.random_mask_prob", getattr(dc, "random_mask_prob", 0.0)), ("model.state_dropout", state_dropout)) if v}
+    if deterministic:
+        if _dc.is_dataclass(dc):
+            dc = _dc.replace(dc, **{k: 0.0 for k in ("wrist_image_dropout_prob", "random_mask_prob") if hasattr(dc, k)})
+        state_dropout = 0.0
+    elif noisy:
+        warnings.warn("create_trained_policy: the serving stack keeps the config's training-time randomness as the reference does "
+                      f"({', '.join(f'{k}={v}' for k, v in noisy.items())}): images are blanked / un-masked and the state dropped at random "
+                      "per request.  Pass deterministic=True (or zero these fields) for a deterministic server.", stacklevel=2)
     strategy = getattr(dc, "transform_strategy", "standard")
     fmt_name = getattr(dc, "language_action_format_name", "verbose_eef_with_rotation")
     # policy_config_adapter.py:137-150: the data config's OWN data-transform group serves too — the same `CoTInputs` as in training,
@@ -171,7 +188,7 @@ def create_trained_policy(train_config, checkpoint_dir, *, tokenizer_model_path=
     transforms = [*rin, pio.InjectDefaultPrompt(default_prompt), data_transform_inputs(dc, mc),
                   pio.Normalize(norm_stats, normalization_type=ntype), pio.InjectDefaultPrompt(None),
                   pio.TokenizePromptAndReasoning(tokenizer, discrete_state_input=mc.discrete_state_input, verbose_mode=mc.verbose_mode,
-                                                 state_dropout=getattr(mc, "state_dropout", 0.0)),
+                                                 state_dropout=state_dropout),
                   pio.PadStatesAndActions(mc.action_dim)]
     detok = pio.DetokenizeReasoning(tokenizer)      # model_transforms.outputs (include_outputs, training/config.py:192-194)
     if strategy == "vla0":      # OutputTransformAssembler._build_vla0_outputs (:44-66): the decoder un-normalises, no Unnormalize

@@ -78,6 +78,8 @@ class OracleCfg:
     language_loss_weight: float = 1.0
     action_loss_weight: float = 1.0
     stop_action_to_vlm_grad: bool = False
+    enable_action_training: bool = True        # lap_config.py:40-47: flow-matching loss + action-expert stream (lap.py:426-462,557-569)
+    enable_langact_training: bool = True       # language-action cross entropy (lap.py:462-556)
     enable_vqa_training: bool = False          # lap_config.py:40-47 / lap.py:101-115
     enable_prediction_training: bool = False
     vqa_loss_weight: float = 0.1
@@ -496,71 +498,90 @@ def build_masks_positions(cfg, obs, prefix_mask, prefix_ar, suffix_mask, suffix_
 
 
 def compute_loss(P, cfg: OracleCfg, obs, actions, noise, time, collect=None):
-    """lap.py:380-602 for enable_action_training=True, enable_langact_training=True, VQA/prediction off,
-    image augmentation off (lap_libero), with the random draws (noise ~ N(0,1), time ~ Beta(1.5,1)*.999+.001,
-    lap.py:193-194) supplied by the caller.  Returns (loss, metrics)."""
+    """lap.py:380-602 (image augmentation off), with the random draws (noise ~ N(0,1), time ~ Beta(1.5,1)*.999+.001,
+    lap.py:193-194) supplied by the caller.  All three branches of the loss assembly:
+      * action + langact training (LAP-3B): both streams, cross entropy + flow matching;
+      * enable_action_training=False (VLA-0 style, lap.py:426-462): `llm([prefix])` with the prefix's own mask and positions,
+        cross entropy only, final loss = sum / active samples (lap.py:590-596);
+      * enable_langact_training=False (pi0 style): both streams, flow matching only (lang_term = 0, lap.py:579-589).
+    Returns (loss, metrics)."""
     r = _mk_round(cfg)
     B = actions.shape[0]
-    te = time[:, None, None]
-    x_t = te * noise + (1 - te) * actions
-    u_t = noise - actions
-    suffix_tokens, suffix_mask, suffix_ar1, cond = embed_suffix(P, cfg, x_t, time)
-    suffix_ar = suffix_ar1[None].expand(B, -1)
+    act_on, lang_on = cfg.enable_action_training, cfg.enable_langact_training
     prefix_tokens, prefix_mask, prefix_ar = embed_prefix(P, cfg, obs, collect)
-    _, mask, positions = build_masks_positions(cfg, obs, prefix_mask, prefix_ar, suffix_mask, suffix_ar)
-    (pre0, pre1), _ = gemma_forward(P, cfg, [prefix_tokens, suffix_tokens], positions, mask, [None, cond], collect=collect)
+    if act_on:
+        te = time[:, None, None]
+        x_t = te * noise + (1 - te) * actions
+        u_t = noise - actions
+        suffix_tokens, suffix_mask, suffix_ar1, cond = embed_suffix(P, cfg, x_t, time)
+        suffix_ar = suffix_ar1[None].expand(B, -1)
+        _, mask, positions = build_masks_positions(cfg, obs, prefix_mask, prefix_ar, suffix_mask, suffix_ar)
+        (pre0, pre1), _ = gemma_forward(P, cfg, [prefix_tokens, suffix_tokens], positions, mask, [None, cond], collect=collect)
+    else:       # lap.py:431-455: prefix_mask_action = prefix_mask, mask = make_attn_mask(prefix), positions = cumsum - 1
+        mask = make_attn_mask(prefix_mask, prefix_ar)
+        positions = torch.cumsum(prefix_mask.long(), 1) - 1
+        (pre0, pre1), _ = gemma_forward(P, cfg, [prefix_tokens, None], positions, mask, [None, None], collect=collect)
     if collect is not None:
         collect["llm/out0"] = pre0
         collect["llm/out1"] = pre1
         collect["mask"] = mask
         collect["positions"] = positions
-    # language loss (lap.py:209-289)
-    tok = obs["tokenized_prompt"].long()
-    tgt = tok[:, 1:]
-    pl = pre0[:, :-1][:, -tgt.shape[1]:]
-    logits = pl @ P["PaliGemma/llm/embedder/input_embedding"].t()  # bf16 x f32 -> f32 (gemma.py:153-154)
-    loss_mask = obs["tokenized_langact_mask"][:, 1:] & obs["tokenized_prompt_mask"][:, 1:] & obs["token_loss_mask"][:, 1:]
     sm = obs.get("sample_mask")
-    lm = loss_mask.to(torch.float32)
-    if sm is not None:
-        lm = lm * sm[:, None].to(torch.float32)
-    logp = torch.log_softmax(logits, dim=-1)
-    token_pplx = logp.gather(-1, tgt[..., None]).squeeze(-1)
-    lang_loss = -(token_pplx * lm).sum(-1) / torch.clamp(lm.sum(-1), min=1)
-    # action loss (lap.py:291-301)
-    v_t = pre1[:, -cfg.action_horizon:] @ P["action_out_proj/kernel"] + P["action_out_proj/bias"]
-    act_loss = torch.mean(torch.square(v_t - u_t), dim=(-1, -2))
-    # combination (lap.py:472-596)
+    smb = sm if sm is not None else torch.ones(B, dtype=torch.bool)
     vqa = obs.get("is_vqa_sample") if cfg.enable_vqa_training else None
     pred = obs.get("is_prediction_sample") if cfg.enable_prediction_training else None
-    smb = sm if sm is not None else torch.ones(B, dtype=torch.bool)
-    if cfg.enable_vqa_training or cfg.enable_prediction_training:
-        vqa_raw = vqa if vqa is not None else torch.zeros(B, dtype=torch.bool)
-        pred_raw = pred if pred is not None else torch.zeros(B, dtype=torch.bool)
-        lang_mask = ~(vqa_raw | pred_raw) & smb
-        vqa_mask, pred_mask = vqa_raw & smb, pred_raw & smb
-        vqa_w = torch.full((B,), cfg.vqa_loss_weight)
-        if cfg.enable_vqa_training and cfg.vqa_loss_weights_by_id and obs.get("vqa_dataset_id") is not None:
-            for did, wgt in cfg.vqa_loss_weights_by_id:
-                vqa_w = torch.where(obs["vqa_dataset_id"] == did, torch.tensor(float(wgt)), vqa_w)
-        lang_ps = vqa_w * lang_loss * vqa_mask + cfg.prediction_loss_weight * lang_loss * pred_mask + cfg.language_loss_weight * lang_loss * lang_mask
-        act_mask = ~vqa_mask & ~pred_mask
-    else:
-        lang_ps = cfg.language_loss_weight * lang_loss
+    lang_loss = torch.zeros(B)
+    lang_ps = torch.zeros(B)
+    vqa_mask = pred_mask = None
+    if lang_on:
+        # language loss (lap.py:209-289)
+        tok = obs["tokenized_prompt"].long()
+        tgt = tok[:, 1:]
+        pl = pre0[:, :-1][:, -tgt.shape[1]:]
+        logits = pl @ P["PaliGemma/llm/embedder/input_embedding"].t()  # bf16 x f32 -> f32 (gemma.py:153-154)
+        loss_mask = obs["tokenized_langact_mask"][:, 1:] & obs["tokenized_prompt_mask"][:, 1:] & obs["token_loss_mask"][:, 1:]
+        lm = loss_mask.to(torch.float32)
+        if sm is not None:
+            lm = lm * sm[:, None].to(torch.float32)
+        logp = torch.log_softmax(logits, dim=-1)
+        token_pplx = logp.gather(-1, tgt[..., None]).squeeze(-1)
+        lang_loss = -(token_pplx * lm).sum(-1) / torch.clamp(lm.sum(-1), min=1)
+        # combination (lap.py:472-556)
+        if cfg.enable_vqa_training or cfg.enable_prediction_training:
+            vqa_raw = vqa if vqa is not None else torch.zeros(B, dtype=torch.bool)
+            pred_raw = pred if pred is not None else torch.zeros(B, dtype=torch.bool)
+            lang_mask = ~(vqa_raw | pred_raw) & smb
+            vqa_mask, pred_mask = vqa_raw & smb, pred_raw & smb
+            vqa_w = torch.full((B,), cfg.vqa_loss_weight)
+            if cfg.enable_vqa_training and cfg.vqa_loss_weights_by_id and obs.get("vqa_dataset_id") is not None:
+                for did, wgt in cfg.vqa_loss_weights_by_id:
+                    vqa_w = torch.where(obs["vqa_dataset_id"] == did, torch.tensor(float(wgt)), vqa_w)
+            lang_ps = vqa_w * lang_loss * vqa_mask + cfg.prediction_loss_weight * lang_loss * pred_mask + cfg.language_loss_weight * lang_loss * lang_mask
+        else:
+            lang_ps = cfg.language_loss_weight * lang_loss
+    metrics = {"lang_loss": lang_loss.mean(), "per_sample_lang": lang_loss}
+    if act_on:
+        # action loss (lap.py:291-301) and its sample mask (lap.py:557-569: the masks as they stand at this point, i.e. AND-ed
+        # with the sample mask only when the langact branch ran with VQA / prediction mixing)
+        v_t = pre1[:, -cfg.action_horizon:] @ P["action_out_proj/kernel"] + P["action_out_proj/bias"]
+        act_loss = torch.mean(torch.square(v_t - u_t), dim=(-1, -2))
         act_mask = torch.ones(B, dtype=torch.bool)
-        if vqa is not None:
-            act_mask = act_mask & ~vqa
-        if pred is not None:
-            act_mask = act_mask & ~pred
-    amf = act_mask.to(torch.float32)
-    action_term = (cfg.action_loss_weight * act_loss * amf).sum() / torch.clamp(amf.sum(), min=1.0)
-    if sm is not None:
-        lang_term = lang_ps.sum() / torch.clamp(sm.to(torch.float32).sum(), min=1.0)
+        for msk, raw in ((vqa_mask, vqa), (pred_mask, pred)):
+            m_ = msk if msk is not None else raw
+            if m_ is not None:
+                act_mask = act_mask & ~m_
+        amf = act_mask.to(torch.float32)
+        action_term = (cfg.action_loss_weight * act_loss * amf).sum() / torch.clamp(amf.sum(), min=1.0)
+        if lang_on:
+            lang_term = lang_ps.sum() / torch.clamp(sm.to(torch.float32).sum(), min=1.0) if sm is not None else lang_ps.mean()
+        else:
+            lang_term = 0.0
+        loss = lang_term + action_term
+        metrics.update(action_loss=act_loss.mean(), per_sample_action=act_loss, v_t=v_t, u_t=u_t)
+    elif lang_on and sm is not None:      # lap.py:590-593
+        loss = lang_ps.sum() / torch.clamp(sm.to(torch.float32).sum(), min=1.0)
     else:
-        lang_term = lang_ps.mean()
-    loss = lang_term + action_term
-    metrics = {"lang_loss": lang_loss.mean(), "action_loss": act_loss.mean(), "per_sample_lang": lang_loss,
-               "per_sample_action": act_loss, "v_t": v_t, "u_t": u_t}
+        loss = lang_ps.mean()
     return loss, metrics
 
 

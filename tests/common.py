@@ -14,6 +14,7 @@ def oracle_cfg(model_cfg, **kw) -> O.OracleCfg:
                        image_size=model_cfg.image_size, image_keys=model_cfg.image_keys, vocab_size=model_cfg.vocab_size,
                        language_loss_weight=model_cfg.language_loss_weight, action_loss_weight=model_cfg.action_loss_weight,
                        stop_action_to_vlm_grad=model_cfg.stop_action_to_vlm_grad,
+                       enable_action_training=model_cfg.enable_action_training, enable_langact_training=model_cfg.enable_langact_training,
                        enable_vqa_training=model_cfg.enable_vqa_training, enable_prediction_training=model_cfg.enable_prediction_training,
                        vqa_loss_weight=model_cfg.vqa_loss_weight, prediction_loss_weight=model_cfg.prediction_loss_weight,
                        vqa_loss_weights_by_id=tuple((VQA_DATASET_ID_MAP[k], v) for k, v in (model_cfg.vqa_loss_weights or {}).items()

@@ -504,6 +504,9 @@ def test_vqa_records_become_samples_and_join_a_mixture(setup):
         assert isv is not None, "the observation carries the VQA flag compute_loss mixes by"
         n_vqa += int(isv.sum()); n += len(isv)
         assert torch.isfinite(actions).all()        # (a VQA sample's dummy actions are masked out of the action loss, lap.py:560-569)
+        # the mixer normalises robot datasets only (dataset_mixer.py:338-341): a VQA sample's all-zero state and actions stay zero
+        sel = torch.as_tensor(isv, dtype=torch.bool)
+        assert float(actions.cpu()[sel].abs().max() if sel.any() else 0.0) == 0.0 and float(obs.state.cpu()[sel].abs().max() if sel.any() else 0.0) == 0.0
     assert 0 < n_vqa < n
     # frames of different native sizes were brought to the model's resolution the way the reference's decode step does it
     small = np.zeros((30, 60, 3), dtype=np.uint8); small[:, :30] = 200

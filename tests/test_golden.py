@@ -62,3 +62,27 @@ def test_engine_matches_golden(hip):
     so = {k: v for k, v in obs.items() if k != "tokenized_langact_mask"}
     a = model.sample_actions(0, to_observation(so | {"tokenized_langact_mask": None}, "cuda"), num_steps=10, noise=noise.cuda())
     assert rel(a, torch.from_numpy(G["sampled_actions"])) < 2e-2
+
+
+def test_oracle_loss_branches_decompose_the_joint_loss():
+    """lap.py:426-462,557-596.  Prefix rows never attend to suffix rows, so the cross entropy of the prefix-only forward
+    (enable_action_training=False) equals the joint forward's per sample, the flow-matching loss without the language loss
+    (enable_langact_training=False) equals the joint one's, and the two branch losses add up to the joint loss."""
+    import dataclasses
+
+    from tests.common import debug_model_cfg, make_inputs, oracle_cfg
+
+    cfg = debug_model_cfg()
+    oc = oracle_cfg(cfg)
+    P = O.init_params(oc, seed=3)
+    obs, a, n, t = make_inputs(cfg, B=3, ragged=True)
+    loss, m = O.compute_loss(P, oc, obs, a, n, t)
+    loss_l, m_l = O.compute_loss(P, dataclasses.replace(oc, enable_action_training=False), obs, a, n, t)
+    loss_a, m_a = O.compute_loss(P, dataclasses.replace(oc, enable_langact_training=False), obs, a, n, t)
+    assert torch.equal(m["per_sample_lang"], m_l["per_sample_lang"]) and "per_sample_action" not in m_l
+    assert torch.equal(m["per_sample_action"], m_a["per_sample_action"]) and float(m_a["per_sample_lang"].abs().max()) == 0.0
+    assert abs(loss.item() - (loss_l.item() + loss_a.item())) < 1e-5
+    # without a sample mask the action-off branch is the batch mean of the weighted per-sample losses (lap.py:594-596)
+    obs2 = {k: v for k, v in obs.items() if k != "sample_mask"}
+    loss_m, m_m = O.compute_loss(P, dataclasses.replace(oc, enable_action_training=False), obs2, a, n, t)
+    assert abs(loss_m.item() - (oc.language_loss_weight * m_m["per_sample_lang"]).mean().item()) < 1e-6

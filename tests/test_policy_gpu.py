@@ -67,3 +67,17 @@ def test_policy_from_checkpoint_serves_raw_requests(hip, tmp_path):
     r = ar.infer(req)
     # output stack of the AR mode: ids -> text -> one end-effector delta (6 values, + gripper when the text names it)
     assert isinstance(r["reasoning"], str) and r["actions"].shape in ((6,), (7,)) and "policy_timing" in r
+    # the reference's wiring carries the data config's training-time randomness into serving; `deterministic=True`
+    # switches it off, the default keeps the reference's behaviour and says so loudly
+    noisy = dataclasses.replace(tc, data=dataclasses.replace(tc.data, wrist_image_dropout_prob=0.5, random_mask_prob=0.5))
+    with pytest.warns(UserWarning, match="training-time randomness"):
+        create_trained_policy(noisy, tmp_path, tokenizer=tok, default_prompt="pick up the block", use_graph=False, device=DEV)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.filterwarnings("error", message=".*training-time randomness.*")
+        det = create_trained_policy(noisy, tmp_path, tokenizer=tok, default_prompt="pick up the block", use_graph=False, device=DEV, deterministic=True)
+    ref_in = det._input_transform(dict(req))
+    for _ in range(20):
+        again = det._input_transform(dict(req))
+        assert bool(again["image_mask"]["left_wrist_0_rgb"]) and np.array_equal(again["tokenized_prompt"], ref_in["tokenized_prompt"])
+        np.testing.assert_array_equal(again["image"]["left_wrist_0_rgb"], ref_in["image"]["left_wrist_0_rgb"])
