@@ -98,6 +98,15 @@ def _barrier():
         d.barrier()
 
 
+def _engine_layout(cfg) -> dict:
+    """What shapes the engine-layout `train_state/` item besides the model config: the SigLIP MLP width after `siglip_mlp_pad`."""
+    from lap_amd.config import get_siglip_config
+    from lap_amd.params import siglip_mlp_pad
+
+    md = get_siglip_config(cfg.siglip_variant).mlp_dim
+    return {"siglip_mlp_dim": md, "siglip_mlp_width": siglip_mlp_pad(md)}
+
+
 def _save_tensors(path: pathlib.Path, tensors: dict, metadata: dict | None = None):
     from safetensors.torch import save_file
 
@@ -201,7 +210,7 @@ def _save_once(mngr: CheckpointManager, state, data_loader, step: int, norm_stat
         if rank == 0:
             (tmp / "train_state" / "meta.json").write_text(json.dumps(
                 {"step": step, "world_size": world, "ema_decay": state.ema_decay, "has_ema": has_ema,
-                 "units": {u.name: ps.padded(u) for u in ps.units}}))
+                 "units": {u.name: ps.padded(u) for u in ps.units}, "layout": _engine_layout(ps.cfg)}))
             # ---- assets (save_assets callback, :216-285)
             if norm_stats is not None:
                 d = tmp / "assets" / asset_id
@@ -261,6 +270,14 @@ def restore_state(checkpoint_manager: CheckpointManager, state, data_loader=None
     if meta["world_size"] != ps.world_size:
         raise ValueError(f"checkpoint was written by {meta['world_size']} ranks, this job has {ps.world_size} "
                          "(train_state is sharded; restore_params() gives the full parameter tree for any world size)")
+    # `train_state/` is engine-layout: the switches that shape it are recorded in the meta (round 5) so that a mismatch
+    # is reported by name.  Older checkpoints carry no "layout": the per-unit sizes below still catch a mismatch.
+    lay, now = meta.get("layout"), _engine_layout(ps.cfg)
+    if lay is not None and lay != now:
+        raise ValueError(
+            f"train_state/ of step {step} was written with engine layout {lay}, this process runs {now}.  The SigLIP MLP padding is chosen "
+            f"by LAP_SIGLIP_PAD (lap_amd/params.py siglip_mlp_pad): resume with LAP_SIGLIP_PAD={'1' if lay['siglip_mlp_width'] != lay['siglip_mlp_dim'] else '0'}, "
+            "or start a new optimizer state from the layout-independent `params/` item (restore_params / weight_loader.kind='checkpoint').")
     for u in ps.units:
         if meta["units"].get(u.name) != ps.padded(u):
             raise ValueError(f"unit {u.name}: checkpoint geometry {meta['units'].get(u.name)} != {ps.padded(u)}")

@@ -126,8 +126,25 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
       offB[j] = (n0 + c * 8 < p.N) ? (unsigned)(((long long)kr * p.ldb + n0 + c * 8) * 2) : OOB;
     }
   }
-  const unsigned stepA = A_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.lda * 2);
-  const unsigned stepB = B_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.ldb * 2);
+  unsigned stepA = A_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.lda * 2);
+  unsigned stepB = B_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.ldb * 2);
+#ifdef LAP_GEMM_EXPERIMENTAL
+  // timing probe (results wrong): operand tiles fetched as if the operand were stored tile by tile, 1 KiB contiguous per LDS-DMA
+  // piece (dbg bit 8: B, bit 16: A) instead of 8 rows x 128 bytes — what a fragment-packed operand image would cost the loop
+  {
+    const int nkt = (p.K + BK - 1) / BK;
+    if (p.dbg & 8) {
+#pragma unroll
+      for (int j = 0; j < PB; ++j) { offB[j] = (unsigned)(((long long)tn * nkt) * B_BYTES + (w * PB + j) * 1024 + lane * 16); kidxB[j] = 0; }
+      stepB = B_BYTES;
+    }
+    if (p.dbg & 16) {
+#pragma unroll
+      for (int j = 0; j < PA; ++j) { offA[j] = (unsigned)(((long long)tm * nkt) * A_BYTES + (w * PA + j) * 1024 + lane * 16); kidxA[j] = 0; }
+      stepA = A_BYTES;
+    }
+  }
+#endif
 
   auto stage = [&](int buf, int kt) {
     const int k0 = kt * BK;

@@ -199,60 +199,84 @@ __global__ __launch_bounds__(256) void reduce_residual_norm_kernel(const float* 
 //   xn = bf16(sum_s part[s] (+ bias) (+ residual));  NORM 1: h = xn * rstd * (1 + scale)  (gemma.py:113-131, plain form);
 //   NORM 2: h = (xn - mean) * (rstd * gamma) + beta  (Flax LayerNorm, use_fast_variance);  NORM 0: no h.
 template <int NCH, int NORM>
-__global__ __launch_bounds__(256) void reduce_norm_kernel(const float* __restrict__ part, int ks, const float* __restrict__ bias,
-                                                          const bf16* __restrict__ resid, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, bf16* __restrict__ xn, bf16* __restrict__ hout,
-                                                          int rows, int D, float eps) {
+__global__ __launch_bounds__(NCH * 64) void reduce_norm_kernel(const float* __restrict__ part, int ks, const float* __restrict__ bias,
+                                                               const bf16* __restrict__ resid, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, bf16* __restrict__ xn, bf16* __restrict__ hout,
+                                                               int rows, int D, float eps) {
+  // One BLOCK per row, one wave per 512-column chunk (round 5; before: one wave per row walking its NCH chunks one after the other,
+  // 2 ks dependent load batches per wave: 10 - 11.6 us per launch at 560 x 2048, a pure latency chain).  Every wave has all the
+  // slab loads of its chunk in flight at once (sum8: 8 slabs x 2 loads), 4 x the blocks.  The row statistics keep the old
+  // kernel's order — lane l's running sum over its 8 values of chunk 0, then chunk 1, ... and only then the wave reduction — by
+  // passing the rounded values through LDS: every wave redoes lane l's running sum over all chunks, so each holds the same bits.
+  __shared__ float sv[NCH][64][8];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= rows) return;
+  const int row = blockIdx.x;
   const long long slab = (long long)rows * D;
-  float v[NCH][8];
+  const int c = (lane + 64 * w) * 8;
+  const long long off = (long long)row * D + c;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (c < D) {
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = 0.f;
+    int s = 0;
+    for (; s + 8 <= ks; s += 8) {      // eight slabs in flight; additions in slab order (= splitk_reduce_kernel)
+      f32x4 a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = *reinterpret_cast<const f32x4*>(part + (s + u) * slab + off);
+        b[u] = *reinterpret_cast<const f32x4*>(part + (s + u) * slab + off + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y[e] += a[u][e]; y[4 + e] += b[u][e]; }
+    }
+    for (; s + 4 <= ks; s += 4) {
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = *reinterpret_cast<const f32x4*>(part + (s + u) * slab + off);
+        b[u] = *reinterpret_cast<const f32x4*>(part + (s + u) * slab + off + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y[e] += a[u][e]; y[4 + e] += b[u][e]; }
+    }
+    for (; s < ks; ++s) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(part + s * slab + off), b = *reinterpret_cast<const f32x4*>(part + s * slab + off + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { y[e] += a[e]; y[4 + e] += b[e]; }
+    }
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] += bias[c + e];
+    }
+    if (resid) {
+      float r[8];
+      ld8(resid + off, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] += r[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = round_bf16(y[e]);
+    st8(xn + off, v);
+  }
+  if (NORM == 0) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sv[w][lane][e] = v[e];
+  __syncthreads();
   float s1 = 0.f, ss = 0.f;
 #pragma unroll
   for (int p = 0; p < NCH; ++p) {
-    const int c = (lane + 64 * p) * 8;
-    if (c < D) {
-      float y[8];
+    if ((lane + 64 * p) * 8 < D) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = 0.f;
-      const long long off = (long long)row * D + c;
-      int s = 0;
-      for (; s + 4 <= ks; s += 4) {      // four slabs in flight; additions in slab order (= splitk_reduce_kernel)
-        f32x4 a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          a[u] = *reinterpret_cast<const f32x4*>(part + (s + u) * slab + off);
-          b[u] = *reinterpret_cast<const f32x4*>(part + (s + u) * slab + off + 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { y[e] += a[u][e]; y[4 + e] += b[u][e]; }
-      }
-      for (; s < ks; ++s) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(part + s * slab + off), b = *reinterpret_cast<const f32x4*>(part + s * slab + off + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { y[e] += a[e]; y[4 + e] += b[e]; }
-      }
-      if (bias) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] += bias[c + e];
-      }
-      if (resid) {
-        float r[8];
-        ld8(resid + off, r);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] += r[e];
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[p][e] = round_bf16(y[e]);
-      st8(xn + off, v[p]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { s1 += v[p][e]; ss += v[p][e] * v[p][e]; }
+      for (int e = 0; e < 8; ++e) { const float t = sv[p][lane][e]; s1 += t; ss += t * t; }
     }
   }
-  if (NORM == 0) return;
   ss = wave_sum(ss);
   float mean = 0.f, r;
   if (NORM == 2) {
@@ -262,20 +286,16 @@ __global__ __launch_bounds__(256) void reduce_norm_kernel(const float* __restric
   } else {
     r = 1.0f / sqrtf(ss / (float)D + eps);
   }
+  if (c < D) {
+    float o[8];
+    if (NORM == 2) {
 #pragma unroll
-  for (int p = 0; p < NCH; ++p) {
-    const int c = (lane + 64 * p) * 8;
-    if (c < D) {
-      float o[8];
-      if (NORM == 2) {
+      for (int e = 0; e < 8; ++e) o[e] = (v[e] - mean) * (r * gamma[c + e]) + beta[c + e];
+    } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (v[p][e] - mean) * (r * gamma[c + e]) + beta[c + e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = v[p][e] * r * (1.0f + gamma[c + e]);
-      }
-      st8(hout + (long long)row * D + c, o);
+      for (int e = 0; e < 8; ++e) o[e] = v[e] * r * (1.0f + gamma[c + e]);
     }
+    st8(hout + (long long)row * D + c, o);
   }
 }
 
@@ -388,8 +408,8 @@ extern "C" int lap_fused_reduce_norm(const float* partials, int ksplit, const fl
   if (norm && (!gamma || !h)) return LAP_ERR_ARG;
   if (norm == 2 && !beta) return LAP_ERR_ARG;
   const int nch = (D / 8 + 63) / 64;
-  dim3 grid((rows + 3) / 4);
-#define GO2(N, NM) hipLaunchKernelGGL((reduce_norm_kernel<N, NM>), grid, dim3(256), 0, S_, partials, ksplit, bias, (const bf16*)residual, \
+  dim3 grid(rows);
+#define GO2(N, NM) hipLaunchKernelGGL((reduce_norm_kernel<N, NM>), grid, dim3(N * 64), 0, S_, partials, ksplit, bias, (const bf16*)residual, \
                                       gamma, beta, (bf16*)xn, (bf16*)h, rows, D, eps)
 #define GO(N) do { if (norm == 0) GO2(N, 0); else if (norm == 1) GO2(N, 1); else GO2(N, 2); } while (0)
   switch (nch) {

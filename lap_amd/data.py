@@ -322,16 +322,47 @@ def compute_norm_stats(dataset: EpisodeDataset, *, action_pad_to: int | None = N
     fields; num_transitions counts those rows) and over the per-frame state as the model sees it ([xyz, rot6d, gripper] for end-effector
     states).  The mixer pads to the model's widths later (`global_norm_stats`); `action_pad_to` zero-pads here for single datasets:
     all-zero columns normalise to 0 by the q01 == q99 rule."""
-    chunks = np.concatenate([dataset.chunks(e).astype(np.float64).reshape(-1, dataset.chunks(e, [0]).shape[-1]) for e in dataset.episodes], 0)
-    chunks = chunks[np.isfinite(chunks).all(1)]
-    if action_pad_to is not None:
-        chunks = pio.pad_to_dim(chunks, action_pad_to, axis=-1)
-    states = np.concatenate([np.asarray(e["state"], dtype=np.float64).reshape(len(e["actions"]), -1) for e in dataset.episodes], 0)
-    out = {}
-    for key, x in (("state", states), ("actions", chunks)):
-        out[key] = {"mean": x.mean(0).tolist(), "std": x.std(0).tolist(), "q01": np.quantile(x, 0.01, axis=0).tolist(),
-                    "q99": np.quantile(x, 0.99, axis=0).tolist(), "min": x.min(0).tolist(), "max": x.max(0).tolist()}
-    return out
+    # Streaming form (ADVICE r4): the chunks of one episode at a time, kept as float32 rows (what the store holds) for the quantiles;
+    # mean / std / min / max from float64 running sums per episode.  Peak memory = 2 x rows x A x 4 bytes (+ one column's sort copy)
+    # instead of 2 x rows x A x 8, and `dataset.chunks` runs once per episode.
+    def stats_of(rows_iter, width):
+        parts, n = [], 0
+        s1 = np.zeros(width, dtype=np.float64); s2 = np.zeros(width, dtype=np.float64)
+        lo = np.full(width, np.inf); hi = np.full(width, -np.inf)
+        for r in rows_iter:
+            r = r[np.isfinite(r).all(1)]
+            if not len(r):
+                continue
+            parts.append(np.ascontiguousarray(r, dtype=np.float32))
+            r64 = r.astype(np.float64)
+            s1 += r64.sum(0); s2 += (r64 * r64).sum(0)
+            lo = np.minimum(lo, r64.min(0)); hi = np.maximum(hi, r64.max(0))
+            n += len(r)
+        buf = np.concatenate(parts, 0) if parts else np.zeros((0, width), dtype=np.float32)
+        del parts
+        mean = s1 / max(n, 1)
+        std = np.sqrt(np.maximum(s2 / max(n, 1) - mean * mean, 0.0))
+        q01 = np.array([np.quantile(buf[:, j].astype(np.float64), 0.01) for j in range(width)])
+        q99 = np.array([np.quantile(buf[:, j].astype(np.float64), 0.99) for j in range(width)])
+        return {"mean": mean.tolist(), "std": std.tolist(), "q01": q01.tolist(), "q99": q99.tolist(), "min": lo.tolist(), "max": hi.tolist()}
+
+    eps = list(dataset.episodes)
+    first = np.asarray(dataset.chunks(eps[0]))
+    A = first.shape[-1]
+    Aw = max(A, action_pad_to or 0)
+
+    def chunk_rows():
+        for i, e in enumerate(eps):
+            c = first if i == 0 else np.asarray(dataset.chunks(e))
+            c = c.reshape(-1, A).astype(np.float32, copy=False)
+            yield c if Aw == A else pio.pad_to_dim(c, Aw, axis=-1)
+
+    def state_rows():
+        for e in eps:
+            yield np.asarray(e["state"], dtype=np.float32).reshape(len(e["actions"]), -1)
+
+    sw = np.asarray(eps[0]["state"]).reshape(len(eps[0]["actions"]), -1).shape[-1]
+    return {"state": stats_of(state_rows(), sw), "actions": stats_of(chunk_rows(), Aw)}
 
 
 # ------------------------------------------------------------------------------ dataset mixture (datasets/dataset_mixer.py)
@@ -445,6 +476,12 @@ class MixtureDataset:
     def __len__(self) -> int:
         return self.length
 
+    @property
+    def num_distinct_samples(self) -> int:
+        """Samples the member datasets actually hold (len() is the weighted EFFECTIVE length): what a one-pass validation loader is
+        bounded by."""
+        return int(sum(self.sizes))
+
     def set_epoch(self, epoch: int):
         """The draws are a pure function of (seed, epoch, index): a resumed loader reproduces them, a new epoch re-samples."""
         self.epoch = int(epoch)
@@ -517,6 +554,11 @@ class DataLoader:
         self.num_batches, self.split, self.device, self._norm_stats = num_batches, split, device, norm_stats
         self._seen_batches = 0
         self.per_epoch = len(dataset) // (batch_size * world_size)    # full global batches only (ragged tail dropped)
+        # A mixture's len() is its EFFECTIVE length (transitions x action horizon / weight: sampling weights, dataset_mixer.py:216-240),
+        # 20-40x its distinct samples; a "one pass" validation loader over it would draw that many times.  The val pass is
+        # bounded by the number of distinct samples the mixture holds (the reference bounds it with val_max_samples / num_val_batches).
+        distinct = getattr(dataset, "num_distinct_samples", None)
+        self.val_batches = self.per_epoch if distinct is None else max(1, min(self.per_epoch, int(distinct) // (batch_size * world_size)))
 
     # ---- checkpoint protocol (train.main / checkpoints.save_state)
     def get_state(self) -> dict:
@@ -555,7 +597,7 @@ class DataLoader:
         while True:
             if self.num_batches is not None and produced >= self.num_batches:
                 return
-            if self.split == "val" and self._seen_batches >= self.per_epoch:
+            if self.split == "val" and self._seen_batches >= self.val_batches:
                 return
             batch = _stack([self.transform(self.dataset[int(i)]) for i in self._indices(self._seen_batches)])
             self._seen_batches += 1

@@ -12,7 +12,12 @@ import pathlib
 
 import torch
 
-_LIB_PATH = pathlib.Path(__file__).resolve().parent / "liblap_hip.so"
+import os as _os
+
+# LAP_HIP_LIB_VARIANT=<v>: load lap_amd/liblap_hip_<v>.so (a probe build with the ablation bits of LAP_GEMM_EXPERIMENTAL compiled in,
+# `python -m lap_amd.build --variant=<v>`) instead of the production library.  Timing probes only; a missing file fails like the default.
+_LIB_PATH = pathlib.Path(__file__).resolve().parent / (
+    f"liblap_hip_{_os.environ['LAP_HIP_LIB_VARIANT']}.so" if _os.environ.get("LAP_HIP_LIB_VARIANT") else "liblap_hip.so")
 
 GEMM_OUT_F32 = 1
 GEMM_ACCUM = 2

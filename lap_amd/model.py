@@ -103,7 +103,9 @@ class LAP:
         self._chain_scratch = None
         self._packed_w = None       # [version, per layer (wqkv, wo, wgu, wd) packed images]
         self._den = None
-        ks = os.environ.get("LAP_PREFILL_KS", "4,1,8,5").split(",")    # K splits of the prefill's qkv / out / down projections, down's tile
+        # K splits of the prefill's qkv / out / down projections, down's tile.  Round 5 sweep incl. the consumer (tools/probes/
+        # prefill_down_sweep.py, us per GEMM + reduce / residual / norm): 256 x 256 x 8 65.0 | 320 x 128 (tile 19) x 8 60.8 | 320 x 256 x 16 64.5
+        ks = os.environ.get("LAP_PREFILL_KS", "4,1,8,19").split(",")
         self._prefill_ks = tuple(int(k) for k in ks)
         self._sfx = None        # the suffix stream's HIP stream (created on first use)
         # which gradients leave the data-gradient path for a third stream (see _off_path): s SigLIP weights, b biases, q / g the

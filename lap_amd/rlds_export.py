@@ -456,6 +456,10 @@ def episode_from_rlds(dataset_name: str, traj: dict, *, hash_bucket=None, rng=No
     kw = dict(hash_bucket=hash_bucket, rng=rng) if dataset_name in NEEDS_FALLBACK else {}
     std = STANDARDIZE[dataset_name](traj, **kw)
     prompt = decode_instruction(std["language_instruction"]) if "language_instruction" in std else ""
+    if dataset_name == "droid" and not prompt.strip():
+        # DROID carries three instructions per episode and the reference filters on the instruction TABLE, not on the first field
+        # (droid_dataset.py:113-120,215-229): an episode whose first instruction is blank keeps training on its 2nd / 3rd
+        prompt = next((a for a in (decode_instruction(std[k]) for k in ("language_instruction_2", "language_instruction_3") if k in std) if a.strip()), "")
     if not prompt.strip() or len(std["language_action"]) == 0:
         return None
     base_key, wrist_key = IMAGE_KEYS[dataset_name]

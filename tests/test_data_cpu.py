@@ -761,3 +761,14 @@ def test_exported_droid_episode_runs_through_the_train_loader_with_eef_labels():
     assert obs.state.shape == (4, 16) and bool(obs.image_masks["left_wrist_0_rgb"].all())
     stats, kind = loader.get_norm_stats_for_checkpoint()
     assert len(stats["actions"]["q99"]) == 16 and len(stats["state"]["q99"]) == 10
+
+
+def test_validation_pass_over_a_mixture_is_bounded_by_its_distinct_samples(setup):
+    """a mixture's len() is its weighted effective length (transitions x horizon / weight); one validation pass draws at most
+    as many samples as the member datasets hold."""
+    cfg, tok, eps_ds = setup
+    mix = D.MixtureDataset({"a": eps_ds, "b": eps_ds}, [("a", 1.0), ("b", 3.0)], seed=0)
+    assert len(mix) > mix.num_distinct_samples == 2 * len(eps_ds)
+    loader = D.create_data_loader(cfg, mix, tok, shuffle=False, seed=1, split="val")
+    n = sum(1 for _ in loader)
+    assert n == max(1, min(len(mix), mix.num_distinct_samples) // loader.batch_size)

@@ -172,6 +172,16 @@ def _checkpoint_round_trip(tmp, world, rank):
     assert ck.load_norm_stats(mngr.step_dir(5) / "assets")["state"]["std"] == [1.0]
     with pytest.raises(FileExistsError):
         ck.initialize_checkpoint_dir(tmp, keep_period=None, overwrite=False, resume=False)
+    # the engine-layout switches are part of the train_state meta: a resume under another layout is refused by NAME
+    import json
+    mp_ = mngr.step_dir(5) / "train_state" / "meta.json"
+    meta = json.loads(mp_.read_text())
+    assert meta["layout"] == ck._engine_layout(cfg)
+    if world == 1:
+        meta["layout"] = dict(meta["layout"], siglip_mlp_width=meta["layout"]["siglip_mlp_width"] + 256)
+        mp_.write_text(json.dumps(meta))
+        with pytest.raises(ValueError, match="LAP_SIGLIP_PAD"):
+            ck.restore_state(mngr, fresh(3), Loader())
     return "ok"
 
 

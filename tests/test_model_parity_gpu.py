@@ -209,9 +209,9 @@ def _check_loss_branch(cfg, B, ragged):
     torch.cuda.synchronize()
     ref_noise = abs(loss16.item() - loss32.item()) / abs(loss32.item())
     assert abs(loss.item() - loss32.item()) / abs(loss32.item()) < max(3 * ref_noise, 5e-3), (loss.item(), loss32.item(), loss16.item())
-    # the forward-only entry point returns the same loss (deterministic kernels)
+    # the forward-only entry point (nothing saved: the unfused GeGLU route, other rounding points than the training forward)
     loss_f, _ = model.compute_loss(0, to_observation(obs, DEV), actions.to(DEV), noise=noise.to(DEV), time=time.to(DEV))
-    assert abs(loss_f.item() - loss.item()) < 1e-6 * max(1.0, abs(loss.item()))
+    assert abs(loss_f.item() - loss.item()) < 1e-3 * max(1.0, abs(loss.item())), (loss_f.item(), loss.item())
     if cfg.enable_langact_training:
         assert rel(col["per_sample_lang"], m32["per_sample_lang"]) < 2e-2
     else:

@@ -26,10 +26,19 @@ tc = dataclasses.replace(get_config("lap_bench"), batch_size=B, fsdp_devices=1)
 state = init_train_state(tc, device=dev, world_size=1, rank=0, use_fsdp=False)
 runner = TrainingStepRunner(tc)
 batches = [synthetic_batch(tc.model, B, dev, seed=i) for i in range(2)]
-E = lambda *sh, dt=torch.bfloat16: torch.empty(sh, dtype=dt, device=dev)
+_zc = {}
+def E(*sh, dt=torch.bfloat16):
+    """A ZERO tensor of that shape, allocated once (the skipped kernels never write: it stays zero; garbage / NaN operands would
+    change the chip's clocks and make the ablation look better than it is)."""
+    k = (tuple(sh), dt)
+    if k not in _zc:
+        _zc[k] = torch.zeros(sh, dtype=dt, device=dev)
+    return _zc[k]
 small = lambda t: t is not None and t.shape[0] == B * S
 
-if "noexpert" in abl:
+ELEM = "noexpert" in abl or "noexpert_elem" in abl
+GEMM = "noexpert" in abl or "noexpert_gemm" in abl
+if ELEM or GEMM:
     o = {n: getattr(hip, n) for n in ("linear_fwd", "linear_dgrad", "linear_wgrad", "rmsnorm_fwd", "rmsnorm_bwd", "geglu_fwd", "geglu_bwd",
                                       "gated_residual_fwd", "gated_residual_bwd", "rope_split_fwd", "rope_split_bwd")}
     def linear_fwd(x, wt, out=None, **kw):
@@ -69,8 +78,9 @@ if "noexpert" in abl:
         if T_seg == S:
             return E(Bq * S, dq.shape[1] + 2 * dk.shape[1])
         return o["rope_split_bwd"](dq, dk, dv, pos, Bq, T_seg, *a, **kw)
+    gemm_names = ("linear_fwd", "linear_dgrad", "linear_wgrad")
     for n, f in list(locals().items()):
-        if n in o:
+        if n in o and ((n in gemm_names and GEMM) or (n not in gemm_names and ELEM)):
             setattr(hip, n, f)
 if "noopt" in abl:
     hip.adamw_ema = lambda *a, **k: None
@@ -79,7 +89,7 @@ if "noattn" in abl:
         outs = [E(Bq * q_len[s], NH * HD) if q[s] is not None else None for s in range(2)]
         return outs, (E(Bq, NH, q_len[0] + q_len[1], dt=torch.float32) if need_lse else None)
     def attention_bwd(q, k, v, o_, d_o, lse, q_len, k_len, *a, **kw):
-        f = lambda lst: [torch.empty_like(t) if t is not None else None for t in lst]
+        f = lambda lst: [E(*t.shape) if t is not None else None for t in lst]
         return f(q), f(k), f(v)
     hip.attention_fwd, hip.attention_bwd = attention_fwd, attention_bwd
 

@@ -1,15 +1,16 @@
-"""Serving prefill, Gemma down projection (560 x 2048 over K = 16384) as split-K partials + fused reduce / residual / next norm:
-tile x split candidates, timed as hipGraph replays of 20 back-to-back pairs.  Also the qkv (560 x 2560 x 2048) and out (560 x 2048 x 2048)
-projections' partial routes."""
+"""Gemma-2B down projection of the serving prefill (560 x 2048 x 16384) as split-K partials + fused reduce / residual / RMSNorm:
+tile x split sweep INCLUDING the consumer (more slabs cost the reduce pass more).  us per (GEMM + reduce) in a replayed graph.
+Also the qkv (560 x 2560 x 2048) and out (560 x 2048 x 2048) projections with their consumers."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from lap_amd import hip
-dev = "cuda"
+
+dev = torch.device("cuda")
 rnd = lambda *s: (torch.rand(*s, device=dev) * 2 - 1).bfloat16()
 
 
-def timed(fn, n=20, reps=10):
+def timed(fn, n=10, reps=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
@@ -23,27 +24,24 @@ def timed(fn, n=20, reps=10):
     return e0.elapsed_time(e1) / (n * reps) * 1e3
 
 
-scratch = hip._gemm_scratch(torch.device(dev))
-for name, (M, N, K) in {"down": (560, 2048, 16384), "out": (560, 2048, 2048), "qkv": (560, 2560, 2048)}.items():
-    a, w, res = rnd(M, K), rnd(N, K) * 0.05, rnd(M, N)
-    gamma = torch.randn(N, device=dev)
-    ref = None
-    line = [f"{name} {M}x{N}x{K}:"]
-    for tile in (5, 6, 15, 19, 16, 18):
-        for ks in (1, 2, 4, 8, 12, 16, 24, 32):
-            if K // ks < 512 or ks * M * N > scratch.numel():
-                continue
-            def fn():
-                part, k2 = hip.linear_partials(a, w, scratch, ksplit=ks, tile=tile)
-                return hip.fused_reduce_norm(part, k2, M, N, residual=res, norm=1, gamma=gamma)
-            try:
-                t = timed(fn)
-            except Exception as e:   # noqa: BLE001
-                line.append(f"t{tile}/k{ks}:{type(e).__name__}")
-                continue
-            x, h = fn()
-            if ref is None:
-                ref = x.float().clone()
-            err = ((x.float() - ref).abs().max() / ref.abs().max()).item()
-            line.append(f"t{tile}/k{ks}:{t:.1f}us" + ("" if err < 2e-2 else f"(err {err:.1e})"))
-    print(" ".join(line), flush=True)
+scratch = hip._gemm_scratch(dev)
+M, N, K = 560, 2048, 16384
+ws = [rnd(N, K) for _ in range(4)]      # rotate: every layer has its own weights (HBM-cold)
+a, res = rnd(M, K), rnd(M, N)
+gamma = torch.zeros(N, device=dev)
+i = [0]
+for tile, splits in ((5, (4, 8, 16)), (15, (4, 8, 16)), (19, (4, 8, 16)), (6, (4, 8, 16)), (16, (8, 16, 32))):
+    line = [f"down t{tile}:"]
+    for ks in splits:
+        def fn():
+            i[0] = (i[0] + 1) % 4
+            part, k2 = hip.linear_partials(a, ws[i[0]], scratch, ksplit=ks, tile=tile)
+            hip.fused_reduce_norm(part, k2, M, N, residual=res, norm=1, gamma=gamma)
+        def fn_g():
+            i[0] = (i[0] + 1) % 4
+            hip.linear_partials(a, ws[i[0]], scratch, ksplit=ks, tile=tile)
+        try:
+            line.append(f"k{ks}: {timed(fn):6.1f} (gemm {timed(fn_g):6.1f})")
+        except Exception as e:   # noqa: BLE001
+            line.append(f"k{ks}: {type(e).__name__}")
+    print("  ".join(line), flush=True)
