@@ -236,31 +236,63 @@ __global__ __launch_bounds__(256) void gated_res_fwd_kernel(const bf16* __restri
   }
   st8(y + r * D + c, o);
 }
-// One block per (sample, 8-column chunk group): du = dy*gate ; dgate[b] = sum_rows dy*u.
+// du = dy * gate;  dgate[b] = sum over the sample's rows of dy * u.  One block per (sample, 32 chunks of 8 columns): 32 column
+// lanes x 8 ROW lanes — row lane j takes rows j, j + 8, ... with all its loads in flight, then the 8 partial sums meet in LDS and
+// are added in row-lane order (deterministic).  (Round 5; before: one thread per chunk walking the sample's 50 rows one after the
+// other, 32 blocks: 29 - 81 us per launch on the action expert's stream.)
 __global__ __launch_bounds__(256) void gated_res_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ u,
                                                             const bf16* __restrict__ gate, bf16* __restrict__ du,
                                                             float* __restrict__ dgate, int D8, int rps, int ldg,
                                                             int ldg_out) {
+  __shared__ float part[8][32][8];
   const int b = blockIdx.y;
-  const int c8 = blockIdx.x * 256 + threadIdx.x;
-  if (c8 >= D8) return;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c8 = blockIdx.x * 32 + cl;
+  const bool live = c8 < D8;
   const int c = c8 * 8;
   const long long D = (long long)D8 * 8;
   float gv[8], acc[8];
-  ld8(gate + (long long)b * ldg + c, gv);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  for (int t = 0; t < rps; ++t) {
-    const long long r = (long long)b * rps + t;
-    float d[8], uv[8], o[8];
-    ld8(dy + r * D + c, d);
-    ld8(u + r * D + c, uv);
+  for (int e = 0; e < 8; ++e) { acc[e] = 0.f; gv[e] = 0.f; }
+  if (live) {
+    ld8(gate + (long long)b * ldg + c, gv);
+    constexpr int U = 4;       // rows in flight per thread
+    for (int t0 = rl; t0 < rps; t0 += 8 * U) {
+      bf16x8 dv[U], uv[U];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { o[e] = d[e] * gv[e]; acc[e] += d[e] * uv[e]; }
-    st8(du + r * D + c, o);
+      for (int i = 0; i < U; ++i) {
+        const int t = t0 + 8 * i;
+        if (t < rps) {
+          const long long r = (long long)b * rps + t;
+          dv[i] = *reinterpret_cast<const bf16x8*>(dy + r * D + c);
+          uv[i] = *reinterpret_cast<const bf16x8*>(u + r * D + c);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const int t = t0 + 8 * i;
+        if (t < rps) {
+          const long long r = (long long)b * rps + t;
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = (float)dv[i][e]; o[e] = d * gv[e]; acc[e] += d * (float)uv[i][e]; }
+          st8(du + r * D + c, o);
+        }
+      }
+    }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) dgate[(long long)b * ldg_out + c + e] = acc[e];
+  for (int e = 0; e < 8; ++e) part[rl][cl][e] = acc[e];
+  __syncthreads();
+  if (rl == 0 && live) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t += part[j][cl][e];
+      dgate[(long long)b * ldg_out + c + e] = t;
+    }
+  }
 }
 
 // ----------------------------------------------------------------- casts/copies
@@ -680,7 +712,7 @@ extern "C" int lap_gated_residual_fwd(const void* x, const void* u, const void* 
 extern "C" int lap_gated_residual_bwd(const void* dy, const void* u, const void* gate, void* du, float* dgate, int rows,
                                       int D, int rows_per_sample, int ldg, int ldg_out, void* stream) {
   if (rows <= 0 || (D & 7) || !gate || rows_per_sample <= 0 || rows % rows_per_sample || (ldg & 7)) return LAP_ERR_ARG;
-  dim3 grid((D / 8 + 255) / 256, rows / rows_per_sample);
+  dim3 grid((D / 8 + 31) / 32, rows / rows_per_sample);
   hipLaunchKernelGGL(gated_res_bwd_kernel, grid, dim3(256), 0, S_, (const bf16*)dy, (const bf16*)u, (const bf16*)gate,
                      (bf16*)du, dgate, D / 8, rows_per_sample, ldg, ldg_out);
   LAP_CHECK_LAUNCH();

@@ -191,7 +191,8 @@ class LAP:
     @contextlib.contextmanager
     def _off_path(self, *tensors):
         wg = self._wg
-        if wg is None or torch.cuda.current_stream() != self._wg_main:
+        cur = torch.cuda.current_stream()
+        if wg is None or cur != self._wg_main:
             yield
             return
         wg.wait_stream(self._wg_main)
