@@ -126,6 +126,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
       offB[j] = (n0 + c * 8 < p.N) ? (unsigned)(((long long)kr * p.ldb + n0 + c * 8) * 2) : OOB;
     }
   }
+  const int kt0_probe = blockIdx.y * p.ktiles_per_split + NS - 1;
   unsigned stepA = A_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.lda * 2);
   unsigned stepB = B_KC ? (unsigned)(BK * 2) : (unsigned)((long long)BK * p.ldb * 2);
 #ifdef LAP_GEMM_EXPERIMENTAL
@@ -146,18 +147,43 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
   }
 #endif
 
+  // K a multiple of the k-tile (every production shape): no piece ever reaches past K, so a piece's per-lane offset is the
+  // loop-invariant offA / offB (OOB for rows outside the matrix: 0x80000000 is out of range whatever is added) and the k-tile's
+  // byte offset travels in the instruction's SCALAR offset — no per-piece compare / select / add in the loop (round 5: the
+  // small-tile loops issue ~100 instructions per k-step around 8 - 16 MFMAs; the selects and their exec-mask branches were 40).
+  const bool k_even = (p.K % BK) == 0;
+#ifdef LAP_GEMM_EXPERIMENTAL
+  const bool probe_no_dma = p.dbg & 32, probe_no_mma = p.dbg & 64;   // timing ablations of the k-loop (results wrong)
+#else
+  constexpr bool probe_no_dma = false, probe_no_mma = false;
+#endif
   auto stage = [&](int buf, int kt) {
     const int k0 = kt * BK;
     char* base = smem + buf * STAGE;
+    if (probe_no_dma && kt >= kt0_probe) return;
+    if (k_even) {
+      const unsigned sa = (unsigned)kt * stepA, sb = (unsigned)kt * stepB;
 #pragma unroll
-    for (int j = 0; j < PA; ++j) {
-      unsigned va = (offA[j] != OOB && k0 + kidxA[j] < p.K) ? offA[j] + (unsigned)kt * stepA : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(base + (w * PA + j) * 1024), 16, va, 0, 0, 0);
-    }
+      for (int j = 0; j < PA; ++j) {
+        const unsigned va = offA[j];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(base + (w * PA + j) * 1024), 16, va, sa, 0, 0);
+      }
 #pragma unroll
-    for (int j = 0; j < PB; ++j) {
-      unsigned vb = (offB[j] != OOB && k0 + kidxB[j] < p.K) ? offB[j] + (unsigned)kt * stepB : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(base + A_BYTES + (w * PB + j) * 1024), 16, vb, 0, 0, 0);
+      for (int j = 0; j < PB; ++j) {
+        const unsigned vb = offB[j];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(base + A_BYTES + (w * PB + j) * 1024), 16, vb, sb, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        unsigned va = (offA[j] != OOB && k0 + kidxA[j] < p.K) ? offA[j] + (unsigned)kt * stepA : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(base + (w * PA + j) * 1024), 16, va, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        unsigned vb = (offB[j] != OOB && k0 + kidxB[j] < p.K) ? offB[j] + (unsigned)kt * stepB : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(base + A_BYTES + (w * PB + j) * 1024), 16, vb, 0, 0, 0);
+      }
     }
   };
 
@@ -220,6 +246,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
           else if (RAW_KC) lds_tie(fb[j]);
         }
       }
+      if (!probe_no_mma) {
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -227,6 +254,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
           // Operands swapped on purpose: D[row = n][col = m], so each lane ends up
           // with 4 consecutive n of one output row m -> one 8/16-byte store.
           acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+      }
     }
     cur = (cur + 1 == NS) ? 0 : cur + 1;
   }
