@@ -138,7 +138,7 @@ class GemmMeter:
                     self.second.append(2.0 * M * N * K); self.second_ev.append((s, e))
                 else:
                     self.records.append((s, e, 2.0 * M * N * K))
-                    sig = ("fused", name, M, N, K, args[0].stride(0))
+                    sig = ("fused", name, M, N, K, args[0].stride(0), args[2].dtype if name == "linear_wgrad_sumsq" else None)
                     self.shapes[sig] = self.shapes.get(sig, 0) + 1
                 return r
             setattr(self.hip, name, fn)
@@ -175,11 +175,11 @@ class GemmMeter:
         rows = []
         for sig, cnt in self.shapes.items():
             if sig[0] == "fused":
-                _, name, M, N, K, lda = sig
+                _, name, M, N, K, lda, odt = sig
                 fn = self.fused_orig[name]
-                if name == "linear_wgrad_sumsq":     # (lda = the row stride of dy: the engine pads d(gate|up))
+                if name == "linear_wgrad_sumsq":     # (lda = the row stride of dy: the engine pads d(gate|up); odt: f32 or bf16 gradient buffer)
                     dy, x = rnd(K, lda)[:, :M], rnd(K, N)
-                    o, acc = torch.empty(M, N, device=dev), torch.zeros(1, device=dev)
+                    o, acc = torch.empty(M, N, device=dev, dtype=odt), torch.zeros(1, device=dev)
                     call, label = (lambda: fn(dy, x, o, acc)), f"TN {M}x{N}x{K}"
                 elif name == "linear_geglu_train":
                     x, w = rnd(M, lda)[:, :K], rnd(N, K) * 0.05

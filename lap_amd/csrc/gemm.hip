@@ -1537,6 +1537,24 @@ extern "C" int lap_gemm_wgrad_f32(const void* A, const void* B, void* C, int M, 
   return lap_gemm_bf16_ex(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, 1.0f, 0, 0, LAP_GEMM_OUT_F32, -1, 0, scratch, scratch_bytes, stream);
 }
 
+// The same for a weight gradient stored as bf16 (dW [M][N] bf16; ParamStore.grad_dtype): the bf16 assembly kernels fold the squares of
+// their f32 accumulators.
+extern "C" int lap_gemm_wgrad_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, float* sumsq,
+                                   int* folded, void* scratch, long long scratch_bytes, void* stream) {
+  if (!folded) return LAP_ERR_ARG;
+  *folded = 0;
+  static const bool no_asm = getenv("LAP_GEMM_NO_ASM") != nullptr;
+  if (sumsq && !no_asm && M > 0 && N > 0 && lap_gemm_asm_ok(0, 0, 0, M, N, K, lda, ldb, ldc)) {
+    const long long t5 = (long long)(M / 256) * (N / 256);
+    const double fill = (double)t5 / (256.0 * ((t5 + 255) / 256));
+    if (t5 >= 128 && fill >= 0.8) {
+      *folded = 1;
+      return lap_gemm_asm_wgrad_b16(A, B, C, M, N, K, lda, ldb, ldc, sumsq, stream);
+    }
+  }
+  return lap_gemm_bf16_ex(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, 1.0f, 0, 0, 0, -1, 0, scratch, scratch_bytes, stream);
+}
+
 extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const void* bias, const void* residual,
                                 int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha,
                                 int a_kc, int b_kc, int flags, int tile, int ksplit, void* scratch,

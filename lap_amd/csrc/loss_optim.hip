@@ -138,13 +138,39 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) atomicAdd(out, acc);
 }
 
+// The same sum over a BF16 gradient buffer (round 5: the GEMM-produced weight gradients are stored as bf16, what the reference's
+// cast boundary hands its f32 master): 8 values per 16-byte load, squares accumulated in f32.
+__global__ __launch_bounds__(256) void sumsq_bf16_kernel(const bf16* __restrict__ x, long long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const long long chunk = 8192;                                  // elements per block and iteration (16 KiB)
+  long long base = (long long)blockIdx.x * chunk;
+  const long long step = (long long)gridDim.x * chunk;
+  const int t8 = threadIdx.x * 8;
+  auto sq8 = [](bf16x8 t) { float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float f = (float)t[e]; s += f * f; }
+    return s; };
+  for (; base + chunk <= n; base += step) {
+    const bf16* p = x + base + t8;
+    const bf16x8 t0 = *reinterpret_cast<const bf16x8*>(p), t1 = *reinterpret_cast<const bf16x8*>(p + 2048);
+    const bf16x8 t2 = *reinterpret_cast<const bf16x8*>(p + 4096), t3 = *reinterpret_cast<const bf16x8*>(p + 6144);
+    a0 += sq8(t0); a1 += sq8(t1); a2 += sq8(t2); a3 += sq8(t3);
+  }
+  if (base < n) {
+    for (long long j = base + threadIdx.x; j < n && j < base + chunk; j += 256) { const float f = (float)x[j]; a0 += f * f; }
+  }
+  const float acc = block_sum<4>((a0 + a1) + (a2 + a3), red);
+  if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+
 // Two parameters per thread and iteration, 32 VGPRs: an optimizer wave fits next to the 256x256 GEMM's 4 waves x 120
 // VGPRs per SIMD, so the side-stream optimizer never evicts GEMM blocks of the next forward.  (Measured: the step time
 // does not change versus a 54-VGPR version - the ~26 ms the overlapped optimizer still costs per step is HBM contention
 // of its 38 B / parameter with the GEMMs' operand traffic, not CU occupancy.)
-template <bool NT>
+template <bool NT, bool G16>      // G16: the gradient buffer holds bf16 (read as 2 x bf16 = 4 bytes per pair of parameters)
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float* __restrict__ ema,
-                      const float* __restrict__ g, bf16* __restrict__ p16, bf16* __restrict__ p16lo, long long n, const float* __restrict__ sc,
+                      const void* __restrict__ g, bf16* __restrict__ p16, bf16* __restrict__ p16lo, long long n, const float* __restrict__ sc,
                       float b1, float b2, float eps, float wd, float max_norm) {
   const float gnorm = sqrtf(sc[0]);
   // optax.clip_by_global_norm: g if norm < max_norm else g / norm * max_norm
@@ -165,7 +191,13 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, f
       auto ldf = [](const f32x2* q) { return NT ? __builtin_nontemporal_load(q) : *q; };
       auto stf = [](f32x2* q, f32x2 val) { if (NT) __builtin_nontemporal_store(val, q); else *q = val; };
       f32x2 pv = ldf(cat(p, o)), mv = ldf(cat(m, o)), vv = ldf(cat(v, o));
-      const f32x2 gv = ldf(cat(g, o));
+      f32x2 gv;
+      if constexpr (G16) {
+        const bf16x2 gq = *reinterpret_cast<const bf16x2*>(reinterpret_cast<const char*>(g) + (o >> 1));
+        gv[0] = (float)gq[0]; gv[1] = (float)gq[1];
+      } else {
+        gv = ldf(cat(reinterpret_cast<const float*>(g), o));
+      }
       f32x2 ev = {0.f, 0.f};
       if (ema_on) ev = ldf(cat(ema, o));
 #pragma unroll
@@ -324,8 +356,8 @@ extern "C" int lap_sumsq_f32(const float* x, long long n, float* sumsq, void* st
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
-static int adamw_launch(float* p, float* m, float* v, float* ema, const float* g, void* p16, void* p16lo, long long n,
-                        const float* scalars, float b1, float b2, float eps, float wd, float max_norm, void* stream) {
+static int adamw_launch(float* p, float* m, float* v, float* ema, const void* g, void* p16, void* p16lo, long long n,
+                        const float* scalars, float b1, float b2, float eps, float wd, float max_norm, void* stream, bool g16 = false) {
   if (n <= 0 || (n & 1) || !scalars) return LAP_ERR_ARG;
   static const long long cap = getenv("LAP_ADAMW_BLOCKS") ? atoll(getenv("LAP_ADAMW_BLOCKS")) : 4096;   // tuning knob (tools/ab_bench.sh)
   const long long CH = 1LL << 29;
@@ -333,14 +365,13 @@ static int adamw_launch(float* p, float* m, float* v, float* ema, const float* g
     const long long cnt = n - o < CH ? n - o : CH;
     const long long blocks = (cnt + 511) / 512;
     static const bool nt = getenv("LAP_ADAMW_NT") ? atoi(getenv("LAP_ADAMW_NT")) != 0 : true;   // (-1.8 ms per train step: tools/ab3.sh)
-    if (nt)
-      hipLaunchKernelGGL(adamw_ema_kernel<true>, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, p + o, m + o, v + o,
-                         ema ? ema + o : nullptr, g + o, p16 ? (bf16*)p16 + o : nullptr, p16lo ? (bf16*)p16lo + o : nullptr, cnt, scalars, b1, b2,
-                         eps, wd, max_norm);
-    else
-      hipLaunchKernelGGL(adamw_ema_kernel<false>, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, p + o, m + o, v + o,
-                         ema ? ema + o : nullptr, g + o, p16 ? (bf16*)p16 + o : nullptr, p16lo ? (bf16*)p16lo + o : nullptr, cnt, scalars, b1, b2,
-                         eps, wd, max_norm);
+    const void* go = g16 ? (const void*)((const bf16*)g + o) : (const void*)((const float*)g + o);
+#define ADAMW_GO(NT_, G16_) hipLaunchKernelGGL((adamw_ema_kernel<NT_, G16_>), dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, p + o, m + o, \
+                         v + o, ema ? ema + o : nullptr, go, p16 ? (bf16*)p16 + o : nullptr, p16lo ? (bf16*)p16lo + o : nullptr, cnt, scalars, b1, b2,     \
+                         eps, wd, max_norm)
+    if (nt) { if (g16) ADAMW_GO(true, true); else ADAMW_GO(true, false); }
+    else { if (g16) ADAMW_GO(false, true); else ADAMW_GO(false, false); }
+#undef ADAMW_GO
     LAP_CHECK_LAUNCH();
   }
   return LAP_OK;
@@ -349,6 +380,19 @@ extern "C" int lap_adamw_ema(float* p, float* m, float* v, float* ema, const flo
                              const float* scalars, float b1, float b2, float eps, float wd, float max_norm,
                              void* stream) {
   return adamw_launch(p, m, v, ema, g, p16, nullptr, n, scalars, b1, b2, eps, wd, max_norm, stream);
+}
+extern "C" int lap_adamw_ema_g16(float* p, float* m, float* v, float* ema, const void* g16, void* p16, long long n,
+                                 const float* scalars, float b1, float b2, float eps, float wd, float max_norm,
+                                 void* stream) {
+  if (!g16 || ((uintptr_t)g16 & 3)) return LAP_ERR_ARG;
+  return adamw_launch(p, m, v, ema, g16, p16, nullptr, n, scalars, b1, b2, eps, wd, max_norm, stream, true);
+}
+extern "C" int lap_sumsq_bf16(const void* x, long long n, float* sumsq, void* stream) {
+  if (n <= 0 || !x || !sumsq || ((uintptr_t)x & 15)) return LAP_ERR_ARG;
+  const long long blocks = (n + 8191) / 8192;
+  hipLaunchKernelGGL(sumsq_bf16_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, S_, (const bf16*)x, n, sumsq);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
 }
 extern "C" int lap_adamw_ema_hilo(float* p, float* m, float* v, float* ema, const float* g, void* p16, void* p16lo, long long n,
                                   const float* scalars, float b1, float b2, float eps, float wd, float max_norm,

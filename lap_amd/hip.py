@@ -111,6 +111,8 @@ SIGNATURES: dict[str, list] = {
     "lap_gemm_asm_geglu_fwd_ok": [_i, _i, _i, _i, _i, _i, _i],
     "lap_gemm_asm_wgrad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "lap_gemm_wgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _ll, _vp],
+    "lap_gemm_asm_wgrad_b16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "lap_gemm_wgrad_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _ll, _vp],
     "lap_gemm_asm_bias_gelu": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_asm_gelu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lap_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
@@ -175,6 +177,8 @@ SIGNATURES: dict[str, list] = {
     "lap_ce_chunk_grad_hilo": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lap_adamw_ema_hilo": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _vp],
     "lap_sumsq_f32": [_vp, _ll, _vp, _vp],
+    "lap_sumsq_bf16": [_vp, _ll, _vp, _vp],
+    "lap_adamw_ema_g16": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _vp],
     "lap_argmax_rows_f32": [_vp, _i, _i, _i, _vp, _vp],
     "lap_adamw_ema": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _vp],
     "lap_fm_mix": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
@@ -298,7 +302,8 @@ def linear_wgrad(dy, x, out, *, accum=False, ksplit=0, tile=-1):
                 b_kc=False, accum=accum, ksplit=ksplit, tile=tile)
 
 
-ASM_KERNELS = ("nt", "nn", "tn", "nt_bias", "tn_t", "nt_res", "nt_bias_res", "nn_geglu_bwd", "nt_geglu", "nn_gelu_bwd", "nt_bias_gelu")
+ASM_KERNELS = ("nt", "nn", "tn", "nt_bias", "tn_t", "nt_res", "nt_bias_res", "nn_geglu_bwd", "nt_geglu", "nn_gelu_bwd", "nt_bias_gelu",
+               "tn_b16", "tn_t_b16")
 
 
 def gemm_asm_launch_counts() -> dict:
@@ -309,15 +314,17 @@ def gemm_asm_launch_counts() -> dict:
 
 
 def linear_wgrad_sumsq(dy, x, out, sumsq):
-    """dWt[out, in] (f32) = dy^T x like linear_wgrad, and where the assembly kernel takes the product sum(dWt^2) is added to the
+    """dWt[out, in] (f32, or bf16: ParamStore.grad_dtype) = dy^T x like linear_wgrad, and where the assembly kernel takes the product sum(dWt^2) is added to the
     one-element f32 tensor `sumsq` on the way out; returns whether that happened (else the caller still owes the norm a pass)."""
     import ctypes
     Mrows, Nout = dy.shape
     Kin = x.shape[1]
-    _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(out, torch.float32, "out"); _req(sumsq, torch.float32, "sumsq")
+    _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(sumsq, torch.float32, "sumsq")
+    if out.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("linear_wgrad_sumsq: out must be f32 or bf16")
     folded = ctypes.c_int(0)
     scratch = _gemm_scratch(dy.device)
-    call("lap_gemm_wgrad_f32", _p(dy), _p(x), _p(out), Nout, Kin, Mrows, dy.stride(0), x.stride(0), out.stride(0), _p(sumsq),
+    call("lap_gemm_wgrad_f32" if out.dtype == torch.float32 else "lap_gemm_wgrad_bf16", _p(dy), _p(x), _p(out), Nout, Kin, Mrows, dy.stride(0), x.stride(0), out.stride(0), _p(sumsq),
          ctypes.byref(folded), _p(scratch), scratch.numel() * 4)
     return bool(folded.value)
 
@@ -725,10 +732,20 @@ def ce_chunk_grad(logits, target, m, l, w, dlogits, v0, dlogits_lo=None):
 
 
 def sumsq_f32(x, out):
+    """out[0] += sum x^2; x: an f32 or a bf16 gradient buffer (squares accumulated in f32 either way)."""
+    if x.dtype == torch.bfloat16:
+        call("lap_sumsq_bf16", _p(x), x.numel(), _p(out))
+        return
     call("lap_sumsq_f32", _p(x), x.numel(), _p(out))
 
 
 def adamw_ema(p, m, v, ema, g, p16, scalars, b1, b2, eps, wd, max_norm, p16lo=None):
+    if g.dtype == torch.bfloat16:       # GEMM-produced weight gradients (round 5): bf16 gradient buffer
+        if p16lo is not None:
+            raise ValueError("the hi / lo unit (embedding table) keeps f32 gradients")
+        call("lap_adamw_ema_g16", _p(p), _p(m), _p(v), _p(ema), _p(g), _p(p16), p.numel(), _p(scalars), float(b1), float(b2),
+             float(eps), float(wd), float(max_norm))
+        return
     if p16lo is not None:
         call("lap_adamw_ema_hilo", _p(p), _p(m), _p(v), _p(ema), _p(g), _p(p16), _p(p16lo), p.numel(), _p(scalars), float(b1), float(b2),
              float(eps), float(wd), float(max_norm))

@@ -1088,7 +1088,8 @@ class LAP:
         return self._loss_impl(rng, observation, actions, train=train, noise=noise, time=time, backward=False, collect=collect)
 
     def loss_and_grad(self, rng, observation, actions, *, train: bool = True, noise=None, time=None, collect=None):
-        """Forward + backward; gradients land in self.ps.grad (f32, engine layout).  Caller zeroes them first."""
+        """Forward + backward; gradients land in self.ps.grad (engine layout; bf16 for the GEMM-weight units, f32 for the embedding table and
+        the small unit: ParamStore.grad_dtype).  The caller zeroes the accumulated (f32) units first."""
         return self._loss_impl(rng, observation, actions, train=train, noise=noise, time=time, backward=True, collect=collect)
 
     # ================================================================== serving

@@ -147,8 +147,8 @@ class ParamStore:
         self.m: dict[str, torch.Tensor] = {}
         self.v: dict[str, torch.Tensor] = {}
         self.ema: dict[str, torch.Tensor] = {}
-        self.grad: dict[str, torch.Tensor] = {}     # unit -> f32 full gradient buffer [padded numel]
-        self.gshard: dict[str, torch.Tensor] = {}   # unit -> f32 gradient shard (aliases grad when N == 1)
+        self.grad: dict[str, torch.Tensor] = {}     # unit -> full gradient buffer [padded numel], f32 or bf16 (grad_dtype)
+        self.gshard: dict[str, torch.Tensor] = {}   # unit -> gradient shard of the same dtype (aliases grad when N == 1)
         self.version = 0                            # bumped whenever parameter values change (derived copies re-quantise)
         self.frozen: dict[str, bool] = {}           # engine tensor -> excluded from gradient / optimizer (set_frozen)
         self._train_ranges: dict[str, list] = {}    # unit -> [(a, b)] trainable ranges in unit coordinates
@@ -163,14 +163,29 @@ class ParamStore:
                 if u.name == "embed":
                     self.lo16[u.name] = z(n, torch.bfloat16)
             if with_grads:
-                self.grad[u.name] = z(n)
-                self.gshard[u.name] = self.grad[u.name] if self.sharded(u) is False else z(sh)
+                gdt = self.grad_dtype(u)
+                self.grad[u.name] = z(n, gdt)
+                self.gshard[u.name] = self.grad[u.name] if self.sharded(u) is False else z(sh, gdt)
             if with_optimizer:
                 self.m[u.name], self.v[u.name] = z(sh), z(sh)
             if with_ema:
                 self.ema[u.name] = z(sh)
 
     # ---- geometry
+    @staticmethod
+    def grad_dtype(u: UnitSpec) -> torch.dtype:
+        """bf16 for the units whose tensors are all weights of bf16 GEMMs with ONE weight-gradient product each (SigLIP blocks, image
+        head, joint Gemma layers, the adaRMS bank): the reference multiplies `w.astype(bf16)` (gemma.py:307,318; lora.Einsum; Flax
+        Dense with dtype=bf16), so the cotangent that reaches its f32 master is a bf16-rounded product — here the weight-gradient
+        GEMM's epilogue rounds once and stores 2 bytes.  -11.3 GB of HBM traffic per train step at N = 1 (the GEMMs' stores and
+        the optimizer's reads) and half the FSDP reduce-scatter volume.  f32 stays where gradients are ACCUMULATED: the embedding
+        table (LM-head product + scatter-add of the prompt tokens' rows) and the small replicated unit (atomics).
+        LAP_GRAD_BF16=0: f32 everywhere (A/B runs, the pre-round-5 layout)."""
+        import os
+        if u.big and u.name != "embed" and os.environ.get("LAP_GRAD_BF16", "1") != "0":
+            return torch.bfloat16
+        return torch.float32
+
     def sharded(self, u: UnitSpec) -> bool:
         return u.big and self.world_size > 1
 

@@ -39,8 +39,11 @@ def _worker(rank, world, port, ret):
         assert rows.shape[1] == D and (hi - lo) * D == rows.numel() and lo == rank * (hi - lo)
         # gradients: rank r contributes (r+1) * g  ->  reduce-scatter gives 3 g on every shard
         g = torch.Generator().manual_seed(0)
-        # (bf16-representable values: (rank + 1) * g and their sum over up to 8 ranks are exact in f32 in ANY summation order)
-        gfull = {u.name: torch.randn(ps.padded(u), generator=g).bfloat16().float() for u in ps.units}
+        # (small integers: (rank + 1) * g and their sum over up to 8 ranks stay below 256, i.e. exact in BF16 — the gradient buffers of
+        #  the GEMM-weight units hold bf16 since round 5 — and in f32, in ANY summation order)
+        gfull = {u.name: torch.randint(-3, 4, (ps.padded(u),), generator=g).float() for u in ps.units}
+        assert {ps.grad[u.name].dtype for u in ps.units} == {torch.float32, torch.bfloat16}
+        assert all(ps.gshard[u.name].dtype == ps.grad[u.name].dtype == ps.grad_dtype(u) for u in ps.units)
         for u in ps.units:
             ps.grad[u.name].copy_(gfull[u.name] * (rank + 1))
             comm.grads_ready(u.name)
@@ -48,11 +51,11 @@ def _worker(rank, world, port, ret):
         scale = sum(range(1, world + 1))
         for u in ps.units:
             a, b = ps.shard_range(u)
-            assert torch.allclose(ps.gshard[u.name], gfull[u.name][a:b] * scale), u.name
+            assert torch.equal(ps.gshard[u.name].float(), gfull[u.name][a:b] * scale), u.name
         # sharded update + in-place all-gather of the bf16 mirror == unsharded update
         for u in ps.units:
             a, b = ps.shard_range(u)
-            newp, _, _ = O.adamw_step(ps.master[u.name], ps.gshard[u.name], ps.m[u.name], ps.v[u.name], 1, 1e-3)
+            newp, _, _ = O.adamw_step(ps.master[u.name], ps.gshard[u.name].float(), ps.m[u.name], ps.v[u.name], 1, 1e-3)
             ps.master[u.name].copy_(newp)
             if u.big:
                 ps.full16[u.name][a:b].copy_(newp)

@@ -134,14 +134,17 @@ def test_gemm_pingpong_matches_single_phase_bitwise(hip):
                 assert torch.equal(gp, g2), (pp, m, n, k)
 
 
-@pytest.mark.parametrize("lay", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("lay", ["nt", "nn", "tn", "tn16"])
 def test_gemm_assembly_kernels_match_hip_tiles_bitwise(hip, lay):
     """csrc/gemm_asm_kernels.s (tile 14): forward / data-gradient / weight-gradient layouts; same accumulation order as the HIP
     tiles, so the outputs must be identical bit for bit — also with a last partial group of m-tiles (9 = 2 * 4 + 1 m-tiles,
     5 n-tiles), fewer tiles than persistent blocks, more tiles than blocks (several tiles per block: the operand stream runs
     across the tile seam), and row strides larger than the row."""
+    # "tn16" (round 5): the weight-gradient layout stored as bf16 (lap_gemm_asm_tn_b16 / _tn_t_b16 for tall outputs): the f32 kernels'
+    # ring main loop with the forward kernels' bf16 staged epilogue, against the HIP tile's bf16 output of the same product
     a_kc, b_kc, f32 = lay[0] == "n", lay[1] == "t", lay == "tn"
     dt = torch.float32 if f32 else torch.bfloat16
+    before = hip.gemm_asm_launch_counts()
     for M, N, K, pad in [(256, 512, 512, 0), (2304, 1280, 512, 0), (1024, 768, 1152, 64), (5120, 4096, 640, 0), (9216, 8192, 512, 0)]:
         a = rnd(M, K + pad, seed=1)[:, :K] if a_kc else rnd(K, M + pad, seed=1)[:, :M]
         b = rnd(N, K + pad, seed=2)[:, :K] if b_kc else rnd(K, N + pad, seed=2)[:, :N]
@@ -155,6 +158,27 @@ def test_gemm_assembly_kernels_match_hip_tiles_bitwise(hip, lay):
         af = a.float() if a_kc else a.float().t()
         bf = b.float().t() if b_kc else b.float()
         assert rel_err(outs[1][:, :N], af @ bf) < (1e-5 if f32 else 5e-3)
+    if lay == "tn16":      # both kernels ran (wide outputs: tn_b16; tall ones: the swapped product with transposed stores)
+        ran = {k: v - before[k] for k, v in hip.gemm_asm_launch_counts().items()}
+        assert ran["tn_b16"] >= 1 and ran["tn_t_b16"] >= 2 and ran["tn"] == ran["tn_t"] == 0, ran
+        # ... and the automatic route takes a bf16 weight gradient with filled rounds to them (linear_wgrad's choice in the train step)
+        dy, x = rnd(1024, 4096, seed=5), rnd(1024, 8192, seed=6)
+        g16 = torch.empty(4096, 8192, device=DEV, dtype=torch.bfloat16)
+        hip.linear_wgrad(dy, x, g16)
+        g32 = torch.empty(4096, 8192, device=DEV)
+        hip.linear_wgrad(dy, x, g32)
+        assert torch.equal(g16, g32.bfloat16()) and hip.gemm_asm_launch_counts()["tn_b16"] > before["tn_b16"] + ran["tn_b16"]
+        # ... and with the gradient norm folded in: same bits, the sum of squares of the stored values to 1e-5
+        ss = torch.zeros(1, device=DEV)
+        g16f = torch.empty_like(g16)
+        assert hip.linear_wgrad_sumsq(dy, x, g16f, ss) and torch.equal(g16f, g16)
+        assert rel_err(ss, (g16.double() ** 2).sum().float().view(1)) < 1e-5
+        dyt, xt = rnd(1024, 8192, seed=7), rnd(1024, 4096, seed=8)          # tall output: transposed stores
+        gt, sst = torch.empty(8192, 4096, device=DEV, dtype=torch.bfloat16), torch.zeros(1, device=DEV)
+        assert hip.linear_wgrad_sumsq(dyt, xt, gt, sst)
+        gt_ref = torch.empty(8192, 4096, device=DEV, dtype=torch.bfloat16)
+        hip.gemm(dyt, xt, gt_ref, M=8192, N=4096, K=1024, lda=8192, ldb=4096, ldc=4096, a_kc=False, b_kc=False, tile=12, ksplit=1)
+        assert torch.equal(gt, gt_ref) and rel_err(sst, (gt.double() ** 2).sum().float().view(1)) < 1e-5
     # what the automatic choice routes here: a plain forward product with filled rounds
     if lay == "nt":
         a, b = rnd(4096, 512, seed=3), rnd(2048, 512, seed=4)
@@ -1087,6 +1111,21 @@ def test_adamw_ema_and_sumsq(hip):
     er = ed * e0 + (1 - ed) * pr
     assert rel_err(m, mr) < 1e-6 and rel_err(v, vr) < 1e-6 and rel_err(p, pr) < 1e-6 and rel_err(ema, er) < 1e-6
     assert torch.equal(p16, p.bfloat16())
+    # bf16 gradient buffers (round 5: the GEMM-weight units): the same pass reading 2 bytes per gradient must equal the f32 pass on the
+    # widened values bit for bit; the norm pass accumulates the squares of the bf16 values in f32
+    for n2 in (10006, 4 * 8192 + 24):
+        g16 = rnd(n2, dtype=torch.float32, scale=3.0, seed=11).bfloat16()
+        ss16, ss32 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+        hip.sumsq_f32(g16, ss16); hip.sumsq_f32(g16.float(), ss32)
+        assert rel_err(ss16, (g16.double() ** 2).sum().float().view(1)) < 1e-5 and rel_err(ss16, ss32) < 1e-5
+        st = [rnd(n2, dtype=torch.float32, seed=12 + i) for i in range(4)]
+        st[2] = st[2].abs()
+        a = [t.clone() for t in st]; b = [t.clone() for t in st]
+        pa, pb = torch.empty(n2, dtype=torch.bfloat16, device=DEV), torch.empty(n2, dtype=torch.bfloat16, device=DEV)
+        sc2 = torch.tensor([ss16.item(), lr, 1 - b1 ** step, 1 - b2 ** step, ed, 1.0, 0, 0], device=DEV)
+        hip.adamw_ema(a[0], a[1], a[2], a[3], g16, pa, sc2, b1, b2, eps, wd, 1.0)
+        hip.adamw_ema(b[0], b[1], b[2], b[3], g16.float(), pb, sc2, b1, b2, eps, wd, 1.0)
+        assert all(torch.equal(x, y) for x, y in zip(a, b)) and torch.equal(pa, pb)
 
 
 def test_flow_matching_bits(hip):

@@ -163,7 +163,7 @@ class Kernel:
         #        pre-activation H [M][N] (C's leading dimension) and stores d(h) = bf16(d(a)) * gelu'(h) (csrc/elementwise.hip gelu_bwd_kernel)
         # gelu:  (with epi) C = H = bf16(x W^T + bias) and a second output A = bf16(gelu(H)) with C's leading dimension (kernarg
         #        0x68): the accumulators are walked twice, the second pass zeroes them (siglip_gemma3.py MlpBlock; gelu_fwd_kernel)
-        # ss: (f32 output, no epilogue extras) the kernel also adds the sum of squares of everything it stores to the f32 word at kernarg 0x68
+        # ss: (no epilogue extras; f32 or plain bf16 output) the kernel also adds the sum of squares of everything it stores to the f32 word at kernarg 0x68
         #     (null: no) — a weight gradient's contribution to the global gradient norm (scripts/train.py:363-371 via optax
         #     clip_by_global_norm), so that no second pass has to read the gradient back.  Per lane across the block's tiles in V_SS,
         #     one atomic per wave when the block is out of tiles.
@@ -850,6 +850,9 @@ class Kernel:
                     geglu_fwd_piece(V_GPK + 2 * (fc - 4), cur + 4)
                     E(f"\tds_write_b64 v{V_WAA + fc - 4}, v[{V_GP}:{V_GP+1}]")
             else:
+                if self.ss:         # (bf16 stores: the squares of the f32 accumulator values, 2^-9 relative rounding noise of either sign
+                    for r in range(4):      #  on each term: the sum differs from the stored values' by ~1e-6 relative)
+                        E(f"\tv_fmac_f32 v{V_SS}, v{cur+r}, v{cur+r}")
                 E(f"\tv_cvt_pk_bf16_f32 v{cur+4}, v{cur}, v{cur+1}")
                 E(f"\tv_cvt_pk_bf16_f32 v{cur+5}, v{cur+2}, v{cur+3}")
                 if self.gelu and h == 1:
@@ -1365,7 +1368,11 @@ KERNELS = [Kernel("lap_gemm_asm_nt", True, True, False), Kernel("lap_gemm_asm_nn
            Kernel("lap_gemm_asm_nn_geglu_bwd", True, False, False, gbwd=True),
            Kernel("lap_gemm_asm_nt_geglu", True, True, False, gfwd=True),
            Kernel("lap_gemm_asm_nn_gelu_bwd", True, False, False, dgelu=True),
-           Kernel("lap_gemm_asm_nt_bias_gelu", True, True, False, epi=True, gelu=True)]
+           Kernel("lap_gemm_asm_nt_bias_gelu", True, True, False, epi=True, gelu=True),
+           # round 5: the weight-gradient layouts with BF16 stores (the reference's cast boundary `w.astype(bf16)` hands the f32 master a
+           # bf16-rounded cotangent, gemma.py:307,318): same ring main loop, the bf16 staged epilogue of the forward kernels
+           Kernel("lap_gemm_asm_tn_b16", False, False, False, ring=RING, ss=True),
+           Kernel("lap_gemm_asm_tn_t_b16", False, False, False, tout=True, ring=RING, ss=True)]
 E('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
 E("\t.amdhsa_code_object_version 6")
 for k in KERNELS:
