@@ -432,6 +432,12 @@ def engine_sources(cfg: LAPConfig) -> dict[str, list[str]]:
     return out
 
 
+def _is_action_expert_key(k: str) -> bool:
+    """Reference parameters that exist only with `enable_action_training` (lap.py:40-62: the second Gemma expert's `_1` arrays, the
+    adaRMS Dense layers, the action / time projections); without it the reference builds `gemma.Module(configs=[paligemma])` alone."""
+    return k.startswith(("action_in_proj/", "action_out_proj/", "time_mlp_in/", "time_mlp_out/")) or (k.startswith("PaliGemma/llm/") and "_1/" in k)
+
+
 def reference_shapes(cfg: LAPConfig) -> dict[str, tuple]:
     """Shapes of the reference's parameter tree, derived from the engine specs through the key map
     (shape-only `meta` tensors: nothing is allocated)."""
@@ -445,7 +451,16 @@ def _cfgs(cfg):
 
 def reference_to_engine(cfg: LAPConfig, P: dict) -> dict[str, torch.Tensor]:
     """Reference tree -> engine tensors.  Pure layout transforms, f32."""
+    full_shapes = None
+
     def T(k):
+        nonlocal full_shapes
+        if k not in P and not cfg.enable_action_training and _is_action_expert_key(k):
+            # (the reference has no action expert without action training: the engine's expert tensors are never read there — zeros)
+            if full_shapes is None:
+                E0 = {t.name: torch.empty(t.shape, dtype=torch.float32, device="meta") for u in build_specs(cfg) for t in u.tensors}
+                full_shapes = {kk: tuple(vv.shape) for kk, vv in _engine_to_reference_full(cfg, E0).items()}
+            return torch.zeros(full_shapes[k], dtype=torch.float32)
         x = P[k]
         return torch.as_tensor(x).to(torch.float32)
 
@@ -507,7 +522,15 @@ def reference_to_engine(cfg: LAPConfig, P: dict) -> dict[str, torch.Tensor]:
 
 
 def engine_to_reference(cfg: LAPConfig, E: dict) -> dict[str, torch.Tensor]:
-    """Inverse of reference_to_engine (checkpoint export: the `params` item of the reference's layout)."""
+    """Inverse of reference_to_engine (checkpoint export: the `params` item of the reference's layout).  Without action training
+    (`vla0_*` configs) the reference's tree has no action expert (lap.py:64-74): its keys are left out."""
+    P = _engine_to_reference_full(cfg, E)
+    if not cfg.enable_action_training:
+        P = {k: v for k, v in P.items() if not _is_action_expert_key(k)}
+    return P
+
+
+def _engine_to_reference_full(cfg: LAPConfig, E: dict) -> dict[str, torch.Tensor]:
     v, e, s = _cfgs(cfg)
     L, NH, HD, KV = v.depth, v.num_heads, v.head_dim, v.num_kv_heads
     hd = s.width // s.num_heads

@@ -211,3 +211,28 @@ def test_config_registry_and_defaults_match_reference_source_fixture():
     for must in ("wrist_image_dropout_prob", "random_mask_prob", "random_base_prob", "use_rough_scale", "language_action_format_name",
                  "transform_strategy", "enable_diverse_questions", "val_fraction", "data_mix", "action_proprio_normalization_type"):
         assert must in carried and must in fx["data_config_defaults"]
+
+
+def test_reference_tree_without_action_training_has_no_action_expert():
+    """lap.py:40-74: with `enable_action_training=False` (the vla0_* configs) the reference builds `gemma.Module(configs=[paligemma])` and none of
+    the action / time projections; the exported `params` item must be that tree, and such a tree must load (the engine's unused expert
+    tensors become zeros)."""
+    import dataclasses
+
+    from lap_amd.params import _is_action_expert_key, engine_to_reference, reference_shapes, reference_to_engine
+
+    cfg = get_config("debug").model
+    full = reference_shapes(cfg)
+    expert = {k for k in full if _is_action_expert_key(k)}
+    assert len(expert) == 19 and all(k.startswith(("PaliGemma/llm/", "action_", "time_mlp_")) for k in expert)
+    assert not any("img" in k for k in expert)
+    off = dataclasses.replace(cfg, enable_action_training=False)
+    sh = reference_shapes(off)
+    assert set(sh) == set(full) - expert
+    g = torch.Generator().manual_seed(0)
+    P = {k: torch.randn(v, generator=g) for k, v in sh.items()}
+    E = reference_to_engine(off, P)
+    back = engine_to_reference(off, E)
+    assert set(back) == set(P) and all(torch.equal(back[k], P[k]) for k in P)
+    assert float(E["ada/w"].abs().max()) == 0.0 and float(E["llm/0/wqkv1"].abs().max()) == 0.0 and float(E["act/in_w"].abs().max()) == 0.0
+    assert get_config("vla0_replicated").model.enable_action_training is False

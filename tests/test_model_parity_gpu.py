@@ -228,10 +228,14 @@ def _check_loss_branch(cfg, B, ragged):
     last = oc.vlm.depth - 1
     x0 = col["x0_out"].view(B, Pn, -1).float().cpu()
     assert rel(x0[pm], col32[f"llm/layer{last:02d}/x0"][pm]) < 2e-2
-    from lap_amd.params import engine_to_reference
+    # (the full key map: without action training the reference's tree — and `engine_to_reference` — has no action expert at all,
+    #  lap.py:64-74; the engine still holds its tensors, unused, and their gradients must stay exact zeros)
+    from lap_amd.params import _engine_to_reference_full, engine_to_reference, _is_action_expert_key
 
     eng = {name: model.ps.g(name).detach().float().cpu() for name in model.ps.names()}
-    gref = engine_to_reference(cfg, eng)
+    gref = _engine_to_reference_full(cfg, eng)
+    exported = engine_to_reference(cfg, eng)
+    assert set(exported) == {k for k in gref if cfg.enable_action_training or not _is_action_expert_key(k)}
     checked = untouched = 0
     for k, v in Pg.items():
         if v.grad is None or float(v.grad.abs().max()) == 0.0:
