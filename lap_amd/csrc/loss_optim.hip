@@ -180,10 +180,10 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, f
   // 32-bit BYTE offsets from the (scalar) array bases: one VGPR of addressing for all six arrays (the host wrapper
   // launches at most 2^29 elements at a time); v_sqrt / v_rcp (1 ulp) instead of the IEEE fix-up sequences
   const unsigned nb = (unsigned)n * 4u;
-  const unsigned stride = gridDim.x * 256u * 8u;
+  const unsigned stride = gridDim.x * blockDim.x * 8u;
   auto at = [](auto* base, unsigned byte_off) { return reinterpret_cast<f32x2*>(reinterpret_cast<char*>(base) + byte_off); };
   auto cat = [](const float* base, unsigned byte_off) { return reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(base) + byte_off); };
-  for (unsigned o = (blockIdx.x * 256u + threadIdx.x) * 8u; o < nb; o += stride) {
+  for (unsigned o = (blockIdx.x * blockDim.x + threadIdx.x) * 8u; o < nb; o += stride) {
     {   // n is even (unit buffers are padded to multiples of 64 elements; checked by the host wrapper)
       // NT: the master values, both moments, the EMA and the gradient are touched once per step — nontemporal, so that the
       // 36 B / parameter streaming past do not push the GEMMs' operand panels out of the L2 (the bf16 copy is stored normally:
@@ -359,14 +359,20 @@ extern "C" int lap_sumsq_f32(const float* x, long long n, float* sumsq, void* st
 static int adamw_launch(float* p, float* m, float* v, float* ema, const void* g, void* p16, void* p16lo, long long n,
                         const float* scalars, float b1, float b2, float eps, float wd, float max_norm, void* stream, bool g16 = false) {
   if (n <= 0 || (n & 1) || !scalars) return LAP_ERR_ARG;
-  static const long long cap = getenv("LAP_ADAMW_BLOCKS") ? atoll(getenv("LAP_ADAMW_BLOCKS")) : 4096;   // tuning knob (tools/ab_bench.sh)
+  // At most ONE optimizer block per CU (round 5, profiles/r05_optimizer_throttle.txt): the pass streams 36 - 38 bytes per parameter and
+  // is worth its full HBM time wherever it runs; as 4096 blocks it takes ~4.3 TB/s in bursts and the GEMM beside it stalls (gate|up
+  // forward 1.8 -> 2.75 ms under a 1 ms burst); as <= 256 persistent blocks it draws less per unit time, spreads under the whole layer
+  // and the pair stays below the HBM roof.  Step, same box, interleaved: 4096 blocks 266.7 | 384 268.4 | 320 263.5 | 288 262.1 | 256 259.3 |
+  // 224 259.2 | 192 260.2 | 160 262.2 | 128 270.6 | 64 291.7 ms.  LAP_ADAMW_BLOCKS / LAP_ADAMW_THREADS: tuning knobs.
+  static const long long cap = getenv("LAP_ADAMW_BLOCKS") ? atoll(getenv("LAP_ADAMW_BLOCKS")) : 240;
+  static const int threads = getenv("LAP_ADAMW_THREADS") ? atoi(getenv("LAP_ADAMW_THREADS")) : 256;
   const long long CH = 1LL << 29;
   for (long long o = 0; o < n; o += CH) {
     const long long cnt = n - o < CH ? n - o : CH;
-    const long long blocks = (cnt + 511) / 512;
+    const long long blocks = (cnt + 2 * threads - 1) / (2 * threads);
     static const bool nt = getenv("LAP_ADAMW_NT") ? atoi(getenv("LAP_ADAMW_NT")) != 0 : true;   // (-1.8 ms per train step: tools/ab3.sh)
     const void* go = g16 ? (const void*)((const bf16*)g + o) : (const void*)((const float*)g + o);
-#define ADAMW_GO(NT_, G16_) hipLaunchKernelGGL((adamw_ema_kernel<NT_, G16_>), dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, p + o, m + o, \
+#define ADAMW_GO(NT_, G16_) hipLaunchKernelGGL((adamw_ema_kernel<NT_, G16_>), dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(threads), 0, S_, p + o, m + o, \
                          v + o, ema ? ema + o : nullptr, go, p16 ? (bf16*)p16 + o : nullptr, p16lo ? (bf16*)p16lo + o : nullptr, cnt, scalars, b1, b2,     \
                          eps, wd, max_norm)
     if (nt) { if (g16) ADAMW_GO(true, true); else ADAMW_GO(true, false); }
