@@ -351,8 +351,9 @@ extern "C" int lap_sumsq_f32(const float* x, long long n, float* sumsq, void* st
   if (n <= 0) return LAP_ERR_ARG;
   const long long blocks = (n + 4095) / 4096;
   static const bool nt = getenv("LAP_SUMSQ_NT") ? atoi(getenv("LAP_SUMSQ_NT")) != 0 : false;
-  if (nt) hipLaunchKernelGGL(sumsq_kernel<true>, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, S_, x, n, sumsq);
-  else hipLaunchKernelGGL(sumsq_kernel<false>, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, S_, x, n, sumsq);
+  static const long long cap = getenv("LAP_SUMSQ_BLOCKS") ? atoll(getenv("LAP_SUMSQ_BLOCKS")) : 2048;     // tuning knob (see adamw_launch)
+  if (nt) hipLaunchKernelGGL(sumsq_kernel<true>, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, x, n, sumsq);
+  else hipLaunchKernelGGL(sumsq_kernel<false>, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, x, n, sumsq);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
@@ -396,7 +397,8 @@ extern "C" int lap_adamw_ema_g16(float* p, float* m, float* v, float* ema, const
 extern "C" int lap_sumsq_bf16(const void* x, long long n, float* sumsq, void* stream) {
   if (n <= 0 || !x || !sumsq || ((uintptr_t)x & 15)) return LAP_ERR_ARG;
   const long long blocks = (n + 8191) / 8192;
-  hipLaunchKernelGGL(sumsq_bf16_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, S_, (const bf16*)x, n, sumsq);
+  static const long long cap = getenv("LAP_SUMSQ_BLOCKS") ? atoll(getenv("LAP_SUMSQ_BLOCKS")) : 2048;
+  hipLaunchKernelGGL(sumsq_bf16_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, S_, (const bf16*)x, n, sumsq);
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }
