@@ -107,7 +107,7 @@ class LAPConfig:
     max_token_len: int = 220
     verbose_mode: bool = False
     pi05: bool = True
-    discrete_state_input: bool = True
+    discrete_state_input: bool | None = True      # lap_config.py:37,79-80: None -> pi05
     prompt_format: str = "lap"
     prediction_format: str = "default"
     use_fast: bool = False
@@ -134,10 +134,10 @@ class LAPConfig:
     def __post_init__(self):
         if self.max_token_len is None:
             object.__setattr__(self, "max_token_len", 200 if self.pi05 else 48)
+        if self.discrete_state_input is None:
+            object.__setattr__(self, "discrete_state_input", self.pi05)
         if self.dtype != "bfloat16":
             raise ValueError("lap_amd computes in bfloat16 (the reference's LAPConfig.dtype default)")
-        if not self.pi05:
-            raise NotImplementedError("pi0-style state token (pi05=False) is not on the LAP-3B path")
         if "gemma3" in self.paligemma_variant:
             raise NotImplementedError("Gemma3 LAP variants are out of scope (SURVEY.md §2)")
 

@@ -475,6 +475,13 @@ class LAP:
         la = obs.tokenized_langact_mask if obs.tokenized_langact_mask is not None else torch.zeros_like(obs.tokenized_prompt_mask)
         return prefix_mask, torch.cat([zeros, la], 1)
 
+    def _suffix_idx(self, B, S, dev):
+        """Block indices of the suffix tokens ([B, S] for pi05; [B, S + 1] with pi0's state token in front, one block earlier)."""
+        idx = torch.full((B, S), SUFFIX_IDX_BASE + 1, dtype=torch.int32, device=dev)
+        if S and not self.config.pi05:
+            idx = torch.cat([idx[:, :1], idx + 1], 1)
+        return idx
+
     def _train_infos(self, obs: CoTObservation, S: int):
         """Per-token info words equivalent to _build_combined_attention_mask / make_attn_mask (lap.py:303-364):
         class bit 1: valid prefix token (seen by prefix queries);  bit 2: in prefix_mask_action (seen by action
@@ -488,8 +495,10 @@ class LAP:
         kcls = prefix_mask.to(torch.int32) | (pma.to(torch.int32) << 1)
         kinfo_p = (kcls << 24) | cs
         qinfo_p = (prefix_mask.to(torch.int32) << 24) | cs
-        # suffix: mask all ones, ar = [1, 0, ...] (embed_suffix pi05) -> one block
-        s_idx = torch.full((B, S), SUFFIX_IDX_BASE + 1, dtype=torch.int32, device=dev)
+        # suffix: mask all ones, ar = [1, 0, ...] (embed_suffix pi05) -> one block; pi0: a state token in front as a block of its
+        # own (ar = [1, 1, 0, ...]): the action tokens see it, it does not see them
+        s_idx = self._suffix_idx(B, S, dev)
+        S = s_idx.shape[1]
         kinfo = torch.cat([kinfo_p, (4 << 24) | s_idx], 1).to(torch.int32).contiguous()  # cumsum promoted to int64
         qinfo = torch.cat([qinfo_p, (6 << 24) | s_idx], 1).to(torch.int32).contiguous()
         ppos = torch.cumsum(prefix_mask.to(torch.int32), 1) - 1
@@ -501,7 +510,7 @@ class LAP:
         """sample_actions masks (lap.py:624-654): prefix attends per make_attn_mask(prefix_mask, prefix_ar); suffix
         queries see every valid prefix token and all suffix tokens; suffix positions follow sum(prefix_mask)."""
         keys = self.config.image_keys
-        if (self.serve_fusions and obs.tokenized_prompt_mask.is_cuda and len(keys) <= 4
+        if (self.config.pi05 and self.serve_fusions and obs.tokenized_prompt_mask.is_cuda and len(keys) <= 4
                 and all(obs.image_masks[k].dtype == torch.bool for k in keys) and obs.tokenized_prompt_mask.dtype == torch.bool):
             la = obs.tokenized_langact_mask
             return hip.serve_infos([obs.image_masks[k].contiguous() for k in keys], self.n_img_tok, obs.tokenized_prompt_mask.contiguous(),
@@ -513,7 +522,8 @@ class LAP:
         pm = prefix_mask.to(torch.int32)
         kinfo_p = ((pm | (pm << 1)) << 24) | cs
         qinfo_p = (pm << 24) | cs
-        s_idx = torch.full((B, S), SUFFIX_IDX_BASE + 1, dtype=torch.int32, device=dev)
+        s_idx = self._suffix_idx(B, S, dev)
+        S = s_idx.shape[1]
         kinfo_s, qinfo_s = (4 << 24) | s_idx, (6 << 24) | s_idx
         ppos = (torch.cumsum(pm, 1) - 1).to(torch.int32).contiguous()
         spos = (pm.sum(-1, keepdim=True) + torch.arange(S, dtype=torch.int32, device=dev)[None]).to(torch.int32)
@@ -576,6 +586,34 @@ class LAP:
         xt2 = x_t.reshape(B * S, ad).contiguous()
         return hip.cast_f32_to_bf16(self._lin32(xt2, "act/in_w", "act/in_b")), xt2
 
+    def _embed_suffix_pi0(self, x_t: torch.Tensor, time: torch.Tensor, state: torch.Tensor, save: bool):
+        """[UPSTREAM-RECALL] openpi Pi0.embed_suffix, pi0 branch (parameters: lap.py:56-61): a state token `state_proj(state)`, then the
+        action tokens mixed with the time embedding: action_time_mlp_out(swish(action_time_mlp_in([action_in_proj(x_t) | posemb(t)]))).
+        f32 nnx.Linear layers; -> bf16 suffix tokens [B * (S + 1), We], no adaRMS condition."""
+        B, S, ad = x_t.shape
+        We = self.e.width
+        xt2 = x_t.reshape(B * S, ad).contiguous()
+        a = self._lin32(xt2, "act/in_w", "act/in_b")
+        temb = hip.posemb_sincos(time.contiguous(), We, 4e-3, 4.0)
+        cat = torch.cat([a.view(B, S, We), temb[:, None, :].expand(B, S, We)], -1).reshape(B * S, 2 * We).contiguous()
+        h1 = self._lin32(cat, "act/atime_in_w", "act/atime_in_b")
+        s1 = hip.swish_fwd(h1)
+        at = self._lin32(s1, "act/atime_out_w", "act/atime_out_b")
+        st2 = state.to(self.device, torch.float32).reshape(B, ad).contiguous()
+        st = self._lin32(st2, "act/state_w", "act/state_b")
+        tok = torch.cat([st[:, None, :], at.view(B, S, We)], 1).reshape(B * (S + 1), We).contiguous()
+        return hip.cast_f32_to_bf16(tok), ((xt2, cat, h1, s1, st2) if save else None)
+
+    def _embed_suffix_pi0_bwd(self, sctx, dx1, B, S):
+        xt2, cat, h1, s1, st2 = sctx
+        We = self.e.width
+        d = hip.cast_bf16_to_f32(dx1).view(B, S + 1, We)
+        self._lin32_bwd(st2, d[:, 0].contiguous(), "act/state_w", "act/state_b", need_dx=False)
+        ds1 = self._lin32_bwd(s1, d[:, 1:].reshape(B * S, We).contiguous(), "act/atime_out_w", "act/atime_out_b")
+        dh1 = hip.swish_bwd(h1, ds1)
+        dcat = self._lin32_bwd(cat, dh1, "act/atime_in_w", "act/atime_in_b")
+        self._lin32_bwd(xt2, dcat[:, :We].contiguous(), "act/in_w", "act/in_b", need_dx=False)      # (the time half has no parameters behind it)
+
     def _embed_suffix(self, x_t: torch.Tensor, time: torch.Tensor, save: bool, overlap: bool = False):
         """overlap (train step): the dozen small kernels go to the second HIP stream and run under whatever the current stream was
         given before (the SigLIP tower); their results are next touched by `_llm_fwd`, which joins the streams."""
@@ -621,7 +659,7 @@ class LAP:
         Ttot = pos.shape[1]
         ctx = [] if save else None
         mld = 0 if mod_shared else (mod.stride(0) if mod is not None else 0)  # 0: one modulation row for every sample
-        sfx = self._suffix_stream(x1, mod) if (x0 is not None and x1 is not None) else None
+        sfx = self._suffix_stream(*([x1, mod] if mod is not None else [x1])) if (x0 is not None and x1 is not None) else None
         main = torch.cuda.current_stream() if sfx is not None else None
         on_sfx = (lambda: torch.cuda.stream(sfx)) if sfx is not None else contextlib.nullcontext
         for l in (range(v.depth) if layers is None else layers):    # `layers`: test hook (teacher-forced per-layer parity)
@@ -637,7 +675,10 @@ class LAP:
                 k[0], vv[0] = kv_cache[l]
             if x1 is not None:
                 with on_sfx():
-                    h[1], rstd_a[1] = hip.rmsnorm_fwd(x1, mod=self._mod_slot(mod, 2 * l), rows_per_sample=n1, save_rstd=save, mod_ld=mld)
+                    if mod is None:     # pi0: plain RMSNorm in the expert (`use_adarms=[False, False]`, lap.py:51)
+                        h[1], rstd_a[1] = hip.rmsnorm_fwd(x1, scale=self.F(p + "n_attn1"), save_rstd=save)
+                    else:
+                        h[1], rstd_a[1] = hip.rmsnorm_fwd(x1, mod=self._mod_slot(mod, 2 * l), rows_per_sample=n1, save_rstd=save, mod_ld=mld)
                     qkv = hip.linear_fwd(h[1], self.W(p + "wqkv1"))
                     q[1], k[1], vv[1] = hip.rope_split_fwd(qkv, pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
                     del qkv
@@ -650,7 +691,14 @@ class LAP:
             self._handoff(main, sfx, o[1])
             xa = [None, None]; y1 = None; hf = [None, None]; rstd_f = [None, None]; gu = [None, None]; act = [None, None]; y1f = None
             xn = [None, None]
-            if x1 is not None:     # (issued first: 8 short kernels that then run under the prefix stream's GEMMs)
+            if x1 is not None and mod is None:       # pi0: plain residuals (gemma.py:577-583 with gate None)
+                with on_sfx():
+                    xa[1] = hip.linear_fwd(o[1], self.W(p + "wo1"), residual=x1)
+                    hf[1], rstd_f[1] = hip.rmsnorm_fwd(xa[1], scale=self.F(p + "n_ffw1"), save_rstd=save)
+                    gu[1] = hip.linear_fwd(hf[1], self.W(p + "wgu1"))
+                    act[1] = hip.geglu_fwd(gu[1])
+                    xn[1] = hip.linear_fwd(act[1], self.W(p + "wd1"), residual=xa[1])
+            elif x1 is not None:     # (issued first: 8 short kernels that then run under the prefix stream's GEMMs)
                 with on_sfx():
                     y1 = hip.linear_fwd(o[1], self.W(p + "wo1"))
                     xa[1] = hip.gated_residual_fwd(x1, y1, self._mod_slot(mod, 2 * l)[:, 2 * e.width:], n1, mld)
@@ -730,9 +778,10 @@ class LAP:
         NH, HD, KV = v.num_heads, v.head_dim, v.num_kv_heads
         Ttot = pos.shape[1]
         has_sfx = dx1 is not None         # False: prefix-only backward (enable_action_training=False, lap.py:449-455)
-        ldm = mod.stride(0) if has_sfx else 0
+        ada = has_sfx and mod is not None  # False with a suffix stream: pi0 (plain norms and residuals in the expert)
+        ldm = mod.stride(0) if ada else 0
         zero_do0 = None
-        sfx = self._suffix_stream(dx1, dmod, mod)
+        sfx = self._suffix_stream(*([dx1, dmod, mod] if ada else [dx1]))
         main = torch.cuda.current_stream() if sfx is not None else None
         on_sfx = (lambda: torch.cuda.stream(sfx)) if sfx is not None else contextlib.nullcontext
         for l in reversed(range(v.depth)):
@@ -741,7 +790,18 @@ class LAP:
             d_o = [None, None]
             # ---- FFN + attention output, suffix stream: xn = xa + y1f * gate_f  (on the second HIP stream, see the module doc)
             slot_f, slot_a = 2 * l + 1, 2 * l
-            if has_sfx:
+            if has_sfx and not ada:
+                with on_sfx():      # xn = xa + act wd^T, xa = x + o wo^T: the residuals pass dx1 through, the norms add onto it in place
+                    self._wgrad(dx1, c["act"][1], p + "wd1")
+                    dact = hip.linear_dgrad(dx1, self.W(p + "wd1"))
+                    dgu = hip.geglu_bwd(c["gu"][1], dact)
+                    self._wgrad(dgu, c["hf"][1], p + "wgu1")
+                    dhf = hip.linear_dgrad(dgu, self.W(p + "wgu1"))
+                    hip.rmsnorm_bwd(c["xa"][1], dhf, c["rstd_f"][1], scale=self.F(p + "n_ffw1"), dx=dx1, dscale=self.G(p + "n_ffw1"), accum_dx=True)
+                    self._wgrad(dx1, c["o"][1], p + "wo1")
+                    d_o[1] = hip.linear_dgrad(dx1, self.W(p + "wo1"))
+                    del dact, dgu, dhf
+            elif has_sfx:
                 with on_sfx():
                     gate_f = self._mod_slot(mod, slot_f)[:, 2 * e.width:]
                     dy1f = hip.gated_residual_bwd(dx1, c["y1f"], gate_f, n1, ldm, self._mod_slot(dmod, slot_f)[:, 2 * e.width:], dmod.stride(0))
@@ -789,8 +849,11 @@ class LAP:
                     dqkv = hip.rope_split_bwd(dq[1], dk[1], dv[1], pos, B, n1, Ttot, Ttot - n1, NH, HD, HD ** -0.5)
                     self._wgrad(dqkv, c["h"][1], p + "wqkv1")
                     dh = hip.linear_dgrad(dqkv, self.W(p + "wqkv1"))
-                    hip.rmsnorm_bwd(c["x"][1], dh, c["rstd_a"][1], mod=self._mod_slot(mod, slot_a), rows_per_sample=n1, dx=dx1,
-                                    dmod=self._mod_slot(dmod, slot_a), accum_dx=True)
+                    if ada:
+                        hip.rmsnorm_bwd(c["x"][1], dh, c["rstd_a"][1], mod=self._mod_slot(mod, slot_a), rows_per_sample=n1, dx=dx1,
+                                        dmod=self._mod_slot(dmod, slot_a), accum_dx=True)
+                    else:
+                        hip.rmsnorm_bwd(c["x"][1], dh, c["rstd_a"][1], scale=self.F(p + "n_attn1"), dx=dx1, dscale=self.G(p + "n_attn1"), accum_dx=True)
                     del dqkv, dh
             if dx0 is not None:
                 dqkv = hip.rope_split_bwd(dq[0], dk[0], dv[0], pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5)
@@ -885,11 +948,17 @@ class LAP:
                 time = u1.pow(1.0 / 1.5) * 0.999 + 0.001  # Beta(a, 1) by inverse CDF
             noise = noise.to(dev, torch.float32).contiguous(); time = time.to(dev, torch.float32).contiguous()
             x_t, u_t = hip.fm_mix(noise, actions, time)
-            # suffix first: its small kernels go to the second HIP stream and run under the SigLIP tower issued next
-            x1, mod, sctx = self._embed_suffix(x_t, time, backward, overlap=True)
-        Sx = S if act_on else 0      # suffix rows in the joint sequence (none without the action expert: lap.py:449-455)
+            if cfg.pi05:
+                # suffix first: its small kernels go to the second HIP stream and run under the SigLIP tower issued next
+                x1, mod, sctx = self._embed_suffix(x_t, time, backward, overlap=True)
+            else:
+                if obs.state is None:
+                    raise ValueError("pi05=False feeds the continuous state through state_proj: the observation has no `state`")
+                x1, sctx = self._embed_suffix_pi0(x_t, time, obs.state, backward)
+        # suffix rows in the joint sequence: none without the action expert (lap.py:449-455); pi0 has its state token in front
+        Sx = (S + (0 if cfg.pi05 else 1)) if act_on else 0
         x0, Pn, pctx = self._embed_prefix(obs, backward, collect)
-        qinfo, kinfo, pos = self._train_infos(obs, Sx)
+        qinfo, kinfo, pos = self._train_infos(obs, S if act_on else 0)
         if collect is not None:
             collect["x0_in"], collect["x1_in"], collect["pos"], collect["mod"] = x0, x1, pos, mod
         xf0, xf1, lctx = self._llm_fwd(x0, x1, mod, pos, qinfo, kinfo, B, Pn, Sx, backward, collect=collect)
@@ -958,7 +1027,11 @@ class LAP:
         # ---- action loss (lap.py:291-301)
         pre1 = v_t = None
         if act_on:
-            pre1, rstd_p1 = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=backward)
+            if cfg.pi05:
+                pre1, rstd_p1 = hip.rmsnorm_fwd(xf1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S, save_rstd=backward)
+            else:       # plain final norm; the action head reads the last S rows of each sample (`suffix_out[:, -ah:]`, lap.py:298)
+                pre1_all, rstd_p1 = hip.rmsnorm_fwd(xf1, scale=self.F("llm/final_norm1"), save_rstd=backward)
+                pre1 = pre1_all.view(B, Sx, self.e.width)[:, 1:].reshape(B * S, self.e.width).contiguous()
             pre1f = hip.cast_bf16_to_f32(pre1)
             v_t = self._lin32(pre1f, "act/out_w", "act/out_b")  # [B*S, ad]
         # ---- combination (lap.py:472-596).  Per-sample weights: language loss x {language, VQA (optionally per dataset),
@@ -1026,10 +1099,15 @@ class LAP:
         We = self.e.width
         dmod = dx1 = None
         if act_on:      # action head
-            dmod = torch.zeros(mod.shape, dtype=torch.float32, device=dev)
             dpre1f = self._lin32_bwd(pre1f, dv.view(B * S, ad), "act/out_w", "act/out_b")
-            dx1 = hip.rmsnorm_bwd(xf1, hip.cast_f32_to_bf16(dpre1f), rstd_p1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S,
-                                  dmod=self._mod_slot(dmod, 2 * self.v.depth))
+            if cfg.pi05:
+                dmod = torch.zeros(mod.shape, dtype=torch.float32, device=dev)
+                dx1 = hip.rmsnorm_bwd(xf1, hip.cast_f32_to_bf16(dpre1f), rstd_p1, mod=self._mod_slot(mod, 2 * self.v.depth), rows_per_sample=S,
+                                      dmod=self._mod_slot(dmod, 2 * self.v.depth))
+            else:
+                dall = torch.zeros((B, Sx, We), dtype=torch.bfloat16, device=dev)      # (the state token's row of the final norm has no consumer)
+                dall[:, 1:] = hip.cast_f32_to_bf16(dpre1f).view(B, S, We)
+                dx1 = hip.rmsnorm_bwd(xf1, dall.view(B * Sx, We), rstd_p1, scale=self.F("llm/final_norm1"), dscale=self.G("llm/final_norm1"))
         skip_prefix = self._prefix_frozen()
         dx0 = None
         if not skip_prefix and not lang_on:
@@ -1071,9 +1149,11 @@ class LAP:
                 hip.copy_rows_bf16(drows, dx0, R, Lt - 1, Dv, Lt - 1, 0, Pn, Pn - Lt)
         dx0, dx1 = self._llm_bwd(lctx, dx0, dx1, mod, dmod, pos, qinfo, kinfo, B, Pn, Sx)
         sfx = None
-        if act_on:
+        if act_on and cfg.pi05:
             sfx = self._embed_suffix_bwd(sctx, dx1, dmod)
-        else:       # the action expert's units saw no gradient (zeros): still declared complete for the optimizer's pipeline
+        elif act_on:
+            self._embed_suffix_pi0_bwd(sctx, dx1, B, S)
+        elif "ada" in self.ps.unit_by_name:   # the action expert's units saw no gradient (zeros): still declared complete for the optimizer's pipeline
             self.comm.grads_ready("ada")
         if not skip_prefix:
             self._embed_prefix_bwd(pctx, dx0, B, Pn)
@@ -1114,6 +1194,8 @@ class LAP:
         x_t = noise.to(dev, torch.float32).contiguous().clone()
         x0, Pn, _ = self._embed_prefix(obs, False, serve=True)
         qinfo_p, kinfo_p, ppos, qinfo_s, kinfo_all, pos_all = self._serve_infos(obs, S)
+        if not cfg.pi05:
+            return self._sample_actions_pi0(obs, x_t, x0, Pn, (qinfo_p, kinfo_p, ppos, qinfo_s, kinfo_all, pos_all), num_steps, collect)
         dt = -1.0 / num_steps
         times, t = [], 1.0
         while t >= -dt / 2:  # lap.py:669-674 loop condition, unrolled on the host (the time grid is data independent)
@@ -1197,6 +1279,32 @@ class LAP:
             hip.axpy_f32(x_t, v_t, dt)
         return x_t
 
+    def _sample_actions_pi0(self, obs, x_t, x0, Pn, infos, num_steps, collect):
+        """`sample_actions` for pi0 (`pi05=False`): the suffix is [state token | action tokens mixed with the time embedding], embedded anew
+        at every Euler step; the expert's layers run on the generic layer loop (plain norms and residuals) against the prefix cache.
+        Functional path: no fused serving kernels, no hipGraph chain (no registry config of the reference is pi0)."""
+        if obs.state is None:
+            raise ValueError("pi05=False feeds the continuous state through state_proj: the observation has no `state`")
+        qinfo_p, kinfo_p, ppos, qinfo_s, kinfo_all, pos_all = infos
+        B, S, ad = x_t.shape
+        Sx, We = S + 1, self.e.width
+        cache = []
+        self._llm_fwd(x0, None, None, ppos, qinfo_p, kinfo_p, B, Pn, 0, False, cache_out=cache)
+        dt = -1.0 / num_steps
+        t, step = 1.0, 0
+        while t >= -dt / 2:      # lap.py:669-674
+            x1, _ = self._embed_suffix_pi0(x_t, torch.full((B,), t, dtype=torch.float32, device=self.device), obs.state, False)
+            _, xf1, _ = self._llm_fwd(None, x1, None, pos_all, qinfo_s, kinfo_all, B, Pn, Sx, False, kv_cache=cache)
+            pre_all, _ = hip.rmsnorm_fwd(xf1, scale=self.F("llm/final_norm1"), save_rstd=False)
+            pre1 = pre_all.view(B, Sx, We)[:, 1:].reshape(B * S, We).contiguous()
+            v_t = self._lin32(hip.cast_bf16_to_f32(pre1), "act/out_w", "act/out_b")
+            if collect is not None:
+                collect[f"v_t/{step}"] = v_t.view(B, S, ad).clone()
+            hip.axpy_f32(x_t, v_t, dt)
+            t += dt
+            step += 1
+        return x_t
+
     def serve_chain_failed(self) -> bool:
         """True if a launch of the one-launch denoise step gave up at a grid barrier since the last check (synchronises)."""
         return self._chain_ctr is not None and hip.serve_chain_failed(self._chain_ctr)
@@ -1263,6 +1371,8 @@ class LAP:
         """Bring the sampler's parameter-derived caches (adaRMS modulations, packed expert weights) up to the current parameter
         version, in place.  Eager `sample_actions` does this itself; a captured graph cannot — call it before a replay."""
         n, dt = self._time_grid(num_steps)
+        if not self.config.pi05:
+            return          # (pi0 has no adaRMS bank and runs on the generic layer loop: nothing is cached)
         self._serve_mods(n, dt)
         if self._packed_w is not None:
             self._serve_packed_weights()

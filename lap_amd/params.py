@@ -100,6 +100,8 @@ def build_specs(cfg: LAPConfig) -> list[UnitSpec]:
     units.append(UnitSpec("embed", [TensorSpec("llm/embed", (cfg.vocab_size, v.width), 0.01)], True))
     for l in range(L):
         small += [TensorSpec(f"llm/{l}/n_attn", (v.width,), 0.0), TensorSpec(f"llm/{l}/n_ffw", (v.width,), 0.0)]
+        if not cfg.pi05:       # pi0: the expert's norms are plain RMSNorms (`use_adarms=[False, False]`, lap.py:51)
+            small += [TensorSpec(f"llm/{l}/n_attn1", (e.width,), 0.0), TensorSpec(f"llm/{l}/n_ffw1", (e.width,), 0.0)]
         units.append(UnitSpec(f"llm{l}", [
             TensorSpec(f"llm/{l}/wqkv0", (QKV, v.width), v.width ** -0.5),
             TensorSpec(f"llm/{l}/wo0", (v.width, NH * HD), (NH * HD) ** -0.5),
@@ -110,13 +112,20 @@ def build_specs(cfg: LAPConfig) -> list[UnitSpec]:
             TensorSpec(f"llm/{l}/wgu1", (2 * e.mlp_dim, e.width), e.width ** -0.5),
             TensorSpec(f"llm/{l}/wd1", (e.width, e.mlp_dim), e.mlp_dim ** -0.5)], True))
     nslots = ADA_SLOTS_PER_LAYER * L + 1
-    small += [TensorSpec("llm/final_norm", (v.width,), 0.0), TensorSpec("ada/b", (nslots * 3 * e.width,), 0.0)]
-    units.append(UnitSpec("ada", [TensorSpec("ada/w", (nslots * 3 * e.width, e.width), 0.0)], True))  # zero-init (gemma.py:128)
+    small += [TensorSpec("llm/final_norm", (v.width,), 0.0)]
     ad, w = cfg.action_dim, e.width
-    small += [TensorSpec("act/in_w", (w, ad), ad ** -0.5), TensorSpec("act/in_b", (w,), 0.0),
-              TensorSpec("act/time_in_w", (w, w), w ** -0.5), TensorSpec("act/time_in_b", (w,), 0.0),
-              TensorSpec("act/time_out_w", (w, w), w ** -0.5), TensorSpec("act/time_out_b", (w,), 0.0),
-              TensorSpec("act/out_w", (ad, w), w ** -0.5), TensorSpec("act/out_b", (ad,), 0.0)]
+    small += [TensorSpec("act/in_w", (w, ad), ad ** -0.5), TensorSpec("act/in_b", (w,), 0.0)]
+    if cfg.pi05:
+        small += [TensorSpec("ada/b", (nslots * 3 * e.width,), 0.0)]
+        units.append(UnitSpec("ada", [TensorSpec("ada/w", (nslots * 3 * e.width, e.width), 0.0)], True))  # zero-init (gemma.py:128)
+        small += [TensorSpec("act/time_in_w", (w, w), w ** -0.5), TensorSpec("act/time_in_b", (w,), 0.0),
+                  TensorSpec("act/time_out_w", (w, w), w ** -0.5), TensorSpec("act/time_out_b", (w,), 0.0)]
+    else:       # pi0 (lap.py:56-61): state token + action/time MLP, no adaRMS bank
+        small += [TensorSpec("llm/final_norm1", (e.width,), 0.0),
+                  TensorSpec("act/state_w", (w, ad), ad ** -0.5), TensorSpec("act/state_b", (w,), 0.0),
+                  TensorSpec("act/atime_in_w", (w, 2 * w), (2 * w) ** -0.5), TensorSpec("act/atime_in_b", (w,), 0.0),
+                  TensorSpec("act/atime_out_w", (w, w), w ** -0.5), TensorSpec("act/atime_out_b", (w,), 0.0)]
+    small += [TensorSpec("act/out_w", (ad, w), w ** -0.5), TensorSpec("act/out_b", (ad,), 0.0)]
     units.insert(0, UnitSpec("small", small, False))
     for u in units:
         off = 0
@@ -417,8 +426,11 @@ def engine_sources(cfg: LAPConfig) -> dict[str, list[str]]:
         out[f"img/{l}/wo"], out[f"img/{l}/bo"] = [f"{mha}/out/kernel"], [f"{mha}/out/bias"]
         out[f"img/{l}/w1"], out[f"img/{l}/b1"] = [f"{blk}/MlpBlock_0/Dense_0/kernel"], [f"{blk}/MlpBlock_0/Dense_0/bias"]
         out[f"img/{l}/w2"], out[f"img/{l}/b2"] = [f"{blk}/MlpBlock_0/Dense_1/kernel"], [f"{blk}/MlpBlock_0/Dense_1/bias"]
-    ada = [f"{lay}/{nm}/Dense_0" for nm in ("pre_attention_norm_1", "pre_ffw_norm_1")] + ["PaliGemma/llm/final_norm_1/Dense_0"]
-    out["ada/w"], out["ada/b"] = [a + "/kernel" for a in ada], [a + "/bias" for a in ada]
+    if cfg.pi05:
+        ada = [f"{lay}/{nm}/Dense_0" for nm in ("pre_attention_norm_1", "pre_ffw_norm_1")] + ["PaliGemma/llm/final_norm_1/Dense_0"]
+        out["ada/w"], out["ada/b"] = [a + "/kernel" for a in ada], [a + "/bias" for a in ada]
+    else:
+        out["llm/final_norm1"] = ["PaliGemma/llm/final_norm_1/scale"]
     for l in range(v.depth):
         for i in range(2):
             sfx = "" if i == 0 else f"_{i}"
@@ -427,7 +439,11 @@ def engine_sources(cfg: LAPConfig) -> dict[str, list[str]]:
             out[f"llm/{l}/wgu{i}"] = [f"{lay}/mlp{sfx}/gating_einsum"]
             out[f"llm/{l}/wd{i}"] = [f"{lay}/mlp{sfx}/linear"]
         out[f"llm/{l}/n_attn"], out[f"llm/{l}/n_ffw"] = [f"{lay}/pre_attention_norm/scale"], [f"{lay}/pre_ffw_norm/scale"]
-    for nm, ref in (("in", "action_in_proj"), ("time_in", "time_mlp_in"), ("time_out", "time_mlp_out"), ("out", "action_out_proj")):
+        if not cfg.pi05:
+            out[f"llm/{l}/n_attn1"], out[f"llm/{l}/n_ffw1"] = [f"{lay}/pre_attention_norm_1/scale"], [f"{lay}/pre_ffw_norm_1/scale"]
+    heads = (("time_in", "time_mlp_in"), ("time_out", "time_mlp_out")) if cfg.pi05 else \
+        (("state", "state_proj"), ("atime_in", "action_time_mlp_in"), ("atime_out", "action_time_mlp_out"))
+    for nm, ref in (("in", "action_in_proj"), *heads, ("out", "action_out_proj")):
         out[f"act/{nm}_w"], out[f"act/{nm}_b"] = [f"{ref}/kernel"], [f"{ref}/bias"]
     return out
 
@@ -435,7 +451,8 @@ def engine_sources(cfg: LAPConfig) -> dict[str, list[str]]:
 def _is_action_expert_key(k: str) -> bool:
     """Reference parameters that exist only with `enable_action_training` (lap.py:40-62: the second Gemma expert's `_1` arrays, the
     adaRMS Dense layers, the action / time projections); without it the reference builds `gemma.Module(configs=[paligemma])` alone."""
-    return k.startswith(("action_in_proj/", "action_out_proj/", "time_mlp_in/", "time_mlp_out/")) or (k.startswith("PaliGemma/llm/") and "_1/" in k)
+    return k.startswith(("action_in_proj/", "action_out_proj/", "time_mlp_in/", "time_mlp_out/", "state_proj/", "action_time_mlp_in/",
+                         "action_time_mlp_out/")) or (k.startswith("PaliGemma/llm/") and "_1/" in k)
 
 
 def reference_shapes(cfg: LAPConfig) -> dict[str, tuple]:
@@ -506,17 +523,27 @@ def reference_to_engine(cfg: LAPConfig, P: dict) -> dict[str, torch.Tensor]:
             out[f"llm/{l}/wd{i}"] = T(f"{lay}/mlp{sfx}/linear")[l].t().contiguous()
         out[f"llm/{l}/n_attn"] = T(f"{lay}/pre_attention_norm/scale")[l]
         out[f"llm/{l}/n_ffw"] = T(f"{lay}/pre_ffw_norm/scale")[l]
+        if not cfg.pi05:
+            out[f"llm/{l}/n_attn1"] = T(f"{lay}/pre_attention_norm_1/scale")[l]
+            out[f"llm/{l}/n_ffw1"] = T(f"{lay}/pre_ffw_norm_1/scale")[l]
+            continue
         for nm in ("pre_attention_norm_1", "pre_ffw_norm_1"):
             ada_w.append(T(f"{lay}/{nm}/Dense_0/kernel")[l].t())
             ada_b.append(T(f"{lay}/{nm}/Dense_0/bias")[l])
-    ada_w.append(T("PaliGemma/llm/final_norm_1/Dense_0/kernel").t())
-    ada_b.append(T("PaliGemma/llm/final_norm_1/Dense_0/bias"))
-    out["ada/w"] = torch.cat(ada_w, 0).contiguous()
-    out["ada/b"] = torch.cat(ada_b, 0)
     out["llm/final_norm"] = T("PaliGemma/llm/final_norm/scale")
     out["act/in_w"], out["act/in_b"] = T("action_in_proj/kernel").t().contiguous(), T("action_in_proj/bias")
-    out["act/time_in_w"], out["act/time_in_b"] = T("time_mlp_in/kernel").t().contiguous(), T("time_mlp_in/bias")
-    out["act/time_out_w"], out["act/time_out_b"] = T("time_mlp_out/kernel").t().contiguous(), T("time_mlp_out/bias")
+    if cfg.pi05:
+        ada_w.append(T("PaliGemma/llm/final_norm_1/Dense_0/kernel").t())
+        ada_b.append(T("PaliGemma/llm/final_norm_1/Dense_0/bias"))
+        out["ada/w"] = torch.cat(ada_w, 0).contiguous()
+        out["ada/b"] = torch.cat(ada_b, 0)
+        out["act/time_in_w"], out["act/time_in_b"] = T("time_mlp_in/kernel").t().contiguous(), T("time_mlp_in/bias")
+        out["act/time_out_w"], out["act/time_out_b"] = T("time_mlp_out/kernel").t().contiguous(), T("time_mlp_out/bias")
+    else:
+        out["llm/final_norm1"] = T("PaliGemma/llm/final_norm_1/scale")
+        out["act/state_w"], out["act/state_b"] = T("state_proj/kernel").t().contiguous(), T("state_proj/bias")
+        out["act/atime_in_w"], out["act/atime_in_b"] = T("action_time_mlp_in/kernel").t().contiguous(), T("action_time_mlp_in/bias")
+        out["act/atime_out_w"], out["act/atime_out_b"] = T("action_time_mlp_out/kernel").t().contiguous(), T("action_time_mlp_out/bias")
     out["act/out_w"], out["act/out_b"] = T("action_out_proj/kernel").t().contiguous(), T("action_out_proj/bias")
     return out
 
@@ -568,14 +595,22 @@ def _engine_to_reference_full(cfg: LAPConfig, E: dict) -> dict[str, torch.Tensor
     P[f"{lay}/pre_attention_norm/scale"] = sl(lambda l: E[f"llm/{l}/n_attn"])
     P[f"{lay}/pre_ffw_norm/scale"] = sl(lambda l: E[f"llm/{l}/n_ffw"])
     W3 = 3 * e.width
-    for j, nm in enumerate(("pre_attention_norm_1", "pre_ffw_norm_1")):
-        P[f"{lay}/{nm}/Dense_0/kernel"] = sl(lambda l: E["ada/w"][(2 * l + j) * W3:(2 * l + j + 1) * W3].t())
-        P[f"{lay}/{nm}/Dense_0/bias"] = sl(lambda l: E["ada/b"][(2 * l + j) * W3:(2 * l + j + 1) * W3])
-    P["PaliGemma/llm/final_norm_1/Dense_0/kernel"] = E["ada/w"][2 * L * W3:].t().contiguous()
-    P["PaliGemma/llm/final_norm_1/Dense_0/bias"] = E["ada/b"][2 * L * W3:]
     P["PaliGemma/llm/final_norm/scale"] = E["llm/final_norm"]
     P["action_in_proj/kernel"], P["action_in_proj/bias"] = E["act/in_w"].t().contiguous(), E["act/in_b"]
-    P["time_mlp_in/kernel"], P["time_mlp_in/bias"] = E["act/time_in_w"].t().contiguous(), E["act/time_in_b"]
-    P["time_mlp_out/kernel"], P["time_mlp_out/bias"] = E["act/time_out_w"].t().contiguous(), E["act/time_out_b"]
+    if cfg.pi05:
+        for j, nm in enumerate(("pre_attention_norm_1", "pre_ffw_norm_1")):
+            P[f"{lay}/{nm}/Dense_0/kernel"] = sl(lambda l: E["ada/w"][(2 * l + j) * W3:(2 * l + j + 1) * W3].t())
+            P[f"{lay}/{nm}/Dense_0/bias"] = sl(lambda l: E["ada/b"][(2 * l + j) * W3:(2 * l + j + 1) * W3])
+        P["PaliGemma/llm/final_norm_1/Dense_0/kernel"] = E["ada/w"][2 * L * W3:].t().contiguous()
+        P["PaliGemma/llm/final_norm_1/Dense_0/bias"] = E["ada/b"][2 * L * W3:]
+        P["time_mlp_in/kernel"], P["time_mlp_in/bias"] = E["act/time_in_w"].t().contiguous(), E["act/time_in_b"]
+        P["time_mlp_out/kernel"], P["time_mlp_out/bias"] = E["act/time_out_w"].t().contiguous(), E["act/time_out_b"]
+    else:       # pi0 (lap.py:51,56-61)
+        P[f"{lay}/pre_attention_norm_1/scale"] = sl(lambda l: E[f"llm/{l}/n_attn1"])
+        P[f"{lay}/pre_ffw_norm_1/scale"] = sl(lambda l: E[f"llm/{l}/n_ffw1"])
+        P["PaliGemma/llm/final_norm_1/scale"] = E["llm/final_norm1"]
+        P["state_proj/kernel"], P["state_proj/bias"] = E["act/state_w"].t().contiguous(), E["act/state_b"]
+        P["action_time_mlp_in/kernel"], P["action_time_mlp_in/bias"] = E["act/atime_in_w"].t().contiguous(), E["act/atime_in_b"]
+        P["action_time_mlp_out/kernel"], P["action_time_mlp_out/bias"] = E["act/atime_out_w"].t().contiguous(), E["act/atime_out_b"]
     P["action_out_proj/kernel"], P["action_out_proj/bias"] = E["act/out_w"].t().contiguous(), E["act/out_b"]
     return {k: v.contiguous() for k, v in P.items()}

@@ -86,7 +86,8 @@ class Policy:
         self.metadata = metadata or {}
         self._sample_kwargs = dict(sample_kwargs or {})
         self.num_steps = self._sample_kwargs.pop("num_steps", num_steps)
-        self._sampler = GraphedSampler(model, 1, self.num_steps) if use_graph else None
+        # (pi0, `pi05=False`, runs on the generic layer loop with its suffix re-embedded by torch ops at every step: served eagerly)
+        self._sampler = GraphedSampler(model, 1, self.num_steps) if (use_graph and model.config.pi05) else None
         self._gen = torch.Generator(device=model.device).manual_seed(seed)
         self._has_transforms = bool(transforms) or bool(output_transforms)
         self._transforms = list(transforms)

@@ -78,6 +78,7 @@ class OracleCfg:
     language_loss_weight: float = 1.0
     action_loss_weight: float = 1.0
     stop_action_to_vlm_grad: bool = False
+    pi05: bool = True                          # lap_config.py:36; False = pi0 suffix: state token + action/time MLP, plain RMSNorm in the expert (lap.py:46-61)
     enable_action_training: bool = True        # lap_config.py:40-47: flow-matching loss + action-expert stream (lap.py:426-462,557-569)
     enable_langact_training: bool = True       # language-action cross entropy (lap.py:462-556)
     enable_vqa_training: bool = False          # lap_config.py:40-47 / lap.py:101-115
@@ -174,6 +175,10 @@ def init_params(cfg: OracleCfg, seed: int = 0, zero_init_like_reference: bool = 
             P["PaliGemma/llm/layers/pre_attention_norm/scale"] = small(L, c.width)
             P["PaliGemma/llm/layers/pre_ffw_norm/scale"] = small(L, c.width)
             P["PaliGemma/llm/final_norm/scale"] = small(c.width)
+        elif not cfg.pi05:  # pi0: `use_adarms=[False, False]` (lap.py:51) — the expert's norms are plain RMSNorms with a scale (gemma.py:121)
+            P[f"PaliGemma/llm/layers/pre_attention_norm{sfx}/scale"] = small(L, c.width)
+            P[f"PaliGemma/llm/layers/pre_ffw_norm{sfx}/scale"] = small(L, c.width)
+            P[f"PaliGemma/llm/final_norm{sfx}/scale"] = small(c.width)
         else:  # adaRMS (pi05): Dense(width -> 3*width), zero-init kernel, zero bias (gemma.py:128)
             for nm in ("pre_attention_norm", "pre_ffw_norm"):
                 P[f"PaliGemma/llm/layers/{nm}{sfx}/Dense_0/kernel"] = small(L, c.width, 3 * c.width) * (0.2 if not zero_init_like_reference else 1)
@@ -207,9 +212,17 @@ def init_params(cfg: OracleCfg, seed: int = 0, zero_init_like_reference: bool = 
     ad, w = cfg.action_dim, e.width
     P["action_in_proj/kernel"] = normal(ad, w, std=ad ** -0.5)
     P["action_in_proj/bias"] = normal(w, std=0.02)
-    for nm in ("time_mlp_in", "time_mlp_out"):
-        P[f"{nm}/kernel"] = normal(w, w, std=w ** -0.5)
-        P[f"{nm}/bias"] = normal(w, std=0.02)
+    if cfg.pi05:
+        for nm in ("time_mlp_in", "time_mlp_out"):
+            P[f"{nm}/kernel"] = normal(w, w, std=w ** -0.5)
+            P[f"{nm}/bias"] = normal(w, std=0.02)
+    else:       # lap.py:56-61
+        P["state_proj/kernel"] = normal(ad, w, std=ad ** -0.5)
+        P["state_proj/bias"] = normal(w, std=0.02)
+        P["action_time_mlp_in/kernel"] = normal(2 * w, w, std=(2 * w) ** -0.5)
+        P["action_time_mlp_in/bias"] = normal(w, std=0.02)
+        P["action_time_mlp_out/kernel"] = normal(w, w, std=w ** -0.5)
+        P["action_time_mlp_out/bias"] = normal(w, std=0.02)
     P["action_out_proj/kernel"] = normal(w, ad, std=w ** -0.5)
     P["action_out_proj/bias"] = normal(ad, std=0.02)
     return P
@@ -461,10 +474,23 @@ def embed_prefix(P, cfg, obs, collect=None):
     return torch.cat(toks, 1), torch.cat(imask, 1), torch.cat(armask, 1)
 
 
-def embed_suffix(P, cfg, noisy_actions, timestep):
-    """[UPSTREAM-RECALL] openpi Pi0.embed_suffix, pi05 branch.  f32."""
+def embed_suffix(P, cfg, noisy_actions, timestep, state=None):
+    """[UPSTREAM-RECALL] openpi Pi0.embed_suffix.  f32.  pi05: action tokens + the time MLP's output as the adaRMS condition.
+    pi0 (`pi05=False`, parameters of lap.py:56-61): a state token `state_proj(obs.state)` in front (an autoregressive block of
+    its own: prefix tokens do not see it, action tokens do), the action tokens mixed with the time embedding through
+    `action_time_mlp_in([action | time]) -> swish -> action_time_mlp_out`, no adaRMS condition."""
     action_tokens = noisy_actions @ P["action_in_proj/kernel"] + P["action_in_proj/bias"]
     time_emb = posemb_sincos(timestep, cfg.expert.width, 4e-3, 4.0)
+    if not cfg.pi05:
+        B, S = action_tokens.shape[:2]
+        state_token = (state.to(torch.float32) @ P["state_proj/kernel"] + P["state_proj/bias"])[:, None, :]
+        at = torch.cat([action_tokens, time_emb[:, None, :].expand(B, S, -1)], dim=-1)
+        at = torch.nn.functional.silu(at @ P["action_time_mlp_in/kernel"] + P["action_time_mlp_in/bias"])
+        at = at @ P["action_time_mlp_out/kernel"] + P["action_time_mlp_out/bias"]
+        tokens = torch.cat([state_token, at], dim=1)
+        ar = torch.zeros(S + 1, dtype=torch.bool)
+        ar[0] = ar[1] = True
+        return tokens, torch.ones(B, S + 1, dtype=torch.bool), ar, None
     time_emb = torch.nn.functional.silu(time_emb @ P["time_mlp_in/kernel"] + P["time_mlp_in/bias"])
     time_emb = torch.nn.functional.silu(time_emb @ P["time_mlp_out/kernel"] + P["time_mlp_out/bias"])
     B, S = action_tokens.shape[:2]
@@ -513,7 +539,7 @@ def compute_loss(P, cfg: OracleCfg, obs, actions, noise, time, collect=None):
         te = time[:, None, None]
         x_t = te * noise + (1 - te) * actions
         u_t = noise - actions
-        suffix_tokens, suffix_mask, suffix_ar1, cond = embed_suffix(P, cfg, x_t, time)
+        suffix_tokens, suffix_mask, suffix_ar1, cond = embed_suffix(P, cfg, x_t, time, state=obs.get("state"))
         suffix_ar = suffix_ar1[None].expand(B, -1)
         _, mask, positions = build_masks_positions(cfg, obs, prefix_mask, prefix_ar, suffix_mask, suffix_ar)
         (pre0, pre1), _ = gemma_forward(P, cfg, [prefix_tokens, suffix_tokens], positions, mask, [None, cond], collect=collect)
@@ -596,7 +622,7 @@ def sample_actions(P, cfg: OracleCfg, obs, noise, num_steps: int = 10, collect=N
     x_t, t = noise.clone(), 1.0
     step = 0
     while t >= -dt / 2:
-        suffix_tokens, suffix_mask, suffix_ar1, cond = embed_suffix(P, cfg, x_t, torch.full((B,), t, dtype=torch.float32))
+        suffix_tokens, suffix_mask, suffix_ar1, cond = embed_suffix(P, cfg, x_t, torch.full((B,), t, dtype=torch.float32), state=obs.get("state"))
         suffix_attn = make_attn_mask(suffix_mask, suffix_ar1[None].expand(B, -1))
         pmask = prefix_mask[:, None, :].expand(B, suffix_tokens.shape[1], -1)
         full = torch.cat([pmask, suffix_attn], dim=-1)

@@ -13,7 +13,7 @@ def oracle_cfg(model_cfg, **kw) -> O.OracleCfg:
                        action_horizon=model_cfg.action_horizon, max_token_len=model_cfg.max_token_len,
                        image_size=model_cfg.image_size, image_keys=model_cfg.image_keys, vocab_size=model_cfg.vocab_size,
                        language_loss_weight=model_cfg.language_loss_weight, action_loss_weight=model_cfg.action_loss_weight,
-                       stop_action_to_vlm_grad=model_cfg.stop_action_to_vlm_grad,
+                       stop_action_to_vlm_grad=model_cfg.stop_action_to_vlm_grad, pi05=model_cfg.pi05,
                        enable_action_training=model_cfg.enable_action_training, enable_langact_training=model_cfg.enable_langact_training,
                        enable_vqa_training=model_cfg.enable_vqa_training, enable_prediction_training=model_cfg.enable_prediction_training,
                        vqa_loss_weight=model_cfg.vqa_loss_weight, prediction_loss_weight=model_cfg.prediction_loss_weight,

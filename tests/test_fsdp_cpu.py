@@ -112,11 +112,14 @@ class _Stub:   # what the checkpoint code needs from a LAP model: the store and 
         self.ps, self.comm = ps, comm
 
 
-def _checkpoint_round_trip(tmp, world, rank):
+def _checkpoint_round_trip(tmp, world, rank, pi05=True):
     import lap_amd.checkpoints as ck
     from lap_amd.train import TrainState
 
     cfg = get_config("debug").model
+    if not pi05:        # the pi0 parameter tree (state_proj, action_time_mlp_*, plain expert norms; no adaRMS unit)
+        import dataclasses
+        cfg = dataclasses.replace(cfg, pi05=False)
 
     def fresh(seed):
         ps = ParamStore(cfg, "cpu", world_size=world, rank=rank)
@@ -190,6 +193,10 @@ def _checkpoint_round_trip(tmp, world, rank):
 
 def test_checkpoint_round_trip_single(tmp_path):
     assert _checkpoint_round_trip(tmp_path / "ck", 1, 0) == "ok"
+
+
+def test_checkpoint_round_trip_single_pi0(tmp_path):
+    assert _checkpoint_round_trip(tmp_path / "ck", 1, 0, pi05=False) == "ok"
 
 
 def test_checkpoint_round_trip_world2_gloo(tmp_path):

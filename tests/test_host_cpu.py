@@ -236,3 +236,50 @@ def test_reference_tree_without_action_training_has_no_action_expert():
     assert set(back) == set(P) and all(torch.equal(back[k], P[k]) for k in P)
     assert float(E["ada/w"].abs().max()) == 0.0 and float(E["llm/0/wqkv1"].abs().max()) == 0.0 and float(E["act/in_w"].abs().max()) == 0.0
     assert get_config("vla0_replicated").model.enable_action_training is False
+
+
+def test_pi0_parameter_tree_and_oracle_suffix():
+    """`pi05=False` (lap.py:46-61): the reference's tree has `state_proj`, `action_time_mlp_in` (2 w -> w), `action_time_mlp_out`, plain
+    `..._norm_1/scale` arrays for the action expert and NO adaRMS Dense layers / `time_mlp_*`; the key map round-trips it, the engine
+    has no adaRMS unit, and the oracle's suffix is [state | actions] with two autoregressive blocks (the action tokens see the state
+    token, the state token does not see them; the prefix sees neither)."""
+    import dataclasses
+
+    from lap_amd.config import LAPConfig
+    from lap_amd.params import build_specs, engine_sources, engine_to_reference, reference_shapes, reference_to_engine
+    from oracle import lap_oracle as O
+    from tests.common import make_inputs, oracle_cfg
+
+    assert LAPConfig(pi05=False, max_token_len=None).max_token_len == 48 and LAPConfig(max_token_len=None).max_token_len == 200   # lap_config.py:78
+    assert LAPConfig(pi05=False, discrete_state_input=None).discrete_state_input is False                                         # lap_config.py:80
+    cfg = dataclasses.replace(get_config("debug").model, pi05=False, enable_action_training=True)
+    sh = reference_shapes(cfg)
+    w = O.GEMMA[cfg.action_expert_variant].width
+    assert sh["state_proj/kernel"] == (cfg.action_dim, w) and sh["action_time_mlp_in/kernel"] == (2 * w, w) and sh["action_time_mlp_out/kernel"] == (w, w)
+    assert "time_mlp_in/kernel" not in sh and not any("Dense_0" in k for k in sh if k.startswith("PaliGemma/llm/"))
+    assert sh["PaliGemma/llm/final_norm_1/scale"] == (w,) and sh["PaliGemma/llm/layers/pre_ffw_norm_1/scale"][1] == w
+    units = build_specs(cfg)
+    assert "ada" not in [u.name for u in units]
+    assert set(engine_sources(cfg)) == {t.name for u in units for t in u.tensors}
+    oc = oracle_cfg(cfg)
+    P = O.init_params(oc, seed=3)
+    assert {k: tuple(v.shape) for k, v in P.items()} == sh
+    back = engine_to_reference(cfg, reference_to_engine(cfg, P))
+    assert set(back) == set(P) and all(torch.equal(back[k], P[k]) for k in P)
+    # the suffix and its mask
+    obs, actions, noise, time = make_inputs(cfg, B=2, ragged=True)
+    S = cfg.action_horizon
+    tok, smask, ar, cond = O.embed_suffix(P, oc, noise, time, state=obs["state"])
+    assert tok.shape == (2, S + 1, w) and cond is None and ar.tolist() == [True, True] + [False] * (S - 1) and bool(smask.all())
+    col = {}
+    loss, m = O.compute_loss(P, oc, obs, actions, noise, time, collect=col)
+    mask, pos = col["mask"], col["positions"]
+    Pn = mask.shape[1] - (S + 1)
+    assert not mask[:, :Pn, Pn:].any()                       # prefix rows never see the suffix
+    assert not mask[:, Pn, Pn + 1:].any() and mask[:, Pn, Pn].all()          # the state token sees itself, not the actions
+    assert mask[:, Pn + 1:, Pn:].all()                       # the action tokens see the state token and each other
+    assert (pos[:, Pn + 1:] - pos[:, Pn:-1] == 1).all()      # suffix positions count on from the state token
+    assert torch.isfinite(loss) and m["v_t"].shape == (2, S, cfg.action_dim)
+    # a different state moves the loss (it reaches the action tokens through attention only)
+    obs2 = dict(obs, state=obs["state"] + 0.5)
+    assert abs(float(O.compute_loss(P, oc, obs2, actions, noise, time)[0]) - float(loss)) > 1e-7

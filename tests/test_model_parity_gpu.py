@@ -188,7 +188,7 @@ def _check_loss_activations_and_grads(cfg, B, ragged):
     assert len(worst) == len(P)
 
 
-def _check_loss_branch(cfg, B, ragged):
+def _check_loss_branch(cfg, B, ragged, min_untouched=1):
     """compute_loss with one of the two losses switched off (lap.py:426-462,557-596) against the f32 oracle's autograd: loss,
     per-sample losses, the last layer's activations, every gradient.  Parameters the branch never touches (the action expert,
     the action / time projections and the adaRMS bank without action training; the final norm without the language loss) have
@@ -243,9 +243,14 @@ def _check_loss_branch(cfg, B, ragged):
             untouched += 1
             continue
         r = rel(gref[k], v.grad)
-        assert r < 5e-2 or (gref[k] - v.grad).abs().max() < 1e-4, (k, r)
+        # (SigLIP's key bias has an analytically zero gradient — softmax is shift invariant —: f32 rounding noise in the oracle, bf16 noise here)
+        assert r < 5e-2 or (gref[k] - v.grad).abs().max() < (4e-4 if k.endswith("key/bias") else 1e-4), (k, r)
         checked += 1
-    assert checked > 10 and untouched > 0, (checked, untouched)
+    assert checked > 10 and untouched >= min_untouched, (checked, untouched)
+    if cfg.enable_action_training:      # the action expert's residual stream behind the last layer (pi0: state token + action tokens)
+        x1 = col["x1_out"].view(B, -1, oc.expert.width).float().cpu()
+        assert x1.shape == col32[f"llm/layer{last:02d}/x1"].shape
+        assert rel(x1, col32[f"llm/layer{last:02d}/x1"]) < 2e-2
     return checked, untouched
 
 
@@ -254,6 +259,31 @@ def test_loss_branches_with_one_loss_off_match_oracle(hip, act, lang):
     """enable_action_training=False: `llm([prefix])`, cross entropy only (the vla0_* configs); enable_langact_training=False:
     both streams, flow matching only (pi0_replicated).  Debug model, ragged batch with an idle sample and an invalid image."""
     _check_loss_branch(debug_model_cfg(enable_action_training=act, enable_langact_training=lang), B=3, ragged=True)
+
+
+@pytest.mark.parametrize("lang", [True, False])
+def test_pi0_suffix_path_matches_oracle(hip, lang):
+    """`pi05=False` (lap.py:46-61 + openpi Pi0.embed_suffix): a state token through `state_proj`, the action tokens mixed with the time
+    embedding through `action_time_mlp_*`, plain RMSNorms and residuals in the action expert (`use_adarms=[False, False]`), the action
+    head on the last S suffix rows.  Loss, per-sample losses, both residual streams and every gradient against the f32 oracle's
+    autograd, with and without the language loss; then the sampler (state token re-embedded at every Euler step)."""
+    cfg = debug_model_cfg(pi05=False, enable_action_training=True, enable_langact_training=lang)
+    checked, untouched = _check_loss_branch(cfg, B=3, ragged=True, min_untouched=0 if lang else 1)
+    assert checked > 25
+    oc = oracle_cfg(cfg)
+    P = O.init_params(oc, seed=11)
+    assert "state_proj/kernel" in P and "time_mlp_in/kernel" not in P and "PaliGemma/llm/final_norm_1/scale" in P
+    obs, _, noise, _ = make_inputs(cfg, B=2, ragged=True)
+    so = {k: v for k, v in obs.items() if k != "tokenized_langact_mask"}
+    col32, col = {}, {}
+    ref = O.sample_actions(P, oc, so, noise, num_steps=10, collect=col32)
+    ref16 = O.sample_actions(P, dataclasses.replace(oc, emulate_bf16=True), so, noise, num_steps=10)
+    model = _engine(cfg, P)
+    out = model.sample_actions(0, to_observation(so | {"tokenized_langact_mask": None}, DEV), num_steps=10, noise=noise.to(DEV), collect=col)
+    assert out.shape == (2, cfg.action_horizon, cfg.action_dim)
+    assert rel(col["v_t/0"], col32["v_t/0"]) < 2e-2
+    err, base = rel(out, ref), rel(ref16, ref)
+    assert err < max(3 * base, 1e-2), (err, base)
 
 
 @pytest.mark.parametrize("act,lang,kw", [
@@ -720,13 +750,17 @@ def test_two_stream_schedule_equals_one_stream(hip, monkeypatch):
         assert loose <= noisy + 2, (loose, noisy)
 
 
-def test_train_step_matches_oracle_adamw(hip):
-    """One full train step (scripts/train.py:329-419): clip -> AdamW -> EMA, against the oracle's autograd + optax restatement."""
+@pytest.mark.parametrize("pi05", [True, False])
+def test_train_step_matches_oracle_adamw(hip, pi05):
+    """One full train step (scripts/train.py:329-419): clip -> AdamW -> EMA, against the oracle's autograd + optax restatement
+    (pi05=False: the pi0 suffix path — no adaRMS unit in the optimizer's schedule)."""
     from lap_amd.config import get_config
     from lap_amd.params import engine_to_reference
     from lap_amd.train import TrainingStepRunner, init_train_state
 
     tc = get_config("debug")
+    if not pi05:
+        tc = dataclasses.replace(tc, model=dataclasses.replace(tc.model, pi05=False))
     cfg = tc.model
     oc = oracle_cfg(cfg)
     P = O.init_params(oc, seed=5)

@@ -81,3 +81,37 @@ def test_policy_from_checkpoint_serves_raw_requests(hip, tmp_path):
         again = det._input_transform(dict(req))
         assert bool(again["image_mask"]["left_wrist_0_rgb"]) and np.array_equal(again["tokenized_prompt"], ref_in["tokenized_prompt"])
         np.testing.assert_array_equal(again["image"]["left_wrist_0_rgb"], ref_in["image"]["left_wrist_0_rgb"])
+
+
+def test_pi0_policy_serves_with_the_continuous_state(hip, tmp_path):
+    """`pi05=False` end to end through the serving stack: the checkpoint holds the pi0 tree (state_proj, action_time_mlp_*), the
+    prompt carries NO discretised state (`discrete_state_input=False`, lap_config.py:80) and the normalised state reaches the action
+    expert as its state token — so two requests that differ in the state alone give different actions (with pi05 they would differ
+    through the prompt's state bins instead).  Served eagerly (no captured graph for the generic layer loop)."""
+    tc = get_config("debug")
+    tc = dataclasses.replace(tc, model=dataclasses.replace(tc.model, pi05=False, discrete_state_input=False),
+                             data=dataclasses.replace(tc.data, asset_id="debug", wrist_image_dropout_prob=0.0, random_mask_prob=0.0))
+    cfg = tc.model
+    model = LAP(cfg, seed=7, device=DEV, with_grads=False)
+    stats = _checkpoint(tmp_path, cfg, model)
+    tok = pio.PaligemmaTokenizer(model_proto=tiny_sentencepiece_proto(), max_len=cfg.max_token_len)
+    policy = create_trained_policy(tc, tmp_path, tokenizer=tok, default_prompt="pick up the block", use_graph=True, device=DEV)
+    assert policy._sampler is None and "act/state_w" in policy.model.ps.names() and "ada/w" not in policy.model.ps.names()
+    rs = np.random.RandomState(4)
+    img = {"base_0_rgb": (rs.rand(56, 56, 3) * 255).astype(np.uint8), "left_wrist_0_rgb": (rs.rand(56, 56, 3) * 255).astype(np.uint8)}
+    noise = rs.randn(cfg.action_horizon, cfg.action_dim).astype(np.float32)
+    s1, s2 = rs.uniform(-1, 1, 7), rs.uniform(-1, 1, 7)
+    out1 = policy.infer({"observation": dict(img, state=s1)}, noise=noise)
+    out1b = policy.infer({"observation": dict(img, state=s1)}, noise=noise)
+    out2 = policy.infer({"observation": dict(img, state=s2)}, noise=noise)
+    assert out1["actions"].shape == (cfg.action_horizon, cfg.action_dim) and np.isfinite(out1["actions"]).all()
+    np.testing.assert_array_equal(out1["actions"], out1b["actions"])
+    assert np.abs(out1["actions"] - out2["actions"]).max() > 1e-4
+    # by hand: the same transforms with the state kept out of the prompt, then the sampler
+    inp = pio.compose([pio.InjectDefaultPrompt("pick up the block"), pio.CoTInputs(action_dim=cfg.action_dim), pio.Normalize(stats, "bounds_q99"),
+                       pio.TokenizePromptAndReasoning(tok, discrete_state_input=False), pio.PadStatesAndActions(cfg.action_dim)])({"observation": dict(img, state=s1)})
+    batched = {k: ({kk: np.asarray(vv)[None] for kk, vv in v.items()} if isinstance(v, dict) else np.asarray(v)[None])
+               for k, v in inp.items() if v is not None and not isinstance(v, str)}
+    o = CoTObservation.from_dict(batched, device=DEV)
+    a = model.sample_actions(0, o, num_steps=10, noise=torch.from_numpy(noise)[None].to(DEV))[0].cpu().numpy()
+    np.testing.assert_array_equal(out1["actions"], pio.Unnormalize(stats, "bounds_q99")({"actions": a})["actions"])
