@@ -23,7 +23,16 @@ def _slice_obs(obs, sl):
     return out
 
 
-def _worker(rank, world, port, ret):
+def _debug_tc(pi05):
+    import dataclasses
+
+    from lap_amd.config import get_config
+
+    tc = get_config("debug")
+    return tc if pi05 else dataclasses.replace(tc, model=dataclasses.replace(tc.model, pi05=False))
+
+
+def _worker(rank, world, port, ret, pi05=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -33,7 +42,7 @@ def _worker(rank, world, port, ret):
         from tests.common import oracle_cfg, to_observation
 
         dev = "cuda:0"
-        tc = get_config("debug")
+        tc = _debug_tc(pi05)
         cfg = tc.model
         P = O.init_params(oracle_cfg(cfg), seed=9)
         obs, actions, noise, time = _batch(cfg, 4)
@@ -57,7 +66,9 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_rank(hip):
+@pytest.mark.parametrize("pi05", [True, False])
+def test_two_rank_step_equals_single_rank(hip, pi05):
+    """(pi05=False: the pi0 parameter tree — no adaRMS unit in the sharded schedule, its extra tensors in the replicated unit)"""
     from lap_amd.config import get_config
     from lap_amd.train import TrainingStepRunner, init_train_state
     from oracle import lap_oracle as O
@@ -67,7 +78,7 @@ def test_two_rank_step_equals_single_rank(hip):
     port = 29600 + os.getpid() % 300
     mgr = mp.get_context("spawn").Manager()   # (a forked manager next to an initialised HIP runtime is not safe)
     ret = mgr.dict()
-    procs = [mp.get_context("spawn").Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    procs = [mp.get_context("spawn").Process(target=_worker, args=(r, world, port, ret, pi05)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -77,7 +88,7 @@ def test_two_rank_step_equals_single_rank(hip):
             p.kill()
     assert all(ret.get(r, ("missing",))[0] == "ok" for r in range(world)), {r: ret.get(r, ("missing",))[:2] for r in range(world)}
     # single rank on the full batch
-    tc = get_config("debug")
+    tc = _debug_tc(pi05)
     cfg = tc.model
     P = O.init_params(oracle_cfg(cfg), seed=9)
     obs, actions, noise, time = _batch(cfg, 4)

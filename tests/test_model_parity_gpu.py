@@ -296,6 +296,13 @@ def test_full_width_loss_branches_match_oracle(hip, monkeypatch, act, lang, kw):
     _check_loss_branch(_full_width_cfg(monkeypatch, enable_action_training=act, enable_langact_training=lang, **kw), B=2, ragged=True)
 
 
+def test_full_width_pi0_matches_oracle(hip, monkeypatch):
+    """pi0 at the LAP-3B widths (2 layers per tower; S + 1 = 51 suffix rows per sample at width 1024 / head size 256): the expert's plain
+    norms, residual epilogues and the state token on the production kernels; loss, both streams, every gradient."""
+    checked, _ = _check_loss_branch(_full_width_cfg(monkeypatch, pi05=False, action_dim=7), B=2, ragged=True, min_untouched=0)
+    assert checked > 25
+
+
 # Per-layer bounds (relative L2 over valid positions), stated once (DESIGN.md §2).  Measured on MI355X (round 2, LAP-3B
 # full depth, gpurun_out/r2_par1.log): the bf16-emulating oracle itself sits 1.7e-3 (stem) ... 1.3e-2 (SigLIP block 26)
 # ... 1.8e-2 (Gemma layer 17) from the f32 oracle, the engine 0.85-1.0x of that, and the two bf16 implementations are as
