@@ -360,12 +360,18 @@ extern "C" int lap_sumsq_f32(const float* x, long long n, float* sumsq, void* st
 static int adamw_launch(float* p, float* m, float* v, float* ema, const void* g, void* p16, void* p16lo, long long n,
                         const float* scalars, float b1, float b2, float eps, float wd, float max_norm, void* stream, bool g16 = false) {
   if (n <= 0 || (n & 1) || !scalars) return LAP_ERR_ARG;
-  // At most ONE optimizer block per CU (round 5, profiles/r05_optimizer_throttle.txt): the pass streams 36 - 38 bytes per parameter and
-  // is worth its full HBM time wherever it runs; as 4096 blocks it takes ~4.3 TB/s in bursts and the GEMM beside it stalls (gate|up
-  // forward 1.8 -> 2.75 ms under a 1 ms burst); as <= 256 persistent blocks it draws less per unit time, spreads under the whole layer
-  // and the pair stays below the HBM roof.  Step, same box, interleaved: 4096 blocks 266.7 | 384 268.4 | 320 263.5 | 288 262.1 | 256 259.3 |
-  // 224 259.2 | 192 260.2 | 160 262.2 | 128 270.6 | 64 291.7 ms.  LAP_ADAMW_BLOCKS / LAP_ADAMW_THREADS: tuning knobs.
-  static const long long cap = getenv("LAP_ADAMW_BLOCKS") ? atoll(getenv("LAP_ADAMW_BLOCKS")) : 240;
+  // At most ONE optimizer block per CU (round 5, profiles/r05_optimizer_throttle.txt, r05_optimizer_coresidency_probe.txt): one 256-thread
+  // block = one 32-register wave per SIMD fits beside the assembly GEMM's 480-register waves, a second one does not (the pass then waits
+  // for GEMM launches to end and delays the next one's blocks), and thousands of short blocks get in the way of the forward's short launches.
+  // Step, same box, interleaved: 4096 blocks 266.7 | 384 268.4 | 320 263.5 | 288 262.1 | 256 259.3 | 224 259.2 | 192 260.2 | 160 262.2 |
+  // 128 270.6 | 64 291.7 ms.  Default: 15/16 of the device's CUs (240 on MI355X; a partitioned device gets its own count).
+  // LAP_ADAMW_BLOCKS / LAP_ADAMW_THREADS: tuning knobs.
+  static const long long cap = [] {
+    if (getenv("LAP_ADAMW_BLOCKS")) return atoll(getenv("LAP_ADAMW_BLOCKS"));
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return (long long)(cus * 15 / 16 > 0 ? cus * 15 / 16 : 1);
+  }();
   static const int threads = getenv("LAP_ADAMW_THREADS") ? atoi(getenv("LAP_ADAMW_THREADS")) : 256;
   const long long CH = 1LL << 29;
   for (long long o = 0; o < n; o += CH) {
