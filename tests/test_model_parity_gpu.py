@@ -954,3 +954,57 @@ def test_vqa_and_prediction_loss_mixing_matches_oracle(hip):
         if v.grad is None:
             continue
         assert rel(gref[k], v.grad) < 5e-2 or (gref[k] - v.grad).abs().max() < 1e-4, (k, rel(gref[k], v.grad))
+
+
+@pytest.mark.parametrize("case", ["all_idle", "no_langact_tokens", "no_valid_image", "batch_of_one", "max_padding"])
+def test_degenerate_batches_match_oracle(hip, case):
+    """Edge cases of the loss assembly (lap.py:209-289,472-596) and the masks (lap.py:118-170,303-377): every sample idle (sample_mask all
+    False: the language term is 0 / max(0, 1)), a sample without language-action tokens (its cross entropy is 0 / max(0, 1)), a sample whose
+    images are all invalid (its prefix keys are the prompt alone), a batch of one, and a prompt that is padding except for three tokens.
+    Loss, per-sample losses and a handful of gradients against the f32 oracle."""
+    cfg = debug_model_cfg()
+    oc = oracle_cfg(cfg)
+    P = O.init_params(oc, seed=21)
+    B = 1 if case == "batch_of_one" else 3
+    obs, actions, noise, time = make_inputs(cfg, B=B, ragged=True)
+    L = cfg.max_token_len
+    if case == "all_idle":
+        obs["sample_mask"][:] = False
+    elif case == "no_langact_tokens":
+        obs["tokenized_langact_mask"][0] = False
+    elif case == "no_valid_image":
+        for k in cfg.image_keys:
+            obs["image_masks"][k][0] = False
+    elif case == "max_padding":
+        obs["tokenized_prompt_mask"][0] = False
+        obs["tokenized_prompt_mask"][0, :3] = True
+        obs["tokenized_langact_mask"][0] = False
+        obs["tokenized_langact_mask"][0, 1:3] = True
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss32, m32 = O.compute_loss(Pg, oc, obs, actions, noise, time)
+    loss32.backward()
+    model = _engine(cfg, P)
+    for g in model.ps.grad.values():
+        g.zero_()
+    col = {}
+    loss, metrics = model.loss_and_grad(0, to_observation(obs, DEV), actions.to(DEV), noise=noise.to(DEV), time=time.to(DEV), collect=col)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and abs(loss.item() - loss32.item()) <= 1e-2 * abs(loss32.item()) + 1e-6, (loss.item(), loss32.item())
+    assert rel(col["per_sample_action"], m32["per_sample_action"]) < 2e-2
+    ps_lang = m32["per_sample_lang"].detach()
+    if float(ps_lang.abs().max()) > 0:
+        assert rel(col["per_sample_lang"], ps_lang) < 2e-2
+    else:
+        assert float(col["per_sample_lang"].abs().max()) == 0.0
+    if case == "no_langact_tokens" or case == "all_idle":
+        assert float(col["per_sample_lang"][0]) == 0.0 and float(ps_lang[0]) == 0.0
+    from lap_amd.params import engine_to_reference
+
+    gref = engine_to_reference(cfg, {name: model.ps.g(name).detach().float().cpu() for name in model.ps.names()})
+    for k in ("PaliGemma/llm/layers/mlp_1/linear", "action_out_proj/kernel", "PaliGemma/llm/layers/attn/kv_einsum/w", "PaliGemma/img/head/kernel",
+              "PaliGemma/llm/embedder/input_embedding"):
+        g32 = Pg[k].grad
+        if g32 is None or float(g32.abs().max()) == 0.0:
+            assert float(gref[k].abs().max()) == 0.0, k
+        else:
+            assert rel(gref[k], g32) < 5e-2 or (gref[k] - g32).abs().max() < 1e-4, (k, rel(gref[k], g32))
