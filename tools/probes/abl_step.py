@@ -3,6 +3,7 @@ stream costs the compute stream how much.  ABL = comma list of:
   noexpert  : the action expert's elementwise + GEMM kernels return uninitialised outputs without launching (rows == B * S)
   noopt     : the optimizer / EMA pass is skipped (LAP_ABL_NOOPT read by nothing: done by patching hip.adamw_ema)
   noattn    : attention forward / backward return uninitialised outputs
+  nosigwgrad: SigLIP's weight-gradient GEMMs are skipped;  nosigbgrad: every bias column sum is skipped
 usage: ABL=noexpert python tools/probes/abl_step.py [steps]"""
 import dataclasses
 import os
@@ -82,6 +83,17 @@ if ELEM or GEMM:
     for n, f in list(locals().items()):
         if n in o and ((n in gemm_names and GEMM) or (n not in gemm_names and ELEM)):
             setattr(hip, n, f)
+if "nosigwgrad" in abl:      # SigLIP's weight gradients (the third stream's GEMMs) are not computed: what they cost the compute stream
+    from lap_amd.model import LAP
+    _wg = LAP._wgrad
+    def _wgrad(self, dy, x, name, **kw):
+        if name.startswith("img/"):
+            return
+        return _wg(self, dy, x, name, **kw)
+    LAP._wgrad = _wgrad
+if "nosigbgrad" in abl:      # ... and the bias column sums
+    from lap_amd.model import LAP
+    LAP._bgrad = lambda self, dy, name: None
 if "noopt" in abl:
     hip.adamw_ema = lambda *a, **k: None
 if "noattn" in abl:
