@@ -428,6 +428,7 @@ def main():
     from lap_amd.train import TrainingStepRunner, init_train_state
 
     comm = None
+    ranks_seen = devices_seen = 1
     if world > 1:
         import torch.distributed as dist
 
@@ -436,6 +437,18 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        # What the communicator itself saw, not the launcher's WORLD_SIZE: every rank contributes a 1 and a one-hot of its
+        # device's PCI bus id slot through the backend's own all-reduce (RCCL for "nccl": the tensors live on the device).
+        one = torch.ones(1, dtype=torch.float32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        uuid = torch.zeros(world, dtype=torch.int64, device=one.device)
+        try:
+            uuid[rank] = hash(str(torch.cuda.get_device_properties(dev).uuid)) & 0x7FFFFFFF
+        except Exception:   # noqa: BLE001
+            uuid[rank] = dev.index if hasattr(dev, "index") and dev.index is not None else rank
+        dist.all_reduce(uuid)
+        devices_seen = len(set(uuid.tolist()))
     tc = dataclasses.replace(get_config(args.config), batch_size=args.batch * world, fsdp_devices=world, gemm_dtype=args.dtype)
     state = init_train_state(tc, device=dev, world_size=world, rank=rank, use_fsdp=world > 1)
     runner = TrainingStepRunner(tc)
@@ -549,8 +562,12 @@ def main():
                 ver = torch.cuda.nccl.version()
             except Exception:   # noqa: BLE001
                 ver = None
-            out["rccl"] = {"ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
-                           "version": ".".join(str(v) for v in ver) if isinstance(ver, tuple) else ver}
+            out["rccl"] = {"ranks": ranks_seen, "ranks_source": "all_reduce(SUM) of one 1 per rank on the process group's backend, device tensor",
+                           "devices_seen": devices_seen, "group_world_size": torch.distributed.get_world_size(),
+                           "backend": torch.distributed.get_backend(), "version": ".".join(str(v) for v in ver) if isinstance(ver, tuple) else ver}
+        # every LAP_* / RCCL / NCCL switch that steers the step and is set in this process's environment (a bench line is
+        # only comparable with another one taken under the same switches)
+        out["env_switches"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("LAP_", "NCCL_", "RCCL_", "HSA_", "HIP_", "GPU_MAX_HW"))}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -366,13 +366,27 @@ static int adamw_launch(float* p, float* m, float* v, float* ema, const void* g,
   // Step, same box, interleaved: 4096 blocks 266.7 | 384 268.4 | 320 263.5 | 288 262.1 | 256 259.3 | 224 259.2 | 192 260.2 | 160 262.2 |
   // 128 270.6 | 64 291.7 ms.  Default: 15/16 of the device's CUs (240 on MI355X; a partitioned device gets its own count).
   // LAP_ADAMW_BLOCKS / LAP_ADAMW_THREADS: tuning knobs.
-  static const long long cap = [] {
-    if (getenv("LAP_ADAMW_BLOCKS")) return atoll(getenv("LAP_ADAMW_BLOCKS"));
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return (long long)(cus * 15 / 16 > 0 ? cus * 15 / 16 : 1);
+  // (the cap is kept per device: a process that drives several devices must not hand the first one's CU count to the others; the knobs are
+  //  clamped to what the kernel's __launch_bounds__(256) and a non-empty grid allow)
+  static long long cap_of[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  long long cap = __atomic_load_n(&cap_of[dev], __ATOMIC_RELAXED);
+  if (cap == 0) {
+    if (getenv("LAP_ADAMW_BLOCKS")) cap = atoll(getenv("LAP_ADAMW_BLOCKS"));
+    else {
+      int cus = 256;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      cap = cus * 15 / 16;
+    }
+    if (cap < 1) cap = 1;
+    __atomic_store_n(&cap_of[dev], cap, __ATOMIC_RELAXED);
+  }
+  static const int threads = [] {
+    int t = getenv("LAP_ADAMW_THREADS") ? atoi(getenv("LAP_ADAMW_THREADS")) : 256;
+    t = t < 64 ? 64 : t > 256 ? 256 : t;
+    return t & ~63;
   }();
-  static const int threads = getenv("LAP_ADAMW_THREADS") ? atoi(getenv("LAP_ADAMW_THREADS")) : 256;
   const long long CH = 1LL << 29;
   for (long long o = 0; o < n; o += CH) {
     const long long cnt = n - o < CH ? n - o : CH;

@@ -322,12 +322,14 @@ def compute_norm_stats(dataset: EpisodeDataset, *, action_pad_to: int | None = N
     fields; num_transitions counts those rows) and over the per-frame state as the model sees it ([xyz, rot6d, gripper] for end-effector
     states).  The mixer pads to the model's widths later (`global_norm_stats`); `action_pad_to` zero-pads here for single datasets:
     all-zero columns normalise to 0 by the q01 == q99 rule."""
-    # Streaming form (ADVICE r4): the chunks of one episode at a time, kept as float32 rows (what the store holds) for the quantiles;
-    # mean / std / min / max from float64 running sums per episode.  Peak memory = 2 x rows x A x 4 bytes (+ one column's sort copy)
-    # instead of 2 x rows x A x 8, and `dataset.chunks` runs once per episode.
+    # Streaming form (ADVICE r4 / r5): the chunks of one episode at a time.  Rows are kept as float32 (the store's own dtype: the cast is a
+    # no-op for stored data and is what the quantiles, min and max are taken from); mean / std come from per-episode (n, mean, M2) in
+    # float64 merged by Chan's formula — E[x^2] - mean^2 loses the digits of a column with a large mean and a small spread.  Rows with a
+    # non-finite entry (NaN proprioception in a few OXE episodes) are dropped from the statistics, states and chunks alike.  Peak memory
+    # = 2 x rows x A x 4 bytes (+ one column's sort copy); `dataset.chunks` runs once per episode.
     def stats_of(rows_iter, width):
         parts, n = [], 0
-        s1 = np.zeros(width, dtype=np.float64); s2 = np.zeros(width, dtype=np.float64)
+        mean = np.zeros(width, dtype=np.float64); m2 = np.zeros(width, dtype=np.float64)
         lo = np.full(width, np.inf); hi = np.full(width, -np.inf)
         for r in rows_iter:
             r = r[np.isfinite(r).all(1)]
@@ -335,13 +337,16 @@ def compute_norm_stats(dataset: EpisodeDataset, *, action_pad_to: int | None = N
                 continue
             parts.append(np.ascontiguousarray(r, dtype=np.float32))
             r64 = r.astype(np.float64)
-            s1 += r64.sum(0); s2 += (r64 * r64).sum(0)
+            k, mk = len(r64), r64.mean(0)
+            m2k = ((r64 - mk) ** 2).sum(0)
+            d = mk - mean
+            m2 += m2k + d * d * (n * k / (n + k))
+            mean += d * (k / (n + k))
             lo = np.minimum(lo, r64.min(0)); hi = np.maximum(hi, r64.max(0))
-            n += len(r)
+            n += k
         buf = np.concatenate(parts, 0) if parts else np.zeros((0, width), dtype=np.float32)
         del parts
-        mean = s1 / max(n, 1)
-        std = np.sqrt(np.maximum(s2 / max(n, 1) - mean * mean, 0.0))
+        std = np.sqrt(m2 / max(n, 1))
         q01 = np.array([np.quantile(buf[:, j].astype(np.float64), 0.01) for j in range(width)])
         q99 = np.array([np.quantile(buf[:, j].astype(np.float64), 0.99) for j in range(width)])
         return {"mean": mean.tolist(), "std": std.tolist(), "q01": q01.tolist(), "q99": q99.tolist(), "min": lo.tolist(), "max": hi.tolist()}

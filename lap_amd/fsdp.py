@@ -326,7 +326,21 @@ class FsdpComm(UnitPipeline):
     # ---- gradients
     def _reduce_grads(self, u):
         if self.ps.sharded(u):
-            self._reduce_scatter(self.ps.gshard[u.name], self.ps.grad[u.name])
+            g, gs = self.ps.grad[u.name], self.ps.gshard[u.name]
+            if g.dtype != gs.dtype:
+                # LAP_FSDP_REDUCE_F32=1: the bf16 buffer is widened into one shared f32 staging buffer and the ring sums in f32 (twice
+                # the bytes on xGMI).  Default: bf16 on the wire — RCCL's ring adds in f32 but rounds the running sum to bf16 at each of
+                # the N - 1 hops, sqrt(N - 1) x 2^-9 / sqrt(3) relative L2 on top of the single rounding the weight-gradient epilogue
+                # does (tests/test_fsdp_cpu.py::test_bf16_ring_reduction_error_bound: 3.7e-3 at N = 8 against 1.7e-3 for one rounding).
+                # That is also what GSPMD does with the reference's bf16 dot outputs (the partial products of `w.astype(bf16)` are reduced
+                # across the batch shards in the dot's own dtype, gemma.py:307,318), so bf16 stays the default.
+                if getattr(self, "_stage32", None) is None or self._stage32.numel() < g.numel():
+                    self._stage32 = torch.empty(max(self.ps.padded(x) for x in self.ps.units if self.ps.sharded(x) and x.name != "embed"),
+                                                dtype=torch.float32, device=g.device)
+                st = self._stage32[:g.numel()]
+                st.copy_(g)
+                g = st
+            self._reduce_scatter(gs, g)
         else:
             self.dist.all_reduce(self.ps.grad[u.name], op=self.dist.ReduceOp.SUM, group=self.group)
 

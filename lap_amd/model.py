@@ -1113,6 +1113,10 @@ class LAP:
         if not skip_prefix and not lang_on:
             # no language loss: the prefix stream's only cotangents are those of its keys / values under the action queries
             dx0 = torch.zeros((B * Pn, Dv), dtype=torch.bfloat16, device=dev)
+            # the LM-head weight-gradient product is what overwrites (beta = 0) the embedding table's f32 gradient buffer; without it the
+            # scatter-add of _embed_prefix_bwd would accumulate onto the previous step's values
+            if self.ps.is_trainable("llm/embed"):
+                self.G("llm/embed").zero_()
         elif not skip_prefix:
             # language head: dlogits = w * (softmax - onehot); w = d loss / d nll.  The cotangent of the f32 logits stays f32 in the
             # reference (d pre_logits = dlogits . table, d table = dlogits^T . pre_logits in f32): dlogits = dh + dl (two bf16

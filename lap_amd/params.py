@@ -174,7 +174,9 @@ class ParamStore:
             if with_grads:
                 gdt = self.grad_dtype(u)
                 self.grad[u.name] = z(n, gdt)
-                self.gshard[u.name] = self.grad[u.name] if self.sharded(u) is False else z(sh, gdt)
+                # LAP_FSDP_REDUCE_F32=1: bf16 gradient buffers are widened before the reduce-scatter and summed in f32 (a bf16
+                # ring rounds the partial sum at every hop; see fsdp.FsdpComm._reduce_grads), so the shard the optimizer reads is f32
+                self.gshard[u.name] = self.grad[u.name] if self.sharded(u) is False else z(sh, torch.float32 if self.reduce_f32() else gdt)
             if with_optimizer:
                 self.m[u.name], self.v[u.name] = z(sh), z(sh)
             if with_ema:
@@ -194,6 +196,11 @@ class ParamStore:
         if u.big and u.name != "embed" and os.environ.get("LAP_GRAD_BF16", "1") != "0":
             return torch.bfloat16
         return torch.float32
+
+    @staticmethod
+    def reduce_f32() -> bool:
+        import os
+        return os.environ.get("LAP_FSDP_REDUCE_F32", "0") == "1"
 
     def sharded(self, u: UnitSpec) -> bool:
         return u.big and self.world_size > 1

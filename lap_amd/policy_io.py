@@ -7,14 +7,16 @@ Reference call chain (policies/policy_config_adapter.py:85-154):
 Restated from: src/lap/transforms.py:27-275 (tokenize / normalize / unnormalize / pad), policies/transforms/
 {input_transforms,image_handler,image_utils,text_utils,output_transforms}.py, models/tokenizer.py:105-331 and the
 openpi pieces they lean on (InjectDefaultPrompt, pad_to_dim, apply_tree, NormStats, msgpack_numpy — absent submodule,
-[UPSTREAM-RECALL] in SURVEY.md §8c).  Parity status: prompt text + state bins are pinned by reference-generated
-fixtures (lap_amd/prompt.py); the arithmetic here is pinned only by the cited lines and by hand-computed cases in
-tests/test_policy_io_cpu.py ("parity unpinned": the reference modules import openpi and cannot run here).
+[UPSTREAM-RECALL] in SURVEY.md §8c).  Parity status: PINNED by outputs of the reference's own classes, executed in the
+build container with stand-ins only for the openpi base classes they subclass (never for arithmetic; each generator's
+docstring says what it stands in for): tests/golden/{tokenize_v1, cot_inputs_v1, cot_outputs_v1, normalize_v1,
+prompt_format_v1, lang_action_v1, question_v1}.json, replayed by tests/test_policy_io_cpu.py / test_questions_cpu.py
+(ids and masks exact, actions to 1e-12, the training-side normalisation bit for bit in float32).  Still recalled from
+openpi, not pinned: InjectDefaultPrompt, pad_to_dim, the msgpack-numpy wire format.
 
-Scope: the inference path of robot samples (what a LIBERO / DROID client sends) plus the training-time tokenisation with
-language actions; text <-> delta conversion lives in lap_amd/lang_actions.py.  Dataset-time sample handlers (VQA / prediction
-question synthesis, per-dataset language-action summarisation inside CoTInputs, wrist-image dropout) belong to the data path
-(§8f rank 4) and raise NotImplementedError.
+Scope: the inference path of robot samples (what a LIBERO / DROID client sends) and the training path of CoTInputs —
+language-action labels through `lang_actions.ActionProcessor`, wrist-image dropout / random un-masking, and the VQA /
+prediction sample handlers (`questions.py`); text <-> delta conversion lives in lap_amd/lang_actions.py.
 """
 from __future__ import annotations
 

@@ -124,6 +124,26 @@ def _mk_round(cfg: OracleCfg):
     return lambda x: x
 
 
+class _RoundWeightSTE(torch.autograd.Function):
+    """`w.astype(bf16)` of an f32 master weight that feeds a bf16 dot (gemma.py:307,318; lora.Einsum; Flax Dense with dtype=bf16): the
+    forward rounds the weight, and the cotangent that comes back through the cast is the bf16 OUTPUT of the weight-gradient dot — it is
+    rounded to bf16 once before it reaches the f32 master.  (`_RoundSTE` passes the f32 cotangent through: right for activations, whose
+    rounding points the backward of this restatement does not model, and one rounding short for weights.)"""
+    @staticmethod
+    def forward(ctx, w):
+        return w.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def _mk_round_w(cfg: OracleCfg):
+    if cfg.emulate_bf16 or cfg.emulate_fp8:
+        return _RoundWeightSTE.apply
+    return lambda x: x
+
+
 class _Fp8STE(torch.autograd.Function):
     """Quantise-dequantise to OCP e4m3 with the per-tensor scale 448 / amax (straight-through in the backward)."""
     @staticmethod
@@ -262,13 +282,13 @@ def apply_rope(x: torch.Tensor, positions: torch.Tensor, max_wavelength: float =
     return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1)
 
 
-def rmsnorm(x, scale=None, cond=None, dense_k=None, dense_b=None, r=lambda t: t):
+def rmsnorm(x, scale=None, cond=None, dense_k=None, dense_b=None, r=lambda t: t, rw=None):
     """gemma.py:113-131.  Returns (normed, gate or None)."""
     var = torch.mean(torch.square(x), dim=-1, keepdim=True)
     normed = x * torch.reciprocal(torch.sqrt(var + 1e-6))
     if cond is None:
         return r(normed * (1 + scale)), None
-    modulation = r(r(r(cond) @ r(dense_k)) + r(dense_b))  # nn.Dense(dtype=bf16)
+    modulation = r(r(r(cond) @ (rw or r)(dense_k)) + r(dense_b))  # nn.Dense(dtype=bf16)
     sc, sh, gate = torch.chunk(modulation[:, None, :], 3, dim=-1)
     return r(normed * r(1 + sc) + sh), gate
 
@@ -278,7 +298,7 @@ def siglip_forward(P, cfg: OracleCfg, image: torch.Tensor, collect: dict | None 
     """openpi.models.siglip._Module.__call__ (missing) restated from the in-tree Gemma3 variant
     siglip_gemma3.py:382-545 minus its soft-embedding RMSNorm (:432) and with the PaliGemma head bias.
     image f32 [B,H,W,3] in [-1,1] -> [B, 256, vlm.width]."""
-    r = _mk_round(cfg)
+    r, rw = _mk_round(cfg), _mk_round_w(cfg)
     s = cfg.img
     B, H, W, C = image.shape
     p = s.patch
@@ -299,26 +319,26 @@ def siglip_forward(P, cfg: OracleCfg, image: torch.Tensor, collect: dict | None 
     for l in range(s.depth):
         mha = f"{blk}/MultiHeadDotProductAttention_0"
         y = ln(x, P[f"{blk}/LayerNorm_0/scale"][l], P[f"{blk}/LayerNorm_0/bias"][l])
-        q = r(r(torch.einsum("btd,dnh->btnh", y, r(P[f"{mha}/query/kernel"][l]))) + r(P[f"{mha}/query/bias"][l]))
-        k = r(r(torch.einsum("btd,dnh->btnh", y, r(P[f"{mha}/key/kernel"][l]))) + r(P[f"{mha}/key/bias"][l]))
-        v = r(r(torch.einsum("btd,dnh->btnh", y, r(P[f"{mha}/value/kernel"][l]))) + r(P[f"{mha}/value/bias"][l]))
+        q = r(r(torch.einsum("btd,dnh->btnh", y, rw(P[f"{mha}/query/kernel"][l]))) + r(P[f"{mha}/query/bias"][l]))
+        k = r(r(torch.einsum("btd,dnh->btnh", y, rw(P[f"{mha}/key/kernel"][l]))) + r(P[f"{mha}/key/bias"][l]))
+        v = r(r(torch.einsum("btd,dnh->btnh", y, rw(P[f"{mha}/value/kernel"][l]))) + r(P[f"{mha}/value/bias"][l]))
         q = r(q / r(torch.tensor(math.sqrt(hd))))  # flax dot_product_attention_weights
         logits = r(torch.einsum("bqnh,bknh->bnqk", q, k))
         probs = r(torch.softmax(logits, dim=-1))
         enc = r(torch.einsum("bnqk,bknh->bqnh", probs, v))
-        y = r(r(torch.einsum("bqnh,nhd->bqd", enc, r(P[f"{mha}/out/kernel"][l]))) + r(P[f"{mha}/out/bias"][l]))
+        y = r(r(torch.einsum("bqnh,nhd->bqd", enc, rw(P[f"{mha}/out/kernel"][l]))) + r(P[f"{mha}/out/bias"][l]))
         x = r(x + y)
         y = ln(x, P[f"{blk}/LayerNorm_1/scale"][l], P[f"{blk}/LayerNorm_1/bias"][l])
-        h = r(r(y @ r(P[f"{blk}/MlpBlock_0/Dense_0/kernel"][l])) + r(P[f"{blk}/MlpBlock_0/Dense_0/bias"][l]))
+        h = r(r(y @ rw(P[f"{blk}/MlpBlock_0/Dense_0/kernel"][l])) + r(P[f"{blk}/MlpBlock_0/Dense_0/bias"][l]))
         h = r(gelu_tanh(h))
-        y = r(r(h @ r(P[f"{blk}/MlpBlock_0/Dense_1/kernel"][l])) + r(P[f"{blk}/MlpBlock_0/Dense_1/bias"][l]))
+        y = r(r(h @ rw(P[f"{blk}/MlpBlock_0/Dense_1/kernel"][l])) + r(P[f"{blk}/MlpBlock_0/Dense_1/bias"][l]))
         x = r(x + y)
         if collect is not None:
             collect[f"img/block{l:02d}"] = x
     x = ln(x, P["PaliGemma/img/Transformer/encoder_norm/scale"], P["PaliGemma/img/Transformer/encoder_norm/bias"])
     if collect is not None:
         collect["img/encoded"] = x
-    x = r(r(x @ r(P["PaliGemma/img/head/kernel"])) + r(P["PaliGemma/img/head/bias"]))
+    x = r(r(x @ rw(P["PaliGemma/img/head/kernel"])) + r(P["PaliGemma/img/head/bias"]))
     if collect is not None:
         collect["img/out"] = x
     return x
@@ -329,7 +349,7 @@ def gemma_forward(P, cfg: OracleCfg, embedded, positions, mask, adarms_cond=None
     """gemma.Module.__call__ (gemma.py:455-531) + Block (336-387) + Attention (167-290).
     embedded: [x0 or None, x1 or None]; positions int [B,T]; mask bool [B,T,S];
     kv_cache: list of (K [B,S0,1,H], V) per layer or None.  Returns (outs, new_cache)."""
-    r = _mk_round(cfg)
+    r, rw = _mk_round(cfg), _mk_round_w(cfg)
     cfgs = (cfg.vlm, cfg.expert)
     if adarms_cond is None:
         adarms_cond = [None, None]
@@ -353,7 +373,7 @@ def gemma_forward(P, cfg: OracleCfg, embedded, positions, mask, adarms_cond=None
                 y, gate = rmsnorm(x, scale=P[f"{lay}/pre_attention_norm{sfx}/scale"][l], r=r)
             else:
                 y, gate = rmsnorm(x, cond=adarms_cond[i], dense_k=P[f"{lay}/pre_attention_norm{sfx}/Dense_0/kernel"][l],
-                                  dense_b=P[f"{lay}/pre_attention_norm{sfx}/Dense_0/bias"][l], r=r)
+                                  dense_b=P[f"{lay}/pre_attention_norm{sfx}/Dense_0/bias"][l], r=r, rw=rw)
             pre.append(y); gates.append(gate)
         qs, ks, vs = [], [], []
         for i, x in enumerate(pre):
@@ -361,7 +381,7 @@ def gemma_forward(P, cfg: OracleCfg, embedded, positions, mask, adarms_cond=None
                 continue
             sfx = "" if i == 0 else f"_{i}"
             q8 = _mk_q8(cfg, i)
-            wq, wkv = r(P[f"{lay}/attn/q_einsum{sfx}/w"][l]), r(P[f"{lay}/attn/kv_einsum{sfx}/w"][l])
+            wq, wkv = rw(P[f"{lay}/attn/q_einsum{sfx}/w"][l]), rw(P[f"{lay}/attn/kv_einsum{sfx}/w"][l])
             if cfg.emulate_fp8 and i == 0:   # the engine quantises the packed q|k|v weight with ONE scale
                 flat = q8(torch.cat([wq.reshape(-1), wkv.reshape(-1)]))
                 wq, wkv = flat[:wq.numel()].view_as(wq), flat[wq.numel():].view_as(wkv)
@@ -406,7 +426,7 @@ def gemma_forward(P, cfg: OracleCfg, embedded, positions, mask, adarms_cond=None
             sfx = "" if i == 0 else f"_{i}"
             end = start + x.shape[1]
             q8 = _mk_q8(cfg, i)
-            outs.append(r(torch.einsum("btnh,nhd->btd", q8(enc[:, start:end]), q8(r(P[f"{lay}/attn/attn_vec_einsum{sfx}/w"][l])))))
+            outs.append(r(torch.einsum("btnh,nhd->btd", q8(enc[:, start:end]), q8(rw(P[f"{lay}/attn/attn_vec_einsum{sfx}/w"][l])))))
             start = end
         xs = [_gated_residual(x, y, g, r) for x, y, g in zip(xs, outs, gates)]
         outs, gates = [], []
@@ -418,14 +438,14 @@ def gemma_forward(P, cfg: OracleCfg, embedded, positions, mask, adarms_cond=None
                 y, gate = rmsnorm(x, scale=P[f"{lay}/pre_ffw_norm{sfx}/scale"][l], r=r)
             else:
                 y, gate = rmsnorm(x, cond=adarms_cond[i], dense_k=P[f"{lay}/pre_ffw_norm{sfx}/Dense_0/kernel"][l],
-                                  dense_b=P[f"{lay}/pre_ffw_norm{sfx}/Dense_0/bias"][l], r=r)
+                                  dense_b=P[f"{lay}/pre_ffw_norm{sfx}/Dense_0/bias"][l], r=r, rw=rw)
             q8 = _mk_q8(cfg, i)
-            wg = q8(r(P[f"{lay}/mlp{sfx}/gating_einsum"][l]))      # gate | up share one scale (packed weight)
+            wg = q8(rw(P[f"{lay}/mlp{sfx}/gating_einsum"][l]))      # gate | up share one scale (packed weight)
             yq = q8(y)
             ff_gate = r(yq @ wg[0])
             ff1 = r(yq @ wg[1])
             act = r(r(gelu_tanh(ff_gate)) * ff1)
-            outs.append(r(q8(act) @ q8(r(P[f"{lay}/mlp{sfx}/linear"][l]))))
+            outs.append(r(q8(act) @ q8(rw(P[f"{lay}/mlp{sfx}/linear"][l]))))
             gates.append(gate)
         xs = [_gated_residual(x, y, g, r) for x, y, g in zip(xs, outs, gates)]
         if collect is not None:
@@ -441,7 +461,7 @@ def gemma_forward(P, cfg: OracleCfg, embedded, positions, mask, adarms_cond=None
             final.append(rmsnorm(x, scale=P[f"PaliGemma/llm/final_norm{sfx}/scale"], r=r)[0])
         else:
             final.append(rmsnorm(x, cond=adarms_cond[i], dense_k=P[f"PaliGemma/llm/final_norm{sfx}/Dense_0/kernel"],
-                                 dense_b=P[f"PaliGemma/llm/final_norm{sfx}/Dense_0/bias"], r=r)[0])
+                                 dense_b=P[f"PaliGemma/llm/final_norm{sfx}/Dense_0/bias"], r=r, rw=rw)[0])
     return final, new_cache
 
 

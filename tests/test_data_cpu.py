@@ -79,6 +79,39 @@ def test_samples_and_batches(setup):
         D.create_data_loader(cfg, D.EpisodeDataset(_episodes(1, 1), action_horizon=10), tok)
 
 
+def test_streamed_norm_stats_equal_the_two_pass_statistics():
+    """compute_norm_stats streams episodes and merges per-episode (n, mean, M2) in float64: held to numpy's two-pass
+    statistics over the concatenated rows, on a column with a large mean and a small spread (where E[x^2] - mean^2 in one pass loses the
+    digits), and with rows that carry NaN (dropped from the state statistics)."""
+    rng = np.random.default_rng(0)
+
+    class _Store:
+        def __init__(self):
+            self.episodes = []
+            for n in (7, 19, 4):
+                st = rng.normal(size=(n, 3)).astype(np.float32)
+                st[:, 0] = (1000.0 + 1e-2 * rng.normal(size=n)).astype(np.float32)
+                self.episodes.append({"state": st, "actions": np.zeros((n, 2), np.float32)})
+            self.episodes[1]["state"][5, 1] = np.nan
+            self._chunks = [(5000.0 + 1e-2 * rng.normal(size=(len(e["actions"]), 4, 2))).astype(np.float32) for e in self.episodes]
+
+        def chunks(self, e):
+            return self._chunks[[id(x) for x in self.episodes].index(id(e))]
+
+    ds = _Store()
+    st = D.compute_norm_stats(ds)
+    rows = np.concatenate([e["state"] for e in ds.episodes], 0)
+    rows = rows[np.isfinite(rows).all(1)].astype(np.float64)
+    acts = np.concatenate([c.reshape(-1, 2) for c in ds._chunks], 0).astype(np.float64)
+    for got, ref in ((st["state"], rows), (st["actions"], acts)):
+        np.testing.assert_allclose(got["mean"], ref.mean(0), rtol=1e-12)
+        np.testing.assert_allclose(got["std"], ref.std(0), rtol=1e-9)
+        np.testing.assert_allclose(got["q01"], np.quantile(ref, 0.01, axis=0), rtol=1e-12)
+        np.testing.assert_allclose(got["q99"], np.quantile(ref, 0.99, axis=0), rtol=1e-12)
+        np.testing.assert_array_equal(got["min"], ref.min(0)); np.testing.assert_array_equal(got["max"], ref.max(0))
+    assert 5e-3 < st["actions"]["std"][0] < 2e-2          # (the one-pass form returns 0 or garbage here: 5000^2 eats 1e-4)
+
+
 def test_resume_and_rank_shards(setup):
     cfg, tok, ds = setup
     a = D.create_data_loader(cfg, ds, tok, seed=5)

@@ -94,6 +94,71 @@ def test_fsdp_step_protocol_gloo(world):
     assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
 
 
+def _reduce_f32_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LAP_FSDP_REDUCE_F32="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lap_amd.fsdp import FsdpComm
+
+        cfg = get_config("debug").model
+        ps = ParamStore(cfg, "cpu", world_size=world, rank=rank)
+        ps.load_reference_tree(O.init_params(oracle_cfg(cfg), seed=2))
+        comm = FsdpComm(ps)
+        assert any(ps.grad[u.name].dtype == torch.bfloat16 for u in ps.units)
+        assert all(ps.gshard[u.name].dtype == torch.float32 for u in ps.units)
+        per_rank = [{u.name: torch.randn(ps.padded(u), generator=torch.Generator().manual_seed(10 * r + i)).to(ps.grad_dtype(u))
+                     for i, u in enumerate(ps.units)} for r in range(world)]
+        for u in ps.units:
+            ps.grad[u.name].copy_(per_rank[rank][u.name])
+            comm.grads_ready(u.name)
+        comm.finish_grads()
+        for u in ps.units:
+            a, b = ps.shard_range(u)
+            exact = sum(per_rank[r][u.name].double() for r in range(world))[a:b]
+            # f32 sum of (bf16-valued) gradients: only f32 rounding of the running sum remains
+            assert (ps.gshard[u.name].double() - exact).abs().max() <= 1e-6 * exact.abs().max(), u.name
+        ret[rank] = "ok"
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fsdp_f32_reduction_option_gloo():
+    """LAP_FSDP_REDUCE_F32=1: bf16 gradient buffers are widened before the reduce-scatter; the optimizer's shard is f32."""
+    world = 2
+    port = 29500 + os.getpid() % 500 + 3
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    procs = [mp.get_context("spawn").Process(target=_reduce_f32_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
+
+
+def test_bf16_ring_reduction_error_bound():
+    """What the default (bf16 on the wire) costs at the node size: a ring reduce-scatter adds in f32 and rounds the running sum to bf16 at each
+    of the N - 1 hops.  Emulated for N = 8 on random gradients of equal scale: relative L2 against the f32 sum of the same bf16 inputs stays
+    below 5e-3 (measured 3.7e-3; ONE bf16 rounding of the exact sum, which the weight-gradient epilogue does anyway, is 1.7e-3), and the
+    global norm — the quantity the clip factor is made of — moves by < 2e-4."""
+    g = torch.Generator().manual_seed(0)
+    N, n = 8, 1 << 18
+    parts = [torch.randn(n, generator=g).to(torch.bfloat16) for _ in range(N)]
+    exact = sum(p.double() for p in parts)
+    run = parts[0]
+    for p in parts[1:]:
+        run = (run.float() + p.float()).to(torch.bfloat16)
+    once = exact.float().to(torch.bfloat16)
+    rel = lambda a, b: ((a.double() - b).norm() / b.norm()).item()
+    e_ring, e_once = rel(run, exact), rel(once, exact)
+    assert e_once < 2e-3 and e_ring < 5e-3 and e_ring < 3.0 * e_once, (e_ring, e_once)
+    assert abs(run.double().norm() - exact.norm()) / exact.norm() < 2e-4
+
+
 def _ckpt_worker(rank, world, port, ret, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
