@@ -213,7 +213,8 @@ def test_full_size_two_rank_step_equals_single_rank(hip, tmp_path):
             if dr.abs().max() > 0:
                 moved += 1
                 assert rel(du, dr) < 0.15, (u.name, r, rel(du, dr))
-                assert rel(rf, f0) < 1e-3, (u.name, r)
+                if ri.norm() > 100 * dr.norm():          # (the zero-initialised adaRMS bank IS its update)
+                    assert rel(rf, f0) < 1e-3, (u.name, r)
     assert moved >= len(ps.units)
     for name, (fsum, losum) in ret[0][2].items():       # both ranks hold the same gathered mirrors; the table's lo plane travelled too
         assert ret[1][2][name] == (fsum, losum), name
