@@ -444,7 +444,8 @@ def main():
         ranks_seen = int(one.item())
         uuid = torch.zeros(world, dtype=torch.int64, device=one.device)
         try:
-            uuid[rank] = hash(str(torch.cuda.get_device_properties(dev).uuid)) & 0x7FFFFFFF
+            import zlib
+            uuid[rank] = zlib.crc32(str(torch.cuda.get_device_properties(dev).uuid).encode()) + 1     # (str hashes are salted per process)
         except Exception:   # noqa: BLE001
             uuid[rank] = dev.index if hasattr(dev, "index") and dev.index is not None else rank
         dist.all_reduce(uuid)
