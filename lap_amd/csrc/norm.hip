@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
       }
     }
   }
-  // one row ahead: the loads of the wave's next row are issued before the reductions / stores of the current one
+  // one row ahead: the loads of the wave's next row are issued before the reductions / stores of the current one.  Round 6: the row of dx an
+  // accumulating call adds onto is requested at the top of its iteration, not behind the wave-wide reduction where nothing covered its latency
+  // (17920 x 2048, accumulate: 62 us = 4.7 TB/s before; a row ahead like x / dy it cost the D = 2048 variant its second wave per SIMD)
   bf16x8 nx[NCH], ndy[NCH];
   float nr = 0.f;
   auto fetch = [&](int row) {
@@ -122,9 +124,14 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
   };
   if (r0 + w < r1) fetch(r0 + w);
   for (int row = r0 + w; row < r1; row += NWAVE) {
-    bf16x8 cx[NCH], cdy[NCH];
+    bf16x8 cx[NCH], cdy[NCH], cold[NCH];
 #pragma unroll
-    for (int p = 0; p < NCH; ++p) { cx[p] = nx[p]; cdy[p] = ndy[p]; }
+    for (int p = 0; p < NCH; ++p) {
+      cx[p] = nx[p]; cdy[p] = ndy[p];
+      const int c = (lane + 64 * p) * 8;
+      if (NCH <= 3 && accum_dx && c < D) cold[p] = *reinterpret_cast<const bf16x8*>(dx + (long long)row * D + c);     // requested HERE: in flight under the row's arithmetic and reduction
+      // (NCH = 4, D = 2048: 16 more live registers cost the kernel its second wave per SIMD — it keeps the late request below)
+    }
     const float r = nr;
     if (row + NWAVE < r1) fetch(row + NWAVE);
     float xv[NCH][8], gv[NCH][8];
@@ -156,10 +163,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = r * gv[p][e] - xv[p][e] * cc;
         if (accum_dx) {
-          float old[8];
-          load8(dxr + c, old);
+          if constexpr (NCH > 3) cold[p] = *reinterpret_cast<const bf16x8*>(dxr + c);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += old[e];
+          for (int e = 0; e < 8; ++e) o[e] += (float)cold[p][e];
         }
         store8(dxr + c, o);
       }
@@ -270,9 +276,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
   };
   if (r0 + w < r1) fetch(r0 + w);
   for (int row = r0 + w; row < r1; row += NWAVE) {
-    bf16x8 cx[NCH], cdy[NCH];
+    bf16x8 cx[NCH], cdy[NCH], cold[NCH];
 #pragma unroll
-    for (int p = 0; p < NCH; ++p) { cx[p] = nx[p]; cdy[p] = ndy[p]; }
+    for (int p = 0; p < NCH; ++p) {
+      cx[p] = nx[p]; cdy[p] = ndy[p];
+      const int c = (lane + 64 * p) * 8;
+      if (NCH <= 3 && accum_dx && c < D) cold[p] = *reinterpret_cast<const bf16x8*>(dx + (long long)row * D + c);     // (as in rmsnorm_bwd_kernel: in flight under the row's arithmetic)
+    }
     const float mu = nmu, r = nr;
     if (row + NWAVE < r1) fetch(row + NWAVE);
     float xh[NCH][8], gv[NCH][8];
@@ -306,10 +316,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = r * (gv[p][e] - s1 - xh[p][e] * s2);
         if (accum_dx) {
-          float old[8];
-          load8(dxr + c, old);
+          if constexpr (NCH > 3) cold[p] = *reinterpret_cast<const bf16x8*>(dxr + c);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += old[e];
+          for (int e = 0; e < 8; ++e) o[e] += (float)cold[p][e];
         }
         store8(dxr + c, o);
         if (dxsum) {
