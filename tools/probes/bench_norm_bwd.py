@@ -22,3 +22,7 @@ us = t(lambda: hip.rmsnorm_bwd(x, dy, rstd, scale=sc, dx=d, dscale=dsc, accum_dx
 print("rmsnorm_bwd 17920 x 2048 accum            %.1f us  %.2f TB/s" % (us, 4 * rows * W * 2 / us / 1e6))
 us = t(lambda: hip.rmsnorm_fwd(x, scale=sc, save_rstd=True))
 print("rmsnorm_fwd 17920 x 2048                  %.1f us  %.2f TB/s" % (us, 2 * rows * W * 2 / us / 1e6))
+rows, W = 16384, 1152
+x = rnd(rows, W); gam = torch.randn(W, device=dev); bet = torch.randn(W, device=dev)
+us = t(lambda: hip.layernorm_fwd(x, gam, bet))
+print("layernorm_fwd 16384 x 1152                %.1f us  %.2f TB/s" % (us, 2 * rows * W * 2 / us / 1e6))
