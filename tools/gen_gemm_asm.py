@@ -1360,6 +1360,250 @@ class Kernel:
     .wavefront_size: 64"""
 
 
+class Kernel8:
+    """ROUND-6 PROBE (ASM_NT8=1 swaps it in for lap_gemm_asm_nt; launch with 512 threads: LAP_ASM_NT_THREADS=512): the forward product on EIGHT waves,
+    two per SIMD, each 128 x 64 = 8 x 4 MFMA tiles in 128 AGPRs, on the same 256 x 256 x 64 tile and the same LDS image.  Section D's ablation
+    says the 4-wave loop loses 27 - 50 % to its own LDS-DMA instructions (a `buffer_load ... lds` holds the wave's issue for 60 - 100 cycles and
+    nobody else feeds the SIMD's matrix pipe); with two waves per SIMD, each issuing 8 pieces per k-tile instead of 16, the partner's MFMAs fill those
+    holes — at 1.5 x the fragment reads (12 per 32 MFMAs).  Static persistent schedule (block b: tiles 32 (b % 8) + b / 8, + 256, ...), operand stream
+    restarted at every tile, direct epilogue: enough to time the loop.  Same accumulation order per output element: bitwise equal to every other tile."""
+    NV = 128
+    V_TID, V_LANE = 0, 1
+    V_DA, V_DB = 2, 4
+    V_RA, V_RB = 6, 10
+    V_CO, V_T = 14, 15
+    FA = {0: 16, 1: 64}
+    FB = {0: 48, 1: 96}
+    V_E = 112
+    S_TILE, S_W4K = 51, 40
+    OFFA, OFFB = 72, 80
+
+    def __init__(self, name):
+        self.name = name
+
+    def acc(self, fm, fn):
+        return (fm * 4 + fn) * 4
+
+    def mfma(self, fm, fn, st):
+        a = self.acc(fm, fn)
+        x, y = self.FB[st] + 4 * fn, self.FA[st] + 4 * fm
+        return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a+3}], v[{x}:{x+3}], v[{y}:{y+3}], a[{a}:{a+3}]"
+
+    def order(self):
+        o = []
+        for fm in range(8):
+            fns = range(4) if fm % 2 == 0 else range(3, -1, -1)
+            o += [(fm, fn) for fn in fns]
+        return o
+
+    def reads(self, kk, stage, st):
+        r = []
+        for f in range(8):
+            d = self.FA[st] + 4 * f
+            r.append(f"ds_read_b128 v[{d}:{d+3}], v{self.V_RA + 2*stage + kk} offset:{f*2048}")
+            if f < 4:
+                d = self.FB[st] + 4 * f
+                r.append(f"ds_read_b128 v[{d}:{d+3}], v{self.V_RB + 2*stage + kk} offset:{f*2048}")
+        return r
+
+    def dma(self, stage):
+        r = []
+        for j in range(4):
+            for rs, soff, vd, boff in ((RA, self.OFFA, self.V_DA, 0), (RB, self.OFFB, self.V_DB, BOFF)):
+                lds = stage * STAGE + boff + j * 1024
+                r.append((f"s_add_u32 m0, s{self.S_W4K}, {lds}", f"buffer_load_dwordx4 v{vd + (j & 1)}, s[{rs}:{rs+3}], s{soff+j} offen lds"))
+        return r
+
+    def bump(self):
+        r = []
+        for rs in (RA, RB):
+            r += [f"s_add_u32 s{rs}, s{rs}, 128", f"s_addc_u32 s{rs+1}, s{rs+1}, 0", f"s_sub_u32 s{rs+2}, s{rs+2}, 128", f"s_max_i32 s{rs+2}, s{rs+2}, 0"]
+        return r
+
+    def phase(self, st, side):
+        byslot = {}
+        for slot, txt in side:
+            byslot.setdefault(slot, []).append(txt)
+        for n, (fm, fn) in enumerate(self.order()):
+            E("\t" + self.mfma(fm, fn, st))
+            for txt in byslot.get(n, []):
+                L(txt)
+
+    def ktile(self, stage):
+        rd = self.reads(1, stage, 1)
+        self.phase(0, [(min(int(2.5 * n), 31), t) for n, t in enumerate(rd)])
+        E("\ts_waitcnt vmcnt(0) lgkmcnt(0)")
+        E("\ts_barrier")
+        rd = self.reads(0, stage ^ 1, 0)
+        side = [(min(int(2.5 * n), 31), t) for n, t in enumerate(rd)]
+        for n, (m0w, ld) in enumerate(self.dma(stage)):
+            slot = min(1 + n * 4, 30)
+            side += [(slot, m0w), (slot, "s_nop 0"), (slot, ld)]
+        side += [(31, t) for t in self.bump()]
+        self.phase(1, side)
+        E("\ts_waitcnt lgkmcnt(0)")
+
+    def setup(self):
+        """logical tile id in s{S_TILE} -> (tm, tn) as Kernel.setup (groups of 2^gsh m-tiles sweep n), then RA / RB / RC of the tile"""
+        t, tr = S_T, self.S_TILE
+        r = [f"s_mul_hi_u32 s{t+10}, s{tr}, s{S_MAGIC}", f"s_lshl_b32 s{t+11}, s{S_TN}, s{S_GSH}", f"s_mul_i32 s{t+12}, s{t+10}, s{t+11}",
+             f"s_sub_u32 s{t+12}, s{tr}, s{t+12}", f"s_lshl_b32 s{t+10}, s{t+10}, s{S_GSH}", f"s_lshl_b32 s{t+14}, 1, s{S_GSH}",
+             f"s_add_u32 s{t+11}, s{t+10}, s{t+14}", f"s_sub_u32 s{t+14}, s{t+14}, 1", f"s_lshr_b32 s{t+9}, s{t+12}, s{S_GSH}",
+             f"s_and_b32 s{t+8}, s{t+12}, s{t+14}", f"s_mul_hi_u32 s{t+13}, s{t+12}, s{S_MAGL}", f"s_mul_i32 s{t+14}, s{t+12}, s{S_ONE}",
+             f"s_add_u32 s{t+13}, s{t+13}, s{t+14}", f"s_mul_i32 s{t+14}, s{t+13}, s{S_GML}", f"s_sub_u32 s{t+14}, s{t+12}, s{t+14}",
+             f"s_cmp_le_u32 s{t+11}, s{S_TM}", f"s_cselect_b32 s{t+9}, s{t+9}, s{t+13}", f"s_cselect_b32 s{t+8}, s{t+8}, s{t+14}",
+             f"s_add_u32 s{t+8}, s{t+8}, s{t+10}", f"s_lshl_b32 s{t+8}, s{t+8}, 8", f"s_lshl_b32 s{t+9}, s{t+9}, 8"]
+        for rs, ptr, row0, ld in ((RA, S_A, t + 8, S_LDA), (RB, S_B, t + 9, S_LDB)):
+            r += [f"s_mul_i32 s{t+10}, s{row0}, s{ld}", f"s_mul_hi_u32 s{t+11}, s{row0}, s{ld}",
+                  f"s_add_u32 s{rs}, s{ptr}, s{t+10}", f"s_addc_u32 s{rs+1}, s{ptr+1}, s{t+11}", f"s_and_b32 s{rs+1}, s{rs+1}, 0xffff",
+                  f"s_mul_i32 s{rs+2}, s{ld}, 255", f"s_add_u32 s{rs+2}, s{rs+2}, s{S_K}"]
+        r += [f"s_mul_i32 s{t+10}, s{t+8}, s{S_LDC}", f"s_mul_hi_u32 s{t+11}, s{t+8}, s{S_LDC}", f"s_lshl_b32 s{t+12}, s{t+9}, 1",
+              f"s_add_u32 s{t+10}, s{t+10}, s{t+12}", f"s_addc_u32 s{t+11}, s{t+11}, 0",
+              f"s_add_u32 s{RC}, s{S_C}, s{t+10}", f"s_addc_u32 s{RC+1}, s{S_C+1}, s{t+11}", f"s_and_b32 s{RC+1}, s{RC+1}, 0xffff"]
+        return r
+
+    def emit(self):
+        nm, t = self.name, S_T
+        W = t + 15
+        VL, VE, VT = self.V_LANE, self.V_E, self.V_T
+        E("\t.text"); E(f"\t.protected\t{nm}"); E(f"\t.globl\t{nm}"); E("\t.p2align\t8"); E(f"\t.type\t{nm},@function"); E(f"{nm}:")
+        E(f"\ts_load_dwordx4 s[{S_A}:{S_A+3}], {S_KARG}, 0x0")
+        E(f"\ts_load_dwordx2 s[{S_C}:{S_C+1}], {S_KARG}, 0x10")
+        E(f"\ts_load_dwordx8 s[{S_M}:{S_M+7}], {S_KARG}, 0x18")
+        E(f"\ts_load_dwordx2 s[{S_TM}:{S_TM+1}], {S_KARG}, 0x38")
+        E(f"\ts_load_dwordx2 s[{S_MAGL}:{S_MAGL+1}], {S_KARG}, 0x40")
+        E(f"\ts_load_dwordx2 s[{S_ONE}:{S_ONE+1}], {S_KARG}, 0x48")
+        E(f"\ts_load_dword s{S_G}, {S_KARG}, 0x50")
+        E(f"\ts_load_dwordx2 s[{S_T+12}:{S_T+13}], {S_KARG}, 0x78")     # the counters of this stream's NEXT launch: block 0 clears them as every kernel here does
+        E(f"\tv_and_b32 v{VL}, 63, v{self.V_TID}")
+        E(f"\tv_lshrrev_b32 v{VT}, 6, v{self.V_TID}")
+        E("\ts_nop 1")
+        E(f"\tv_readfirstlane_b32 s{W}, v{VT}")
+        E("\ts_nop 4")
+        E("\ts_waitcnt lgkmcnt(0)")
+        E(f"\ts_cmp_lg_u32 {S_WG}, 0"); E(f"\ts_cbranch_scc1 .Lzeroed_{nm}")
+        E(f"\ts_cmp_eq_u64 s[{S_T+12}:{S_T+13}], 0"); E(f"\ts_cbranch_scc1 .Lzeroed_{nm}")
+        E("\ts_mov_b64 exec, 1")
+        for r_ in range(16, 21):
+            E(f"\tv_mov_b32 v{r_}, 0")
+        E(f"\tglobal_store_dwordx4 v20, v[16:19], s[{S_T+12}:{S_T+13}]")
+        E(f"\tglobal_store_dwordx4 v20, v[16:19], s[{S_T+12}:{S_T+13}] offset:16")
+        E("\ts_waitcnt vmcnt(0)")
+        E("\ts_mov_b64 exec, -1")
+        E(f".Lzeroed_{nm}:")
+        E(f"\ts_and_b32 s{t}, {S_WG}, 7"); E(f"\ts_lshl_b32 s{t}, s{t}, 5"); E(f"\ts_lshr_b32 s{t+1}, {S_WG}, 3")
+        E(f"\ts_add_u32 s{self.S_TILE}, s{t}, s{t+1}")
+        E(f"\ts_cmp_lt_u32 s{self.S_TILE}, s{S_NT}"); E(f"\ts_cbranch_scc1 .Lhave_work_{nm}"); E("\ts_endpgm"); E(f".Lhave_work_{nm}:")
+        for r_ in (S_LDA, S_LDB, S_LDC, S_K):
+            E(f"\ts_lshl_b32 s{r_}, s{r_}, 1")
+        E(f"\ts_lshr_b32 s{S_NKT}, s{S_K}, 7")
+        for rs in (RA, RB, RC):
+            E(f"\ts_mov_b32 s{rs+3}, 0x00020000")
+        E(f"\ts_mul_i32 s{RC+2}, s{S_LDC}, 255"); E(f"\ts_add_u32 s{RC+2}, s{RC+2}, 512")
+        E(f"\ts_lshl_b32 s{self.S_W4K}, s{W}, 12")
+        # ---- DMA lane offsets: piece (4 w + j) of an operand covers tile rows (4 w + j) * 8 .. + 7; lane l: row l >> 3, physical chunk l & 7,
+        # logical chunk = physical ^ ((row >> 1) & 7) = (l & 7) ^ (l >> 4) [even piece] / ^ 4 [odd piece]
+        for soff, ld, vd in ((self.OFFA, S_LDA, self.V_DA), (self.OFFB, S_LDB, self.V_DB)):
+            E(f"\ts_lshl_b32 s{t+12}, s{W}, 5")
+            for j in range(4):
+                E(f"\ts_add_u32 s{t+13}, s{t+12}, {8*j}"); E(f"\ts_mul_i32 s{soff+j}, s{t+13}, s{ld}")
+            E(f"\tv_lshrrev_b32 v{VE}, 3, v{VL}"); E(f"\tv_lshrrev_b32 v{VE+1}, 4, v{VL}"); E(f"\tv_and_b32 v{VE+2}, 7, v{VL}")
+            E(f"\tv_xor_b32 v{VE+2}, v{VE+2}, v{VE+1}"); E(f"\tv_xor_b32 v{VE+3}, 4, v{VE+2}")
+            E(f"\tv_lshlrev_b32 v{VE+2}, 4, v{VE+2}"); E(f"\tv_lshlrev_b32 v{VE+3}, 4, v{VE+3}")
+            E(f"\tv_mul_lo_u32 v{VE+4}, v{VE}, s{ld}")
+            E(f"\tv_add_u32 v{vd}, v{VE+4}, v{VE+2}"); E(f"\tv_add_u32 v{vd+1}, v{VE+4}, v{VE+3}")
+        # ---- fragment read addresses: A rows wm*128 + 16 f + i, B rows wn*64 + 16 f + i; chunk (4 kk + g) ^ ((i >> 1) & 7)
+        E(f"\ts_lshr_b32 s{t+12}, s{W}, 2")       # wm
+        E(f"\ts_and_b32 s{t+13}, s{W}, 3")        # wn
+        for VR, wreg, sh, boff in ((self.V_RA, t + 12, 14, 0), (self.V_RB, t + 13, 13, BOFF)):
+            E(f"\tv_and_b32 v{VE}, 15, v{VL}"); E(f"\tv_lshrrev_b32 v{VE+1}, 4, v{VL}"); E(f"\tv_bfe_u32 v{VE+2}, v{VL}, 1, 3")
+            E(f"\tv_xor_b32 v{VE+3}, v{VE+1}, v{VE+2}"); E(f"\tv_xor_b32 v{VE+4}, 4, v{VE+3}")
+            E(f"\tv_lshlrev_b32 v{VE+3}, 4, v{VE+3}"); E(f"\tv_lshlrev_b32 v{VE+4}, 4, v{VE+4}"); E(f"\tv_lshlrev_b32 v{VE}, 7, v{VE}")
+            E(f"\ts_lshl_b32 s{t+14}, s{wreg}, {sh}")
+            if boff:
+                E(f"\ts_add_u32 s{t+14}, s{t+14}, {boff}")
+            for kk in (0, 1):
+                E(f"\tv_add_u32 v{VR+kk}, v{VE}, v{VE+3+kk}"); E(f"\tv_add_u32 v{VR+kk}, s{t+14}, v{VR+kk}"); E(f"\tv_add_u32 v{VR+2+kk}, {STAGE}, v{VR+kk}")
+        # ---- epilogue lane offset: m = wm*128 + fm*16 + (l & 15), n = wn*64 + fn*16 + 4 (l >> 4)
+        E(f"\tv_and_b32 v{VE}, 15, v{VL}"); E(f"\tv_lshrrev_b32 v{VE+1}, 4, v{VL}")
+        E(f"\ts_lshl_b32 s{t+14}, s{t+12}, 7"); E(f"\tv_add_u32 v{VE}, s{t+14}, v{VE}"); E(f"\tv_mul_lo_u32 v{VE}, v{VE}, s{S_LDC}")
+        E(f"\tv_lshlrev_b32 v{VE+1}, 3, v{VE+1}"); E(f"\ts_lshl_b32 s{t+14}, s{t+13}, 7")
+        E(f"\tv_add_u32 v{VE}, v{VE}, v{VE+1}"); E(f"\tv_add_u32 v{self.V_CO}, s{t+14}, v{VE}")
+        E(f"\ts_lshl_b32 s{S_C16}, s{S_LDC}, 4")
+        E(f".Ltile_{nm}:")
+        for x in self.setup():
+            L(x)
+        for stage in (0, 1):
+            for m0w, ld in self.dma(stage):
+                E("\t" + m0w); E("\ts_nop 0"); E("\t" + ld)
+            for x in self.bump():
+                L(x)
+        for a in range(128):
+            E(f"\tv_accvgpr_write_b32 a{a}, 0")
+        E("\ts_waitcnt vmcnt(8)")
+        E("\ts_barrier")
+        for x in self.reads(0, 0, 0):
+            E("\t" + x)
+        E("\ts_waitcnt lgkmcnt(0)")
+        E(f"\ts_lshr_b32 s{S_LOOP}, s{S_NKT}, 1")
+        E(f".Lloop_{nm}:")
+        self.ktile(0)
+        self.ktile(1)
+        E(f"\ts_sub_u32 s{S_LOOP}, s{S_LOOP}, 1"); E(f"\ts_cmp_lg_u32 s{S_LOOP}, 0"); E(f"\ts_cbranch_scc1 .Lloop_{nm}")
+        # ---- direct epilogue: 16 rows x 32 bytes per store instruction
+        E("\ts_nop 15"); E("\ts_nop 15")
+        E(f"\ts_mov_b32 s{S_CROW}, 0")
+        if "noepi" not in ABL:
+            for fm in range(8):
+                for fn in range(4):
+                    a = self.acc(fm, fn)
+                    cur = VE + ((fm * 4 + fn) & 1) * 8
+                    for r_ in range(4):
+                        E(f"\tv_accvgpr_read_b32 v{cur+r_}, a{a+r_}")
+                    E(f"\tv_cvt_pk_bf16_f32 v{cur+4}, v{cur}, v{cur+1}"); E(f"\tv_cvt_pk_bf16_f32 v{cur+5}, v{cur+2}, v{cur+3}")
+                    E(f"\tbuffer_store_dwordx2 v[{cur+4}:{cur+5}], v{self.V_CO}, s[{RC}:{RC+3}], s{S_CROW} offen offset:{fn*32}")
+                E(f"\ts_add_u32 s{S_CROW}, s{S_CROW}, s{S_C16}")
+        E(f"\ts_add_u32 s{self.S_TILE}, s{self.S_TILE}, s{S_G}")
+        E(f"\ts_cmp_lt_u32 s{self.S_TILE}, s{S_NT}")
+        E(f"\ts_cbranch_scc1 .Ltile_{nm}")
+        E("\ts_endpgm")
+        E("\t.section\t.rodata,\"a\",@progbits"); E("\t.p2align\t6, 0x0"); E(f"\t.amdhsa_kernel {nm}")
+        for k, v in (("group_segment_fixed_size", 131072), ("private_segment_fixed_size", 0), ("kernarg_size", 128),
+                     ("user_sgpr_count", 2), ("user_sgpr_dispatch_ptr", 0), ("user_sgpr_queue_ptr", 0), ("user_sgpr_kernarg_segment_ptr", 1),
+                     ("user_sgpr_dispatch_id", 0), ("user_sgpr_kernarg_preload_length", 0), ("user_sgpr_kernarg_preload_offset", 0),
+                     ("user_sgpr_private_segment_size", 0), ("uses_dynamic_stack", 0), ("enable_private_segment", 0),
+                     ("system_sgpr_workgroup_id_x", 1), ("system_sgpr_workgroup_id_y", 0), ("system_sgpr_workgroup_id_z", 0),
+                     ("system_sgpr_workgroup_info", 0), ("system_vgpr_workitem_id", 0), ("next_free_vgpr", self.NV + 128), ("next_free_sgpr", 102),
+                     ("accum_offset", self.NV), ("reserve_vcc", 1), ("float_round_mode_32", 0), ("float_round_mode_16_64", 0),
+                     ("float_denorm_mode_32", 3), ("float_denorm_mode_16_64", 3), ("dx10_clamp", 1), ("ieee_mode", 1), ("fp16_overflow", 0),
+                     ("tg_split", 0), ("exception_fp_ieee_invalid_op", 0), ("exception_fp_denorm_src", 0), ("exception_fp_ieee_div_zero", 0),
+                     ("exception_fp_ieee_overflow", 0), ("exception_fp_ieee_underflow", 0), ("exception_fp_ieee_inexact", 0),
+                     ("exception_int_div_zero", 0)):
+            E(f"\t\t.amdhsa_{k} {v}")
+        E("\t.end_amdhsa_kernel")
+
+    def meta(self):
+        return f"""  - .agpr_count:     128
+    .args:
+      - .offset:         0
+        .size:           128
+        .value_kind:     by_value
+    .group_segment_fixed_size: 131072
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: 128
+    .max_flat_workgroup_size: 512
+    .name:           {self.name}
+    .private_segment_fixed_size: 0
+    .sgpr_count:     106
+    .sgpr_spill_count: 0
+    .symbol:         {self.name}.kd
+    .uniform_work_group_size: 1
+    .uses_dynamic_stack: false
+    .vgpr_count:     {self.NV + 128}
+    .vgpr_spill_count: 0
+    .wavefront_size: 64"""
+
+
 KERNELS = [Kernel("lap_gemm_asm_nt", True, True, False), Kernel("lap_gemm_asm_nn", True, False, False),
            Kernel("lap_gemm_asm_tn", False, False, True, ring=RING, ss=True), Kernel("lap_gemm_asm_nt_bias", True, True, False, epi=True),
            Kernel("lap_gemm_asm_tn_t", False, False, True, tout=True, ring=RING, ss=True),
@@ -1373,6 +1617,8 @@ KERNELS = [Kernel("lap_gemm_asm_nt", True, True, False), Kernel("lap_gemm_asm_nn
            # bf16-rounded cotangent, gemma.py:307,318): same ring main loop, the bf16 staged epilogue of the forward kernels
            Kernel("lap_gemm_asm_tn_b16", False, False, False, ring=RING, ss=True),
            Kernel("lap_gemm_asm_tn_t_b16", False, False, False, tout=True, ring=RING, ss=True)]
+if os.environ.get("ASM_NT8") == "1":       # round-6 probe: the 8-wave forward kernel in place of lap_gemm_asm_nt (512 threads per block)
+    KERNELS[0] = Kernel8("lap_gemm_asm_nt")
 E('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
 E("\t.amdhsa_code_object_version 6")
 for k in KERNELS:
