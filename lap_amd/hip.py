@@ -25,6 +25,7 @@ GEMM_GELU = 4
 GEMM_BIAS_F32 = 8
 GEMM_PARTIALS = 16
 GEMM_GELU_BF16 = 32
+GEMM_GELU_EXP2 = 128
 GEMM_GEGLU = 64
 
 
@@ -171,6 +172,9 @@ SIGNATURES: dict[str, list] = {
     "lap_serve_chain_status": [_vp, C.POINTER(_i)],
     "lap_serve_chain": [C.POINTER(ServeChainArgs), _vp],
     "lap_serve_pack_weight": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "lap_panel_gemm_ok": [_i, _i, _i, _i],
+    "lap_panel_gemm_pf": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _ll, _vp],
+    "lap_panel_gemm": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "lap_serve_final_euler": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp],
     "lap_ce_chunk_update": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lap_ce_chunk_grad": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -939,6 +943,41 @@ def serve_pack_weight(w, kind: int, HD: int = 0, out=None):
         out = torch.empty_like(w)
     call("lap_serve_pack_weight", _p(w), _p(out), N, K, kind, HD)
     return out
+
+
+def panel_gemm_ok(M, N, K, ksplit=1) -> bool:
+    return bool(_fn["lap_panel_gemm_ok"](M, N, K, ksplit))
+
+
+def _nbytes(t):
+    return 0 if t is None else t.numel() * t.element_size()
+
+
+def panel_linear(x, wp, N, *, bias=None, residual=None, norm=0, gamma=None, beta=None, eps=1e-6, gelu=False, out=None, nt=0, prefetch=None):
+    """y[M, N] = epi(norm(x)[M, K] @ W[N, K]^T) on the row-panel kernel (csrc/serve_panel.hip); wp = serve_pack_weight(W, PACK_PLAIN).
+    prefetch: the weight tensor of the NEXT launch of the chain (pulled into the Infinity Cache beside this product)."""
+    M, K = x.shape
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    flags = 0
+    if gelu:    # "bf16": the pre-activation rounded to bf16 first; "exp2": that, with the GELU through v_exp / v_rcp (the training kernels' form)
+        flags |= GEMM_GELU | (GEMM_GELU_BF16 if gelu in ("bf16", "exp2") else 0) | (GEMM_GELU_EXP2 if gelu == "exp2" else 0)
+    call("lap_panel_gemm_pf", _p(x), x.stride(0), _p(wp), _p(out), out.stride(0), _p(bias), _p(residual),
+         residual.stride(0) if residual is not None else 0, norm, _p(gamma), _p(beta), float(eps), M, N, K, flags, 1, None, nt,
+         _p(prefetch), _nbytes(prefetch))
+    return out
+
+
+def panel_partials(x, wp, N, scratch, ksplit, nt=0, prefetch=None):
+    """Raw f32 partial products [ksplit, M, N] of x @ W^T on the row-panel kernel (the consumers: fused_reduce_norm,
+    fused_reduce_rope_split); ksplit = 1: the whole product as one f32 slab."""
+    M, K = x.shape
+    need = ksplit * M * N
+    if scratch.numel() < need:
+        raise ValueError("scratch too small for the requested split")
+    call("lap_panel_gemm_pf", _p(x), x.stride(0), _p(wp), None, 0, None, None, 0, 0, None, None, 0.0, M, N, K, 0, ksplit, _p(scratch), nt,
+         _p(prefetch), _nbytes(prefetch))
+    return scratch[:need].view(ksplit, M, N), ksplit
 
 
 def serve_chain_tp_ok(B, S, D, H, NH, HD, NKV, prefix_len) -> bool:

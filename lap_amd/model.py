@@ -99,6 +99,17 @@ class LAP:
         # ... mapped onto the chip as 8-way tensor parallelism over the XCDs (csrc/serve_chain_tp.hpp: two chip-wide seams per layer
         # instead of five; bf16-rounding-noise equal to the flat chain, not bitwise).  LAP_SERVE_TP=0: the flat packed chain
         self.serve_tp = os.environ.get("LAP_SERVE_TP", "0") != "0"
+        # the serving prefill's small projections (SigLIP qkv / out / fc1 / fc2, Gemma qkv / out at <= 640 rows) on the row-panel kernel
+        # (csrc/serve_panel.hip: the rows of A resident in LDS, packed weights streamed into MFMA fragments, no barrier in the k-loop)
+        # against packed weight images kept per parameter version (+1.0 GB for LAP-3B).  qkv / out / fc1 are bitwise equal to the
+        # unsplit tiles they replace.  LAP_SERVE_PANEL=0: the LDS-tiled kernels (A/B runs, tests)
+        self.serve_panel = os.environ.get("LAP_SERVE_PANEL", "1") != "0"
+        self._prefill_pw: dict = {}     # name -> [version, packed image]
+        self._panel_gelu = os.environ.get("LAP_SERVE_PANEL_GELU", "exp2")    # "bf16": tanhf (A/B)
+        self._panel_llm = os.environ.get("LAP_SERVE_PANEL_LLM", "o")          # which Gemma prefill projections take the panel kernel: q, o
+        # ... and every panel launch pulls the NEXT launch's weights into the Infinity Cache with a fifth wave per block (the chain's
+        # launches otherwise meet their weights HBM-cold).  LAP_SERVE_PREFETCH=0: off (A/B runs)
+        self.serve_prefetch = os.environ.get("LAP_SERVE_PREFETCH", "1") != "0"
         self._chain_ctr = None
         self._chain_scratch = None
         self._packed_w = None       # [version, per layer (wqkv, wo, wgu, wd) packed images]
@@ -360,15 +371,32 @@ class LAP:
         scratch = hip._gemm_scratch(self.device)
         self.comm.wait_unit("img0")
         y, _, _ = hip.layernorm_fwd(x, self.F("img/0/ln1_g"), self.F("img/0/ln1_b"))
+        rows = x.shape[0]
+        mlp = self.W("img/0/w1").shape[0]
+        panel = (self.serve_panel and rows <= 640 and hip.panel_gemm_ok(rows, 3 * W, W) and hip.panel_gemm_ok(rows, mlp, W)
+                 and hip.panel_gemm_ok(rows, W, mlp, 4))
+        pf = (lambda name: self._pw(name)) if panel and self.serve_prefetch else (lambda name: None)   # the next launch's weights
         for l in range(s.depth):
             p = f"img/{l}/"
-            qkv = hip.linear_fwd(y, self.W(p + "wqkv"), bias=self.F(p + "bqkv"))
+            if panel:    # us per launch at 512 rows, replayed graph (tools/probes/panel_bench.py): 11.6 -> 11.0, 9.0 -> 8.0, 14.5 -> 12.8, 14.9 -> 12.0
+                qkv = hip.panel_linear(y, self._pw(p + "wqkv"), 3 * W, bias=self.F(p + "bqkv"), nt=2, prefetch=pf(p + "wo"))
+            else:
+                qkv = hip.linear_fwd(y, self.W(p + "wqkv"), bias=self.F(p + "bqkv"))
             (o, _), _ = hip.attention_fwd([qkv[:, :W]], [qkv[:, W:2 * W]], [qkv[:, 2 * W:]], [T], [T], N, s.num_heads, s.num_heads, hd,
                                           scale=hd ** -0.5, q_rs=(3 * W, 0), kv_rs=(3 * W, 0), need_lse=False)
-            x1 = hip.linear_fwd(o, self.W(p + "wo"), bias=self.F(p + "bo"), residual=x)
+            if panel:
+                x1 = hip.panel_linear(o, self._pw(p + "wo"), W, bias=self.F(p + "bo"), residual=x, nt=1, prefetch=pf(p + "w1"))
+            else:
+                x1 = hip.linear_fwd(o, self.W(p + "wo"), bias=self.F(p + "bo"), residual=x)
             y2, _, _ = hip.layernorm_fwd(x1, self.F(p + "ln2_g"), self.F(p + "ln2_b"))
-            a = hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"), gelu="bf16")
-            part, ks = hip.linear_partials(a, self.W(p + "w2"), scratch)
+            if panel:
+                a = hip.panel_linear(y2, self._pw(p + "w1"), mlp, bias=self.F(p + "b1"), gelu=self._panel_gelu, nt=3, prefetch=pf(p + "w2"))
+                if l + 1 < s.depth:
+                    self.comm.wait_unit(f"img{l + 1}")
+                part, ks = hip.panel_partials(a, self._pw(p + "w2"), W, scratch, 4, nt=3, prefetch=pf(f"img/{l + 1}/wqkv") if l + 1 < s.depth else None)
+            else:
+                a = hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"), gelu="bf16")
+                part, ks = hip.linear_partials(a, self.W(p + "w2"), scratch)
             if l + 1 < s.depth:
                 self.comm.wait_unit(f"img{l + 1}")
                 g, b = self.F(f"img/{l + 1}/ln1_g"), self.F(f"img/{l + 1}/ln1_b")
@@ -745,9 +773,15 @@ class LAP:
         self.comm.wait_unit("llm0")
         h, _ = hip.rmsnorm_fwd(x0, scale=self.F("llm/0/n_attn"), save_rstd=False)
         rows = x0.shape[0]
+        panel = (self.serve_panel and rows <= 640 and hip.panel_gemm_ok(rows, (NH + 2 * KV) * HD, Dv) and hip.panel_gemm_ok(rows, Dv, NH * HD))
+        panel_q, panel_o = panel and "q" in self._panel_llm, panel and "o" in self._panel_llm
+        pf = (lambda name: self._pw(name)) if panel_o and self.serve_prefetch else (lambda name: None)   # the next panel launch's weights
         for l in range(v.depth):
             p = f"llm/{l}/"
-            part, ks = hip.linear_partials(h, self.W(p + "wqkv0"), scratch, ksplit=self._prefill_ks[0])
+            if panel_q:   # one f32 slab, no K split (us, 560 rows: 23.5 -> 16.9 in front of the same consumer)
+                part, ks = hip.panel_partials(h, self._pw(p + "wqkv0"), (NH + 2 * KV) * HD, scratch, 1, nt=2, prefetch=pf(p + "wo0"))
+            else:
+                part, ks = hip.linear_partials(h, self.W(p + "wqkv0"), scratch, ksplit=self._prefill_ks[0])
             q, k, vv = hip.fused_reduce_rope_split(part, ks, pos, B, n0, Ttot, 0, NH, HD, HD ** -0.5, table=tab)
             cache_out.append((k, vv))
             if kv_events is not None:     # layer l's K / V exist from here on: the first denoise step may use them (sample_actions)
@@ -755,7 +789,10 @@ class LAP:
                 ev.record()
                 kv_events.append(ev)
             o, _ = hip.attention_fwd([q, None], [k, None], [vv, None], [n0, 0], [n0, 0], B, NH, KV, HD, qinfo, kinfo, need_lse=False)
-            if self._prefill_ks[1] > 1:
+            if panel_o:   # (16.2 -> 14.6)
+                xa = hip.panel_linear(o[0], self._pw(p + "wo0"), Dv, residual=x0, nt=4)   # (the next panel launch is 200 MB of gate|up and down weights away)
+                hf, _ = hip.rmsnorm_fwd(xa, scale=self.F(p + "n_ffw"), save_rstd=False)
+            elif self._prefill_ks[1] > 1:
                 part, ks = hip.linear_partials(o[0], self.W(p + "wo0"), scratch, ksplit=self._prefill_ks[1])
                 xa, hf = hip.fused_reduce_norm(part, ks, rows, Dv, residual=x0, norm=1, gamma=self.F(p + "n_ffw"))
             else:   # (measured: the unsplit 64-row tile with the residual epilogue + a norm launch beats split + fused consumer here)
@@ -1363,6 +1400,17 @@ class LAP:
         self._packed_w = [self.ps.version, out]
         return out
 
+    def _pw(self, name):
+        """Fragment-packed image (lap_serve_pack_weight kind 3) of a prefill projection for the row-panel kernel, persistent like
+        `_serve_packed_weights` and re-packed in place per parameter version."""
+        rec = self._prefill_pw.get(name)
+        if rec is None or rec[0] != self.ps.version:
+            if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("serving caches are stale inside a stream capture: call refresh_serve_caches() first")
+            img = hip.serve_pack_weight(self.W(name), hip.PACK_PLAIN, out=None if rec is None else rec[1])
+            self._prefill_pw[name] = rec = [self.ps.version, img]
+        return rec[1]
+
     def _time_grid(self, num_steps: int):
         dt = -1.0 / num_steps
         n, t = 0, 1.0
@@ -1375,8 +1423,12 @@ class LAP:
         """Bring the sampler's parameter-derived caches (adaRMS modulations, packed expert weights) up to the current parameter
         version, in place.  Eager `sample_actions` does this itself; a captured graph cannot — call it before a replay."""
         n, dt = self._time_grid(num_steps)
+        for name in list(self._prefill_pw):
+            kind, l = name.split("/")[:2]
+            self.comm.wait_unit(f"{kind}{l}")
+            self._pw(name)
         if not self.config.pi05:
-            return          # (pi0 has no adaRMS bank and runs on the generic layer loop: nothing is cached)
+            return          # (pi0 has no adaRMS bank and runs on the generic layer loop: nothing else is cached)
         self._serve_mods(n, dt)
         if self._packed_w is not None:
             self._serve_packed_weights()
