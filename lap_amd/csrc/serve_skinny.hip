@@ -133,6 +133,131 @@ __global__ __launch_bounds__(256) void final_norm_out_euler_kernel(const bf16* _
   }
 }
 
+// The same with the NEXT step's action_in_proj behind it (lap_serve_embed_actions: tokens = bf16(x_t W_in^T + b_in)), action_dim 7 / 8, D = 1024:
+// the wave that updates a row of x_t holds the whole new row, so it embeds it — one launch per Euler step instead of two, and the 32 dot
+// products of the out projection in batches of 8 with their reductions interleaved (the loop above walks them one by one: load ->
+// 16 FMAs -> six ds_bpermute round trips, 32 times: 12 us for 50 rows).  wave_sum through permlane swaps / DPP (bit-identical: serve_panel.hip).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp_(float v) {
+  unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u = __float_as_uint(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+  auto r2 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+  v = dpp_add_<0x128>(v);
+  v = dpp_add_<0x124>(v);
+  v = dpp_add_<0x4E>(v);
+  v = dpp_add_<0xB1>(v);
+  return v;
+}
+
+template <int NCH, int AD>
+__global__ __launch_bounds__(64) void final_euler_embed_kernel(const bf16* __restrict__ x, const bf16* __restrict__ mod, int mod_ld, int rps,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               float* __restrict__ xt, float* __restrict__ vout, int rows, int D,
+                                                               float dt, float eps, const float* __restrict__ w_in,
+                                                               const float* __restrict__ b_in, bf16* __restrict__ tokens) {
+  // One wave per block: 50 rows on 50 CUs.  The launch is a chain of memory round trips (the row the denoise chain just wrote
+  // device-scope, the modulation row, both projections' weights, x_t): everything that does not depend on the row is requested
+  // FIRST, so the round trips overlap instead of queueing behind the reductions (separately: 12.2 + 4.9 us per Euler step).
+  constexpr int AB = AD < 8 ? AD : 8, NC = 16;      // NC: embedding columns per lane (D / 64 <= 32: two passes at D = 2048)
+  const int lane = threadIdx.x;
+  const int row = blockIdx.x;
+  if (row >= rows) return;
+  const bf16* mrow = mod + (long long)(row / rps) * mod_ld;
+  bf16x8 xr[NCH], sc[NCH], sh[NCH];
+  f32x4 wo[AD][NCH][2];
+  float bo[AD], xo[AD];
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int c = (lane + 64 * q) * 8;      // (D = 512 NCH: every chunk is inside the row)
+    xr[q] = *reinterpret_cast<const bf16x8*>(x + (long long)row * D + c);
+    sc[q] = *reinterpret_cast<const bf16x8*>(mrow + c);
+    sh[q] = *reinterpret_cast<const bf16x8*>(mrow + D + c);
+#pragma unroll
+    for (int a = 0; a < AD; ++a) {
+      wo[a][q][0] = *reinterpret_cast<const f32x4*>(w + (long long)a * D + c);
+      wo[a][q][1] = *reinterpret_cast<const f32x4*>(w + (long long)a * D + c + 4);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < AD; ++a) { bo[a] = b[a]; xo[a] = xt[row * AD + a]; }
+  __builtin_amdgcn_sched_barrier(0);
+
+  float v[NCH][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < NCH; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[q][e] = (float)xr[q][e]; ss += v[q][e] * v[q][e]; }
+  ss = wave_sum_dpp_(ss);
+  const float r = 1.0f / sqrtf(ss / (float)D + eps);
+#pragma unroll
+  for (int q = 0; q < NCH; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[q][e] = round_bf16(v[q][e] * r * round_bf16(1.0f + (float)sc[q][e]) + (float)sh[q][e]);
+  float xn[AD];
+#pragma unroll
+  for (int a0 = 0; a0 < AD; a0 += AB) {
+    float acc[AB];
+#pragma unroll
+    for (int k = 0; k < AB; ++k) {
+      acc[k] = 0.f;
+      if (a0 + k >= AD) continue;
+#pragma unroll
+      for (int q = 0; q < NCH; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[k] += v[q][e] * wo[a0 + k][q][0][e] + v[q][4 + e] * wo[a0 + k][q][1][e];
+    }
+#pragma unroll
+    for (int k = 0; k < AB; ++k) acc[k] = wave_sum_dpp_(acc[k]);
+#pragma unroll
+    for (int k = 0; k < AB; ++k) {
+      const int a = a0 + k;
+      if (a >= AD) continue;
+      const float vt = acc[k] + bo[a];
+      float xv = xo[a];
+      xv += dt * vt;
+      xn[a] = xv;
+      if (lane == 0) {
+        if (vout) vout[row * AD + a] = vt;
+        xt[row * AD + a] = xv;
+      }
+    }
+  }
+  if (!tokens) return;
+  for (int c0 = lane; c0 < D; c0 += 64 * NC) {
+    float wi[NC][AD], bi[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int c = min(c0 + 64 * j, D - 1);
+      bi[j] = b_in[c];
+      if constexpr (AD % 4 == 0) {
+#pragma unroll
+        for (int k4 = 0; k4 < AD / 4; ++k4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(w_in + c * AD + 4 * k4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wi[j][4 * k4 + e] = t[e];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < AD; ++k) wi[j][k] = w_in[c * AD + k];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int c = c0 + 64 * j;
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < AD; ++k) a += xn[k] * wi[j][k];
+      if (c < D) tokens[(long long)row * D + c] = f2bf(a + bi[j]);
+    }
+  }
+}
+
 // one thread per 16-byte chunk of the packed image (serve_skinny_body.hpp PK; the row maps are skinny_load_w's)
 __global__ __launch_bounds__(256) void pack_weight_kernel(const bf16* __restrict__ W, bf16* __restrict__ out, int N, int K, int kind, int HD) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -207,6 +332,22 @@ extern "C" int lap_serve_embed_actions(const float* x_t, const float* w_in, cons
   if (!x_t || !w_in || !b_in || !tokens || rows <= 0 || action_dim <= 0 || D <= 0) return LAP_ERR_ARG;
   const long long n = (long long)rows * D;
   hipLaunchKernelGGL(embed_actions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_, x_t, w_in, b_in, (bf16*)tokens, rows, action_dim, D);
+  LAP_CHECK_LAUNCH();
+  return LAP_OK;
+}
+
+extern "C" int lap_serve_final_euler_embed(const void* x, const void* mod, int mod_ld, int rows_per_sample, const float* w_out,
+                                           const float* b_out, float* x_t, float* v_t, int rows, int D, int action_dim, float dt,
+                                           float eps, const float* w_in, const float* b_in, void* tokens, void* stream) {
+  if (!x || !mod || !w_out || !b_out || !x_t || rows <= 0 || rows_per_sample <= 0 || D <= 0 || (D & 7) || (mod_ld & 7)) return LAP_ERR_ARG;
+  if (action_dim != 7 && action_dim != 8) return LAP_ERR_ARG;      // (the projection weights of a row live in registers: 8 x D / 64 x 2 f32x4)
+  if (tokens && (!w_in || !b_in)) return LAP_ERR_ARG;
+  if (D != 1024) return LAP_ERR_ARG;                               // LAP-3B's action expert
+  const dim3 grid(rows);
+#define GO(A) hipLaunchKernelGGL((final_euler_embed_kernel<2, A>), grid, dim3(64), 0, S_, (const bf16*)x, (const bf16*)mod, mod_ld, \
+                                 rows_per_sample, w_out, b_out, x_t, v_t, rows, D, dt, eps, w_in, b_in, (bf16*)tokens)
+  if (action_dim == 7) GO(7); else GO(8);
+#undef GO
   LAP_CHECK_LAUNCH();
   return LAP_OK;
 }

@@ -172,6 +172,7 @@ SIGNATURES: dict[str, list] = {
     "lap_serve_chain_status": [_vp, C.POINTER(_i)],
     "lap_serve_chain": [C.POINTER(ServeChainArgs), _vp],
     "lap_serve_pack_weight": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "lap_serve_final_euler_embed": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
     "lap_panel_gemm_ok": [_i, _i, _i, _i],
     "lap_panel_gemm_pf": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _ll, _vp],
     "lap_panel_gemm": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp],
@@ -1053,6 +1054,13 @@ def serve_embed_actions(x_t, w_in, b_in):
 def serve_final_euler(x, mod, mod_ld, rps, w_out, b_out, x_t, dt, v_out=None, eps=1e-6):
     rows, D = x.shape
     call("lap_serve_final_euler", _p(x), _p(mod), mod_ld, rps, _p(w_out), _p(b_out), _p(x_t), _p(v_out), rows, D, w_out.shape[0], float(dt), float(eps))
+
+
+def serve_final_euler_embed(x, mod, mod_ld, rps, w_out, b_out, x_t, dt, v_out=None, eps=1e-6, w_in=None, b_in=None, tokens=None):
+    """serve_final_euler (action_dim 32) and, with `tokens` (a [rows, D] bf16 tensor to fill), the next step's serve_embed_actions in one launch."""
+    rows, D = x.shape
+    call("lap_serve_final_euler_embed", _p(x), _p(mod), mod_ld, rps, _p(w_out), _p(b_out), _p(x_t), _p(v_out), rows, D, w_out.shape[0], float(dt), float(eps),
+         _p(w_in), _p(b_in), _p(tokens))
 
 
 def serve_set_variant(feature_tiles: int):

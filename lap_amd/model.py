@@ -99,6 +99,9 @@ class LAP:
         # ... mapped onto the chip as 8-way tensor parallelism over the XCDs (csrc/serve_chain_tp.hpp: two chip-wide seams per layer
         # instead of five; bf16-rounding-noise equal to the flat chain, not bitwise).  LAP_SERVE_TP=0: the flat packed chain
         self.serve_tp = os.environ.get("LAP_SERVE_TP", "0") != "0"
+        # an Euler step's tail (final adaRMS + action_out_proj + x_t update) and the next step's action_in_proj in one launch
+        # (csrc/serve_skinny.hip final_euler_embed_kernel; same arithmetic).  LAP_SERVE_EULER_EMBED=0: the two launches
+        self.serve_euler_embed = os.environ.get("LAP_SERVE_EULER_EMBED", "1") != "0"
         # the serving prefill's small projections (SigLIP qkv / out / fc1 / fc2, Gemma qkv / out at <= 640 rows) on the row-panel kernel
         # (csrc/serve_panel.hip: the rows of A resident in LDS, packed weights streamed into MFMA fragments, no barrier in the k-loop)
         # against packed weight images kept per parameter version (+1.0 GB for LAP-3B).  qkv / out / fc1 are bitwise equal to the
@@ -1282,12 +1285,19 @@ class LAP:
         for step in range(len(times)):
             mod = mods[step:step + 1]
             if chain:
-                x1 = hip.serve_embed_actions(x_t.view(B * S, ad), self.F("act/in_w"), self.F("act/in_b"))
+                fuse_tail = self.serve_euler_embed and ad in (7, 8) and self.e.width == 1024     # the step's tail embeds the next step's tokens in the same launch
+                if not fuse_tail or step == 0:
+                    x1 = hip.serve_embed_actions(x_t.view(B * S, ad), self.F("act/in_w"), self.F("act/in_b"))
                 xf1 = hip.serve_chain(x1, mod, 3 * self.e.width, chain_w, cache, rope_tab, qinfo_s, kinfo_all, B, S, self.v.num_heads,
                                       self.v.head_dim, self.e.mlp_dim, Pn, self.v.head_dim ** -0.5, self._chain_ctr,
                                       packed_scratch=self._chain_scratch if self.serve_packed else None, tp=tp)
                 v_t = torch.empty((B * S, ad), dtype=torch.float32, device=dev) if collect is not None else None
-                hip.serve_final_euler(xf1, self._mod_slot(mod, nslot), 0, S, self.F("act/out_w"), self.F("act/out_b"), x_t.view(B * S, ad), dt, v_t)
+                if fuse_tail:
+                    x1 = torch.empty((B * S, self.e.width), dtype=torch.bfloat16, device=dev) if step + 1 < len(times) else None
+                    hip.serve_final_euler_embed(xf1, self._mod_slot(mod, nslot), 0, S, self.F("act/out_w"), self.F("act/out_b"), x_t.view(B * S, ad), dt, v_t,
+                                                w_in=self.F("act/in_w"), b_in=self.F("act/in_b"), tokens=x1)
+                else:
+                    hip.serve_final_euler(xf1, self._mod_slot(mod, nslot), 0, S, self.F("act/out_w"), self.F("act/out_b"), x_t.view(B * S, ad), dt, v_t)
                 if collect is not None:
                     collect[f"v_t/{step}"] = v_t.view(B, S, ad)
                 continue

@@ -1254,6 +1254,23 @@ def test_serve_skinny_projections_match_unfused_ops(hip, M, rps, shared):
     hip.serve_final_euler(x, mod, mld, rps, w_out, b_out, xt2, -0.1, vt)
     ref_v = h @ w_out.t() + b_out
     assert rel_err(vt, ref_v) < 2e-3 and rel_err(xt2, xt - 0.1 * ref_v) < 1e-3
+    # ... and the fused form: the step's tail + the next step's action_in_proj in one launch — the same bits as the two
+    for ad in (7, 8):
+        xt = rnd(M, ad, dtype=torch.float32, seed=17)
+        w_in, b_in = rnd(D, ad, dtype=torch.float32, scale=ad ** -0.5, seed=18), rnd(D, dtype=torch.float32, scale=0.02, seed=19)
+        w_out, b_out = rnd(ad, D, dtype=torch.float32, scale=D ** -0.5, seed=20), rnd(ad, dtype=torch.float32, scale=0.02, seed=21)
+        xa, va = xt.clone(), torch.empty(M, ad, device=DEV)
+        hip.serve_final_euler(x, mod, mld, rps, w_out, b_out, xa, -0.1, va)
+        tok_a = hip.serve_embed_actions(xa, w_in, b_in)
+        xb, vb = xt.clone(), torch.empty(M, ad, device=DEV)
+        tok_b = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+        hip.serve_final_euler_embed(x, mod, mld, rps, w_out, b_out, xb, -0.1, vb, w_in=w_in, b_in=b_in, tokens=tok_b)
+        assert torch.equal(va, vb) and torch.equal(xa, xb) and torch.equal(tok_a, tok_b), ad
+        xc = xt.clone()
+        hip.serve_final_euler_embed(x, mod, mld, rps, w_out, b_out, xc, -0.1)      # without the embedding (the last step)
+        assert torch.equal(xa, xc), ad
+    with pytest.raises(hip.LapHipError):
+        hip.serve_final_euler_embed(x, mod, mld, rps, w_out[:5].contiguous(), b_out[:5].contiguous(), xt[:, :5].contiguous(), -0.1)
     # unsupported shapes are rejected, not mis-computed
     with pytest.raises(hip.LapHipError):
         hip.serve_proj_residual(rnd(M, 1536), rnd(D, 1536), x, None, 0, rps)
