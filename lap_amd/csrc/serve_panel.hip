@@ -389,6 +389,8 @@ extern "C" int lap_panel_gemm_pf(const void* A, int lda, const void* Wp, void* C
   if (!A || !Wp || !lap_panel_gemm_ok(M, N, K, ksplit) || (lda & 7) || norm < 0 || norm > 2) return LAP_ERR_ARG;
   if (ksplit > 1 && !partials) return LAP_ERR_ARG;
   if (partials ? (bias || residual || (flags & LAP_GEMM_GELU) || (ksplit > 1 && norm)) : (!C || (ldc & 3))) return LAP_ERR_ARG;
+  // buffer descriptors: 32-bit byte ranges, and the A side marks rows past M with offset 0x80000000
+  if (((long long)(M - 1) * lda + K) * 2 >= (1LL << 31) || (long long)N * K * 2 >= (1LL << 32)) return LAP_ERR_ARG;
   if (norm && !gamma) return LAP_ERR_ARG;
   if (norm == 2 && !beta) return LAP_ERR_ARG;
   if (residual && (ldr & 3)) return LAP_ERR_ARG;
