@@ -102,14 +102,16 @@ class LAP:
         # an Euler step's tail (final adaRMS + action_out_proj + x_t update) and the next step's action_in_proj in one launch
         # (csrc/serve_skinny.hip final_euler_embed_kernel; same arithmetic).  LAP_SERVE_EULER_EMBED=0: the two launches
         self.serve_euler_embed = os.environ.get("LAP_SERVE_EULER_EMBED", "1") != "0"
-        # the serving prefill's small projections (SigLIP qkv / out / fc1 / fc2, Gemma qkv / out at <= 640 rows) on the row-panel kernel
+        # the serving prefill's small projections (SigLIP qkv / out / fc1 / fc2; Gemma's qkv / out opt-in, see _panel_llm) on the row-panel kernel
         # (csrc/serve_panel.hip: the rows of A resident in LDS, packed weights streamed into MFMA fragments, no barrier in the k-loop)
         # against packed weight images kept per parameter version (+1.0 GB for LAP-3B).  qkv / out / fc1 are bitwise equal to the
         # unsplit tiles they replace.  LAP_SERVE_PANEL=0: the LDS-tiled kernels (A/B runs, tests)
         self.serve_panel = os.environ.get("LAP_SERVE_PANEL", "1") != "0"
         self._prefill_pw: dict = {}     # name -> [version, packed image]
         self._panel_gelu = os.environ.get("LAP_SERVE_PANEL_GELU", "exp2")    # "bf16": tanhf (A/B)
-        self._panel_llm = os.environ.get("LAP_SERVE_PANEL_LLM", "o")          # which Gemma prefill projections take the panel kernel: q, o
+        # which Gemma prefill projections take the panel kernel (q, o): none by default — in the chunk the out projection takes 23 us there
+        # against 19.6 on the LDS tile (14.6 on cache-warm weights), qkv as one f32 slab 25 against the split-K tile's 17 (12.06 / 12.14 / 12.22 ms)
+        self._panel_llm = os.environ.get("LAP_SERVE_PANEL_LLM", "")
         # ... and every panel launch pulls the NEXT launch's weights into the Infinity Cache with a fifth wave per block (the chain's
         # launches otherwise meet their weights HBM-cold).  LAP_SERVE_PREFETCH=0: off (A/B runs)
         self.serve_prefetch = os.environ.get("LAP_SERVE_PREFETCH", "1") != "0"
