@@ -53,6 +53,18 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   float u = k0 * (x + k1 * x * x * x);
   return 0.5f * x * (1.0f + tanhf(u));
 }
+// tanh-GELU in its sigmoid form, x / (1 + exp2(x (c1 x^2 + c0))), c0 = -2 sqrt(2/pi) log2(e), c1 = 0.044715 c0, through v_exp_f32 /
+// v_rcp_f32: the arithmetic of the training step's lap_gemm_asm_nt_bias_gelu epilogue (tools/gen_gemm_asm.py gelu_packed), instruction
+// for instruction.  jax.nn.gelu(approximate=True) to ~2 ulp of f32 before the bf16 rounding; ~9 VALU operations instead of tanhf's ~40
+// (a 64 x 192 tile of one wave per SIMD spends 3 us in tanhf).  Used by the serving prefill's epilogues (serve_panel.hip, gemm.hip's GeGLU tile).
+__device__ __forceinline__ float gelu_exp2_f(float x) {
+  float p = __builtin_fmaf(x * x, __builtin_bit_cast(float, 0xbdd2d3e8u), __builtin_bit_cast(float, 0xc0135761u));
+  p = x * p;
+  asm("" : "+v"(p));     // (keeps x * p a product of its own: no re-association into the fma)
+  const float d = 1.0f + __builtin_amdgcn_exp2f(p);
+  return x * __builtin_amdgcn_rcpf(d);
+}
+
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   float u = k0 * (x + k1 * x * x * x);

@@ -276,7 +276,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(GemmParams p) {
           const int gc = tn * 128 + wn * 32 + j * 16 + 4 * lg;
           bf16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf(round_bf16(gelu_tanh_f(round_bf16(acc[i][j][e]))) * round_bf16(acc[i][j + 2][e]));
+          for (int e = 0; e < 4; ++e) {
+            const float gt = round_bf16(acc[i][j][e]);
+            // geglu 2: the GELU of lap_gemm_asm_geglu_fwd (the training step's kernel: v_exp / v_rcp), 80 of them per lane are 10 us of tanhf otherwise
+            o[e] = f2bf(round_bf16(p.geglu == 2 ? gelu_exp2_f(gt) : gelu_tanh_f(gt)) * round_bf16(acc[i][j + 2][e]));
+          }
           *reinterpret_cast<bf16x4*>((bf16*)p.C + (long long)m * p.ldc + gc) = o;
         }
       }
@@ -1574,7 +1578,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   if ((flags & LAP_GEMM_GELU) && f32) return LAP_ERR_ARG;
   if (tile < -1 || tile > 19 || ksplit < 0) return LAP_ERR_ARG;
   if (flags & LAP_GEMM_GEGLU) {   // gate|up projection + GeGLU in one launch (serving prefill): the 320-row tile only
-    if (!a_kc || !b_kc || f32 || bias || residual || (flags & ~LAP_GEMM_GEGLU) || (N & 255) || M > 640 || alpha != 1.0f || ksplit > 1 || (tile >= 0 && tile != 15))
+    if (!a_kc || !b_kc || f32 || bias || residual || (flags & ~(LAP_GEMM_GEGLU | LAP_GEMM_GELU_EXP2)) || (N & 255) || M > 640 || alpha != 1.0f || ksplit > 1 || (tile >= 0 && tile != 15))
       return LAP_ERR_ARG;
     tile = 15; ksplit = 1;
   }
@@ -1767,7 +1771,7 @@ extern "C" int lap_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
   p.bias_kind = bias ? ((flags & LAP_GEMM_BIAS_F32) ? 2 : 1) : 0;
   p.gelu = (flags & LAP_GEMM_GELU) ? ((flags & LAP_GEMM_GELU_BF16) ? 2 : 1) : 0;
   p.accum = (flags & LAP_GEMM_ACCUM) ? 1 : 0;
-  p.geglu = (flags & LAP_GEMM_GEGLU) ? 1 : 0;
+  p.geglu = (flags & LAP_GEMM_GEGLU) ? ((flags & LAP_GEMM_GELU_EXP2) ? 2 : 1) : 0;
   p.ksplit = ksplit > 1 ? ksplit : 1;
   p.dbg = g_gemm_dbg;
   p.part = two_phase ? (float*)scratch : nullptr;

@@ -279,12 +279,14 @@ def linear_fwd(x, wt, out=None, *, bias=None, residual=None, gelu=False, out_dty
                 ksplit=ksplit)
 
 
-def linear_geglu(x, wgu):
-    """act[M, H] = GeGLU(x @ wgu[2H, in]^T): the gate|up projection and lap_geglu_fwd in one launch (serving prefill, M <= 640)."""
+def linear_geglu(x, wgu, exp2=False):
+    """act[M, H] = GeGLU(x @ wgu[2H, in]^T): the gate|up projection and lap_geglu_fwd in one launch (serving prefill, M <= 640).
+    exp2: the GELU through v_exp / v_rcp (the training kernel lap_gemm_asm_geglu_fwd's arithmetic) instead of tanhf."""
     M, K = x.shape
     H = wgu.shape[0] // 2
     act = torch.empty((M, H), dtype=torch.bfloat16, device=x.device)
-    call("lap_gemm_bf16_ex", _p(x), _p(wgu), _p(act), None, None, M, 2 * H, K, x.stride(0), wgu.stride(0), H, 0, 1.0, 1, 1, GEMM_GEGLU, -1, 0,
+    call("lap_gemm_bf16_ex", _p(x), _p(wgu), _p(act), None, None, M, 2 * H, K, x.stride(0), wgu.stride(0), H, 0, 1.0, 1, 1,
+         GEMM_GEGLU | (GEMM_GELU_EXP2 if exp2 else 0), -1, 0,
          None, 0)
     return act
 

@@ -108,7 +108,9 @@ class LAP:
         # unsplit tiles they replace.  LAP_SERVE_PANEL=0: the LDS-tiled kernels (A/B runs, tests)
         self.serve_panel = os.environ.get("LAP_SERVE_PANEL", "1") != "0"
         self._prefill_pw: dict = {}     # name -> [version, packed image]
-        self._panel_gelu = os.environ.get("LAP_SERVE_PANEL_GELU", "exp2")    # "bf16": tanhf (A/B)
+        # the prefill's fused GELU / GeGLU epilogues (SigLIP fc1 on the panel kernel, Gemma's gate|up tile) through v_exp / v_rcp, the training
+        # kernels' arithmetic; "bf16": tanhf (A/B)
+        self._panel_gelu = os.environ.get("LAP_SERVE_PANEL_GELU", "exp2")
         # which Gemma prefill projections take the panel kernel (q, o): none by default — in the chunk the out projection takes 23 us there
         # against 19.6 on the LDS tile (14.6 on cache-warm weights), qkv as one f32 slab 25 against the split-K tile's 17 (12.06 / 12.14 / 12.22 ms)
         self._panel_llm = os.environ.get("LAP_SERVE_PANEL_LLM", "")
@@ -804,7 +806,7 @@ class LAP:
                 xa = hip.linear_fwd(o[0], self.W(p + "wo0"), residual=x0)
                 hf, _ = hip.rmsnorm_fwd(xa, scale=self.F(p + "n_ffw"), save_rstd=False)
             if rows <= 640 and (v.mlp_dim & 127) == 0:    # gate|up projection + GeGLU in one launch (the 320-row tile's paired epilogue)
-                act = hip.linear_geglu(hf, self.W(p + "wgu0"))
+                act = hip.linear_geglu(hf, self.W(p + "wgu0"), exp2=self._panel_gelu == "exp2")
             else:
                 act = hip.geglu_fwd(hip.linear_fwd(hf, self.W(p + "wgu0")))
             part, ks = hip.linear_partials(act, self.W(p + "wd0"), scratch, ksplit=self._prefill_ks[2], tile=self._prefill_ks[3])

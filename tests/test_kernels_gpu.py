@@ -1561,3 +1561,14 @@ def test_gemm_geglu_epilogue_equals_projection_then_geglu_kernel(hip, M, H, K):
     """LAP_GEMM_GEGLU (serving prefill): gate|up projection + GeGLU in one launch = linear_fwd then geglu_fwd, bit for bit."""
     x = rnd(M, K, scale=0.3); w = rnd(2 * H, K, scale=0.3, seed=1)
     assert torch.equal(hip.linear_geglu(x, w), hip.geglu_fwd(hip.linear_fwd(x, w, tile=6)))
+    # exp2 = True (the serving default): the GELU of the training step's lap_gemm_asm_geglu_fwd — within two bf16 ulps of the tanhf form
+    # (one for bf16(gelu), one for the product; the two forms part where 1 + tanh(u) cancels, i.e. in gelu's negative tail: 13 % of the
+    # outputs at these gate magnitudes differ, by <= 4e-6 where |act| < 1e-3) ...
+    fast, ref = hip.linear_geglu(x, w, exp2=True), hip.linear_geglu(x, w)
+    d = (fast.float() - ref.float()).abs()
+    assert bool((d <= ref.float().abs() * 2 ** -7 + 1e-5).all())
+    if M == 560:      # ... and bit for bit that kernel's act where it takes the shape (whole 256-row tiles)
+        xt = x[:512].contiguous()
+        if hip.linear_geglu_train_ok(xt, w):
+            _, act = hip.linear_geglu_train(xt, w)
+            assert torch.equal(act, hip.linear_geglu(xt, w, exp2=True))
