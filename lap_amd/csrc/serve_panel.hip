@@ -6,8 +6,9 @@
 // SIMD nothing else to run).  This kernel has no barrier and no LDS write inside its k-loop:
 //   * a block owns BM = 64 (K <= 1216) or 32 (K <= 2048) complete rows of A: the panel [BM][K] goes into LDS ONCE (by LDS-DMA,
 //     as K/64 swizzled k-tiles: fragment reads cover the 64 banks once), optionally through the LayerNorm / RMSNorm the
-//     reference applies in front of the projection (the block has the whole row, so the statistics cost one wave reduction
-//     per row and the separate norm launch — 4.7 us of latency in the prefill chain — disappears);
+//     reference applies in front of the projection (the block has the whole row; bit-identical to the norm kernels, but every
+//     column block of a panel normalises the same rows again: +10 us per launch against 3.4 us for the separate norm launch, so
+//     the model does not use it: docs/EXPERIMENTS.md K);
 //   * each of the 4 waves owns NT feature tiles of 16 weight rows and streams them straight from the fragment-packed image
 //     (lap_serve_pack_weight kind 3: 1 KiB per wave instruction, the 130 GB/s-per-CU pattern of tools/probes/cu_pull.hip) into
 //     a register ring PF k-steps deep;
