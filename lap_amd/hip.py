@@ -960,6 +960,9 @@ def panel_linear(x, wp, N, *, bias=None, residual=None, norm=0, gamma=None, beta
     """y[M, N] = epi(norm(x)[M, K] @ W[N, K]^T) on the row-panel kernel (csrc/serve_panel.hip); wp = serve_pack_weight(W, PACK_PLAIN).
     prefetch: the weight tensor of the NEXT launch of the chain (pulled into the Infinity Cache beside this product)."""
     M, K = x.shape
+    _req(x, torch.bfloat16, "x"); _req(wp, torch.bfloat16, "wp")
+    if wp.numel() != N * K or not wp.is_contiguous():
+        raise ValueError(f"panel_linear: wp must be the contiguous packed image of a [{N}, {K}] weight, got {tuple(wp.shape)}")
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     flags = 0
@@ -975,6 +978,9 @@ def panel_partials(x, wp, N, scratch, ksplit, nt=0, prefetch=None):
     """Raw f32 partial products [ksplit, M, N] of x @ W^T on the row-panel kernel (the consumers: fused_reduce_norm,
     fused_reduce_rope_split); ksplit = 1: the whole product as one f32 slab."""
     M, K = x.shape
+    _req(x, torch.bfloat16, "x"); _req(wp, torch.bfloat16, "wp")
+    if wp.numel() != N * K or not wp.is_contiguous():
+        raise ValueError(f"panel_partials: wp must be the contiguous packed image of a [{N}, {K}] weight, got {tuple(wp.shape)}")
     need = ksplit * M * N
     if scratch.numel() < need:
         raise ValueError("scratch too small for the requested split")
