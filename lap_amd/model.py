@@ -114,6 +114,8 @@ class LAP:
         # which Gemma prefill projections take the panel kernel (q, o): none by default — in the chunk the out projection takes 23 us there
         # against 19.6 on the LDS tile (14.6 on cache-warm weights), qkv as one f32 slab 25 against the split-K tile's 17 (12.06 / 12.14 / 12.22 ms)
         self._panel_llm = os.environ.get("LAP_SERVE_PANEL_LLM", "")
+        # feature tiles of 16 per wave for SigLIP's qkv / out / fc1 / fc2 on the panel kernel (tuning knob; sweep in the chunk: docs/EXPERIMENTS.md K)
+        self._panel_nt = tuple(int(v) for v in os.environ.get("LAP_SERVE_PANEL_NT", "2,1,3,3").split(","))
         # ... and every panel launch pulls the NEXT launch's weights into the Infinity Cache with a fifth wave per block (the chain's
         # launches otherwise meet their weights HBM-cold).  LAP_SERVE_PREFETCH=0: off (A/B runs)
         self.serve_prefetch = os.environ.get("LAP_SERVE_PREFETCH", "1") != "0"
@@ -386,21 +388,21 @@ class LAP:
         for l in range(s.depth):
             p = f"img/{l}/"
             if panel:    # us per launch at 512 rows, replayed graph (tools/probes/panel_bench.py): 11.6 -> 11.0, 9.0 -> 8.0, 14.5 -> 12.8, 14.9 -> 12.0
-                qkv = hip.panel_linear(y, self._pw(p + "wqkv"), 3 * W, bias=self.F(p + "bqkv"), nt=2, prefetch=pf(p + "wo"))
+                qkv = hip.panel_linear(y, self._pw(p + "wqkv"), 3 * W, bias=self.F(p + "bqkv"), nt=self._panel_nt[0], prefetch=pf(p + "wo"))
             else:
                 qkv = hip.linear_fwd(y, self.W(p + "wqkv"), bias=self.F(p + "bqkv"))
             (o, _), _ = hip.attention_fwd([qkv[:, :W]], [qkv[:, W:2 * W]], [qkv[:, 2 * W:]], [T], [T], N, s.num_heads, s.num_heads, hd,
                                           scale=hd ** -0.5, q_rs=(3 * W, 0), kv_rs=(3 * W, 0), need_lse=False)
             if panel:
-                x1 = hip.panel_linear(o, self._pw(p + "wo"), W, bias=self.F(p + "bo"), residual=x, nt=1, prefetch=pf(p + "w1"))
+                x1 = hip.panel_linear(o, self._pw(p + "wo"), W, bias=self.F(p + "bo"), residual=x, nt=self._panel_nt[1], prefetch=pf(p + "w1"))
             else:
                 x1 = hip.linear_fwd(o, self.W(p + "wo"), bias=self.F(p + "bo"), residual=x)
             y2, _, _ = hip.layernorm_fwd(x1, self.F(p + "ln2_g"), self.F(p + "ln2_b"))
             if panel:
-                a = hip.panel_linear(y2, self._pw(p + "w1"), mlp, bias=self.F(p + "b1"), gelu=self._panel_gelu, nt=3, prefetch=pf(p + "w2"))
+                a = hip.panel_linear(y2, self._pw(p + "w1"), mlp, bias=self.F(p + "b1"), gelu=self._panel_gelu, nt=self._panel_nt[2], prefetch=pf(p + "w2"))
                 if l + 1 < s.depth:
                     self.comm.wait_unit(f"img{l + 1}")
-                part, ks = hip.panel_partials(a, self._pw(p + "w2"), W, scratch, 4, nt=3, prefetch=pf(f"img/{l + 1}/wqkv") if l + 1 < s.depth else None)
+                part, ks = hip.panel_partials(a, self._pw(p + "w2"), W, scratch, 4, nt=self._panel_nt[3], prefetch=pf(f"img/{l + 1}/wqkv") if l + 1 < s.depth else None)
             else:
                 a = hip.linear_fwd(y2, self.W(p + "w1"), bias=self.F(p + "b1"), gelu="bf16")
                 part, ks = hip.linear_partials(a, self.W(p + "w2"), scratch)
