@@ -689,6 +689,41 @@ def test_graphed_sampler_replay_equals_eager_and_oracle(hip):
     assert torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
 
 
+def test_graphed_sampler_follows_parameter_updates_at_full_width(hip, monkeypatch):
+    """The captured sampler holds the ADDRESSES of parameter-derived images: the adaRMS modulations, the packed expert weights of the
+    denoise chain and (round 6) the packed SigLIP weights of the row-panel prefill kernels.  After the parameters change they must be
+    rebuilt in place before the next replay (GraphedSampler.__call__ -> refresh_serve_caches): replay == eager before and after an
+    update, at the LAP-3B widths (where the panel kernels, the one-launch denoise step and — action_dim 7 — the fused Euler tail run)."""
+    from lap_amd.serve import GraphedSampler
+
+    cfg = _full_width_cfg(monkeypatch, action_dim=7)
+    oc = oracle_cfg(cfg)
+    P = O.init_params(oc, seed=5)
+    obs, _, noise, _ = make_inputs(cfg, B=1, ragged=False)
+    so = {k: v for k, v in obs.items() if k != "tokenized_langact_mask"}
+    o = to_observation(so | {"tokenized_langact_mask": None}, DEV)
+    model = _engine(cfg, P)
+    sampler = GraphedSampler(model, 1, 10).capture()
+    assert model._prefill_pw and model._packed_w is not None and model.serve_euler_embed      # the paths this test is about are live
+    out1 = sampler(o, noise.to(DEV)).clone()
+    assert torch.equal(out1, model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV)))
+    with torch.no_grad():
+        for name in model.ps.master:
+            model.ps.master[name].mul_(1.03)
+    model.ps.refresh_mirror_local()                      # bf16 mirrors follow the masters; ParamStore.version moves
+    out2 = sampler(o, noise.to(DEV)).clone()
+    eager2 = model.sample_actions(0, o, num_steps=10, noise=noise.to(DEV))
+    assert torch.equal(out2, eager2)
+    assert not torch.equal(out1, out2) and bool(torch.isfinite(out2).all())
+    # ... and against a model that held the new parameters from the start (nothing stale survives anywhere)
+    fresh = _engine(cfg, P)
+    with torch.no_grad():
+        for name in fresh.ps.master:
+            fresh.ps.master[name].mul_(1.03)
+    fresh.ps.refresh_mirror_local()
+    assert torch.equal(out2, fresh.sample_actions(0, o, num_steps=10, noise=noise.to(DEV)))
+
+
 def test_sample_actions_matches_oracle(hip):
     cfg = debug_model_cfg()
     oc = oracle_cfg(cfg)
