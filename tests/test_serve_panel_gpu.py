@@ -21,7 +21,7 @@ def rel_err(a, b):
 
 # SigLIP So400m block at 2 x 256 tokens (qkv, out, fc1 with the engine's padded MLP width), Gemma-2B prefix rows (560: ragged last panel)
 @pytest.mark.parametrize("M,N,K", [(512, 3456, 1152), (512, 1152, 1152), (512, 4352, 1152), (560, 2560, 2048), (560, 2048, 2048),
-                                   (50, 1024, 1024), (520, 144, 64)])
+                                   (50, 1024, 1024), (520, 144, 64), (256, 3456, 1152), (768, 1152, 1152)])   # one / three camera images
 @pytest.mark.parametrize("nt", [0, 1, 2, 3, 4])
 def test_panel_plain_bitwise(hip, M, N, K, nt):
     x = rnd(M, K); w = rnd(N, K, seed=1, scale=0.05)
